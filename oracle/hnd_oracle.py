@@ -1,0 +1,384 @@
+"""Functional CPU oracle of the reference's HND/GHND distillation step.
+
+TEST INFRASTRUCTURE (see oracle/__init__.py) -- never imported by the product.
+
+The reference expresses the step as nn.Modules (torch 1.3.1 + torchvision 0.4.2);
+this file restates the same arithmetic as plain functions over a *state dict*
+(keys identical to the reference checkpoints) so that the HIP path,
+which is also state-dict driven, can be compared tensor by tensor.  Works in fp32
+(parity target) and fp64 (gradient oracle).  Pinned against the reference run over
+``oracle/shim`` by ``tests/golden/make_golden.py`` (fixtures in ``tests/golden``).
+
+Reference lines restated (all relative to /root/reference):
+  transform            src/models/org/rcnn.py:25-82  (+ torchvision 0.4.2 normalize/batch_images)
+  stem / layers        src/models/custom/resnet.py:26-30,95-105 ; torchvision resnet Bottleneck
+  student layer1       src/models/mimic/resnet_layer.py:40-70 ; src/models/mimic/base.py:21-22,50-58
+  FrozenBatchNorm2d    torchvision 0.4.2 ops/misc.py (no eps), built at src/models/org/rcnn.py:391,394
+  FPN                  torchvision 0.4.2 ops/feature_pyramid_network.py via src/models/org/rcnn.py:399-414
+  early exit           src/models/org/rcnn.py:102-110
+  hooks / loss         src/distillation/tool.py:40-61 ; src/distillation/loss.py:25-34
+  optimisation step    src/mimic_runner.py:38-59 ; src/utils/main_util.py:65-72
+"""
+import math
+from collections import OrderedDict
+
+import torch
+import torch.nn.functional as F
+
+RESNET50_BLOCKS = (3, 4, 6, 3)
+IMAGE_MEAN = (0.485, 0.456, 0.406)      # src/models/org/rcnn.py:222-226
+IMAGE_STD = (0.229, 0.224, 0.225)
+BN_EPS, BN_MOMENTUM = 1e-5, 0.1         # torch nn.BatchNorm2d defaults
+B = 'backbone.body.'
+
+# (kind, index) layout of the two nn.Sequential of Bottleneck4LargeResNet, resnet_layer.py:42-65
+ENCODER_SPEC = (('conv', 0, 1), ('bn', 1), ('conv', 2, 1), ('bn', 3), ('relu', 4),
+                ('conv', 5, 1), ('bn', 6), ('conv', 7, 1))
+DECODER_SPEC = (('bn', 0), ('relu', 1), ('conv', 2, 0), ('bn', 3), ('conv', 4, 0), ('bn', 5), ('relu', 6),
+                ('conv', 7, 0), ('bn', 8), ('conv', 9, 0), ('bn', 10), ('relu', 11))
+
+
+def head_channels(bch):
+    """(Cin, Cout) of the eight 2x2 convs, resnet_layer.py:43-50,55-62."""
+    enc = {0: (64, 64), 2: (64, 256), 5: (256, 64), 7: (64, bch)}
+    dec = {2: (bch, 64), 4: (64, 128), 7: (128, 256), 9: (256, 256)}
+    enc_bn = {1: 64, 3: 256, 6: 64}
+    dec_bn = {0: bch, 3: 64, 5: 128, 8: 256, 10: 256}
+    return enc, dec, enc_bn, dec_bn
+
+
+# ----------------------------------------------------------------------------- init
+def _kaiming_fan_out(gen, cout, cin, kh, kw, dtype):
+    # custom/resnet.py:55-57: kaiming_normal_(mode='fan_out', nonlinearity='relu')
+    std = math.sqrt(2.0 / (cout * kh * kw))
+    return torch.randn(cout, cin, kh, kw, generator=gen, dtype=torch.float32).mul_(std).to(dtype)
+
+
+def _uniform(gen, shape, bound, dtype):
+    return ((torch.rand(shape, generator=gen, dtype=torch.float32) * 2 - 1) * bound).to(dtype)
+
+
+def _frozen_bn(gen, sd, prefix, c, dtype):
+    # recipe of SURVEY.md C.6: keep activations O(1) through 50 random layers
+    sd[prefix + 'weight'] = (torch.rand(c, generator=gen) * 0.5 + 0.25).to(dtype)
+    sd[prefix + 'bias'] = (torch.randn(c, generator=gen) * 0.1).to(dtype)
+    sd[prefix + 'running_mean'] = (torch.randn(c, generator=gen) * 0.1).to(dtype)
+    sd[prefix + 'running_var'] = (torch.rand(c, generator=gen) * 1.5 + 0.5).to(dtype)
+
+
+def _resnet_layer_init(gen, sd, prefix, inplanes, planes, blocks, stride, dtype):
+    for i in range(blocks):
+        p = '%s%d.' % (prefix, i)
+        cin = inplanes if i == 0 else planes * 4
+        sd[p + 'conv1.weight'] = _kaiming_fan_out(gen, planes, cin, 1, 1, dtype)
+        _frozen_bn(gen, sd, p + 'bn1.', planes, dtype)
+        sd[p + 'conv2.weight'] = _kaiming_fan_out(gen, planes, planes, 3, 3, dtype)
+        _frozen_bn(gen, sd, p + 'bn2.', planes, dtype)
+        sd[p + 'conv3.weight'] = _kaiming_fan_out(gen, planes * 4, planes, 1, 1, dtype)
+        _frozen_bn(gen, sd, p + 'bn3.', planes * 4, dtype)
+        if i == 0 and (stride != 1 or inplanes != planes * 4):
+            sd[p + 'downsample.0.weight'] = _kaiming_fan_out(gen, planes * 4, cin, 1, 1, dtype)
+            _frozen_bn(gen, sd, p + 'downsample.1.', planes * 4, dtype)
+
+
+def _linear(gen, sd, prefix, cin, cout, dtype):
+    b = 1.0 / math.sqrt(cin)
+    sd[prefix + 'weight'] = _uniform(gen, (cout, cin), b, dtype)
+    sd[prefix + 'bias'] = _uniform(gen, (cout,), b, dtype)
+
+
+def _conv_b(gen, sd, prefix, cin, cout, k, dtype, transposed=False):
+    b = 1.0 / math.sqrt(cin * k * k)
+    shape = (cin, cout, k, k) if transposed else (cout, cin, k, k)
+    sd[prefix + 'weight'] = _uniform(gen, shape, b, dtype)
+    sd[prefix + 'bias'] = _uniform(gen, (cout,), b, dtype)
+
+
+def init_teacher_state(seed, model_name='faster_rcnn', num_classes=91, num_keypoints=17, dtype=torch.float32):
+    """Seeded stand-in for the COCO-pretrained detector (weights are not downloadable here)."""
+    gen = torch.Generator().manual_seed(seed)
+    sd = OrderedDict()
+    sd[B + 'conv1.weight'] = _kaiming_fan_out(gen, 64, 3, 7, 7, dtype)
+    _frozen_bn(gen, sd, B + 'bn1.', 64, dtype)
+    inplanes = 64
+    for li, (planes, blocks) in enumerate(zip((64, 128, 256, 512), RESNET50_BLOCKS), 1):
+        _resnet_layer_init(gen, sd, '%slayer%d.' % (B, li), inplanes, planes, blocks, 1 if li == 1 else 2, dtype)
+        inplanes = planes * 4
+    for i, c in enumerate((256, 512, 1024, 2048)):
+        _conv_b(gen, sd, 'backbone.fpn.inner_blocks.%d.' % i, c, 256, 1, dtype)
+    for i in range(4):
+        _conv_b(gen, sd, 'backbone.fpn.layer_blocks.%d.' % i, 256, 256, 3, dtype)
+    _conv_b(gen, sd, 'rpn.head.conv.', 256, 256, 3, dtype)
+    _conv_b(gen, sd, 'rpn.head.cls_logits.', 256, 3, 1, dtype)
+    _conv_b(gen, sd, 'rpn.head.bbox_pred.', 256, 12, 1, dtype)
+    _linear(gen, sd, 'roi_heads.box_head.fc6.', 256 * 7 * 7, 1024, dtype)
+    _linear(gen, sd, 'roi_heads.box_head.fc7.', 1024, 1024, dtype)
+    _linear(gen, sd, 'roi_heads.box_predictor.cls_score.', 1024, num_classes, dtype)
+    _linear(gen, sd, 'roi_heads.box_predictor.bbox_pred.', 1024, num_classes * 4, dtype)
+    if model_name == 'mask_rcnn':
+        for i in range(1, 5):
+            _conv_b(gen, sd, 'roi_heads.mask_head.mask_fcn%d.' % i, 256, 256, 3, dtype)
+        _conv_b(gen, sd, 'roi_heads.mask_predictor.conv5_mask.', 256, 256, 2, dtype, transposed=True)
+        _conv_b(gen, sd, 'roi_heads.mask_predictor.mask_fcn_logits.', 256, num_classes, 1, dtype)
+    elif model_name == 'keypoint_rcnn':
+        cin = 256
+        for i in range(8):
+            _conv_b(gen, sd, 'roi_heads.keypoint_head.%d.' % (2 * i), cin, 512, 3, dtype)
+            cin = 512
+        _conv_b(gen, sd, 'roi_heads.keypoint_predictor.kps_score_lowres.', 512, num_keypoints, 4, dtype,
+                transposed=True)
+    return sd
+
+
+def init_student_state(teacher_sd, seed, bch=3, dtype=torch.float32):
+    """Student = teacher weights everywhere except layer1 (rcnn.py:446-450, strict=False load) plus a
+    freshly initialised bottleneck layer1 (custom/resnet.py:55-60: kaiming fan_out convs, gamma=1, beta=0)."""
+    gen = torch.Generator().manual_seed(seed)
+    sd = OrderedDict()
+    for k, v in teacher_sd.items():
+        if not k.startswith(B + 'layer1.'):
+            sd[k] = v.clone()
+    enc, dec, enc_bn, dec_bn = head_channels(bch)
+    new = OrderedDict()
+    for prefix, convs, bns in ((B + 'layer1.encoder.encoder.', enc, enc_bn), (B + 'layer1.decoder.', dec, dec_bn)):
+        for idx in sorted(list(convs) + list(bns)):
+            if idx in convs:
+                cin, cout = convs[idx]
+                new['%s%d.weight' % (prefix, idx)] = _kaiming_fan_out(gen, cout, cin, 2, 2, dtype)
+            else:
+                c = bns[idx]
+                new['%s%d.weight' % (prefix, idx)] = torch.ones(c, dtype=dtype)
+                new['%s%d.bias' % (prefix, idx)] = torch.zeros(c, dtype=dtype)
+                new['%s%d.running_mean' % (prefix, idx)] = torch.zeros(c, dtype=dtype)
+                new['%s%d.running_var' % (prefix, idx)] = torch.ones(c, dtype=dtype)
+                new['%s%d.num_batches_tracked' % (prefix, idx)] = torch.tensor(0, dtype=torch.long)
+    # keep the reference's state_dict() order: conv1, bn1, layer1, layer2...
+    out = OrderedDict()
+    for k, v in sd.items():
+        out[k] = v
+        if k == B + 'bn1.running_var':
+            out.update(new)
+    return out
+
+
+def trainable_keys(student_sd):
+    """conv1.weight + every *parameter* of layer1: the reference's 25 updatable tensors
+    (mimic_runner.py:32-35 with yaml frozen_modules)."""
+    keys = [B + 'conv1.weight']
+    for k in student_sd:
+        if k.startswith(B + 'layer1.') and (k.endswith('.weight') or k.endswith('.bias')):
+            keys.append(k)
+    return keys
+
+
+def cast_state(sd, dtype):
+    return OrderedDict((k, v.to(dtype) if v.is_floating_point() else v.clone()) for k, v in sd.items())
+
+
+# ----------------------------------------------------------------------------- transform
+def transform_images(images, min_size=(800,), max_size=1333, training=False, fixed_sizes=None,
+                     mean=IMAGE_MEAN, std=IMAGE_STD, rng=None):
+    """rcnn.py:65-82: normalise, bilinear resize (rcnn.py:29-45), zero-pad batch to a multiple of 32."""
+    if not isinstance(min_size, (list, tuple)):
+        min_size = (min_size,)
+    out, sizes = [], []
+    for i, img in enumerate(images):
+        m = torch.as_tensor(mean, dtype=img.dtype)[:, None, None]
+        s = torch.as_tensor(std, dtype=img.dtype)[:, None, None]
+        img = (img - m) / s
+        h, w = img.shape[-2:]
+        lo, hi = float(min(h, w)), float(max(h, w))
+        if fixed_sizes is not None:
+            size = fixed_sizes[i]
+        elif training:
+            size = (rng or __import__('random')).choice(min_size)
+        else:
+            size = min_size[-1]
+        scale = size / lo
+        if hi * scale > max_size:
+            scale = max_size / hi
+        img = F.interpolate(img[None], scale_factor=scale, mode='bilinear', align_corners=False)[0]
+        out.append(img)
+        sizes.append(tuple(img.shape[-2:]))
+    hp = int(math.ceil(max(o.shape[1] for o in out) / 32.0) * 32)
+    wp = int(math.ceil(max(o.shape[2] for o in out) / 32.0) * 32)
+    batch = out[0].new_zeros((len(out), 3, hp, wp))
+    for b, o in zip(batch, out):
+        b[:, :o.shape[1], :o.shape[2]].copy_(o)
+    return batch, sizes
+
+
+# ----------------------------------------------------------------------------- network pieces
+def frozen_bn(x, sd, p):
+    scale = sd[p + 'weight'] * sd[p + 'running_var'].rsqrt()          # no eps (0.4.2)
+    shift = sd[p + 'bias'] - sd[p + 'running_mean'] * scale
+    return x * scale.reshape(1, -1, 1, 1) + shift.reshape(1, -1, 1, 1)
+
+
+def stem(x, sd):
+    x = F.conv2d(x, sd[B + 'conv1.weight'], None, stride=2, padding=3)
+    x = F.relu(frozen_bn(x, sd, B + 'bn1.'))
+    return F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
+
+
+def bottleneck_block(x, sd, p, stride):
+    y = F.relu(frozen_bn(F.conv2d(x, sd[p + 'conv1.weight']), sd, p + 'bn1.'))
+    y = F.relu(frozen_bn(F.conv2d(y, sd[p + 'conv2.weight'], None, stride=stride, padding=1), sd, p + 'bn2.'))
+    y = frozen_bn(F.conv2d(y, sd[p + 'conv3.weight']), sd, p + 'bn3.')
+    if (p + 'downsample.0.weight') in sd:
+        x = frozen_bn(F.conv2d(x, sd[p + 'downsample.0.weight'], None, stride=stride), sd, p + 'downsample.1.')
+    return F.relu(y + x)
+
+
+def resnet_layer(x, sd, li):
+    for i in range(RESNET50_BLOCKS[li - 1]):
+        x = bottleneck_block(x, sd, '%slayer%d.%d.' % (B, li, i), 2 if (i == 0 and li > 1) else 1)
+    return x
+
+
+def _train_bn(x, sd, p, training, update_buffers):
+    rm, rv = sd[p + 'running_mean'], sd[p + 'running_var']
+    if training and not update_buffers:
+        rm, rv = rm.clone(), rv.clone()
+    y = F.batch_norm(x, rm, rv, sd[p + 'weight'], sd[p + 'bias'], training, BN_MOMENTUM, BN_EPS)
+    if training and update_buffers:
+        sd[p + 'num_batches_tracked'] += 1
+    return y
+
+
+def student_layer1(x, sd, training=True, update_buffers=True, intermediates=None):
+    """Bottleneck4LargeResNet.forward == decoder(encoder(x)) (base.py:50-58 with
+    use_bottleneck_transformer False, as mimic_runner.py:90 forces during distillation)."""
+    for prefix, spec in ((B + 'layer1.encoder.encoder.', ENCODER_SPEC), (B + 'layer1.decoder.', DECODER_SPEC)):
+        for op in spec:
+            name = '%s%d' % (prefix, op[1])
+            if op[0] == 'conv':
+                x = F.conv2d(x, sd[name + '.weight'], None, stride=1, padding=op[2])
+            elif op[0] == 'bn':
+                x = _train_bn(x, sd, name + '.', training, update_buffers)
+            else:
+                x = F.relu(x)
+            if intermediates is not None:
+                intermediates[name] = x
+    return x
+
+
+def fpn(feats, sd):
+    p = 'backbone.fpn.'
+    last = F.conv2d(feats[3], sd[p + 'inner_blocks.3.weight'], sd[p + 'inner_blocks.3.bias'])
+    outs = [F.conv2d(last, sd[p + 'layer_blocks.3.weight'], sd[p + 'layer_blocks.3.bias'], padding=1)]
+    for i in (2, 1, 0):
+        lat = F.conv2d(feats[i], sd[p + 'inner_blocks.%d.weight' % i], sd[p + 'inner_blocks.%d.bias' % i])
+        last = lat + F.interpolate(last, size=lat.shape[-2:], mode='nearest')
+        outs.insert(0, F.conv2d(last, sd[p + 'layer_blocks.%d.weight' % i], sd[p + 'layer_blocks.%d.bias' % i],
+                                padding=1))
+    outs.append(F.max_pool2d(outs[-1], 1, 2, 0))
+    return OrderedDict(zip((0, 1, 2, 3, 'pool'), outs))
+
+
+def backbone_forward(x, sd, student, training=True, update_buffers=True, with_fpn=True, intermediates=None):
+    """body (IntermediateLayerGetter) + fpn; returns (hooked layer outputs, fpn features)."""
+    hooked = OrderedDict()
+    x = stem(x, sd)
+    if intermediates is not None:
+        intermediates['stem'] = x
+    if student:
+        x = student_layer1(x, sd, training, update_buffers, intermediates)
+    else:
+        x = resnet_layer(x, sd, 1)
+    hooked['layer1'] = x
+    for li in (2, 3, 4):
+        x = resnet_layer(x, sd, li)
+        hooked['layer%d' % li] = x
+    feats = fpn([hooked['layer%d' % i] for i in (1, 2, 3, 4)], sd) if with_fpn else None
+    return hooked, feats
+
+
+def mimic_loss(t_hooked, s_hooked, terms):
+    """loss.py:27-33: sum_k factor_k * MSELoss(reduction='sum')(teacher_k, student_k)."""
+    per_term = OrderedDict()
+    for name, factor in terms.items():
+        per_term[name] = F.mse_loss(t_hooked[name], s_hooked[name], reduction='sum') * factor
+    return sum(per_term.values()), per_term
+
+
+# decoder.3.bias / decoder.8.bias feed an unpadded bias-free conv followed by a train-mode BN, so their true
+# gradient is exactly zero; in fp32 it is rounding noise that Adam turns into +-lr steps.
+# Parity checks on gradients / parameter trajectories must skip them.
+ZERO_GRAD_KEYS = (B + 'layer1.decoder.3.bias', B + 'layer1.decoder.8.bias')
+
+GHND_TERMS = OrderedDict((('layer1', 1.0), ('layer2', 1.0), ('layer3', 1.0), ('layer4', 1.0)))
+HND_TERMS = OrderedDict((('layer1', 1.0),))
+
+
+# ----------------------------------------------------------------------------- the step
+class DistillOracle(object):
+    """Mirrors mimic_runner.distill_model (:38-59) for a fixed teacher/student pair on CPU."""
+
+    def __init__(self, teacher_sd, student_sd, terms=GHND_TERMS, lr=1e-3, min_size=(800,), max_size=1333,
+                 warmup_iters=0, warmup_factor=1e-3, with_fpn=True, dtype=torch.float32):
+        self.dtype = dtype
+        self.t = cast_state(teacher_sd, dtype)
+        self.s = cast_state(student_sd, dtype)
+        self.terms, self.min_size, self.max_size, self.with_fpn = terms, min_size, max_size, with_fpn
+        self.keys = trainable_keys(self.s)
+        for k in self.keys:
+            self.s[k] = self.s[k].clone().requires_grad_(True)
+        # func_util.get_optimizer('Adam', {'lr': 1e-3}) over student.parameters(); frozen ones have no grad
+        self.opt = torch.optim.Adam([self.s[k] for k in self.keys], lr=lr)
+        self.sched = None
+        if warmup_iters > 0:        # main_util.py:65-72, used for epoch 0 (mimic_runner.py:43-46)
+            def f(x):
+                if x >= warmup_iters:
+                    return 1
+                a = float(x) / warmup_iters
+                return warmup_factor * (1 - a) + a
+            self.sched = torch.optim.lr_scheduler.LambdaLR(self.opt, f)
+
+    def forward(self, images, fixed_sizes=None, update_buffers=True, intermediates=None):
+        images = [im.to(self.dtype) for im in images]
+        x, _ = transform_images(images, self.min_size, self.max_size, training=False, fixed_sizes=fixed_sizes)
+        with torch.no_grad():
+            t_hooked, t_feats = backbone_forward(x, self.t, student=False, with_fpn=self.with_fpn)
+        # student transform in train mode draws random.choice(min_size) (rcnn.py:36-37): identical to
+        # eval for single-size configs; Keypoint passes fixed_sizes (tool.py:45-48)
+        s_hooked, s_feats = backbone_forward(x, self.s, student=True, training=True,
+                                             update_buffers=update_buffers, with_fpn=self.with_fpn,
+                                             intermediates=intermediates)
+        loss, per_term = mimic_loss(t_hooked, s_hooked, self.terms)
+        return loss, per_term, t_hooked, s_hooked, t_feats, s_feats, x
+
+    def step(self, images, fixed_sizes=None):
+        loss, per_term, *_ = self.forward(images, fixed_sizes)
+        self.opt.zero_grad()
+        loss.backward()
+        grads = OrderedDict((k, self.s[k].grad.detach().clone()) for k in self.keys)
+        self.opt.step()
+        lr = self.opt.param_groups[0]['lr']
+        if self.sched is not None:
+            self.sched.step()
+        return float(loss.detach()), OrderedDict((k, float(v.detach())) for k, v in per_term.items()), grads, lr
+
+
+def synthetic_batch(batch, h=800, w=1333, seed=1234, rank=0, model_name='faster_rcnn'):
+    """SURVEY.md section 8(d) synthetic inputs: uniform [0,1) images, one box per image."""
+    g = torch.Generator().manual_seed(seed + rank)
+    images = [torch.rand(3, h, w, generator=g) for _ in range(batch)]
+    targets = []
+    for _ in range(batch):
+        t = {'boxes': torch.tensor([[0.125 * w, 0.125 * h, 0.5 * w, 0.5 * h]], dtype=torch.float32),
+             'labels': torch.tensor([1], dtype=torch.int64)}
+        if model_name == 'mask_rcnn':
+            t['masks'] = torch.zeros(1, h, w, dtype=torch.uint8)
+        if model_name == 'keypoint_rcnn':
+            t['keypoints'] = torch.zeros(1, 17, 3, dtype=torch.float32)
+        targets.append(t)
+    return images, targets
+
+
+def checksum(t, nsamples=64):
+    """Size-independent fingerprint of a tensor: (sum, sum of squares, strided samples) in fp64."""
+    f = t.detach().double().flatten()
+    n = min(nsamples, f.numel())
+    idx = (torch.arange(n, dtype=torch.int64) * (f.numel() - 1)) // max(n - 1, 1)
+    return float(f.sum()), float((f * f).sum()), f[idx].clone()

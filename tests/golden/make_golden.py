@@ -1,0 +1,224 @@
+#!/usr/bin/env python
+"""Generate the golden fixtures in tests/golden/*.npz FROM THE REFERENCE ITSELF.
+
+Runs only in the build container (needs /root/reference).  The reference's own modules
+(src/mimic_runner.py, src/distillation/*, src/models/*) are imported UNMODIFIED over
+oracle/shim (torchvision 0.4.2 / myutils restatements), built from the reference's real
+YAML configs with a ``--json``-style override (pretrained off, small transform sizes for
+the tiny cases), loaded with the seeded state dicts of oracle.hnd_oracle and driven through
+DistillationBox -> backward -> Adam exactly as mimic_runner.distill_model does.
+
+Every tensor written here is an OUTPUT OF THE REFERENCE CODE.  While generating, the
+functional oracle is run on the same inputs and must agree (bit-exact is expected, the
+achieved max abs difference is stored in each fixture as ``oracle_vs_reference_maxabs``).
+
+usage:  python tests/golden/make_golden.py [--only NAME]
+"""
+import argparse
+import json
+import os
+import random
+import sys
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from oracle import shim_install  # noqa: E402
+
+shim_install.install()
+from oracle import hnd_oracle as O  # noqa: E402
+
+import mimic_runner  # noqa: E402  (reference)
+from distillation.tool import DistillationBox  # noqa: E402  (reference)
+from models import get_model  # noqa: E402  (reference)
+from myutils.common import yaml_util  # noqa: E402  (shim)
+from myutils.pytorch import func_util, module_util  # noqa: E402  (shim)
+from utils import main_util  # noqa: E402  (reference)
+
+REF_CONFIG = '/root/reference/config'
+
+CASES = OrderedDict((
+    ('tiny_ghnd_faster', dict(yaml='ghnd/faster_rcnn-backbone_resnet50-b3ch.yaml', model='faster_rcnn',
+                              sizes=[(60, 90), (56, 100)], min_size=64, max_size=128, steps=2, seed=11)),
+    ('tiny_hnd_faster', dict(yaml='hnd/faster_rcnn-backbone_resnet50-b3ch.yaml', model='faster_rcnn',
+                             sizes=[(64, 96), (64, 96)], min_size=64, max_size=128, steps=2, seed=12)),
+    ('tiny_ghnd_mask', dict(yaml='ghnd/mask_rcnn-backbone_resnet50-b3ch.yaml', model='mask_rcnn',
+                            sizes=[(48, 80), (64, 64)], min_size=64, max_size=128, steps=1, seed=13)),
+    ('tiny_ghnd_keypoint', dict(yaml='ghnd/keypoint_rcnn-backbone_resnet50-b3ch.yaml', model='keypoint_rcnn',
+                                sizes=[(64, 96), (60, 84)], min_size=[48, 56, 64], max_size=128, steps=2, seed=14,
+                                num_classes=2)),
+    ('tiny_ghnd_faster_b6', dict(yaml='ghnd/faster_rcnn-backbone_resnet50-b6ch.yaml', model='faster_rcnn',
+                                 sizes=[(64, 96)], min_size=64, max_size=128, steps=1, seed=15, bch=6)),
+    ('full_ghnd_faster', dict(yaml='ghnd/faster_rcnn-backbone_resnet50-b3ch.yaml', model='faster_rcnn',
+                              sizes=[(800, 1333)], min_size=800, max_size=1333, steps=1, seed=16, full=True)),
+))
+
+
+def build_reference_models(case):
+    config = yaml_util.load_yaml_file(os.path.join(REF_CONFIG, case['yaml']))
+    override = {'teacher_model': {'backbone': {'params': {'pretrained': False}},
+                                  'params': {'pretrained': False, 'min_size': case['min_size'],
+                                             'max_size': case['max_size']}},
+                'student_model': {'backbone': {'params': {'pretrained': False}},
+                                  'params': {'pretrained': False, 'min_size': case['min_size'],
+                                             'max_size': case['max_size']}}}
+    main_util.overwrite_config(config, json.dumps(override))       # same path as the CLI's --json
+    device = torch.device('cpu')
+    teacher = get_model(config['teacher_model'], device)
+    module_util.freeze_module_params(teacher)                      # mimic_runner.py:132
+    student = get_model(config['student_model'], device)
+    mimic_runner.freeze_modules(student, config['student_model'])  # mimic_runner.py:134
+    return config, teacher, student
+
+
+def make_inputs(case):
+    g = torch.Generator().manual_seed(1234 + case['seed'])
+    images, targets = [], []
+    for h, w in case['sizes']:
+        images.append(torch.rand(3, h, w, generator=g))
+        t = {'boxes': torch.tensor([[0.125 * w, 0.125 * h, 0.5 * w, 0.5 * h]]), 'labels': torch.tensor([1])}
+        if case['model'] == 'mask_rcnn':
+            m = torch.zeros(1, h, w, dtype=torch.uint8)
+            m[:, h // 8:h // 2, w // 8:w // 2] = 1
+            t['masks'] = m
+        if case['model'] == 'keypoint_rcnn':
+            kp = torch.rand(1, 17, 3, generator=g)
+            kp[..., 0] *= w
+            kp[..., 1] *= h
+            kp[..., 2] = 1
+            t['keypoints'] = kp
+        targets.append(t)
+    return images, targets
+
+
+def hooked(model, path):
+    return module_util.get_module(model, path).__dict__['distillation_box']['output']
+
+
+def put(dst, name, t, full_limit=70000):
+    """store small tensors whole, big ones as checksum (sum, sumsq, 64 strided samples)."""
+    t = t.detach()
+    if t.numel() <= full_limit:
+        dst[name] = t.cpu().numpy()
+    else:
+        s, ss, samples = O.checksum(t)
+        dst[name + '@sum'] = np.float64(s)
+        dst[name + '@sumsq'] = np.float64(ss)
+        dst[name + '@samples'] = samples.numpy()
+        dst[name + '@shape'] = np.array(t.shape, dtype=np.int64)
+
+
+def run_case(name, case):
+    print('== %s' % name)
+    bch = case.get('bch', 3)
+    t_sd = O.init_teacher_state(case['seed'], case['model'], num_classes=case.get('num_classes', 91))
+    s_sd = O.init_student_state(t_sd, case['seed'] + 1000, bch=bch)
+    config, teacher, student = build_reference_models(case)
+    teacher.load_state_dict(t_sd, strict=True)      # also proves the oracle's key layout == reference's
+    student.load_state_dict(s_sd, strict=True)
+    updatable = module_util.get_updatable_param_names(student)
+    assert updatable == O.trainable_keys(s_sd), (updatable, O.trainable_keys(s_sd))
+
+    crit = config['train']['criterion']
+    terms = OrderedDict((k, v['factor']) for k, v in crit['terms'].items())
+    box = DistillationBox(teacher, student, crit)
+    opt_cfg = config['train']['optimizer']
+    optimizer = func_util.get_optimizer(student, opt_cfg['type'], opt_cfg['params'])
+    warm = main_util.warmup_lr_scheduler(optimizer, 4, 1.0 / 1000.0)   # mimic_runner.py:43-46 (iters shortened)
+    teacher.eval()
+    student.train()                                                    # mimic_runner.py:86-90
+    teacher.distill_backbone_only = True
+    student.distill_backbone_only = True
+    student.backbone.body.layer1.use_bottleneck_transformer = False
+
+    min_size = case['min_size'] if isinstance(case['min_size'], list) else [case['min_size']]
+    oracle = O.DistillOracle(t_sd, s_sd, terms=terms, lr=opt_cfg['params']['lr'], min_size=tuple(min_size),
+                             max_size=case['max_size'], warmup_iters=4, warmup_factor=1e-3)
+    images, targets = make_inputs(case)
+    out = OrderedDict()
+    out['meta'] = np.array(json.dumps({k: v for k, v in case.items()}))
+    worst = 0.0
+    worst_grad = 0.0
+    is_kp = case['model'] == 'keypoint_rcnn'
+    for step in range(case['steps']):
+        fixed_sizes = None
+        if is_kp:                       # tool.py:45-48 draws from python's random
+            random.seed(100 + step)
+            st = random.getstate()
+            fixed_sizes = [random.choice(teacher.transform.min_size) for _ in images]
+            random.setstate(st)
+            out['step%d/fixed_sizes' % step] = np.array(fixed_sizes)
+        ims = [im.clone() for im in images]
+        tgs = [{k: v.clone() for k, v in t.items()} for t in targets]
+        loss = box(ims, tgs)
+        optimizer.zero_grad()
+        loss.backward()
+        grads = OrderedDict((n, p.grad.detach().clone()) for n, p in student.named_parameters() if p.requires_grad)
+        lr_used = optimizer.param_groups[0]['lr']
+        optimizer.step()
+        warm.step()
+
+        o_loss, o_terms, _, _, _, _, o_x = oracle.forward(images, fixed_sizes, update_buffers=False)
+        o_l, o_t, o_grads, o_lr = oracle.step(images, fixed_sizes)
+        pre = 'step%d/' % step
+        out[pre + 'loss'] = np.float64(loss.item())
+        out[pre + 'lr'] = np.float64(lr_used)
+        worst = max(worst, abs(o_l - loss.item()) / max(1.0, abs(loss.item())))
+        assert abs(o_lr - lr_used) < 1e-12
+        for k, f in terms.items():
+            path = crit['terms'][k]['ts_modules']
+            t_out, s_out = hooked(teacher, path[0]), hooked(student, path[1])
+            out[pre + 'term/' + k] = np.float64((torch.nn.functional.mse_loss(t_out, s_out, reduction='sum') * f).item())
+            if step == 0:
+                put(out, pre + 'teacher/' + k, t_out)
+                put(out, pre + 'student/' + k, s_out)
+        for n, g in grads.items():
+            put(out, pre + 'grad/' + n, g, full_limit=20000)
+            if n not in O.ZERO_GRAD_KEYS:       # autograd accumulation order differs -> noise-level only
+                worst_grad = max(worst_grad, float((g - o_grads[n]).norm() / g.norm()))
+        if step == 0:
+            out['batched_shape'] = np.array(o_x.shape)
+            # transform output of the reference: re-run it (pure function for fixed sizes / eval mode)
+            teacher_x = teacher.transform([im.clone() for im in images], None, fixed_sizes)[0].tensors
+            put(out, 'transform', teacher_x)
+            worst = max(worst, float((teacher_x - o_x).abs().max()))
+            feats = student.backbone.fpn(OrderedDict((i, hooked(student, 'backbone.body.layer%d' % (i + 1)))
+                                                     for i in range(4))) if len(terms) == 4 else None
+            if feats is not None:
+                for k, v in feats.items():
+                    put(out, 'student_fpn/%s' % k, v, full_limit=30000)
+    sd_after = student.state_dict()
+    for n in O.trainable_keys(s_sd):
+        put(out, 'after/param/' + n, sd_after[n], full_limit=20000)
+        if n not in O.ZERO_GRAD_KEYS:
+            worst = max(worst, float((sd_after[n] - oracle.s[n].detach()).abs().max()))
+    for n, v in sd_after.items():
+        if 'layer1' in n and ('running_' in n or 'num_batches' in n):
+            out['after/buffer/' + n] = v.numpy()
+            worst = max(worst, float((v.double() - oracle.s[n].double()).abs().max()))
+    out['oracle_vs_reference_maxabs'] = np.float64(worst)
+    out['oracle_vs_reference_grad_rel_l2'] = np.float64(worst_grad)
+    print('   loss(step0)=%.6f  oracle-vs-reference worst abs=%.3e  grad relL2=%.3e'
+          % (float(out['step0/loss']), worst, worst_grad))
+    assert worst < 1e-5 and worst_grad < (2e-4 if case.get('full') else 1e-5), 'oracle restatement diverges from the reference'
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **out)
+    print('   wrote %s (%.1f KB)' % (path, os.path.getsize(path) / 1024.0))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--only')
+    args = ap.parse_args()
+    torch.set_num_threads(8)
+    for name, case in CASES.items():
+        if args.only and args.only != name:
+            continue
+        run_case(name, case)
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,63 @@
+"""Helpers to read tests/golden/*.npz (written by tests/golden/make_golden.py)."""
+import json
+import os
+
+import numpy as np
+import torch
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+ZERO_GRAD_SUFFIXES = ('layer1.decoder.3.bias', 'layer1.decoder.8.bias')
+
+
+def load(name):
+    z = np.load(os.path.join(GOLDEN_DIR, name + '.npz'), allow_pickle=False)
+    meta = json.loads(str(z['meta']))
+    return z, meta
+
+
+def case_inputs(meta):
+    """Re-create the seeded inputs of make_golden.make_inputs (kept in sync by test_oracle_golden)."""
+    g = torch.Generator().manual_seed(1234 + meta['seed'])
+    images, targets = [], []
+    for h, w in meta['sizes']:
+        images.append(torch.rand(3, h, w, generator=g))
+        t = {'boxes': torch.tensor([[0.125 * w, 0.125 * h, 0.5 * w, 0.5 * h]]), 'labels': torch.tensor([1])}
+        if meta['model'] == 'mask_rcnn':
+            m = torch.zeros(1, h, w, dtype=torch.uint8)
+            m[:, h // 8:h // 2, w // 8:w // 2] = 1
+            t['masks'] = m
+        if meta['model'] == 'keypoint_rcnn':
+            kp = torch.rand(1, 17, 3, generator=g)
+            kp[..., 0] *= w
+            kp[..., 1] *= h
+            kp[..., 2] = 1
+            t['keypoints'] = kp
+        targets.append(t)
+    return images, targets
+
+
+def checksum(t, nsamples=64):
+    f = t.detach().double().flatten().cpu()
+    n = min(nsamples, f.numel())
+    idx = (torch.arange(n, dtype=torch.int64) * (f.numel() - 1)) // max(n - 1, 1)
+    return float(f.sum()), float((f * f).sum()), f[idx].clone()
+
+
+def compare(z, name, t, rtol, what='', atol=0.0):
+    """Compare tensor ``t`` with fixture entry ``name`` (full tensor or checksum form).
+    Returns the achieved relative error (L2 for full tensors; max over checksum parts otherwise)."""
+    t = t.detach().cpu()
+    if name in z.files:
+        ref = torch.from_numpy(z[name]).double()
+        err = float((t.double() - ref).norm() / (ref.norm() + atol * ref.numel() ** 0.5 + 1e-30))
+    else:
+        s, ss, samples = checksum(t)
+        assert tuple(z[name + '@shape']) == tuple(t.shape), (name, tuple(z[name + '@shape']), tuple(t.shape))
+        ref_samples = torch.from_numpy(z[name + '@samples'])
+        scale = float(np.sqrt(float(z[name + '@sumsq']) / t.numel())) + 1e-30   # rms of the tensor
+        e_samples = float((samples - ref_samples).abs().max()) / scale
+        e_ss = abs(ss - float(z[name + '@sumsq'])) / (abs(float(z[name + '@sumsq'])) + 1e-30)
+        e_s = abs(s - float(z[name + '@sum'])) / (scale * t.numel() ** 0.5 * 8 + abs(float(z[name + '@sum'])))
+        err = max(e_samples, e_ss, e_s)
+    assert err <= rtol, '%s %s: rel err %.3e > %.1e' % (what, name, err, rtol)
+    return err

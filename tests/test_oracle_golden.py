@@ -1,0 +1,82 @@
+"""CPU: the functional oracle reproduces the reference-generated golden fixtures."""
+from collections import OrderedDict
+
+import pytest
+import torch
+
+from oracle import hnd_oracle as O
+from tests import golden_util as G
+
+TINY = ['tiny_ghnd_faster', 'tiny_hnd_faster', 'tiny_ghnd_mask', 'tiny_ghnd_keypoint', 'tiny_ghnd_faster_b6']
+
+
+def _oracle_for(meta, z):
+    t_sd = O.init_teacher_state(meta['seed'], meta['model'], num_classes=meta.get('num_classes', 91))
+    s_sd = O.init_student_state(t_sd, meta['seed'] + 1000, bch=meta.get('bch', 3))
+    terms = O.HND_TERMS if meta['yaml'].startswith('hnd/') else O.GHND_TERMS
+    ms = meta['min_size'] if isinstance(meta['min_size'], list) else [meta['min_size']]
+    return O.DistillOracle(t_sd, s_sd, terms=terms, min_size=tuple(ms), max_size=meta['max_size'],
+                           warmup_iters=4, warmup_factor=1e-3), terms
+
+
+@pytest.mark.parametrize('name', TINY)
+def test_oracle_matches_reference_fixture(name):
+    z, meta = G.load(name)
+    assert float(z['oracle_vs_reference_maxabs']) < 1e-5
+    orc, terms = _oracle_for(meta, z)
+    images, _ = G.case_inputs(meta)
+    for step in range(meta['steps']):
+        fs = [int(v) for v in z['step%d/fixed_sizes' % step]] if meta['model'] == 'keypoint_rcnn' else None
+        if step == 0:
+            _, _, t_h, s_h, _, s_f, x = orc.forward(images, fs, update_buffers=False)
+            G.compare(z, 'transform', x, 1e-6)
+            for k in terms:
+                G.compare(z, 'step0/teacher/' + k, t_h[k], 1e-6)
+                G.compare(z, 'step0/student/' + k, s_h[k], 1e-6)
+            if len(terms) == 4:
+                for k, v in s_f.items():
+                    G.compare(z, 'student_fpn/%s' % k, v, 1e-6)
+        loss, per_term, grads, lr = orc.step(images, fs)
+        assert abs(loss - float(z['step%d/loss' % step])) <= 1e-6 * abs(loss)
+        assert abs(lr - float(z['step%d/lr' % step])) < 1e-12
+        for k in terms:
+            assert abs(per_term[k] - float(z['step%d/term/%s' % (step, k)])) <= 1e-6 * abs(per_term[k])
+        for n, g in grads.items():
+            if n.endswith(G.ZERO_GRAD_SUFFIXES):
+                continue
+            G.compare(z, 'step%d/grad/%s' % (step, n), g, 2e-5)
+    for n in orc.keys:
+        if not n.endswith(G.ZERO_GRAD_SUFFIXES):
+            G.compare(z, 'after/param/' + n, orc.s[n], 1e-4, atol=1e-6)  # Adam amplifies grad rounding noise
+    for n in z.files:
+        if n.startswith('after/buffer/'):
+            key = n[len('after/buffer/'):]
+            ref = torch.from_numpy(z[n]).double()
+            assert float((orc.s[key].double() - ref).abs().max()) <= 1e-5 * (1 + float(ref.abs().max()))
+
+
+def test_state_layout():
+    t_sd = O.init_teacher_state(0)
+    s_sd = O.init_student_state(t_sd, 1)
+    keys = O.trainable_keys(s_sd)
+    assert len(keys) == 25
+    assert sum(s_sd[k].numel() for k in keys) == 586566
+    assert len(s_sd) == 293
+    assert sum(v.numel() for v in s_sd.values()) == 42222250
+
+
+def test_fp64_gradient_noise_floor():
+    z, meta = G.load('tiny_ghnd_faster')
+    orc32, _ = _oracle_for(meta, z)
+    t_sd = O.init_teacher_state(meta['seed'])
+    s_sd = O.init_student_state(t_sd, meta['seed'] + 1000)
+    orc64 = O.DistillOracle(t_sd, s_sd, min_size=(64,), max_size=128, dtype=torch.float64)
+    images, _ = G.case_inputs(meta)
+    _, _, g32, _ = orc32.step(images)
+    _, _, g64, _ = orc64.step(images)
+    for n in g32:
+        if n.endswith(G.ZERO_GRAD_SUFFIXES):
+            assert float(g64[n].abs().max()) < 1e-6      # mathematically zero gradient
+            continue
+        rel = float((g32[n].double() - g64[n]).norm() / g64[n].norm())
+        assert rel < 1e-4, (n, rel)
