@@ -1,0 +1,105 @@
+"""ctypes binding of libhnd_hip.so (C ABI declared in include/hnd_hip.h).
+
+The library is the ONLY compute path of this package: if it is missing the import of any
+compute module fails loudly (no CPU / eager fallback exists on purpose).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libhnd_hip.so')
+ABI_VERSION = 1
+
+c_float_p = C.POINTER(C.c_float)
+vp = C.c_void_p
+
+
+class ConvDesc(C.Structure):
+    """struct hnd_conv_desc"""
+    _fields_ = [(n, vp) for n in ('x', 'w', 'y', 'pro_scale', 'pro_shift', 'epi_scale', 'epi_shift',
+                                  'res1', 'res2', 'mask', 'stats')] + \
+               [(n, C.c_int32) for n in ('n', 'h', 'w_', 'cin', 'oh', 'ow', 'yh', 'yw', 'cout', 'ldc',
+                                         'y_sh', 'y_oh', 'y_sw', 'y_ow', 'kh', 'kw',
+                                         'sh', 'dh', 'bh', 'sw', 'dw', 'bw', 'kdim', 'pro_relu', 'relu',
+                                         'res1_mode', 'res1_h', 'res1_w')]
+
+
+class WgradDesc(C.Structure):
+    """struct hnd_wgrad_desc"""
+    _fields_ = [(n, vp) for n in ('x', 'dy', 'dw', 'slabs', 'pro_scale', 'pro_shift')] + \
+               [(n, C.c_int32) for n in ('n', 'h', 'w_', 'cin', 'cin_real', 'oh', 'ow', 'cout', 'ldy',
+                                         'kh', 'kw', 'stride', 'pad', 'pro_relu', 'splitk')]
+
+
+class MsePair(C.Structure):
+    """struct hnd_mse_pair"""
+    _fields_ = [('teacher', vp), ('student', vp), ('grad', vp), ('numel', C.c_int64),
+                ('factor', C.c_float), ('relu_mask', C.c_int32)]
+
+
+_SIGNATURES = {
+    'hnd_last_error_string': (C.c_char_p, []),
+    'hnd_abi_version': (C.c_int, []),
+    'hnd_sync_check': (C.c_int, [vp]),
+    'hnd_device_arch': (C.c_char_p, []),
+    'hnd_conv2d_igemm': (C.c_int, [C.POINTER(ConvDesc), vp]),
+    'hnd_conv2d_wgrad_workspace': (C.c_size_t, [C.POINTER(WgradDesc)]),
+    'hnd_conv2d_wgrad': (C.c_int, [C.POINTER(WgradDesc), vp]),
+    'hnd_pack_weights': (C.c_int, [vp, vp] + [C.c_int] * 12 + [vp]),
+    'hnd_fbn_fold': (C.c_int, [vp] * 6 + [C.c_int, C.c_int, C.c_float, vp]),
+    'hnd_transform_image': (C.c_int, [vp, C.c_int, C.c_int, vp] + [C.c_int] * 5 + [C.c_float, C.c_float,
+                                                                                    c_float_p, c_float_p, vp]),
+    'hnd_maxpool3x3s2_fwd': (C.c_int, [vp, vp, vp] + [C.c_int] * 6 + [vp]),
+    'hnd_maxpool3x3s2_bwd_relu_scale': (C.c_int, [vp] * 5 + [C.c_int] * 6 + [vp]),
+    'hnd_bn_finalize': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int64, vp, vp, vp, vp, vp,
+                                  C.c_float, C.c_float, vp, vp, vp, vp, vp]),
+    'hnd_affine_relu': (C.c_int, [vp, vp, vp, vp, C.c_int64, C.c_int, C.c_int, vp]),
+    'hnd_bn_bwd_ntiles': (C.c_int, [C.c_int64]),
+    'hnd_bn_bwd_reduce': (C.c_int, [vp] * 6 + [C.c_int, C.c_int64, C.c_int, vp, vp]),
+    'hnd_bn_bwd_finalize': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int64, vp, vp, vp, vp, vp, vp, vp]),
+    'hnd_bn_bwd_apply': (C.c_int, [vp] * 5 + [C.c_int, vp, C.c_int64, C.c_int, vp]),
+    'hnd_mse_scratch_elems': (C.c_size_t, []),
+    'hnd_mse_sum_fwd_bwd': (C.c_int, [C.POINTER(MsePair), C.c_int, vp, vp, vp]),
+    'hnd_scale_by_device_scalar': (C.c_int, [vp, C.c_int64, vp, vp]),
+    'hnd_adam_step_flat': (C.c_int, [vp, vp, vp, vp, C.c_int64] + [C.c_float] * 4 + [C.c_int64, C.c_float, vp]),
+    'hnd_subsample2': (C.c_int, [vp, vp] + [C.c_int] * 6 + [vp]),
+    'hnd_fill': (C.c_int, [vp, C.c_int64, C.c_float, vp]),
+}
+
+EXPORTED_SYMBOLS = tuple(sorted(_SIGNATURES))
+
+_lib = None
+
+
+class HndLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen libhnd_hip.so and declare every entry point; raises if it is missing or stale."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HndLibraryError(
+            'libhnd_hip.so not found at %s: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+            '(or make -C hnd_ghnd_object_detectors_amd/csrc). There is no CPU fallback.' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise HndLibraryError('libhnd_hip.so does not export %s (stale build?)' % name)
+        fn.restype = res
+        fn.argtypes = args
+    if lib.hnd_abi_version() != ABI_VERSION:
+        raise HndLibraryError('libhnd_hip.so ABI %d != expected %d' % (lib.hnd_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = load().hnd_last_error_string()
+        raise RuntimeError('%s failed (status %d): %s' % (what or 'libhnd_hip call', rc,
+                                                          msg.decode() if msg else '?'))

@@ -1,0 +1,53 @@
+// Error reporting and misc entry points of libhnd_hip.so.
+#include "common.h"
+
+#include <string.h>
+
+namespace hnd {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) return HND_OK;
+  set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+  return HND_ERR_LAUNCH;
+}
+
+}  // namespace hnd
+
+extern "C" {
+
+const char* hnd_last_error_string(void) { return hnd::g_err; }
+
+int hnd_abi_version(void) { return HND_ABI_VERSION; }
+
+int hnd_sync_check(void* stream) {
+  hipError_t e = hipStreamSynchronize(hnd::as_stream(stream));
+  if (e == hipSuccess) e = hipGetLastError();
+  if (e == hipSuccess) return HND_OK;
+  hnd::set_error("hnd_sync_check: %s", hipGetErrorString(e));
+  return HND_ERR_ASYNC;
+}
+
+const char* hnd_device_arch(void) {
+  static thread_local char arch[256] = "";
+  int dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+    arch[0] = 0;
+    (void)hipGetLastError();
+    return arch;
+  }
+  strncpy(arch, prop.gcnArchName, sizeof(arch) - 1);
+  return arch;
+}
+
+}  // extern "C"

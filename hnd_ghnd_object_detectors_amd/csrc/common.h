@@ -1,0 +1,48 @@
+// Shared helpers for libhnd_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "hnd_hip.h"
+
+namespace hnd {
+
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);   // hipGetLastError -> status
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// floor(x / d) for 0 <= x < 2^31 with a precomputed multiplier (d >= 1)
+struct FastDiv {
+  unsigned mul, shr, d;
+};
+inline FastDiv make_fastdiv(unsigned d) {
+  FastDiv f;
+  f.d = d;
+  if (d == 1) { f.mul = 0; f.shr = 0; return f; }
+  unsigned l = 0;
+  while ((1u << l) < d) ++l;                       // l = ceil(log2 d)
+  unsigned long long m = ((1ull << 32) * ((1ull << l) - d)) / d + 1;
+  f.mul = (unsigned)m;
+  f.shr = l;
+  return f;
+}
+__device__ __forceinline__ unsigned fdiv(unsigned x, const FastDiv f) {
+  if (f.d == 1) return x;
+  unsigned t = __umulhi(x, f.mul);
+  return (t + ((x - t) >> 1)) >> (f.shr - 1);
+}
+
+inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }
+
+#define HND_REQUIRE(cond, ...)                \
+  do {                                        \
+    if (!(cond)) {                            \
+      hnd::set_error(__VA_ARGS__);            \
+      return HND_ERR_INVALID;                 \
+    }                                         \
+  } while (0)
+
+}  // namespace hnd

@@ -1,0 +1,287 @@
+// Implicit-GEMM convolution on fp32 MFMA for gfx950 (MI355X): forward convs and data-gradients.
+//
+//   C[m][co] = sum_k A[m][k] * W[co][k],   m = output pixel, k = (tap, ci)
+//
+// Block tile 128 (pixels) x BN (channels, 128 or 64) x 32 (k); 256 threads = 4 waves in a 2x2
+// grid, each wave owns 64 x BN/2 as 2 x (BN/64) accumulators of v_mfma_f32_32x32x2_f32.
+// Both operands are staged K-contiguous in LDS ([row][32+4 floats]; the 4-float pad makes the
+// ds_read_b128 fragment reads conflict-free) so a lane reads 4 consecutive k of its row with one
+// ds_read_b128 and feeds 4 MFMAs.  The reduction order inside a 8-wide k group is permuted
+// (lane half h takes k = 4h..4h+3) identically for A and B, which fp32 addition tolerates.
+// Global -> register -> LDS staging is double buffered: tile t+1 is in flight while tile t is on
+// the matrix cores; one barrier per k-step.  The A gather applies the fused BatchNorm/ReLU
+// prologue in registers, and zero-fills out-of-range taps AFTER the prologue (padding is a zero
+// of the normalised tensor, resnet_layer.py:43-50).
+//
+// Roofline: compute bound on the fp32 matrix pipe (157.3 TFLOP/s): per block k-step 128*BN*32*2
+// flop vs (128+BN)*32*4 B staged => 64 flop/B at BN=128.
+#include "common.h"
+
+namespace {
+
+using hnd::f32x16;
+using hnd::f32x4;
+
+constexpr int BM = 128;
+constexpr int BK = 32;
+constexpr int LDK = BK + 4;   // padded LDS row (floats)
+
+template <int BN>
+constexpr size_t lds_bytes() {
+  return (size_t)(2 * BM * LDK + 2 * BN * LDK) * sizeof(float) + 2 * BM * sizeof(int);
+}
+
+template <int BN, bool CIN4>
+__global__ void __launch_bounds__(256, 2) igemm_kernel(const hnd_conv_desc d, const int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                          // [2][BM][LDK]
+  float* Bs = smem + 2 * BM * LDK;           // [2][BN][LDK]
+  int* rowoff = (int*)(Bs + 2 * BN * LDK);   // [BM] output pixel index (or -1)
+  int* resoff = rowoff + BM;                 // [BM] res1 pixel index (mode 1)
+
+  // XCD-aware bijective remap: blocks b and b+8 share an XCD/L2, give each XCD a contiguous run
+  // of logical tiles so the N-tiles of one pixel tile hit the same L2.
+  int bid = blockIdx.x;
+  {
+    const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, xcd = bid & 7, slot = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  }
+  const int mt = bid / ntiles, nt = bid - mt * ntiles;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int M = d.n * d.oh * d.ow;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 1, wn = wave >> 1;
+  const int arow = tid >> 3, kq = tid & 7;
+
+  if (tid < BM) {
+    const int m = m0 + tid;
+    int po = -1, pr = -1;
+    if (m < M) {
+      const int ow_ = m % d.ow, t = m / d.ow, oh_ = t % d.oh, n_ = t / d.oh;
+      const int yr = oh_ * d.y_sh + d.y_oh, yc = ow_ * d.y_sw + d.y_ow;
+      po = (n_ * d.yh + yr) * d.yw + yc;
+      if (d.res1_mode == 1)
+        pr = (n_ * d.res1_h + (yr * d.res1_h) / d.yh) * d.res1_w + (yc * d.res1_w) / d.yw;
+    }
+    rowoff[tid] = po;
+    resoff[tid] = pr;
+  }
+
+  // per-thread gather rows (4 rows of the pixel tile, fixed for the whole k loop)
+  int a_nb[4], a_ih[4], a_iw[4];
+  bool a_ok[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + arow + 32 * i;
+    a_ok[i] = m < M;
+    const int mm = a_ok[i] ? m : 0;
+    const int ow_ = mm % d.ow, t = mm / d.ow, oh_ = t % d.oh, n_ = t / d.oh;
+    a_nb[i] = n_ * d.h * d.w_;
+    a_ih[i] = oh_ * d.sh + d.bh;
+    a_iw[i] = ow_ * d.sw + d.bw;
+  }
+  const float* wrow[BN / 32];
+#pragma unroll
+  for (int i = 0; i < BN / 32; ++i) wrow[i] = d.w + (size_t)(n0 + arow + 32 * i) * d.kdim + kq * 4;
+
+  const bool has_pro = d.pro_scale != nullptr;
+  const int ntaps = d.kh * d.kw;
+  const unsigned kw_inv = (65536u + d.kw - 1) / d.kw;
+  const int T = d.kdim / BK;
+
+  f32x4 ra[4], rb[BN / 32], rps, rpb;
+  unsigned okmask = 0;
+  // uniform tap state of the NEXT tile to load (CIN_VEC mode)
+  int c0 = 0, khi = 0, kwi = 0;
+
+  auto gload = [&](int t) {
+    int ti = khi, tj = kwi, cc = c0 + kq * 4;
+    bool tap_ok = true;
+    if (CIN4) {
+      const int tap = t * 8 + kq;
+      ti = (int)((tap * kw_inv) >> 16);
+      tj = tap - ti * d.kw;
+      tap_ok = tap < ntaps;
+      cc = 0;
+    }
+    okmask = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int ih = a_ih[i] + ti * d.dh, iw = a_iw[i] + tj * d.dw;
+      const bool ok = a_ok[i] && tap_ok && (unsigned)ih < (unsigned)d.h && (unsigned)iw < (unsigned)d.w_;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (ok) {
+        const size_t off = (size_t)(a_nb[i] + ih * d.w_ + iw) * d.cin + cc;
+        v = *(const f32x4*)(d.x + off);
+        okmask |= 1u << i;
+      }
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < BN / 32; ++i) rb[i] = *(const f32x4*)(wrow[i] + (size_t)t * BK);
+    if (has_pro) {
+      rps = *(const f32x4*)(d.pro_scale + cc);
+      if (d.pro_shift) rpb = *(const f32x4*)(d.pro_shift + cc);
+      else rpb = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (!CIN4) {   // advance the uniform tap state
+      c0 += BK;
+      if (c0 >= d.cin) {
+        c0 = 0;
+        if (++kwi == d.kw) { kwi = 0; ++khi; }
+      }
+    }
+  };
+
+  auto lstore = [&](int buf) {
+    float* Ab = As + buf * BM * LDK + arow * LDK + kq * 4;
+    float* Bb = Bs + buf * BN * LDK + arow * LDK + kq * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f32x4 v = ra[i];
+      if (has_pro && ((okmask >> i) & 1)) {
+        v = v * rps + rpb;
+        if (d.pro_relu) {
+          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+      }
+      *(f32x4*)(Ab + 32 * i * LDK) = v;
+    }
+#pragma unroll
+    for (int i = 0; i < BN / 32; ++i) *(f32x4*)(Bb + 32 * i * LDK) = rb[i];
+  };
+
+  f32x16 acc[2][BN / 64];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < BN / 64; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  auto compute = [&](int buf) {
+    const float* Ap = As + buf * BM * LDK + (wm * 64 + (lane & 31)) * LDK + (lane >> 5) * 4;
+    const float* Bp = Bs + buf * BN * LDK + (wn * (BN / 2) + (lane & 31)) * LDK + (lane >> 5) * 4;
+#pragma unroll
+    for (int kk = 0; kk < BK / 8; ++kk) {
+      f32x4 a[2], b[BN / 64];
+      a[0] = *(const f32x4*)(Ap + kk * 8);
+      a[1] = *(const f32x4*)(Ap + 32 * LDK + kk * 8);
+#pragma unroll
+      for (int ni = 0; ni < BN / 64; ++ni) b[ni] = *(const f32x4*)(Bp + ni * 32 * LDK + kk * 8);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < BN / 64; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][s], b[ni][s], acc[mi][ni], 0, 0, 0);
+    }
+  };
+
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  int cur = 0;
+  for (int t = 0; t < T; ++t) {
+    const bool more = (t + 1) < T;
+    if (more) gload(t + 1);
+    compute(cur);
+    if (more) lstore(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---------------------------------------------------------------- epilogue
+  float* red = As;   // [2 (wm)][2 (sum,sumsq)][BN], reused after the final barrier
+#pragma unroll
+  for (int ni = 0; ni < BN / 64; ++ni) {
+    const int ct = wn * (BN / 2) + ni * 32 + (lane & 31);
+    const int col = n0 + ct;
+    const bool col_ok = col < d.cout;
+    const float es = (d.epi_scale && col_ok) ? d.epi_scale[col] : 1.f;
+    const float eb = (d.epi_shift && col_ok) ? d.epi_shift[col] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rit = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int po = rowoff[rit];
+        if (po >= 0 && col_ok) {
+          const size_t o = (size_t)po * d.ldc + col;
+          float v = acc[mi][ni][r] * es + eb;
+          if (d.res1) v += d.res1[d.res1_mode == 1 ? (size_t)resoff[rit] * d.ldc + col : o];
+          if (d.res2) v += d.res2[o];
+          if (d.mask) v = d.mask[o] > 0.f ? v : 0.f;
+          if (d.relu) v = fmaxf(v, 0.f);
+          d.y[o] = v;
+          s1 += v;
+          s2 += v * v;
+        }
+      }
+    }
+    if (d.stats) {
+      s1 += __shfl_xor(s1, 32);
+      s2 += __shfl_xor(s2, 32);
+      if (lane < 32) {
+        red[(wm * 2 + 0) * BN + ct] = s1;
+        red[(wm * 2 + 1) * BN + ct] = s2;
+      }
+    }
+  }
+  if (d.stats) {
+    __syncthreads();
+    if (tid < BN && (n0 + tid) < d.cout) {
+      float* st = d.stats + (size_t)mt * 2 * d.cout + n0 + tid;
+      st[0] = red[(0 * 2 + 0) * BN + tid] + red[(1 * 2 + 0) * BN + tid];
+      st[d.cout] = red[(0 * 2 + 1) * BN + tid] + red[(1 * 2 + 1) * BN + tid];
+    }
+  }
+}
+
+template <int BN, bool CIN4>
+int launch(const hnd_conv_desc& d, hipStream_t stream) {
+  static bool attr_set = false;
+  auto kern = igemm_kernel<BN, CIN4>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds_bytes<BN>());
+    if (e != hipSuccess) {
+      hnd::set_error("hipFuncSetAttribute(igemm<%d>) failed: %s", BN, hipGetErrorString(e));
+      return HND_ERR_LAUNCH;
+    }
+    attr_set = true;
+  }
+  const long long M = (long long)d.n * d.oh * d.ow;
+  const int mtiles = (int)((M + BM - 1) / BM);
+  const int ntiles = (d.cout + BN - 1) / BN;
+  hipLaunchKernelGGL(kern, dim3(mtiles * ntiles), dim3(256), lds_bytes<BN>(), stream, d, ntiles);
+  return hnd::check_launch("hnd_conv2d_igemm");
+}
+
+}  // namespace
+
+extern "C" int hnd_conv2d_igemm(const hnd_conv_desc* desc, void* stream) {
+  HND_REQUIRE(desc != nullptr, "hnd_conv2d_igemm: null descriptor");
+  const hnd_conv_desc& d = *desc;
+  HND_REQUIRE(d.x && d.w && d.y, "hnd_conv2d_igemm: null x/w/y");
+  HND_REQUIRE(d.n > 0 && d.h > 0 && d.w_ > 0 && d.oh > 0 && d.ow > 0 && d.cout > 0 && d.kh > 0 && d.kw > 0,
+              "hnd_conv2d_igemm: non-positive geometry");
+  HND_REQUIRE(d.cin == 4 || d.cin % 32 == 0, "hnd_conv2d_igemm: cin=%d must be 4 or a multiple of 32", d.cin);
+  HND_REQUIRE(d.kdim % 32 == 0 && d.kdim >= d.kh * d.kw * d.cin,
+              "hnd_conv2d_igemm: kdim=%d must be a multiple of 32 covering kh*kw*cin=%d", d.kdim,
+              d.kh * d.kw * d.cin);
+  HND_REQUIRE(d.cin != 4 || d.kh * d.kw <= 64, "hnd_conv2d_igemm: at most 64 taps when cin==4");
+  HND_REQUIRE(d.ldc >= d.cout, "hnd_conv2d_igemm: ldc < cout");
+  HND_REQUIRE((long long)d.n * d.oh * d.ow < (1ll << 31) && (long long)d.n * d.yh * d.yw < (1ll << 31) &&
+                  (long long)d.n * d.h * d.w_ < (1ll << 31),
+              "hnd_conv2d_igemm: pixel count exceeds int32");
+  HND_REQUIRE(d.res1_mode == 0 || (d.res1_h > 0 && d.res1_w > 0), "hnd_conv2d_igemm: res1 upsample needs dims");
+  hipStream_t s = hnd::as_stream(stream);
+  if (d.cin == 4) {
+    return launch<64, true>(d, s);   // stem (cout 64) and the 3->64 decoder conv
+  }
+  if (d.cout % 128 == 0) return launch<128, false>(d, s);
+  return launch<64, false>(d, s);
+}

@@ -1,0 +1,248 @@
+// Weight gradient of the trainable convs as a split-K implicit GEMM on fp32 MFMA (gfx950).
+//
+//   dW[co][col] = sum_m dy[m][co] * a(m; col),   col = (tap, ci),  m = n*oh*ow output pixels
+//
+// The reduction runs over pixels (1.1M..4.3M at batch 16), so both operands are staged exactly as
+// they lie in HBM -- [pixel][channel], channel contiguous -- and the MFMA fragments are read from
+// LDS with conflict-free ds_read_b32 (lane = channel).  fp32 MFMA issues one 32x32x2 every 64
+// cycles per SIMD, so one 4-byte LDS read per operand per MFMA is far below the LDS rate.
+// Block tile: BMW (64|128 output channels) x 128 (cols) x 32 (pixels); 4 waves 2x2.
+// Each block reduces one contiguous pixel range (split-K); partial tiles go to slabs
+// [split][co_pad][ncols_pad] and a second kernel sums the slabs in fixed order and writes the
+// torch OIHW layout -> bitwise reproducible, no float atomics.
+#include "common.h"
+
+namespace {
+
+using hnd::FastDiv;
+using hnd::f32x16;
+using hnd::f32x4;
+using hnd::fdiv;
+
+constexpr int BNW = 128;
+constexpr int BKW = 32;
+
+struct WgradArgs {
+  hnd_wgrad_desc d;
+  FastDiv div_ow, div_oh, div_cin;
+  int ncols, ncols_pad, co_pad, rtiles, ctiles, steps_per_split, M;
+};
+
+template <int BMW>
+__global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradArgs a) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * BKW * (BMW + BNW)];
+  float* As = smem;                       // [2][BKW][BMW]   dy tile
+  float* Bs = smem + 2 * BKW * BMW;       // [2][BKW][BNW]   gathered activation tile
+  const hnd_wgrad_desc& d = a.d;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 1, wn = wave >> 1;
+
+  int bid = blockIdx.x;
+  const int tiles = a.rtiles * a.ctiles;
+  const int split = bid / tiles;
+  bid -= split * tiles;
+  const int rt = bid / a.ctiles, ct = bid - rt * a.ctiles;
+  const int r0 = rt * BMW, c0 = ct * BNW;
+  const int step0 = split * a.steps_per_split;
+  int nsteps = (a.M + BKW - 1) / BKW - step0;
+  if (nsteps > a.steps_per_split) nsteps = a.steps_per_split;
+
+  // A (dy) loader: thread -> 4 channels (float4) of rows (tid / (BMW/4)) + i*(256/(BMW/4))
+  constexpr int A_TPR = BMW / 4;            // threads per row
+  constexpr int A_RPI = 256 / A_TPR;        // rows per pass
+  constexpr int A_N = BKW / A_RPI;          // passes
+  const int a_c4 = (tid % A_TPR) * 4, a_r = tid / A_TPR;
+  const bool a_cok = (r0 + a_c4) < d.cout;  // cout is a multiple of 4 on this path (or masked below)
+  // B (activation) loader: thread -> fixed column group (4 consecutive ci of one tap)
+  const int b_c4 = (tid & 31) * 4, b_r = tid >> 5;   // 8 rows per pass, 4 passes
+  const int col = c0 + b_c4;
+  const bool b_cok = col < a.ncols;
+  const int tap = b_cok ? (int)fdiv((unsigned)col, a.div_cin) : 0;
+  const int ci = col - tap * d.cin;
+  const int ti = tap / d.kw, tj = tap - ti * d.kw;
+  const bool has_pro = d.pro_scale != nullptr;
+  f32x4 ps = {1.f, 1.f, 1.f, 1.f}, pb = {0.f, 0.f, 0.f, 0.f};
+  if (has_pro && b_cok) {
+    ps = *(const f32x4*)(d.pro_scale + ci);
+    if (d.pro_shift) pb = *(const f32x4*)(d.pro_shift + ci);
+  }
+
+  f32x4 ra[A_N], rb[4];
+  auto gload = [&](int s) {
+    const int mbase = (step0 + s) * BKW;
+#pragma unroll
+    for (int i = 0; i < A_N; ++i) {
+      const int m = mbase + a_r + i * A_RPI;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (m < a.M && a_cok) {
+        const float* p = d.dy + (size_t)m * d.ldy + r0 + a_c4;
+        if (r0 + a_c4 + 3 < d.cout) v = *(const f32x4*)p;
+        else { v.x = p[0]; if (r0 + a_c4 + 1 < d.cout) v.y = p[1]; if (r0 + a_c4 + 2 < d.cout) v.z = p[2]; }
+      }
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = mbase + b_r + i * 8;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (m < a.M && b_cok) {
+        const unsigned t = fdiv((unsigned)m, a.div_ow);
+        const int ow_ = m - (int)t * d.ow;
+        const unsigned n_ = fdiv(t, a.div_oh);
+        const int oh_ = (int)t - (int)n_ * d.oh;
+        const int ih = oh_ * d.stride - d.pad + ti, iw = ow_ * d.stride - d.pad + tj;
+        if ((unsigned)ih < (unsigned)d.h && (unsigned)iw < (unsigned)d.w_) {
+          v = *(const f32x4*)(d.x + ((size_t)((int)n_ * d.h + ih) * d.w_ + iw) * d.cin + ci);
+          if (has_pro) {
+            v = v * ps + pb;
+            if (d.pro_relu) {
+              v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+            }
+          }
+        }
+      }
+      rb[i] = v;
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < A_N; ++i)
+      *(f32x4*)(As + (buf * BKW + a_r + i * A_RPI) * BMW + a_c4) = ra[i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *(f32x4*)(Bs + (buf * BKW + b_r + i * 8) * BNW + b_c4) = rb[i];
+  };
+
+  constexpr int MI = BMW / 64;   // 32-row MFMA tiles per wave along co
+  f32x16 acc[MI][2];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  auto compute = [&](int buf) {
+    const float* Ap = As + buf * BKW * BMW + (lane >> 5) * BMW + wm * (BMW / 2) + (lane & 31);
+    const float* Bp = Bs + buf * BKW * BNW + (lane >> 5) * BNW + wn * 64 + (lane & 31);
+#pragma unroll
+    for (int kk = 0; kk < BKW / 2; ++kk) {
+      float av[MI], bv[2];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) av[mi] = Ap[kk * 2 * BMW + mi * 32];
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) bv[ni] = Bp[kk * 2 * BNW + ni * 32];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi], bv[ni], acc[mi][ni], 0, 0, 0);
+    }
+  };
+
+  if (nsteps > 0) {
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    int cur = 0;
+    for (int s = 0; s < nsteps; ++s) {
+      const bool more = (s + 1) < nsteps;
+      if (more) gload(s + 1);
+      compute(cur);
+      if (more) lstore(cur ^ 1);
+      __syncthreads();
+      cur ^= 1;
+    }
+  }
+  // partial tile -> slab[split][co][col]; D[i=co][j=col]: lane -> col, regs -> co
+  float* slab = d.slabs + (size_t)split * a.co_pad * a.ncols_pad;
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = r0 + wm * (BMW / 2) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int cc = c0 + wn * 64 + ni * 32 + (lane & 31);
+        slab[(size_t)co * a.ncols_pad + cc] = acc[mi][ni][r];
+      }
+}
+
+// sum the slabs in split order and write dW in torch OIHW layout
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int splitk, int co_pad,
+                                    int ncols_pad, int cout, int cin, int cin_real, int kh, int kw) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // over cout * kh*kw * cin_real in (co, tap, ci) order
+  const int per_co = kh * kw * cin_real;
+  if (idx >= cout * per_co) return;
+  const int co = idx / per_co, rem = idx - co * per_co;
+  const int tap = rem / cin_real, ci = rem - tap * cin_real;
+  const size_t off = (size_t)co * ncols_pad + tap * cin + ci;
+  const size_t stride = (size_t)co_pad * ncols_pad;
+  float s = 0.f;
+  for (int k = 0; k < splitk; ++k) s += slabs[off + k * stride];
+  const int i = tap / kw, j = tap - i * kw;
+  dw[(((size_t)co * cin_real + ci) * kh + i) * kw + j] = s;
+}
+
+int plan(const hnd_wgrad_desc& d, WgradArgs& a) {
+  a.d = d;
+  a.M = d.n * d.oh * d.ow;
+  a.ncols = d.kh * d.kw * d.cin;
+  a.ctiles = (a.ncols + BNW - 1) / BNW;
+  a.ncols_pad = a.ctiles * BNW;
+  const int bmw = d.cout >= 128 ? 128 : 64;
+  a.rtiles = (d.cout + bmw - 1) / bmw;
+  a.co_pad = a.rtiles * bmw;
+  a.div_ow = hnd::make_fastdiv((unsigned)d.ow);
+  a.div_oh = hnd::make_fastdiv((unsigned)d.oh);
+  a.div_cin = hnd::make_fastdiv((unsigned)d.cin);
+  const int total_steps = (a.M + BKW - 1) / BKW;
+  int splitk = d.splitk;
+  if (splitk <= 0) {
+    const int tiles = a.rtiles * a.ctiles;
+    splitk = (1024 + tiles - 1) / tiles;          // ~4 blocks per CU
+    const int max_by_work = (total_steps + 15) / 16;   // at least 16 k-steps per split
+    if (splitk > max_by_work) splitk = max_by_work;
+    if (splitk < 1) splitk = 1;
+    if (splitk > 512) splitk = 512;
+  }
+  a.steps_per_split = (total_steps + splitk - 1) / splitk;
+  a.d.splitk = (total_steps + a.steps_per_split - 1) / a.steps_per_split;   // drop empty splits
+  return bmw;
+}
+
+}  // namespace
+
+extern "C" size_t hnd_conv2d_wgrad_workspace(const hnd_wgrad_desc* desc) {
+  if (!desc) return 0;
+  WgradArgs a;
+  hnd_wgrad_desc d = *desc;
+  if (d.cin <= 0 || d.cout <= 0 || d.kh <= 0 || d.kw <= 0 || d.oh <= 0 || d.ow <= 0 || d.n <= 0) return 0;
+  plan(d, a);
+  return (size_t)a.d.splitk * a.co_pad * a.ncols_pad * sizeof(float);
+}
+
+extern "C" int hnd_conv2d_wgrad(const hnd_wgrad_desc* desc, void* stream) {
+  HND_REQUIRE(desc != nullptr, "hnd_conv2d_wgrad: null descriptor");
+  const hnd_wgrad_desc& d = *desc;
+  HND_REQUIRE(d.x && d.dy && d.dw && d.slabs, "hnd_conv2d_wgrad: null x/dy/dw/slabs");
+  HND_REQUIRE(d.n > 0 && d.h > 0 && d.w_ > 0 && d.oh > 0 && d.ow > 0 && d.cout > 0 && d.kh > 0 && d.kw > 0 &&
+                  d.stride > 0,
+              "hnd_conv2d_wgrad: non-positive geometry");
+  HND_REQUIRE(d.cin == 4 || d.cin % 32 == 0, "hnd_conv2d_wgrad: cin=%d must be 4 or a multiple of 32", d.cin);
+  HND_REQUIRE(d.cin_real > 0 && d.cin_real <= d.cin, "hnd_conv2d_wgrad: bad cin_real");
+  HND_REQUIRE(d.ldy >= d.cout && d.ldy % 4 == 0, "hnd_conv2d_wgrad: ldy=%d must be a multiple of 4 >= cout", d.ldy);
+  HND_REQUIRE((long long)d.n * d.oh * d.ow < (1ll << 31) && (long long)d.n * d.h * d.w_ < (1ll << 31),
+              "hnd_conv2d_wgrad: pixel count exceeds int32");
+  WgradArgs a;
+  const int bmw = plan(d, a);
+  hipStream_t s = hnd::as_stream(stream);
+  const int grid = a.rtiles * a.ctiles * a.d.splitk;
+  if (bmw == 128) hipLaunchKernelGGL(wgrad_kernel<128>, dim3(grid), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(wgrad_kernel<64>, dim3(grid), dim3(256), 0, s, a);
+  int rc = hnd::check_launch("hnd_conv2d_wgrad");
+  if (rc) return rc;
+  const int total = d.cout * d.kh * d.kw * d.cin_real;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, s, d.slabs, d.dw, a.d.splitk,
+                     a.co_pad, a.ncols_pad, d.cout, d.cin, d.cin_real, d.kh, d.kw);
+  return hnd::check_launch("hnd_conv2d_wgrad(reduce)");
+}

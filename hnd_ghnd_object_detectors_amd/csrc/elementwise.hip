@@ -1,0 +1,616 @@
+// HBM-bound kernels of the HND/GHND step (gfx950): transform, pooling, BatchNorm statistics /
+// backward, the fused L2 mimic loss + gradient, fused flat Adam, weight packing.
+// All are streaming passes: 16-byte accesses per lane, grid-stride over <= 2048*8 blocks,
+// per-wave shuffle reductions then per-block partials (no float atomics -> deterministic).
+#include "common.h"
+
+#include <math.h>
+
+namespace {
+
+using hnd::f32x4;
+
+constexpr int kMaxBlocks = 256 * 16;
+
+inline int grid_for(long long work_items, int threads = 256) {
+  long long b = (work_items + threads - 1) / threads;
+  if (b < 1) b = 1;
+  if (b > kMaxBlocks) b = kMaxBlocks;
+  return (int)b;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// ------------------------------------------------------------------------------------ pack / fold
+__global__ void pack_weights_kernel(const float* __restrict__ src, float* __restrict__ dst, int cout, int cin, int kh,
+                                    int kw, int transposed, int chan_pad, int i0, int istep, int ni, int j0,
+                                    int jstep, int nj, int rows_pad, int kdim) {
+  const long long total = (long long)rows_pad * kdim;
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    const int r = (int)(e / kdim), k = (int)(e - (long long)r * kdim);
+    const int tap = k / chan_pad, c = k - tap * chan_pad;
+    float v = 0.f;
+    const int rows = transposed ? cin : cout, chans = transposed ? cout : cin;
+    if (r < rows && c < chans && tap < ni * nj) {
+      const int a = tap / nj, b = tap - a * nj;
+      const int i = i0 + a * istep, j = j0 + b * jstep;
+      const int o = transposed ? c : r, ic = transposed ? r : c;
+      v = src[(((size_t)o * cin + ic) * kh + i) * kw + j];
+    }
+    dst[e] = v;
+  }
+}
+
+__global__ void fbn_fold_kernel(const float* w, const float* b, const float* mean, const float* var, float* scale,
+                                float* shift, int c, int cs, float eps) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= cs) return;
+  if (i >= c) { scale[i] = 0.f; shift[i] = 0.f; return; }
+  const float s = w[i] * (1.0f / sqrtf(var[i] + eps));   // weight * running_var.rsqrt(); eps = 0 for torchvision 0.4.2
+  scale[i] = s;
+  shift[i] = b[i] - mean[i] * s;
+}
+
+// ------------------------------------------------------------------------------------ transform
+struct TransformArgs {
+  const float* src;
+  float* dst;
+  int h, w, out_h, out_w, hp, wp;
+  float rh, rw;
+  float mean[3], inv_unused[3], std[3];
+};
+
+__global__ void transform_kernel(const TransformArgs a) {
+  const int total = a.hp * a.wp;
+  const size_t plane = (size_t)a.h * a.w;
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < total; p += gridDim.x * blockDim.x) {
+    const int y = p / a.wp, x = p - y * a.wp;
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+    if (y < a.out_h && x < a.out_w) {
+      // F.interpolate(mode='bilinear', align_corners=False) source index (area_pixel_compute_source_index)
+      float sy = a.rh * ((float)y + 0.5f) - 0.5f, sx = a.rw * ((float)x + 0.5f) - 0.5f;
+      sy = sy < 0.f ? 0.f : sy;
+      sx = sx < 0.f ? 0.f : sx;
+      int y0 = (int)sy, x0 = (int)sx;
+      if (y0 > a.h - 1) y0 = a.h - 1;
+      if (x0 > a.w - 1) x0 = a.w - 1;
+      const int y1 = y0 + (y0 < a.h - 1 ? 1 : 0), x1 = x0 + (x0 < a.w - 1 ? 1 : 0);
+      const float ly = sy - (float)y0, lx = sx - (float)x0;
+      const float hy = 1.f - ly, hx = 1.f - lx;
+      float v[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float* s = a.src + c * plane;
+        // normalise first ((x-mean)/std, rcnn.py:74), then interpolate (rcnn.py:75)
+        const float p00 = (s[(size_t)y0 * a.w + x0] - a.mean[c]) / a.std[c];
+        const float p01 = (s[(size_t)y0 * a.w + x1] - a.mean[c]) / a.std[c];
+        const float p10 = (s[(size_t)y1 * a.w + x0] - a.mean[c]) / a.std[c];
+        const float p11 = (s[(size_t)y1 * a.w + x1] - a.mean[c]) / a.std[c];
+        v[c] = hy * (hx * p00 + lx * p01) + ly * (hx * p10 + lx * p11);
+      }
+      o.x = v[0]; o.y = v[1]; o.z = v[2];
+    }
+    *(f32x4*)(a.dst + (size_t)p * 4) = o;
+  }
+}
+
+// ------------------------------------------------------------------------------------ max pool
+__global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, uint8_t* __restrict__ idx,
+                                   int n, int h, int w, int c, int oh, int ow) {
+  const int c4n = c >> 2;
+  const long long total = (long long)n * oh * ow * c4n;
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(e % c4n);
+    long long p = e / c4n;
+    const int ox = (int)(p % ow);
+    p /= ow;
+    const int oy = (int)(p % oh), b = (int)(p / oh);
+    f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    int bi[4] = {0, 0, 0, 0};
+    bool any = false;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int iy = oy * 2 - 1 + i;
+      if ((unsigned)iy >= (unsigned)h) continue;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int ix = ox * 2 - 1 + j;
+        if ((unsigned)ix >= (unsigned)w) continue;
+        const f32x4 v = *(const f32x4*)(x + (((size_t)b * h + iy) * w + ix) * c + c4 * 4);
+        const int tap = i * 3 + j;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          // torch: first element always taken, then strictly greater (or NaN) wins
+          if (!any || v[k] > best[k] || v[k] != v[k]) { best[k] = v[k]; bi[k] = tap; }
+        }
+        any = true;
+      }
+    }
+    const size_t o = (((size_t)b * oh + oy) * ow + ox) * c + c4 * 4;
+    *(f32x4*)(y + o) = best;
+    *(uchar4*)(idx + o) = make_uchar4((unsigned char)bi[0], (unsigned char)bi[1], (unsigned char)bi[2],
+                                      (unsigned char)bi[3]);
+  }
+}
+
+__global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ idx,
+                                   const float* __restrict__ act, const float* __restrict__ scale,
+                                   float* __restrict__ dx, int n, int h, int w, int c, int oh, int ow) {
+  const int c4n = c >> 2;
+  const long long total = (long long)n * h * w * c4n;
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(e % c4n);
+    long long p = e / c4n;
+    const int ix = (int)(p % w);
+    p /= w;
+    const int iy = (int)(p % h), b = (int)(p / h);
+    f32x4 g = {0.f, 0.f, 0.f, 0.f};
+    // windows oy with oy*2-1 <= iy <= oy*2+1
+    const int oy_lo = (iy) >> 1, oy_hi = (iy + 1) >> 1;   // ceil((iy-1)/2) .. floor((iy+1)/2)
+    const int ox_lo = (ix) >> 1, ox_hi = (ix + 1) >> 1;
+    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+      if (oy >= oh) continue;
+      for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+        if (ox >= ow) continue;
+        const int tap = (iy - (oy * 2 - 1)) * 3 + (ix - (ox * 2 - 1));
+        const size_t o = (((size_t)b * oh + oy) * ow + ox) * c + c4 * 4;
+        const uchar4 id = *(const uchar4*)(idx + o);
+        const f32x4 d = *(const f32x4*)(dy + o);
+        if (id.x == tap) g.x += d.x;
+        if (id.y == tap) g.y += d.y;
+        if (id.z == tap) g.z += d.z;
+        if (id.w == tap) g.w += d.w;
+      }
+    }
+    const size_t xo = (size_t)e * 4;
+    const f32x4 a = *(const f32x4*)(act + xo);
+    const f32x4 s = *(const f32x4*)(scale + c4 * 4);
+    f32x4 r;
+    r.x = a.x > 0.f ? g.x * s.x : 0.f;
+    r.y = a.y > 0.f ? g.y * s.y : 0.f;
+    r.z = a.z > 0.f ? g.z * s.z : 0.f;
+    r.w = a.w > 0.f ? g.w * s.w : 0.f;
+    *(f32x4*)(dx + xo) = r;
+  }
+}
+
+// ------------------------------------------------------------------------------------ BN forward
+// one wave per channel; lanes stride over the tile partials, fp64 accumulate
+__global__ void bn_finalize_kernel(const float* __restrict__ partials, int ntiles, int c, int cs, double count,
+                                   const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                   long long* nbt, float momentum, float eps, float* scale, float* shift,
+                                   float* save_mean, float* save_rstd) {
+  const int lane = threadIdx.x & 63;
+  const int ch = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (ch >= cs) return;
+  if (ch >= c) {
+    if (lane == 0) { scale[ch] = 0.f; shift[ch] = 0.f; save_mean[ch] = 0.f; save_rstd[ch] = 0.f; }
+    return;
+  }
+  double s1 = 0.0, s2 = 0.0;
+  for (int t = lane; t < ntiles; t += 64) {
+    s1 += (double)partials[((size_t)t * 2 + 0) * cs + ch];
+    s2 += (double)partials[((size_t)t * 2 + 1) * cs + ch];
+  }
+  s1 = wave_sum_d(s1);
+  s2 = wave_sum_d(s2);
+  if (lane == 0) {
+    const double mean = s1 / count;
+    double var = s2 / count - mean * mean;   // biased, used for normalisation
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = gamma[ch] * rstd;
+    scale[ch] = sc;
+    shift[ch] = beta[ch] - (float)mean * sc;
+    save_mean[ch] = (float)mean;
+    save_rstd[ch] = rstd;
+    if (running_mean) {
+      const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+      running_mean[ch] = (1.f - momentum) * running_mean[ch] + momentum * (float)mean;
+      running_var[ch] = (1.f - momentum) * running_var[ch] + momentum * (float)unbiased;
+    }
+    if (nbt && ch == 0) *nbt += 1;
+  }
+}
+
+__global__ void affine_relu_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                   const float* __restrict__ shift, float* __restrict__ y, long long n4, int cs4,
+                                   int relu) {
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < n4; e += (long long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(e % cs4);
+    const f32x4 v = *(const f32x4*)(x + e * 4);
+    const f32x4 s = *(const f32x4*)(scale + c4 * 4), b = *(const f32x4*)(shift + c4 * 4);
+    f32x4 r = v * s + b;
+    if (relu) { r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f); }
+    *(f32x4*)(y + e * 4) = r;
+  }
+}
+
+// ------------------------------------------------------------------------------------ BN backward
+constexpr int kBnTilePix = 1024;   // pixels per block in the reduce pass
+
+// partials[tile][0][ch] = sum d, partials[tile][1][ch] = sum d*xhat, d = relu-masked g
+__global__ void bn_bwd_reduce_kernel(const float* __restrict__ g, const float* __restrict__ x,
+                                     const float* __restrict__ scale, const float* __restrict__ shift,
+                                     const float* __restrict__ mean, const float* __restrict__ rstd, int relu,
+                                     long long npix, int cs, float* __restrict__ partials) {
+  __shared__ float red[2][256][4];
+  const int cs4 = cs >> 2;                 // float4 groups per pixel: 1, 16, 32 or 64 (divides 256)
+  const int rows = 256 / cs4;              // pixels per pass
+  const int c4 = threadIdx.x % cs4, r = threadIdx.x / cs4;
+  const f32x4 sc = *(const f32x4*)(scale + c4 * 4), sh = *(const f32x4*)(shift + c4 * 4);
+  const f32x4 mu = *(const f32x4*)(mean + c4 * 4), rs = *(const f32x4*)(rstd + c4 * 4);
+  const long long p0 = (long long)blockIdx.x * kBnTilePix;
+  long long p1 = p0 + kBnTilePix;
+  if (p1 > npix) p1 = npix;
+  f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+  for (long long p = p0 + r; p < p1; p += rows) {
+    const size_t o = (size_t)p * cs + c4 * 4;
+    f32x4 d = *(const f32x4*)(g + o);
+    const f32x4 xv = *(const f32x4*)(x + o);
+    if (relu) {
+      const f32x4 out = xv * sc + sh;
+      d.x = out.x > 0.f ? d.x : 0.f; d.y = out.y > 0.f ? d.y : 0.f;
+      d.z = out.z > 0.f ? d.z : 0.f; d.w = out.w > 0.f ? d.w : 0.f;
+    }
+    s1 += d;
+    s2 += d * ((xv - mu) * rs);
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { red[0][threadIdx.x][k] = s1[k]; red[1][threadIdx.x][k] = s2[k]; }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < cs * 2; idx += 256) {
+    const int which = idx / cs, ch = idx - which * cs;
+    const int g4 = ch >> 2, k = ch & 3;
+    float s = 0.f;
+    for (int rr = 0; rr < rows; ++rr) s += red[which][rr * cs4 + g4][k];
+    partials[((size_t)blockIdx.x * 2 + which) * cs + ch] = s;
+  }
+}
+
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partials, int ntiles, int c, int cs, double count,
+                                       const float* gamma, const float* mean, const float* rstd, float* dgamma,
+                                       float* dbeta, float* k123) {
+  const int lane = threadIdx.x & 63;
+  const int ch = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (ch >= cs) return;
+  if (ch >= c) {
+    if (lane == 0) { k123[ch] = 0.f; k123[cs + ch] = 0.f; k123[2 * cs + ch] = 0.f; }
+    return;
+  }
+  double s1 = 0.0, s2 = 0.0;
+  for (int t = lane; t < ntiles; t += 64) {
+    s1 += (double)partials[((size_t)t * 2 + 0) * cs + ch];
+    s2 += (double)partials[((size_t)t * 2 + 1) * cs + ch];
+  }
+  s1 = wave_sum_d(s1);
+  s2 = wave_sum_d(s2);
+  if (lane == 0) {
+    dbeta[ch] = (float)s1;
+    dgamma[ch] = (float)s2;
+    const double k1 = (double)gamma[ch] * (double)rstd[ch];
+    const double k2 = -k1 * (double)rstd[ch] * s2 / count;
+    const double k3 = k1 * ((double)mean[ch] * (double)rstd[ch] * s2 - s1) / count;
+    k123[ch] = (float)k1;
+    k123[cs + ch] = (float)k2;
+    k123[2 * cs + ch] = (float)k3;
+  }
+}
+
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ x,
+                                    const float* __restrict__ scale, const float* __restrict__ shift,
+                                    const float* __restrict__ k123, int relu, float* __restrict__ dx, long long n4,
+                                    int cs) {
+  const int cs4 = cs >> 2;
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < n4; e += (long long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(e % cs4);
+    f32x4 d = *(const f32x4*)(g + e * 4);
+    const f32x4 xv = *(const f32x4*)(x + e * 4);
+    if (relu) {
+      const f32x4 out = xv * *(const f32x4*)(scale + c4 * 4) + *(const f32x4*)(shift + c4 * 4);
+      d.x = out.x > 0.f ? d.x : 0.f; d.y = out.y > 0.f ? d.y : 0.f;
+      d.z = out.z > 0.f ? d.z : 0.f; d.w = out.w > 0.f ? d.w : 0.f;
+    }
+    const f32x4 k1 = *(const f32x4*)(k123 + c4 * 4), k2 = *(const f32x4*)(k123 + cs + c4 * 4),
+                k3 = *(const f32x4*)(k123 + 2 * cs + c4 * 4);
+    *(f32x4*)(dx + e * 4) = k1 * d + k2 * xv + k3;
+  }
+}
+
+// ------------------------------------------------------------------------------------ loss
+constexpr int kMseBlocks = 2048;
+constexpr int kMaxPairs = 8;
+struct MseArgs {
+  hnd_mse_pair pair[kMaxPairs];
+  int first_block[kMaxPairs + 1];
+  int npairs;
+};
+
+__global__ void mse_kernel(const MseArgs a, double* __restrict__ scratch) {
+  __shared__ double wsum[4];
+  int k = 0;
+  while (k + 1 < a.npairs && (int)blockIdx.x >= a.first_block[k + 1]) ++k;
+  const hnd_mse_pair P = a.pair[k];
+  const int nb = a.first_block[k + 1] - a.first_block[k], lb = blockIdx.x - a.first_block[k];
+  const long long n4 = P.numel >> 2;                 // numel is a multiple of 4 (NHWC, C % 4 == 0)
+  const long long per = (n4 + nb - 1) / nb;
+  const long long e0 = (long long)lb * per;
+  long long e1 = e0 + per;
+  if (e1 > n4) e1 = n4;
+  const float gf = 2.f * P.factor;
+  float acc = 0.f;
+  for (long long e = e0 + threadIdx.x; e < e1; e += blockDim.x) {
+    const f32x4 t = *(const f32x4*)(P.teacher + e * 4), s = *(const f32x4*)(P.student + e * 4);
+    const f32x4 df = s - t;
+    acc += (df.x * df.x + df.y * df.y) + (df.z * df.z + df.w * df.w);
+    if (P.grad) {
+      f32x4 gg = df * gf;
+      if (P.relu_mask) {
+        gg.x = s.x > 0.f ? gg.x : 0.f; gg.y = s.y > 0.f ? gg.y : 0.f;
+        gg.z = s.z > 0.f ? gg.z : 0.f; gg.w = s.w > 0.f ? gg.w : 0.f;
+      }
+      *(f32x4*)(P.grad + e * 4) = gg;
+    }
+  }
+  double dsum = wave_sum_d((double)acc);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = dsum;
+  __syncthreads();
+  if (threadIdx.x == 0) scratch[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+}
+
+__global__ void mse_finalize_kernel(const MseArgs a, const double* __restrict__ scratch, double* __restrict__ out) {
+  __shared__ double term[kMaxPairs];
+  const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (k < a.npairs) {
+    double s = 0.0;
+    for (int b = a.first_block[k] + lane; b < a.first_block[k + 1]; b += 64) s += scratch[b];
+    s = wave_sum_d(s);
+    if (lane == 0) {
+      term[k] = s * (double)a.pair[k].factor;
+      out[1 + k] = term[k];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double tot = 0.0;
+    for (int i = 0; i < a.npairs; ++i) tot += term[i];
+    out[0] = tot;
+  }
+}
+
+__global__ void scale_by_scalar_kernel(float* x, long long n, const float* s) {
+  const float f = *s;
+  if (f == 1.0f) return;
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x)
+    x[e] *= f;
+}
+
+// ------------------------------------------------------------------------------------ Adam
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, long long n, float step_size, float beta1, float beta2, float eps,
+                            float bc2_sqrt, float grad_scale) {
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
+    const float gr = g[e] * grad_scale;
+    const float mm = m[e] + (gr - m[e]) * (1.f - beta1);          // exp_avg.lerp_(grad, 1-beta1)
+    const float vv = v[e] * beta2 + (1.f - beta2) * gr * gr;      // exp_avg_sq.mul_(b2).addcmul_(g,g,1-b2)
+    m[e] = mm;
+    v[e] = vv;
+    const float denom = sqrtf(vv) / bc2_sqrt + eps;
+    p[e] = p[e] - step_size * (mm / denom);
+  }
+}
+
+__global__ void subsample2_kernel(const float* __restrict__ x, float* __restrict__ y, int n, int h, int w, int c,
+                                  int oh, int ow) {
+  const int c4n = c >> 2;
+  const long long total = (long long)n * oh * ow * c4n;
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(e % c4n);
+    long long p = e / c4n;
+    const int ox = (int)(p % ow);
+    p /= ow;
+    const int oy = (int)(p % oh), b = (int)(p / oh);
+    *(f32x4*)(y + e * 4) = *(const f32x4*)(x + (((size_t)b * h + oy * 2) * w + ox * 2) * c + c4 * 4);
+  }
+}
+
+__global__ void fill_kernel(float* x, long long n, float v) {
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x)
+    x[e] = v;
+}
+
+}  // namespace
+
+// ======================================================================================== C ABI
+extern "C" {
+
+int hnd_pack_weights(const float* src, float* dst, int cout, int cin, int kh, int kw, int transposed, int chan_pad,
+                     int i0, int istep, int ni, int j0, int jstep, int nj, void* stream) {
+  HND_REQUIRE(src && dst, "hnd_pack_weights: null pointer");
+  HND_REQUIRE(cout > 0 && cin > 0 && kh > 0 && kw > 0 && ni > 0 && nj > 0 && istep > 0 && jstep > 0,
+              "hnd_pack_weights: bad geometry");
+  HND_REQUIRE(i0 >= 0 && i0 + (ni - 1) * istep < kh && j0 >= 0 && j0 + (nj - 1) * jstep < kw,
+              "hnd_pack_weights: tap sub-grid outside the kernel");
+  const int chans = transposed ? cout : cin, rows = transposed ? cin : cout;
+  HND_REQUIRE(chan_pad >= chans, "hnd_pack_weights: chan_pad < channels");
+  const int rows_pad = (rows + 63) / 64 * 64;
+  const int kdim = (ni * nj * chan_pad + 31) / 32 * 32;
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(grid_for((long long)rows_pad * kdim)), dim3(256), 0,
+                     hnd::as_stream(stream), src, dst, cout, cin, kh, kw, transposed, chan_pad, i0, istep, ni, j0,
+                     jstep, nj, rows_pad, kdim);
+  return hnd::check_launch("hnd_pack_weights");
+}
+
+int hnd_fbn_fold(const float* weight, const float* bias, const float* mean, const float* var, float* scale,
+                 float* shift, int c, int cs, float eps, void* stream) {
+  HND_REQUIRE(weight && bias && mean && var && scale && shift && c > 0 && cs >= c, "hnd_fbn_fold: bad arguments");
+  hipLaunchKernelGGL(fbn_fold_kernel, dim3((cs + 255) / 256), dim3(256), 0, hnd::as_stream(stream), weight, bias, mean,
+                     var, scale, shift, c, cs, eps);
+  return hnd::check_launch("hnd_fbn_fold");
+}
+
+int hnd_transform_image(const float* src, int h, int w, float* dst, int index, int out_h, int out_w, int hp, int wp,
+                        float scale_h, float scale_w, const float mean[3], const float std[3], void* stream) {
+  HND_REQUIRE(src && dst && mean && std, "hnd_transform_image: null pointer");
+  HND_REQUIRE(h > 0 && w > 0 && out_h > 0 && out_w > 0 && out_h <= hp && out_w <= wp && index >= 0,
+              "hnd_transform_image: bad geometry (out %dx%d, padded %dx%d)", out_h, out_w, hp, wp);
+  TransformArgs a;
+  a.src = src;
+  a.dst = dst + (size_t)index * hp * wp * 4;
+  a.h = h; a.w = w; a.out_h = out_h; a.out_w = out_w; a.hp = hp; a.wp = wp;
+  a.rh = scale_h; a.rw = scale_w;
+  for (int i = 0; i < 3; ++i) { a.mean[i] = mean[i]; a.std[i] = std[i]; a.inv_unused[i] = 0.f; }
+  hipLaunchKernelGGL(transform_kernel, dim3(grid_for((long long)hp * wp)), dim3(256), 0, hnd::as_stream(stream), a);
+  return hnd::check_launch("hnd_transform_image");
+}
+
+int hnd_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* idx, int n, int h, int w, int c, int oh, int ow,
+                         void* stream) {
+  HND_REQUIRE(x && y && idx, "hnd_maxpool3x3s2_fwd: null pointer");
+  HND_REQUIRE(c % 4 == 0 && oh == (h + 2 - 3) / 2 + 1 && ow == (w + 2 - 3) / 2 + 1,
+              "hnd_maxpool3x3s2_fwd: bad geometry");
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for((long long)n * oh * ow * (c / 4))), dim3(256), 0,
+                     hnd::as_stream(stream), x, y, idx, n, h, w, c, oh, ow);
+  return hnd::check_launch("hnd_maxpool3x3s2_fwd");
+}
+
+int hnd_maxpool3x3s2_bwd_relu_scale(const float* dy, const uint8_t* idx, const float* act, const float* fbn_scale,
+                                    float* dx, int n, int h, int w, int c, int oh, int ow, void* stream) {
+  HND_REQUIRE(dy && idx && act && fbn_scale && dx, "hnd_maxpool3x3s2_bwd_relu_scale: null pointer");
+  HND_REQUIRE(c % 4 == 0, "hnd_maxpool3x3s2_bwd_relu_scale: c %% 4 != 0");
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for((long long)n * h * w * (c / 4))), dim3(256), 0,
+                     hnd::as_stream(stream), dy, idx, act, fbn_scale, dx, n, h, w, c, oh, ow);
+  return hnd::check_launch("hnd_maxpool3x3s2_bwd_relu_scale");
+}
+
+int hnd_bn_finalize(const float* partials, int ntiles, int c, int cs, int64_t count, const float* gamma,
+                    const float* beta, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                    float momentum, float eps, float* scale, float* shift, float* save_mean, float* save_rstd,
+                    void* stream) {
+  HND_REQUIRE(partials && gamma && beta && scale && shift && save_mean && save_rstd, "hnd_bn_finalize: null pointer");
+  HND_REQUIRE(ntiles > 0 && c > 0 && cs >= c && count > 0, "hnd_bn_finalize: bad sizes");
+  HND_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "hnd_bn_finalize: running stats mismatch");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((cs + 3) / 4), dim3(256), 0, hnd::as_stream(stream), partials, ntiles, c,
+                     cs, (double)count, gamma, beta, running_mean, running_var, (long long*)num_batches_tracked,
+                     momentum, eps, scale, shift, save_mean, save_rstd);
+  return hnd::check_launch("hnd_bn_finalize");
+}
+
+int hnd_affine_relu(const float* x, const float* scale, const float* shift, float* y, int64_t npix, int cs, int relu,
+                    void* stream) {
+  HND_REQUIRE(x && scale && shift && y && npix > 0 && cs > 0 && cs % 4 == 0, "hnd_affine_relu: bad arguments");
+  const long long n4 = (long long)npix * (cs / 4);
+  hipLaunchKernelGGL(affine_relu_kernel, dim3(grid_for(n4)), dim3(256), 0, hnd::as_stream(stream), x, scale, shift, y,
+                     n4, cs / 4, relu);
+  return hnd::check_launch("hnd_affine_relu");
+}
+
+int hnd_bn_bwd_ntiles(int64_t npix) { return (int)((npix + kBnTilePix - 1) / kBnTilePix); }
+
+int hnd_bn_bwd_reduce(const float* g, const float* x, const float* scale, const float* shift, const float* mean,
+                      const float* rstd, int relu, int64_t npix, int cs, float* partials, void* stream) {
+  HND_REQUIRE(g && x && scale && shift && mean && rstd && partials, "hnd_bn_bwd_reduce: null pointer");
+  HND_REQUIRE(npix > 0 && cs % 4 == 0 && cs <= 1024 && 256 % (cs / 4) == 0,
+              "hnd_bn_bwd_reduce: channel stride %d must be 4*2^k <= 1024", cs);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(hnd_bn_bwd_ntiles(npix)), dim3(256), 0, hnd::as_stream(stream), g, x,
+                     scale, shift, mean, rstd, relu, (long long)npix, cs, partials);
+  return hnd::check_launch("hnd_bn_bwd_reduce");
+}
+
+int hnd_bn_bwd_finalize(const float* partials, int ntiles, int c, int cs, int64_t count, const float* gamma,
+                        const float* mean, const float* rstd, float* dgamma, float* dbeta, float* k123, void* stream) {
+  HND_REQUIRE(partials && gamma && mean && rstd && dgamma && dbeta && k123, "hnd_bn_bwd_finalize: null pointer");
+  HND_REQUIRE(ntiles > 0 && c > 0 && cs >= c && count > 0, "hnd_bn_bwd_finalize: bad sizes");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((cs + 3) / 4), dim3(256), 0, hnd::as_stream(stream), partials, ntiles,
+                     c, cs, (double)count, gamma, mean, rstd, dgamma, dbeta, k123);
+  return hnd::check_launch("hnd_bn_bwd_finalize");
+}
+
+int hnd_bn_bwd_apply(const float* g, const float* x, const float* scale, const float* shift, const float* k123,
+                     int relu, float* dx, int64_t npix, int cs, void* stream) {
+  HND_REQUIRE(g && x && scale && shift && k123 && dx && npix > 0 && cs % 4 == 0, "hnd_bn_bwd_apply: bad arguments");
+  const long long n4 = (long long)npix * (cs / 4);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(n4)), dim3(256), 0, hnd::as_stream(stream), g, x, scale, shift,
+                     k123, relu, dx, n4, cs);
+  return hnd::check_launch("hnd_bn_bwd_apply");
+}
+
+size_t hnd_mse_scratch_elems(void) { return kMseBlocks; }
+
+int hnd_mse_sum_fwd_bwd(const hnd_mse_pair* pairs, int npairs, double* loss_out, double* scratch, void* stream) {
+  HND_REQUIRE(pairs && loss_out && scratch, "hnd_mse_sum_fwd_bwd: null pointer");
+  HND_REQUIRE(npairs >= 1 && npairs <= kMaxPairs, "hnd_mse_sum_fwd_bwd: 1..%d pairs supported", kMaxPairs);
+  MseArgs a;
+  a.npairs = npairs;
+  long long total = 0;
+  for (int k = 0; k < npairs; ++k) {
+    HND_REQUIRE(pairs[k].teacher && pairs[k].student && pairs[k].numel > 0 && pairs[k].numel % 4 == 0,
+                "hnd_mse_sum_fwd_bwd: pair %d invalid (numel must be a positive multiple of 4)", k);
+    a.pair[k] = pairs[k];
+    total += pairs[k].numel;
+  }
+  int used = 0;
+  for (int k = 0; k < npairs; ++k) {
+    a.first_block[k] = used;
+    long long nb = (long long)(kMseBlocks - npairs) * pairs[k].numel / total + 1;
+    const long long maxb = (pairs[k].numel / 4 + 255) / 256;
+    if (nb > maxb) nb = maxb;
+    if (nb < 1) nb = 1;
+    used += (int)nb;
+  }
+  a.first_block[npairs] = used;
+  hipStream_t s = hnd::as_stream(stream);
+  hipLaunchKernelGGL(mse_kernel, dim3(used), dim3(256), 0, s, a, scratch);
+  int rc = hnd::check_launch("hnd_mse_sum_fwd_bwd");
+  if (rc) return rc;
+  hipLaunchKernelGGL(mse_finalize_kernel, dim3(1), dim3(64 * kMaxPairs), 0, s, a, scratch, loss_out);
+  return hnd::check_launch("hnd_mse_sum_fwd_bwd(finalize)");
+}
+
+int hnd_scale_by_device_scalar(float* x, int64_t numel, const float* scale_dev, void* stream) {
+  HND_REQUIRE(x && scale_dev && numel > 0, "hnd_scale_by_device_scalar: bad arguments");
+  hipLaunchKernelGGL(scale_by_scalar_kernel, dim3(grid_for(numel)), dim3(256), 0, hnd::as_stream(stream), x,
+                     (long long)numel, scale_dev);
+  return hnd::check_launch("hnd_scale_by_device_scalar");
+}
+
+int hnd_adam_step_flat(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t numel, float lr,
+                       float beta1, float beta2, float eps, int64_t step, float grad_scale, void* stream) {
+  HND_REQUIRE(param && grad && exp_avg && exp_avg_sq && numel > 0 && step >= 1, "hnd_adam_step_flat: bad arguments");
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  const float step_size = (float)((double)lr / bc1);
+  const float bc2_sqrt = (float)sqrt(bc2);
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(numel)), dim3(256), 0, hnd::as_stream(stream), param, grad, exp_avg,
+                     exp_avg_sq, (long long)numel, step_size, beta1, beta2, eps, bc2_sqrt, grad_scale);
+  return hnd::check_launch("hnd_adam_step_flat");
+}
+
+int hnd_subsample2(const float* x, float* y, int n, int h, int w, int c, int oh, int ow, void* stream) {
+  HND_REQUIRE(x && y && c % 4 == 0 && oh == (h + 1) / 2 && ow == (w + 1) / 2, "hnd_subsample2: bad arguments");
+  hipLaunchKernelGGL(subsample2_kernel, dim3(grid_for((long long)n * oh * ow * (c / 4))), dim3(256), 0,
+                     hnd::as_stream(stream), x, y, n, h, w, c, oh, ow);
+  return hnd::check_launch("hnd_subsample2");
+}
+
+int hnd_fill(float* x, int64_t numel, float value, void* stream) {
+  HND_REQUIRE(x && numel > 0, "hnd_fill: bad arguments");
+  hipLaunchKernelGGL(fill_kernel, dim3(grid_for(numel)), dim3(256), 0, hnd::as_stream(stream), x, (long long)numel,
+                     value);
+  return hnd::check_launch("hnd_fill");
+}
+
+}  // extern "C"

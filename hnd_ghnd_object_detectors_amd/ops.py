@@ -1,0 +1,336 @@
+"""Thin Python host over the C ABI: descriptor builders and launch helpers.
+
+Tensors are torch-ROCm allocations used for STORAGE ONLY (NHWC fp32); every arithmetic op on
+the hot path goes through libhnd_hip.so.  Launch objects are built once per geometry and
+replayed each step (no per-step ctypes struct construction).
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, WgradDesc, MsePair, check
+
+_L = _lib.load()
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+def chan_pad_of(c):
+    """channel stride used for a logical channel count: the kernels take cin == 4 or cin % 32 == 0, so the
+    3-channel image / bottleneck is stored as 4 and other bottleneck widths (6, 9, 12, 15) as 32."""
+    return 4 if c <= 4 else round_up(c, 32)
+
+
+def sync_check():
+    check(_L.hnd_sync_check(stream_ptr()), 'hnd_sync_check')
+
+
+def device_arch():
+    return (_L.hnd_device_arch() or b'').decode()
+
+
+# --------------------------------------------------------------------------------------- weights
+class PackedWeight(object):
+    """K-contiguous GEMM operand made by hnd_pack_weights."""
+    __slots__ = ('buf', 'rows', 'kdim', 'ni', 'nj', 'chan_pad', 'src', 'args')
+
+    def repack(self):
+        check(_L.hnd_pack_weights(self.src.data_ptr(), self.buf.data_ptr(), *self.args, stream_ptr()),
+              'hnd_pack_weights')
+
+
+def pack_weights(w, transposed=False, chan_pad=None, taps=None):
+    """w: torch OIHW parameter (device, contiguous).  taps = (i0, istep, ni, j0, jstep, nj) or None = all."""
+    cout, cin, kh, kw = w.shape
+    assert w.is_contiguous() and w.dtype == torch.float32
+    if taps is None:
+        taps = (0, 1, kh, 0, 1, kw)
+    i0, istep, ni, j0, jstep, nj = taps
+    chans = cout if transposed else cin
+    rows = cin if transposed else cout
+    if chan_pad is None:
+        chan_pad = chan_pad_of(chans)
+    pw = PackedWeight()
+    pw.rows, pw.ni, pw.nj, pw.chan_pad, pw.src = rows, ni, nj, chan_pad, w
+    pw.kdim = round_up(ni * nj * chan_pad, 32)
+    pw.buf = torch.empty(round_up(rows, 64) * pw.kdim, dtype=torch.float32, device=w.device)
+    pw.args = (cout, cin, kh, kw, int(transposed), chan_pad, i0, istep, ni, j0, jstep, nj)
+    pw.repack()
+    return pw
+
+
+def fbn_fold(weight, bias, mean, var, eps=0.0, cs=None):
+    c = weight.numel()
+    cs = cs or c
+    scale = torch.empty(cs, dtype=torch.float32, device=weight.device)
+    shift = torch.empty(cs, dtype=torch.float32, device=weight.device)
+    check(_L.hnd_fbn_fold(ptr(weight), ptr(bias), ptr(mean), ptr(var), ptr(scale), ptr(shift), c, cs, float(eps),
+                          stream_ptr()), 'hnd_fbn_fold')
+    return scale, shift
+
+
+# --------------------------------------------------------------------------------------- conv launches
+class ConvLaunch(object):
+    """One prebuilt hnd_conv2d_igemm launch (descriptor + keep-alive references)."""
+    __slots__ = ('desc', 'ref', 'keep', 'flops')
+
+    def __init__(self, desc, keep, flops=0):
+        self.desc, self.keep, self.flops = desc, keep, flops
+        self.ref = C.byref(desc)
+
+    def run(self, stream=None):
+        rc = _L.hnd_conv2d_igemm(self.ref, stream if stream is not None else stream_ptr())
+        if rc:
+            check(rc, 'hnd_conv2d_igemm')
+
+
+def _nhwc(t):
+    assert t.dim() == 4 and t.is_contiguous() and t.dtype == torch.float32, (t.shape, t.stride(), t.dtype)
+    return t.shape
+
+
+def conv_desc(x, pw, y, *, kh, kw, oh, ow, sh, dh, bh, sw, dw, bw, cout, y_sh=1, y_oh=0, y_sw=1, y_ow=0,
+              pro_scale=None, pro_shift=None, pro_relu=False, epi_scale=None, epi_shift=None, res1=None,
+              res1_up=False, res2=None, mask=None, relu=False, stats=None):
+    """Generic descriptor (see include/hnd_hip.h).  x, y, res*, mask are NHWC tensors."""
+    n, h, w, cin = _nhwc(x)
+    ny, yh, yw, ldc = _nhwc(y)
+    assert ny == n and pw.kdim >= kh * kw * cin and pw.chan_pad == cin, (pw.kdim, kh, kw, cin, pw.chan_pad)
+    d = ConvDesc()
+    d.x, d.w, d.y = ptr(x), ptr(pw.buf), ptr(y)
+    d.pro_scale, d.pro_shift = ptr(pro_scale), ptr(pro_shift)
+    d.epi_scale, d.epi_shift = ptr(epi_scale), ptr(epi_shift)
+    d.res1, d.res2, d.mask, d.stats = ptr(res1), ptr(res2), ptr(mask), ptr(stats)
+    d.n, d.h, d.w_, d.cin = n, h, w, cin
+    d.oh, d.ow, d.yh, d.yw, d.cout, d.ldc = oh, ow, yh, yw, cout, ldc
+    d.y_sh, d.y_oh, d.y_sw, d.y_ow = y_sh, y_oh, y_sw, y_ow
+    d.kh, d.kw = kh, kw
+    d.sh, d.dh, d.bh, d.sw, d.dw, d.bw = sh, dh, bh, sw, dw, bw
+    d.kdim = pw.kdim
+    d.pro_relu, d.relu = int(pro_relu), int(relu)
+    if res1 is not None and res1_up:
+        d.res1_mode, d.res1_h, d.res1_w = 1, res1.shape[1], res1.shape[2]
+        assert res1.shape[0] == n and res1.shape[3] == ldc
+    elif res1 is not None:
+        assert tuple(res1.shape) == tuple(y.shape)
+    for t in (res2, mask):
+        assert t is None or tuple(t.shape) == tuple(y.shape)
+    if stats is not None:
+        assert stats.numel() >= stats_tiles(n * oh * ow) * 2 * cout
+    keep = (x, pw, y, pro_scale, pro_shift, epi_scale, epi_shift, res1, res2, mask, stats)
+    return ConvLaunch(d, keep, flops=2 * n * oh * ow * cout * kh * kw * cin)
+
+
+def stats_tiles(m):
+    return (m + 127) // 128
+
+
+def conv_out_size(h, k, stride, pad):
+    return (h + 2 * pad - k) // stride + 1
+
+
+def conv_forward(x, pw, y, k, stride=1, pad=0, **kw_):
+    """nn.Conv2d(k, stride, pad) forward: x [N,H,W,Cin] -> y [N,OH,OW,ldc]; cout defaults to pw.rows."""
+    kh, kwid = (k, k) if isinstance(k, int) else k
+    n, h, w, cin = x.shape
+    oh, ow = conv_out_size(h, kh, stride, pad), conv_out_size(w, kwid, stride, pad)
+    assert (y.shape[1], y.shape[2]) == (oh, ow), (y.shape, oh, ow)
+    cout = kw_.pop('cout', y.shape[3])     # pad channels get zero weight rows -> written as exact zeros
+    assert cout <= round_up(pw.rows, 64)
+    return conv_desc(x, pw, y, kh=kh, kw=kwid, oh=oh, ow=ow, sh=stride, dh=1, bh=-pad, sw=stride, dw=1, bw=-pad,
+                     cout=cout, **kw_)
+
+
+def dgrad_tap_classes(k, stride, pad):
+    """Per output parity ph: (i0, istep, ni, bh) of the taps that reach it (stride-s conv, kernel k, pad p)."""
+    out = []
+    for ph in range(stride):
+        i0 = (ph + pad) % stride
+        ni = len(range(i0, k, stride))
+        bh = (ph + pad - i0) // stride
+        out.append((i0, stride, ni, bh))
+    return out
+
+
+def conv_dgrad(dy, w_param, dx, k, stride=1, pad=0, accumulate=False, **kw_):
+    """Data gradient of nn.Conv2d(k, stride, pad): dy [N,OH,OW,Cout] -> dx [N,H,W,Cin_pad].
+    Returns (launches, packed_weights).  Stride 2 is decomposed into one dense launch per output parity.
+    With accumulate=True each launch adds into dx (res1 = dx), which also lets tap-less parities be skipped."""
+    n, h, w, ldc = dx.shape
+    cout_w, cin_w, kh, kwid = w_param.shape
+    assert kh == k and kwid == k and dy.shape[3] == chan_pad_of(cout_w)
+    launches, packs = [], []
+    classes = dgrad_tap_classes(k, stride, pad)
+    for ph, (i0, istep, ni, bh) in enumerate(classes):
+        for pw_, (j0, jstep, nj, bw) in enumerate(classes):
+            if ni == 0 or nj == 0:
+                assert accumulate, 'tap-less output parity: caller must accumulate into a defined dx'
+                continue
+            ohv, owv = len(range(ph, h, stride)), len(range(pw_, w, stride))
+            if ohv == 0 or owv == 0:
+                continue
+            pk = pack_weights(w_param, transposed=True, chan_pad=dy.shape[3], taps=(i0, istep, ni, j0, jstep, nj))
+            packs.append(pk)
+            extra = dict(kw_)
+            if accumulate:
+                extra['res1'] = dx
+            launches.append(conv_desc(dy, pk, dx, kh=ni, kw=nj, oh=ohv, ow=owv, sh=1, dh=-1, bh=bh, sw=1, dw=-1,
+                                      bw=bw, cout=ldc, y_sh=stride, y_oh=ph, y_sw=stride,
+                                      y_ow=pw_, **extra))
+    return launches, packs
+
+
+class WgradLaunch(object):
+    __slots__ = ('desc', 'ref', 'keep', 'flops')
+
+    def __init__(self, desc, keep, flops):
+        self.desc, self.keep, self.flops = desc, keep, flops
+        self.ref = C.byref(desc)
+
+    def run(self, stream=None):
+        rc = _L.hnd_conv2d_wgrad(self.ref, stream if stream is not None else stream_ptr())
+        if rc:
+            check(rc, 'hnd_conv2d_wgrad')
+
+
+def conv_wgrad(x, dy, dw, k, stride=1, pad=0, pro_scale=None, pro_shift=None, pro_relu=False, splitk=0,
+               slabs=None):
+    """dW of nn.Conv2d(k, stride, pad): x [N,H,W,Cin_pad], dy [N,OH,OW,ldy] -> dw [Cout,Cin,k,k] (torch layout)."""
+    n, h, w, cin = _nhwc(x)
+    _, oh, ow, ldy = _nhwc(dy)
+    cout, cin_real, kh, kwid = dw.shape
+    assert dw.is_contiguous() and kh == k and kwid == k
+    d = WgradDesc()
+    d.x, d.dy, d.dw = ptr(x), ptr(dy), ptr(dw)
+    d.pro_scale, d.pro_shift, d.pro_relu = ptr(pro_scale), ptr(pro_shift), int(pro_relu)
+    d.n, d.h, d.w_, d.cin, d.cin_real = n, h, w, cin, cin_real
+    d.oh, d.ow, d.cout, d.ldy = oh, ow, cout, ldy
+    d.kh, d.kw, d.stride, d.pad, d.splitk = k, k, stride, pad, splitk
+    need = _L.hnd_conv2d_wgrad_workspace(C.byref(d))
+    if slabs is None or slabs.numel() * 4 < need:
+        slabs = torch.empty((need + 3) // 4, dtype=torch.float32, device=x.device)
+    d.slabs = ptr(slabs)
+    return WgradLaunch(d, (x, dy, dw, slabs, pro_scale, pro_shift), 2 * n * oh * ow * cout * k * k * cin_real)
+
+
+def wgrad_workspace_bytes(n, h, w, cin, oh, ow, cout, k, stride, pad):
+    d = WgradDesc()
+    d.n, d.h, d.w_, d.cin, d.cin_real, d.oh, d.ow, d.cout, d.ldy = n, h, w, cin, cin, oh, ow, cout, chan_pad_of(cout)
+    d.kh, d.kw, d.stride, d.pad = k, k, stride, pad
+    return _L.hnd_conv2d_wgrad_workspace(C.byref(d))
+
+
+# --------------------------------------------------------------------------------------- elementwise
+def transform_image(src, dst, index, out_h, out_w, rscale_h, rscale_w, mean, std):
+    """src CHW fp32 -> image `index` of dst [N,Hp,Wp,4] (normalise, bilinear resize, zero pad)."""
+    c, h, w = src.shape
+    assert c == 3 and src.is_contiguous() and dst.shape[3] == 4
+    m = (C.c_float * 3)(*mean)
+    s = (C.c_float * 3)(*std)
+    check(_L.hnd_transform_image(ptr(src), h, w, ptr(dst), index, out_h, out_w, dst.shape[1], dst.shape[2],
+                                 float(rscale_h), float(rscale_w), m, s, stream_ptr()), 'hnd_transform_image')
+
+
+def maxpool_fwd(x, y, idx):
+    n, h, w, c = x.shape
+    check(_L.hnd_maxpool3x3s2_fwd(ptr(x), ptr(y), ptr(idx), n, h, w, c, y.shape[1], y.shape[2], stream_ptr()),
+          'hnd_maxpool3x3s2_fwd')
+
+
+def maxpool_bwd_relu_scale(dy, idx, act, scale, dx):
+    n, h, w, c = act.shape
+    check(_L.hnd_maxpool3x3s2_bwd_relu_scale(ptr(dy), ptr(idx), ptr(act), ptr(scale), ptr(dx), n, h, w, c,
+                                             dy.shape[1], dy.shape[2], stream_ptr()),
+          'hnd_maxpool3x3s2_bwd_relu_scale')
+
+
+def bn_finalize(partials, ntiles, c, cs, count, gamma, beta, running_mean, running_var, nbt, momentum, eps,
+                scale, shift, save_mean, save_rstd):
+    check(_L.hnd_bn_finalize(ptr(partials), ntiles, c, cs, count, ptr(gamma), ptr(beta), ptr(running_mean),
+                             ptr(running_var), ptr(nbt), momentum, eps, ptr(scale), ptr(shift), ptr(save_mean),
+                             ptr(save_rstd), stream_ptr()), 'hnd_bn_finalize')
+
+
+def affine_relu(x, scale, shift, y, relu):
+    cs = x.shape[-1]
+    check(_L.hnd_affine_relu(ptr(x), ptr(scale), ptr(shift), ptr(y), x.numel() // cs, cs, int(relu), stream_ptr()),
+          'hnd_affine_relu')
+
+
+def bn_bwd_ntiles(npix):
+    return _L.hnd_bn_bwd_ntiles(npix)
+
+
+def bn_bwd_reduce(g, x, scale, shift, mean, rstd, relu, partials):
+    cs = x.shape[-1]
+    check(_L.hnd_bn_bwd_reduce(ptr(g), ptr(x), ptr(scale), ptr(shift), ptr(mean), ptr(rstd), int(relu),
+                               x.numel() // cs, cs, ptr(partials), stream_ptr()), 'hnd_bn_bwd_reduce')
+
+
+def bn_bwd_finalize(partials, ntiles, c, cs, count, gamma, mean, rstd, dgamma, dbeta, k123):
+    check(_L.hnd_bn_bwd_finalize(ptr(partials), ntiles, c, cs, count, ptr(gamma), ptr(mean), ptr(rstd), ptr(dgamma),
+                                 ptr(dbeta), ptr(k123), stream_ptr()), 'hnd_bn_bwd_finalize')
+
+
+def bn_bwd_apply(g, x, scale, shift, k123, relu, dx):
+    cs = x.shape[-1]
+    check(_L.hnd_bn_bwd_apply(ptr(g), ptr(x), ptr(scale), ptr(shift), ptr(k123), int(relu), ptr(dx),
+                              x.numel() // cs, cs, stream_ptr()), 'hnd_bn_bwd_apply')
+
+
+class MseLaunch(object):
+    """Prebuilt multi-pair fused loss + gradient launch."""
+
+    def __init__(self, pairs, device):
+        """pairs: list of (teacher, student, grad_or_None, factor, relu_mask)."""
+        self.n = len(pairs)
+        self.arr = (MsePair * self.n)()
+        self.keep = pairs
+        for i, (t, s, g, f, rm) in enumerate(pairs):
+            assert t.numel() == s.numel() and t.is_contiguous() and s.is_contiguous()
+            self.arr[i].teacher, self.arr[i].student, self.arr[i].grad = ptr(t), ptr(s), ptr(g)
+            self.arr[i].numel, self.arr[i].factor, self.arr[i].relu_mask = t.numel(), float(f), int(rm)
+        self.out = torch.zeros(1 + self.n, dtype=torch.float64, device=device)
+        self.scratch = torch.empty(_L.hnd_mse_scratch_elems(), dtype=torch.float64, device=device)
+
+    def run(self):
+        check(_L.hnd_mse_sum_fwd_bwd(self.arr, self.n, ptr(self.out), ptr(self.scratch), stream_ptr()),
+              'hnd_mse_sum_fwd_bwd')
+        return self.out
+
+
+def scale_by_device_scalar(x, scalar_dev):
+    check(_L.hnd_scale_by_device_scalar(ptr(x), x.numel(), ptr(scalar_dev), stream_ptr()),
+          'hnd_scale_by_device_scalar')
+
+
+def adam_step_flat(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, grad_scale=1.0):
+    check(_L.hnd_adam_step_flat(ptr(param), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), param.numel(), float(lr),
+                                float(beta1), float(beta2), float(eps), int(step), float(grad_scale), stream_ptr()),
+          'hnd_adam_step_flat')
+
+
+def subsample2(x, y):
+    n, h, w, c = x.shape
+    check(_L.hnd_subsample2(ptr(x), ptr(y), n, h, w, c, y.shape[1], y.shape[2], stream_ptr()), 'hnd_subsample2')
+
+
+def fill(x, value):
+    check(_L.hnd_fill(ptr(x), x.numel(), float(value), stream_ptr()), 'hnd_fill')
+
+
+def interp_out_size(size, scale):
+    """F.interpolate(scale_factor=scale) output size: floor(size * scale) in double (torch semantics)."""
+    return int(math.floor(float(size) * scale))

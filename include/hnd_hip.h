@@ -1,0 +1,214 @@
+/*
+ * hnd_hip.h -- C ABI of libhnd_hip.so: the MI355X (gfx950) kernels behind the HND/GHND
+ * head-network-distillation step.
+ *
+ * The reference (yoshitomo-matsubara/hnd-ghnd-object-detectors) has NO native/FFI layer: every
+ * FLOP of its hot path is a torch 1.3.1 / torchvision 0.4.2 nn.Module call made from
+ *   src/mimic_runner.py:38-59      distill_model (zero_grad / backward / step)
+ *   src/distillation/tool.py:40-61 DistillationBox.forward
+ *   src/distillation/loss.py:25-34 GeneralizedCustomLoss.forward
+ *   src/models/org/rcnn.py:65-110  CustomRCNNTransform.forward, CustomRCNN.forward
+ *   src/models/custom/resnet.py:26-30,95-105 ; src/models/mimic/resnet_layer.py:40-70
+ * so each entry point below names the reference call (file:line) whose arithmetic it replaces.
+ * INTEGRATION.md shows the ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain C: pointers are DEVICE pointers into caller-owned buffers (torch-ROCm tensors in the
+ *     Python host); the library allocates nothing and keeps no pointer after return.
+ *   - activations are NHWC fp32 (physical layout of a torch channels_last tensor).
+ *   - `stream` is a hipStream_t passed as void*; every call only enqueues work on it.
+ *   - return 0 on success, a negative hnd_status otherwise; hnd_last_error_string() explains.
+ *     Nothing throws across the ABI and nothing calls exit().
+ */
+#ifndef HND_HIP_H
+#define HND_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HND_ABI_VERSION 1
+
+typedef enum hnd_status {
+  HND_OK = 0,
+  HND_ERR_INVALID = -1,   /* bad argument / unsupported geometry */
+  HND_ERR_LAUNCH = -2,    /* HIP reported an error at launch */
+  HND_ERR_ASYNC = -3      /* a previously enqueued kernel failed (see hnd_sync_check) */
+} hnd_status;
+
+const char* hnd_last_error_string(void);
+int hnd_abi_version(void);
+/* hipStreamSynchronize + hipGetLastError; surfaces asynchronous faults. */
+int hnd_sync_check(void* stream);
+/* name of the device the library sees ("gfx950..."), or "" */
+const char* hnd_device_arch(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Implicit-GEMM convolution, fp32 MFMA (v_mfma_f32_32x32x2_f32), NHWC.
+ * One kernel serves forward convs and data-gradients: the launch describes, per output pixel
+ * (oh, ow) of a *virtual* output grid and per tap (i, j), the source pixel
+ *      ih = oh*sh + i*dh + bh,   iw = ow*sw + j*dw + bw        (zero when out of range)
+ * and where the virtual pixel lands in the real output tensor
+ *      yh_idx = oh*y_sh + y_oh,  yw_idx = ow*y_sw + y_ow.
+ *   forward conv (stride s, pad p):           sh=s dh=+1 bh=-p,  y_s=1 y_o=0
+ *   dgrad of a stride-1 conv:                 sh=1 dh=-1 bh=+p   (weights packed transposed)
+ *   dgrad of a stride-2 conv: four launches, one per output parity, each with its tap subset.
+ * Replaces nn.Conv2d forward / autograd conv backward(input) reached from
+ * src/models/custom/resnet.py:96, src/models/mimic/resnet_layer.py:43-62, torchvision Bottleneck
+ * and FeaturePyramidNetwork (src/models/org/rcnn.py:391-414), autograd at src/mimic_runner.py:53.
+ *
+ * Fused prologue (on the gathered input, per input channel; padding taps stay exactly 0):
+ *      a = x*pro_scale[c] + pro_shift[c]; if (pro_relu) a = max(a, 0)
+ *   = train-mode BatchNorm2d(+ReLU) of resnet_layer.py:44-64 applied on load, or the
+ *     FrozenBatchNorm2d scale of a frozen layer during dgrad.
+ * Fused epilogue (per output channel c / element):
+ *      v = acc; v = v*epi_scale[c] + epi_shift[c]      FrozenBatchNorm2d (no eps) or conv bias
+ *      v += res1 (+ nearest-upsampled when res1_mode=1: FPN top-down path); v += res2
+ *      if (mask)  v = mask>0 ? v : 0                   ReLU backward of a frozen block
+ *      if (relu)  v = max(v, 0)
+ *      store; if (stats) per-channel partial (sum v, sum v^2) per 128-row tile -> stats[tile][2][cout]
+ *   stats feed hnd_bn_finalize (train-mode BN batch statistics without a second pass).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct hnd_conv_desc {
+  const float* x;          /* input  [n][h][w][cin]   (cin multiple of 32, or exactly 4)          */
+  const float* w;          /* packed weights [round_up(cout,64)][kdim], K contiguous (hnd_pack_weights) */
+  float* y;                /* output [n][yh][yw][ldc]                                              */
+  const float* pro_scale;  /* [cin] or NULL                                                        */
+  const float* pro_shift;  /* [cin] or NULL (treated as 0)                                         */
+  const float* epi_scale;  /* [cout] or NULL                                                       */
+  const float* epi_shift;  /* [cout] or NULL                                                       */
+  const float* res1;       /* same geometry as y (mode 0) or [n][res1_h][res1_w][ldc] (mode 1), or NULL */
+  const float* res2;       /* same geometry as y, or NULL                                          */
+  const float* mask;       /* same geometry as y, or NULL                                          */
+  float* stats;            /* [ceil(M/128)][2][cout] or NULL, M = n*oh*ow                          */
+  int32_t n, h, w_, cin;
+  int32_t oh, ow;          /* virtual output grid of this launch                                   */
+  int32_t yh, yw, cout, ldc;
+  int32_t y_sh, y_oh, y_sw, y_ow;
+  int32_t kh, kw;
+  int32_t sh, dh, bh, sw, dw, bw;
+  int32_t kdim;            /* row stride of w: kh*kw*cin rounded up to a multiple of 32            */
+  int32_t pro_relu, relu;
+  int32_t res1_mode, res1_h, res1_w;
+} hnd_conv_desc;
+
+int hnd_conv2d_igemm(const hnd_conv_desc* desc, void* stream);
+
+/* Weight gradient (autograd conv backward(weight), src/mimic_runner.py:53) of the trainable convs:
+ * student stem conv1 (custom/resnet.py:26) and the eight 2x2 convs (resnet_layer.py:43-62).
+ *      dW[co][ci][i][j] = sum_m dy[m][co] * a(m; i, j, ci),  a = prologue(x) as in the forward.
+ * Split-K implicit GEMM (K = n*oh*ow) on fp32 MFMA into `splitk` partial slabs, then a
+ * fixed-order reduce that writes the torch OIHW layout into `dw` (deterministic, no atomics). */
+typedef struct hnd_wgrad_desc {
+  const float* x;          /* conv input [n][h][w][cin] (cin multiple of 32, or 4 = padded 3)     */
+  const float* dy;         /* grad of conv output [n][oh][ow][cout]                                */
+  float* dw;               /* [cout][cin_real][kh][kw] (torch layout)                              */
+  float* slabs;            /* workspace, hnd_conv2d_wgrad_workspace() bytes                        */
+  const float* pro_scale;
+  const float* pro_shift;
+  int32_t n, h, w_, cin, cin_real;
+  int32_t oh, ow, cout, ldy;    /* ldy = channel stride of dy (>= cout; 4 for the 3-channel bottleneck) */
+  int32_t kh, kw, stride, pad;
+  int32_t pro_relu;
+  int32_t splitk;          /* 0 = choose */
+} hnd_wgrad_desc;
+
+size_t hnd_conv2d_wgrad_workspace(const hnd_wgrad_desc* desc);
+int hnd_conv2d_wgrad(const hnd_wgrad_desc* desc, void* stream);
+
+/* Re-layout torch OIHW weights [cout][cin][kh][kw] into the K-contiguous GEMM operand of
+ * hnd_conv2d_igemm.  transposed=0: rows=cout, K=(tap, cin_pad) (forward);  transposed=1: rows=cin,
+ * K=(tap, cout_pad) (dgrad).  Taps are the sub-grid i = i0 + a*istep (a < ni), j likewise, in
+ * (a, b) order, so stride-2 dgrad parity classes get their own operand.  Rows are padded to a
+ * multiple of 64 and K to a multiple of 32 with zeros; dst must hold rows_pad*kdim floats. */
+int hnd_pack_weights(const float* src, float* dst, int cout, int cin, int kh, int kw, int transposed,
+                     int chan_pad, int i0, int istep, int ni, int j0, int jstep, int nj, void* stream);
+
+/* FrozenBatchNorm2d (torchvision 0.4.2 ops/misc.py, built at src/models/org/rcnn.py:391,394):
+ *   scale = weight * rsqrt(running_var + eps),  shift = bias - running_mean*scale,
+ * eps = 0 for FrozenBatchNorm2d (0.4.2 has none); eps = 1e-5 folds an eval-mode nn.BatchNorm2d.
+ * scale/shift have cs >= c entries, pad entries are zeroed. */
+int hnd_fbn_fold(const float* weight, const float* bias, const float* mean, const float* var,
+                 float* scale, float* shift, int c, int cs, float eps, void* stream);
+
+/* CustomRCNNTransform.forward for one image (src/models/org/rcnn.py:65-82 + torchvision
+ * GeneralizedRCNNTransform.normalize / batch_images): (x-mean)/std, bilinear resize
+ * (align_corners=False, scale as passed to F.interpolate) to out_h x out_w, written into image
+ * `index` of the zero-padded NHWC4 batch [n][hp][wp][4] (4th channel 0). src is CHW fp32. */
+int hnd_transform_image(const float* src, int h, int w, float* dst, int index, int out_h, int out_w,
+                        int hp, int wp, float scale_h, float scale_w, const float mean[3], const float std[3],
+                        void* stream);
+
+/* nn.MaxPool2d(3, 2, 1) (custom/resnet.py:30,99) NHWC; idx (uint8 tap 0..8) kept for backward. */
+int hnd_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* idx, int n, int h, int w, int c, int oh, int ow,
+                         void* stream);
+/* backward of maxpool -> ReLU -> FrozenBN of the stem in one pass:
+ *   dx = (sum of pooled grads routed here) * [act > 0] * fbn_scale[c]     (act = stem ReLU output) */
+int hnd_maxpool3x3s2_bwd_relu_scale(const float* dy, const uint8_t* idx, const float* act, const float* fbn_scale,
+                                    float* dx, int n, int h, int w, int c, int oh, int ow, void* stream);
+
+/* Train-mode nn.BatchNorm2d (resnet_layer.py:44-64; eps 1e-5, momentum 0.1):
+ * finalize batch statistics from the conv epilogue partials.  Outputs scale=gamma*rstd,
+ * shift=beta-mean*scale (consumed as the next conv's prologue), saves mean/rstd for backward and
+ * updates running_mean/var (unbiased var) and num_batches_tracked exactly like torch. */
+/* `c` real channels; `cs` = channel stride of the activation tensor / partials (cs==c except the
+ * 3-channel bottleneck stored as 4).  gamma/beta/running_* have c entries; scale/shift/save_* have cs
+ * entries and are zeroed for the pad channels. */
+int hnd_bn_finalize(const float* partials, int ntiles, int c, int cs, int64_t count, const float* gamma,
+                    const float* beta, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                    float momentum, float eps, float* scale, float* shift, float* save_mean, float* save_rstd,
+                    void* stream);
+/* y = x*scale[ch] + shift[ch] (+ReLU), NHWC with channel stride cs (multiple of 4). */
+int hnd_affine_relu(const float* x, const float* scale, const float* shift, float* y, int64_t npix, int cs,
+                    int relu, void* stream);
+
+/* BatchNorm backward, pass 1: with d = g * [ (x*scale+shift) > 0 ] (mask only when relu),
+ * partial sums over pixels of  d  and  d * xhat  (xhat = (x-mean)*rstd) per channel. */
+int hnd_bn_bwd_ntiles(int64_t npix);
+int hnd_bn_bwd_reduce(const float* g, const float* x, const float* scale, const float* shift,
+                      const float* mean, const float* rstd, int relu, int64_t npix, int cs,
+                      float* partials /* [hnd_bn_bwd_ntiles][2][cs] */, void* stream);
+/* pass 2 (finalize): dgamma, dbeta and the per-channel coefficients of
+ *   dx = k1*d + k2*x + k3,  k1 = gamma*rstd, k2 = -k1*rstd*dgamma/N, k3 = k1*(mean*rstd*dgamma - dbeta)/N */
+int hnd_bn_bwd_finalize(const float* partials, int ntiles, int c, int cs, int64_t count, const float* gamma,
+                        const float* mean, const float* rstd, float* dgamma, float* dbeta,
+                        float* k123 /* [3][cs] */, void* stream);
+/* pass 3: dx = k1*d + k2*x + k3 with the same mask recomputed. */
+int hnd_bn_bwd_apply(const float* g, const float* x, const float* scale, const float* shift, const float* k123,
+                     int relu, float* dx, int64_t npix, int cs, void* stream);
+
+/* GHND/HND loss (src/distillation/loss.py:27-33 with nn.MSELoss(reduction='sum')): for up to 8
+ * (teacher, student) pairs  loss = sum_k factor_k * sum (t_k - s_k)^2, and in the same pass the
+ * gradient w.r.t. the student tensor  grad_k = 2*factor_k*(s_k - t_k)  (masked by s_k>0 when
+ * relu_mask, i.e. already pushed through the ReLU that produced s_k).
+ * loss_out: device double[1 + npairs] = total, per-term.  scratch: device double, hnd_mse_scratch_elems(). */
+typedef struct hnd_mse_pair {
+  const float* teacher;
+  const float* student;
+  float* grad;            /* may be NULL */
+  int64_t numel;
+  float factor;
+  int32_t relu_mask;
+} hnd_mse_pair;
+size_t hnd_mse_scratch_elems(void);
+int hnd_mse_sum_fwd_bwd(const hnd_mse_pair* pairs, int npairs, double* loss_out, double* scratch, void* stream);
+/* grad *= *scale_dev unless *scale_dev == 1 (autograd's grad_output of the scalar loss) */
+int hnd_scale_by_device_scalar(float* x, int64_t numel, const float* scale_dev, void* stream);
+
+/* torch.optim.Adam.step (func_util.get_optimizer at src/mimic_runner.py:67-68; defaults
+ * betas (0.9,0.999), eps 1e-8, no weight decay, no amsgrad) over one flat arena; `step` is the
+ * 1-based step count; grad_scale folds the 1/world_size of the DDP gradient average. */
+int hnd_adam_step_flat(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t numel,
+                       float lr, float beta1, float beta2, float eps, int64_t step, float grad_scale, void* stream);
+
+/* LastLevelMaxPool: F.max_pool2d(x, 1, 2, 0) == x[:, ::2, ::2] (torchvision FPN). */
+int hnd_subsample2(const float* x, float* y, int n, int h, int w, int c, int oh, int ow, void* stream);
+int hnd_fill(float* x, int64_t numel, float value, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HND_HIP_H */

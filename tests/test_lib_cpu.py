@@ -1,0 +1,40 @@
+"""CPU: the C-ABI library builds, loads, and exports every symbol include/hnd_hip.h declares."""
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, 'include', 'hnd_hip.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(hnd_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_library_exports_every_declared_symbol():
+    import __graft_entry__ as g
+    g.build()
+    from hnd_ghnd_object_detectors_amd import _lib
+    lib = _lib.load()
+    declared = _declared()
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert sorted(_lib.EXPORTED_SYMBOLS) == declared
+    assert lib.hnd_abi_version() == 1
+
+
+def test_ctypes_structs_match_header_layout():
+    from hnd_ghnd_object_detectors_amd import _lib
+    import ctypes
+    assert ctypes.sizeof(_lib.ConvDesc) == 11 * 8 + 28 * 4
+    assert ctypes.sizeof(_lib.WgradDesc) == 6 * 8 + 15 * 4 + 4     # padded to 8
+    assert ctypes.sizeof(_lib.MsePair) == 3 * 8 + 8 + 4 + 4
+
+
+def test_invalid_arguments_are_reported_not_thrown():
+    from hnd_ghnd_object_detectors_amd import _lib
+    lib = _lib.load()
+    assert lib.hnd_conv2d_igemm(None, None) == -1
+    assert b'null descriptor' in lib.hnd_last_error_string()
+    assert lib.hnd_adam_step_flat(None, None, None, None, 0, 0.0, 0.0, 0.0, 0.0, 0, 1.0, None) == -1

@@ -1,0 +1,407 @@
+"""GPU: every C-ABI kernel against a plain PyTorch fp32 (CPU) reference of the same op.
+
+Tolerances are written per test; convs are fp32 MFMA (exact fp32 products, different summation
+order than oneDNN) so 1e-4 relative-to-max is generous; the north-star bar is 1e-3.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = 'cuda:0'
+
+
+@pytest.fixture(scope='module')
+def ops():
+    assert torch.cuda.is_available(), 'GPU tests need a device'
+    from hnd_ghnd_object_detectors_amd import ops as o
+    assert 'gfx950' in o.device_arch(), o.device_arch()
+    return o
+
+
+def nhwc(t_nchw, cpad=None):
+    """NCHW cpu tensor -> NHWC device tensor (channels zero-padded to cpad)."""
+    t = t_nchw.permute(0, 2, 3, 1).contiguous()
+    if cpad is not None and cpad != t.shape[-1]:
+        t = F.pad(t, (0, cpad - t.shape[-1]))
+    return t.to(DEV).contiguous()
+
+
+def nchw(t_nhwc, c=None):
+    t = t_nhwc.cpu()
+    if c is not None:
+        t = t[..., :c]
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+def relerr(a, b):
+    return float((a.double() - b.double()).abs().max() / (b.double().abs().max() + 1e-30))
+
+
+def gen(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+CONV_CASES = [
+    # n, cin, h, w, cout, k, stride, pad
+    (2, 64, 13, 17, 64, 2, 1, 1),      # encoder.0-like (padded 2x2, odd sizes)
+    (2, 64, 14, 18, 256, 2, 1, 1),     # encoder.2
+    (1, 256, 9, 11, 64, 2, 1, 1),      # encoder.5
+    (2, 64, 10, 12, 3, 2, 1, 1),       # encoder.7: cout 3 stored as 4
+    (2, 3, 12, 14, 64, 2, 1, 0),       # decoder.2: cin 3 stored as 4
+    (2, 128, 11, 13, 256, 2, 1, 0),    # decoder.7
+    (1, 256, 10, 12, 256, 2, 1, 0),    # decoder.9
+    (2, 3, 37, 45, 64, 7, 2, 3),       # stem
+    (2, 64, 16, 20, 64, 3, 1, 1),      # layer1 3x3
+    (2, 128, 17, 21, 128, 3, 2, 1),    # stride-2 3x3 (odd input)
+    (2, 256, 8, 10, 512, 1, 2, 0),     # stride-2 1x1 downsample
+    (1, 512, 7, 9, 128, 1, 1, 0),      # 1x1
+    (3, 64, 33, 41, 64, 1, 1, 0),      # M not a multiple of 128
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv_forward_plain(ops, case):
+    n, cin, h, w, cout, k, s, p = case
+    g = gen(sum(case))
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k)
+    ref = F.conv2d(x, wt, None, s, p)
+    xd = nhwc(x, ops.chan_pad_of(cin))
+    wd = wt.to(DEV).contiguous()
+    pw = ops.pack_weights(wd, chan_pad=ops.chan_pad_of(cin))
+    y = torch.full((n, ref.shape[2], ref.shape[3], ops.chan_pad_of(cout)), float('nan'), device=DEV)
+    ops.conv_forward(xd, pw, y, k, s, p).run()
+    ops.sync_check()
+    got = nchw(y, cout)
+    assert relerr(got, ref) < 1e-4, relerr(got, ref)
+    if ops.chan_pad_of(cout) != cout:
+        assert float(y[..., cout:].abs().max()) == 0.0
+
+
+def test_conv_forward_fused_prologue_epilogue_stats(ops):
+    """train-BN on load (+ReLU, zero padding AFTER normalisation), FBN epilogue, residuals, mask, ReLU, stats."""
+    g = gen(7)
+    n, cin, h, w, cout, k, s, p = 2, 64, 15, 19, 128, 2, 1, 1
+    x = torch.randn(n, cin, h, w, generator=g)
+    ps, pb = torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k)
+    es, eb = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
+    a = F.relu(x * ps[None, :, None, None] + pb[None, :, None, None])
+    conv = F.conv2d(a, wt, None, s, p)
+    r1, r2 = torch.randn(conv.shape, generator=g), torch.randn(conv.shape, generator=g)
+    mk = torch.randn(conv.shape, generator=g)
+    pre = conv * es[None, :, None, None] + eb[None, :, None, None] + r1 + r2
+    ref = F.relu(torch.where(mk > 0, pre, torch.zeros_like(pre)))
+    xd, wd = nhwc(x), wt.to(DEV)
+    pw = ops.pack_weights(wd)
+    y = torch.empty(n, conv.shape[2], conv.shape[3], cout, device=DEV)
+    m = n * conv.shape[2] * conv.shape[3]
+    stats = torch.zeros(ops.stats_tiles(m), 2, cout, device=DEV)
+    ops.conv_forward(xd, pw, y, k, s, p, pro_scale=ps.to(DEV), pro_shift=pb.to(DEV), pro_relu=True,
+                     epi_scale=es.to(DEV), epi_shift=eb.to(DEV), res1=nhwc(r1), res2=nhwc(r2), mask=nhwc(mk),
+                     relu=True, stats=stats).run()
+    ops.sync_check()
+    assert relerr(nchw(y), ref) < 1e-4
+    st = stats.cpu().double().sum(0)
+    assert relerr(st[0], ref.double().sum((0, 2, 3))) < 1e-4
+    assert relerr(st[1], (ref.double() ** 2).sum((0, 2, 3))) < 1e-4
+
+
+def test_conv_forward_upsampled_residual(ops):
+    """FPN top-down: lateral 1x1 conv + bias + nearest-upsampled coarser map."""
+    g = gen(8)
+    n, cin, h, w, cout = 2, 512, 10, 14, 256
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 1, 1, generator=g) / math.sqrt(cin)
+    b = torch.randn(cout, generator=g)
+    coarse = torch.randn(n, cout, 5, 7, generator=g)
+    ref = F.conv2d(x, wt, b) + F.interpolate(coarse, size=(h, w), mode='nearest')
+    y = torch.empty(n, h, w, cout, device=DEV)
+    ops.conv_forward(nhwc(x), ops.pack_weights(wt.to(DEV)), y, 1, 1, 0, epi_shift=b.to(DEV), res1=nhwc(coarse),
+                     res1_up=True).run()
+    ops.sync_check()
+    assert relerr(nchw(y), ref) < 1e-4
+
+
+DGRAD_CASES = [
+    (2, 64, 13, 17, 64, 2, 1, 1),
+    (2, 64, 10, 12, 3, 2, 1, 1),       # dy has 3 (4) channels
+    (2, 3, 12, 14, 64, 2, 1, 0),       # dx has 3 (4) channels
+    (1, 256, 10, 12, 256, 2, 1, 0),
+    (2, 64, 16, 20, 64, 3, 1, 1),
+    (2, 128, 17, 21, 128, 3, 2, 1),    # stride 2, odd input
+    (2, 128, 16, 20, 128, 3, 2, 1),    # stride 2, even input
+    (1, 512, 7, 9, 128, 1, 1, 0),
+]
+
+
+@pytest.mark.parametrize('case', DGRAD_CASES)
+def test_conv_dgrad(ops, case):
+    n, cin, h, w, cout, k, s, p = case
+    g = gen(1000 + sum(case))
+    x = torch.randn(n, cin, h, w, generator=g, requires_grad=True)
+    wt = torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k)
+    out = F.conv2d(x, wt, None, s, p)
+    dy = torch.randn(out.shape, generator=g)
+    out.backward(dy)
+    dx = torch.full((n, h, w, ops.chan_pad_of(cin)), float('nan'), device=DEV)
+    launches, _ = ops.conv_dgrad(nhwc(dy, ops.chan_pad_of(cout)), wt.to(DEV).contiguous(), dx, k, s, p)
+    for l in launches:
+        l.run()
+    ops.sync_check()
+    assert relerr(nchw(dx, cin), x.grad) < 1e-4
+
+
+def test_conv_dgrad_1x1_stride2_accumulate_with_mask(ops):
+    """downsample dgrad adds into an existing gradient at even pixels only, then the block mask applies."""
+    g = gen(5)
+    n, cin, h, w, cout = 2, 256, 9, 12, 512
+    x = torch.randn(n, cin, h, w, generator=g, requires_grad=True)
+    wt = torch.randn(cout, cin, 1, 1, generator=g) / math.sqrt(cin)
+    sc = torch.rand(cout, generator=g) + 0.5
+    out = F.conv2d(x, wt, None, 2, 0)
+    dy = torch.randn(out.shape, generator=g)
+    out.backward(dy * sc[None, :, None, None])
+    base = torch.randn(n, cin, h, w, generator=g)
+    mk = torch.randn(n, cin, h, w, generator=g)
+    ref = torch.where(mk > 0, base + x.grad, torch.zeros_like(base))
+    ref_odd = base          # pixels not reached by the stride-2 1x1 keep the previous value
+    dx = nhwc(base)
+    launches, _ = ops.conv_dgrad(nhwc(dy), wt.to(DEV).contiguous(), dx, 1, 2, 0, accumulate=True,
+                                 pro_scale=sc.to(DEV), mask=nhwc(mk))
+    assert len(launches) == 1
+    launches[0].run()
+    ops.sync_check()
+    got = nchw(dx)
+    assert relerr(got[:, :, ::2, ::2], ref[:, :, ::2, ::2]) < 1e-4
+    assert torch.equal(got[:, :, 1::2, :], ref_odd[:, :, 1::2, :])
+
+
+WGRAD_CASES = [
+    (2, 64, 13, 17, 64, 2, 1, 1),
+    (2, 64, 14, 18, 256, 2, 1, 1),
+    (1, 256, 9, 11, 64, 2, 1, 1),
+    (2, 64, 10, 12, 3, 2, 1, 1),
+    (2, 3, 12, 14, 64, 2, 1, 0),
+    (2, 128, 11, 13, 256, 2, 1, 0),
+    (2, 3, 37, 45, 64, 7, 2, 3),
+]
+
+
+@pytest.mark.parametrize('case', WGRAD_CASES)
+@pytest.mark.parametrize('splitk', [0, 1, 3])
+def test_conv_wgrad(ops, case, splitk):
+    n, cin, h, w, cout, k, s, p = case
+    g = gen(2000 + sum(case))
+    x = torch.randn(n, cin, h, w, generator=g)
+    ps, pb = torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g) * 0.3
+    wt = (torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k)).requires_grad_(True)
+    a = F.relu(x * ps[None, :, None, None] + pb[None, :, None, None])
+    out = F.conv2d(a, wt, None, s, p)
+    dy = torch.randn(out.shape, generator=g)
+    out.backward(dy)
+    cp = ops.chan_pad_of(cin)
+    psd = F.pad(ps, (0, cp - cin)).to(DEV)
+    pbd = F.pad(pb, (0, cp - cin)).to(DEV)
+    dw = torch.full((cout, cin, k, k), float('nan'), device=DEV)
+    ops.conv_wgrad(nhwc(x, cp), nhwc(dy, ops.chan_pad_of(cout)), dw, k, s, p, pro_scale=psd, pro_shift=pbd,
+                   pro_relu=True, splitk=splitk).run()
+    ops.sync_check()
+    assert relerr(dw.cpu(), wt.grad) < 1e-4
+
+
+def test_wgrad_is_deterministic(ops):
+    g = gen(3)
+    x = torch.randn(2, 64, 40, 50, generator=g)
+    dy = torch.randn(2, 128, 39, 49, generator=g)
+    xd, dyd = nhwc(x), nhwc(dy)
+    outs = []
+    for _ in range(2):
+        dw = torch.empty(128, 64, 2, 2, device=DEV)
+        ops.conv_wgrad(xd, dyd, dw, 2, 1, 0).run()
+        outs.append(dw.cpu())
+    assert torch.equal(outs[0], outs[1])
+
+
+def test_pack_weights_layouts(ops):
+    g = gen(4)
+    wt = torch.randn(5, 3, 3, 3, generator=g)
+    pw = ops.pack_weights(wt.to(DEV).contiguous())
+    buf = pw.buf.cpu().view(64, pw.kdim)
+    assert pw.kdim == 64 and pw.chan_pad == 4
+    ref = torch.zeros(64, 64)
+    ref[:5, :36] = F.pad(wt.permute(0, 2, 3, 1), (0, 1)).reshape(5, 36)
+    assert torch.equal(buf, ref)
+    pt = ops.pack_weights(wt.to(DEV).contiguous(), transposed=True, chan_pad=8, taps=(1, 2, 1, 0, 2, 2))
+    buf = pt.buf.cpu().view(64, pt.kdim)
+    ref = torch.zeros(64, pt.kdim)
+    sub = wt[:, :, 1:2, 0::2]                                  # [o, i, 1, 2]
+    ref[:3, :16] = F.pad(sub.permute(1, 2, 3, 0), (0, 3)).reshape(3, 16)
+    assert torch.equal(buf, ref)
+
+
+def test_fbn_fold(ops):
+    g = gen(6)
+    w, b, m = torch.rand(64, generator=g), torch.randn(64, generator=g), torch.randn(64, generator=g)
+    v = torch.rand(64, generator=g) + 0.5
+    sc, sh = ops.fbn_fold(w.to(DEV), b.to(DEV), m.to(DEV), v.to(DEV))
+    ops.sync_check()
+    rs = w * v.rsqrt()
+    assert relerr(sc.cpu(), rs) < 1e-6 and relerr(sh.cpu(), b - m * rs) < 1e-6
+
+
+@pytest.mark.parametrize('shape,size,max_size', [((3, 60, 90), 64, 128), ((3, 56, 100), 64, 128),
+                                                  ((3, 64, 96), 64, 128), ((3, 50, 70), 80, 100)])
+def test_transform_matches_oracle(ops, shape, size, max_size):
+    from oracle import hnd_oracle as O
+    img = torch.rand(*shape, generator=gen(9))
+    ref, sizes = O.transform_images([img], min_size=(size,), max_size=max_size)
+    lo, hi = float(min(shape[1:])), float(max(shape[1:]))
+    scale = size / lo
+    if hi * scale > max_size:
+        scale = max_size / hi
+    oh, ow = ops.interp_out_size(shape[1], scale), ops.interp_out_size(shape[2], scale)
+    assert (oh, ow) == sizes[0]
+    dst = torch.full((1, ref.shape[2], ref.shape[3], 4), float('nan'), device=DEV)
+    ops.transform_image(img.to(DEV), dst, 0, oh, ow, 1.0 / scale, 1.0 / scale, O.IMAGE_MEAN, O.IMAGE_STD)
+    ops.sync_check()
+    got = nchw(dst, 3)
+    assert float((got - ref).abs().max()) < 2e-5
+    assert float(dst[..., 3].abs().max()) == 0.0
+
+
+def test_maxpool_fwd_bwd(ops):
+    g = gen(10)
+    n, c, h, w = 2, 64, 21, 30
+    x = F.relu(torch.randn(n, c, h, w, generator=g)).requires_grad_(True)     # many exact-zero ties, as after ReLU
+    y = F.max_pool2d(x, 3, 2, 1)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    xd = nhwc(x.detach())
+    yd = torch.empty(n, y.shape[2], y.shape[3], c, device=DEV)
+    idx = torch.empty(n, y.shape[2], y.shape[3], c, dtype=torch.uint8, device=DEV)
+    ops.maxpool_fwd(xd, yd, idx)
+    assert torch.equal(nchw(yd), y.detach())
+    sc = torch.rand(c, generator=g) + 0.5
+    dx = torch.empty(n, h, w, c, device=DEV)
+    ops.maxpool_bwd_relu_scale(nhwc(dy), idx, xd, sc.to(DEV), dx)
+    ops.sync_check()
+    ref = x.grad * (x.detach() > 0) * sc[None, :, None, None]
+    assert relerr(nchw(dx), ref) < 1e-6
+
+
+@pytest.mark.parametrize('c,relu', [(64, False), (256, True), (3, True), (128, False)])
+def test_train_bn_forward_backward(ops, c, relu):
+    """stats from the conv epilogue -> finalize -> apply; backward reduce/finalize/apply; vs torch BN autograd."""
+    g = gen(11 + c)
+    n, h, w = 2, 13, 17
+    cs = ops.chan_pad_of(c)
+    x = (torch.randn(n, c, h, w, generator=g) * 1.7 + 0.4).requires_grad_(True)
+    gamma = (torch.rand(c, generator=g) + 0.5).requires_grad_(True)
+    beta = torch.randn(c, generator=g).requires_grad_(True)
+    rm, rv = torch.randn(c, generator=g), torch.rand(c, generator=g) + 0.5
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    out = F.batch_norm(x, rm_ref, rv_ref, gamma, beta, True, 0.1, 1e-5)
+    if relu:
+        out = F.relu(out)
+    gout = torch.randn(out.shape, generator=g)
+    out.backward(gout)
+
+    xd = nhwc(x.detach(), cs)
+    npix = n * h * w
+    # partial statistics as the conv epilogue would emit them (per 128-pixel tile)
+    nt = ops.stats_tiles(npix)
+    flat = xd.view(npix, cs)
+    part = torch.zeros(nt, 2, cs, device=DEV)
+    for t in range(nt):
+        blk = flat[t * 128:(t + 1) * 128]
+        part[t, 0], part[t, 1] = blk.sum(0), (blk * blk).sum(0)
+    dev = lambda t: t.detach().to(DEV).contiguous()
+    gam, bet, rmd, rvd = dev(gamma), dev(beta), dev(rm), dev(rv)
+    nbt = torch.zeros((), dtype=torch.int64, device=DEV)
+    scale, shift, mean, rstd = (torch.empty(cs, device=DEV) for _ in range(4))
+    ops.bn_finalize(part, nt, c, cs, npix, gam, bet, rmd, rvd, nbt, 0.1, 1e-5, scale, shift, mean, rstd)
+    y = torch.empty_like(xd)
+    ops.affine_relu(xd, scale, shift, y, relu)
+    ops.sync_check()
+    assert relerr(nchw(y, c), out.detach()) < 1e-5
+    assert relerr(rmd.cpu(), rm_ref) < 1e-5 and relerr(rvd.cpu(), rv_ref) < 1e-5 and int(nbt) == 1
+    if cs != c:
+        assert float(scale[c:].abs().max()) == 0 and float(y[..., c:].abs().max()) == 0
+
+    gd = nhwc(gout, cs)
+    ntb = ops.bn_bwd_ntiles(npix)
+    bpart = torch.empty(ntb, 2, cs, device=DEV)
+    ops.bn_bwd_reduce(gd, xd, scale, shift, mean, rstd, relu, bpart)
+    dgamma, dbeta = torch.empty(c, device=DEV), torch.empty(c, device=DEV)
+    k123 = torch.empty(3, cs, device=DEV)
+    ops.bn_bwd_finalize(bpart, ntb, c, cs, npix, gam, mean, rstd, dgamma, dbeta, k123)
+    dx = torch.empty_like(xd)
+    ops.bn_bwd_apply(gd, xd, scale, shift, k123, relu, dx)
+    ops.sync_check()
+    assert relerr(dgamma.cpu(), gamma.grad) < 2e-5 and relerr(dbeta.cpu(), beta.grad) < 2e-5
+    assert relerr(nchw(dx, c), x.grad) < 2e-5
+
+
+def test_mse_fused_loss_and_grad(ops):
+    g = gen(12)
+    shapes = [(2, 9, 11, 256), (2, 5, 6, 512), (2, 3, 3, 1024), (2, 2, 2, 2048)]
+    factors = [1.0, 0.5, 2.0, 1.0]
+    pairs, ref_terms, ref_grads = [], [], []
+    for shp, f in zip(shapes, factors):
+        t = torch.randn(shp, generator=g)
+        s = F.relu(torch.randn(shp, generator=g))
+        grad = torch.empty(shp, device=DEV)
+        pairs.append((t.to(DEV), s.to(DEV), grad, f, True))
+        ref_terms.append(F.mse_loss(t, s, reduction='sum').double() * f)
+        ref_grads.append(2 * f * (s - t) * (s > 0))
+    ml = ops.MseLaunch(pairs, DEV)
+    out = ml.run().cpu()
+    ops.sync_check()
+    assert abs(float(out[0]) - float(sum(ref_terms))) <= 1e-6 * float(sum(ref_terms))
+    for i in range(4):
+        assert abs(float(out[1 + i]) - float(ref_terms[i])) <= 1e-6 * float(ref_terms[i])
+        assert relerr(pairs[i][2].cpu(), ref_grads[i]) < 1e-6
+    one, two = torch.ones((), device=DEV), torch.full((), 2.0, device=DEV)
+    before = pairs[0][2].clone()
+    ops.scale_by_device_scalar(pairs[0][2], one)
+    assert torch.equal(pairs[0][2], before)
+    ops.scale_by_device_scalar(pairs[0][2], two)
+    assert torch.equal(pairs[0][2], before * 2)
+
+
+def test_adam_matches_torch(ops):
+    g = gen(13)
+    p0 = torch.randn(10007, generator=g)
+    ref_p = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref_p], lr=1e-3)
+    p, m, v = p0.to(DEV), torch.zeros(10007, device=DEV), torch.zeros(10007, device=DEV)
+    for step in range(1, 4):
+        grad = torch.randn(10007, generator=g) * (10.0 ** step)
+        ref_p.grad = grad.clone()
+        opt.step()
+        ops.adam_step_flat(p, (grad * 4).to(DEV), m, v, 1e-3, 0.9, 0.999, 1e-8, step, grad_scale=0.25)
+    ops.sync_check()
+    assert float((p.cpu() - ref_p.detach()).abs().max()) < 1e-6
+
+
+def test_subsample_and_fill(ops):
+    x = torch.randn(2, 256, 7, 9, generator=gen(14))
+    y = torch.empty(2, 4, 5, 256, device=DEV)
+    ops.subsample2(nhwc(x), y)
+    assert torch.equal(nchw(y), F.max_pool2d(x, 1, 2, 0))
+    ops.fill(y, 3.5)
+    ops.sync_check()
+    assert float(y.min()) == 3.5 and float(y.max()) == 3.5
+
+
+def test_bad_arguments_raise(ops):
+    x = torch.zeros(1, 4, 4, 48, device=DEV)      # cin 48: neither 4 nor a multiple of 32
+    w = torch.zeros(64, 48, 1, 1, device=DEV)
+    with pytest.raises(RuntimeError, match='cin=48'):
+        pw = ops.pack_weights(w, chan_pad=48)
+        ops.conv_forward(x, pw, torch.zeros(1, 4, 4, 64, device=DEV), 1).run()
