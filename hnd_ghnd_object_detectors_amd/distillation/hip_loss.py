@@ -1,0 +1,132 @@
+"""Fused L2 feature-mimic loss on the HIP path.
+
+``HipMSELoss`` is what ``func_util.get_loss('MSELoss', {'reduction': 'sum'})`` returns;
+``distill_loss`` fuses all terms of GeneralizedCustomLoss (reference src/distillation/loss.py:27-33) into ONE
+launch that produces the scalar loss and, in the same pass over the features, the gradient w.r.t. every
+student tensor.  ``loss.backward()`` then replays the hand-written backward plan of the student
+(hipnn.IntermediateLayerGetter.hnd_backward) and hands parameter gradients to autograd's AccumulateGrad, so
+``optimizer.zero_grad(); loss.backward(); optimizer.step()`` (src/mimic_runner.py:52-54) works unchanged.
+"""
+import torch
+from torch import nn
+
+from .. import ops
+from ..hipnn import to_nhwc
+
+
+class HipMSELoss(nn.Module):
+    def __init__(self, reduction='mean', size_average=None, reduce=None):
+        super().__init__()
+        if reduction != 'sum':
+            raise NotImplementedError("HIP path implements MSELoss(reduction='sum') (all hnd/ghnd configs)")
+        self.reduction = reduction
+
+    def forward(self, input, target):
+        """standalone use: (teacher, student) -> loss with gradient to the student through distill_loss."""
+        return distill_loss([('term', input, target, 1.0)])
+
+
+class GradArena(object):
+    """Flat fp32 gradient storage for the trainable tensors; two alternating arenas so that an autograd
+    accumulation into a still-referenced .grad never aliases the buffer being written."""
+
+    def __init__(self, params):
+        self.params = list(params)
+        self.offsets, total = [], 0
+        for p in self.params:
+            self.offsets.append(total)
+            total += (p.numel() + 63) // 64 * 64
+        self.total = total
+        dev = self.params[0].device
+        self.flat = [torch.zeros(total, dtype=torch.float32, device=dev) for _ in range(2)]
+        self.cur = 0
+
+    def pick(self):
+        """choose the arena not referenced by any live .grad."""
+        for k in (self.cur, 1 - self.cur):
+            lo = self.flat[k].data_ptr()
+            hi = lo + self.total * 4
+            if not any(p.grad is not None and lo <= p.grad.data_ptr() < hi for p in self.params):
+                self.cur = k
+                return self.flat[k]
+        raise RuntimeError('both gradient arenas are referenced by live .grad tensors')
+
+    def views(self, flat):
+        return [flat[o:o + p.numel()].view(p.shape) for o, p in zip(self.offsets, self.params)]
+
+
+class _DistillLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, loss_value, state, *params):
+        ctx.state = state
+        return loss_value.clone()
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        st = ctx.state
+        body, arena = st['body'], st['arena']
+        flat = arena.pick()
+        views = arena.views(flat)
+        grad_dst = {p: v for p, v in zip(arena.params, views)}
+        # autograd hands the scalar dL/dloss (1 for loss.backward()); fold it in only if it is not 1
+        go = grad_output.detach().reshape(()).float().contiguous()
+        for buf in st['grad_bufs']:
+            ops.scale_by_device_scalar(buf, go)
+        body.hnd_backward(st['top'], st['loss_grads'], grad_dst)
+        del views
+        # fresh views (refcount 1) so AccumulateGrad adopts them without a copy
+        return (None, None) + tuple(arena.views(flat))
+
+
+_ORDER = ('layer1', 'layer2', 'layer3', 'layer4')
+
+
+def distill_loss(terms):
+    """terms: list of (name, teacher_out, student_out, factor).  Returns a 0-dim float32 loss tensor."""
+    srcs = [getattr(s, '_hnd_src', None) for _, _, s, _ in terms]
+    body = srcs[0][0] if srcs[0] is not None else None
+    trainable = body is not None and getattr(body, '_last_keep', False)
+    if any(src is None or src[0] is not body or src[1] not in _ORDER for src in srcs):
+        raise NotImplementedError('HIP distillation loss expects student tensors produced by backbone.body.layer1-4 '
+                                  '(the ts_modules of every hnd/ghnd config)')
+    dev = terms[0][2].device
+    names = [src[1] for src in srcs]
+    top = max(names, key=_ORDER.index)
+    pairs, loss_grads, grad_bufs = [], {}, []
+    for (tname, t_out, s_out, factor), lname in zip(terms, names):
+        t_buf, s_buf = to_nhwc(t_out), to_nhwc(s_out)
+        if tuple(t_buf.shape) != tuple(s_buf.shape):
+            raise ValueError('teacher/student shapes differ for term %s: %s vs %s'
+                             % (tname, tuple(t_buf.shape), tuple(s_buf.shape)))
+        grad = None
+        if trainable:
+            layer = body[lname]
+            eng = layer.engine() if hasattr(layer, 'engine') else layer.head_engine()
+            if lname == top:
+                grad = eng.grad_out_buffer()            # masked by the producing ReLU in the same pass
+            else:
+                grad = eng.bufs.get('loss_grad', s_buf.shape)
+                loss_grads[lname] = grad
+            grad_bufs.append(grad)
+        pairs.append((t_buf, s_buf, grad, float(factor), lname == top))
+    key = tuple((p[0].data_ptr(), p[1].data_ptr(), None if p[2] is None else p[2].data_ptr(), p[3], p[4])
+                for p in pairs)
+    cache = getattr(body, '_mse_cache', None)
+    if cache is None or cache[0] != key:
+        cache = (key, ops.MseLaunch(pairs, dev))
+        body._mse_cache = cache
+    out = cache[1].run()
+    loss_value = out[0].float()
+    per_term = out[1:]
+    if not trainable:
+        loss_value.per_term = per_term
+        return loss_value
+    params = body.trainable_plan()
+    arena = getattr(body, '_grad_arena', None)
+    if arena is None or [id(p) for p in arena.params] != [id(p) for p in params]:
+        arena = GradArena(params)
+        body._grad_arena = arena
+    state = {'body': body, 'arena': arena, 'top': top, 'loss_grads': loss_grads, 'grad_bufs': grad_bufs}
+    loss = _DistillLossFn.apply(loss_value, state, *params)
+    loss.per_term = per_term
+    return loss

@@ -1,0 +1,595 @@
+"""Execution engines behind the nn.Module tree: prebuilt launch plans over libhnd_hip.so.
+
+Each engine owns, per input geometry, its activation buffers (torch-ROCm tensors, NHWC) and a
+list of prebuilt launches that is replayed every step.  Nothing here computes with torch ops.
+
+  TransformEngine   CustomRCNNTransform.forward          (reference src/models/org/rcnn.py:65-82)
+  StemEngine        conv1 -> FrozenBN -> ReLU -> maxpool (src/models/custom/resnet.py:26-30,96-99)
+  HeadEngine        Bottleneck4LargeResNet, train-mode BN (src/models/mimic/resnet_layer.py:40-70)
+  FrozenLayerEngine nn.Sequential of torchvision Bottleneck with FrozenBatchNorm2d (rcnn.py:391-395)
+  FpnEngine         FeaturePyramidNetwork + LastLevelMaxPool (rcnn.py:399-414)
+
+Backward is a hand-written plan as well (no autograd graph): dgrad through the frozen layers with
+the ReLU mask / FrozenBN scale / residual fan-in fused into the conv kernel, train-BN backward and
+dgrad+wgrad for the head, maxpool/ReLU/FBN backward and wgrad for the stem.
+"""
+import math
+from collections import OrderedDict
+
+import torch
+
+from . import ops
+
+BN_EPS, BN_MOMENTUM = 1e-5, 0.1
+PROFILE = {'enabled': False, 'records': []}     # bench.py: per-launch HIP events on the launch stream
+
+
+def _run(launch, tag=None):
+    if PROFILE['enabled'] and launch.flops:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        launch.run()
+        e1.record()
+        PROFILE['records'].append((tag or type(launch).__name__, launch, e0, e1))
+    else:
+        launch.run()
+
+
+def version_of(tensors):
+    return tuple(t._version for t in tensors)
+
+
+class Buffers(object):
+    """Named persistent device buffers of one engine (re-allocated only when a shape changes)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.t = {}
+
+    def get(self, name, shape, dtype=torch.float32):
+        shape = tuple(int(s) for s in shape)
+        cur = self.t.get(name)
+        if cur is None or tuple(cur.shape) != shape or cur.dtype != dtype:
+            cur = torch.empty(shape, dtype=dtype, device=self.device)
+            self.t[name] = cur
+        return cur
+
+    def nbytes(self):
+        return sum(t.numel() * t.element_size() for t in self.t.values())
+
+
+def logical(t_nhwc, c=None):
+    """NHWC buffer -> logical NCHW view (what forward hooks / callers observe)."""
+    if c is not None and c != t_nhwc.shape[3]:
+        t_nhwc = t_nhwc[..., :c]
+    return t_nhwc.permute(0, 3, 1, 2)
+
+
+def physical(t_nchw):
+    """logical NCHW tensor backed by an NHWC buffer -> the NHWC buffer view; else a contiguous NHWC copy is
+    refused (callers must hand over channels_last device tensors produced by this package)."""
+    p = t_nchw.permute(0, 2, 3, 1)
+    if not p.is_contiguous():
+        raise RuntimeError('expected a channels_last tensor produced by the HIP path; got strides %s'
+                           % (tuple(t_nchw.stride()),))
+    return p
+
+
+class FrozenAffine(object):
+    """FrozenBatchNorm2d folded to per-channel (scale, shift) by hnd_fbn_fold; refreshed when buffers change."""
+
+    def __init__(self, bn):
+        self.bn = bn
+        self.ver = None
+        self.scale = self.shift = None
+
+    def get(self):
+        ts = (self.bn.weight, self.bn.bias, self.bn.running_mean, self.bn.running_var)
+        ver = version_of(ts) + tuple(t.data_ptr() for t in ts)
+        if ver != self.ver:
+            self.scale, self.shift = ops.fbn_fold(*ts, eps=0.0)
+            self.ver = ver
+        return self.scale, self.shift
+
+
+class WeightCache(object):
+    """Packed GEMM operands of one conv weight; frozen weights are packed once, trainable ones every step."""
+
+    def __init__(self, weight):
+        self.weight = weight
+        self.packs = {}
+        self.ver = None
+
+    def get(self, transposed=False, chan_pad=None, taps=None):
+        """the PackedWeight for this layout; its buffer address is stable for the life of the cache (prebuilt
+        launch descriptors point at it), refresh() re-runs the pack kernel into the same buffer."""
+        key = (transposed, chan_pad, taps)
+        pk = self.packs.get(key)
+        if pk is None:
+            pk = ops.pack_weights(self.weight.detach(), transposed, chan_pad, taps)
+            self.packs[key] = pk
+        return pk
+
+    def refresh(self, force=False):
+        """re-run the pack kernels if the parameter changed (or always, for trainable weights)."""
+        ver = (self.weight._version, self.weight.data_ptr())
+        if force or ver != self.ver:
+            for pk in self.packs.values():
+                pk.src = self.weight.detach()
+                pk.repack()
+            self.ver = ver
+
+
+# =========================================================================================== transform
+_TRANSFORMS = {}
+
+
+def shared_transform(mean, std, device):
+    """teacher and student normalise identically (rcnn.py:222-226), so they share one engine: the second
+    model's transform of the same image list is a cache hit instead of a second pass."""
+    key = (tuple(float(m) for m in mean), tuple(float(s) for s in std), str(device))
+    if key not in _TRANSFORMS:
+        _TRANSFORMS[key] = TransformEngine(mean, std)
+    return _TRANSFORMS[key]
+
+
+_SCOPE = {'id': None, 'next': 1}
+
+
+def transform_scope_begin():
+    """DistillationBox.forward brackets its teacher+student calls with a scope: inside it the image list is
+    alive and unchanged, so the second model's identical transform is served from the first one's batch."""
+    _SCOPE['id'] = _SCOPE['next']
+    _SCOPE['next'] += 1
+
+
+def transform_scope_end():
+    _SCOPE['id'] = None
+
+
+class TransformEngine(object):
+    def __init__(self, mean, std):
+        self.mean, self.std = [float(m) for m in mean], [float(s) for s in std]
+        self.bufs = None
+        self.last_key = None
+
+    def run(self, images, sizes, max_size):
+        """images: list of CHW device tensors; sizes: per-image target min side. Returns (NHWC4 batch, image_sizes)."""
+        dev = images[0].device
+        if self.bufs is None:
+            self.bufs = Buffers(dev)
+        plans = []
+        for img, size in zip(images, sizes):
+            if img.dim() != 3 or img.shape[0] != 3:
+                raise ValueError('images is expected to be a list of 3d tensors of shape [3, H, W], got %s'
+                                 % (tuple(img.shape),))
+            h, w = int(img.shape[1]), int(img.shape[2])
+            scale = float(size) / float(min(h, w))              # rcnn.py:41-43
+            if float(max(h, w)) * scale > max_size:
+                scale = float(max_size) / float(max(h, w))
+            plans.append((h, w, scale, ops.interp_out_size(h, scale), ops.interp_out_size(w, scale)))
+        hp = int(math.ceil(max(p[3] for p in plans) / 32.0) * 32)
+        wp = int(math.ceil(max(p[4] for p in plans) / 32.0) * 32)
+        key = (_SCOPE['id'],) + tuple((id(im), im.data_ptr(), im._version) + p for im, p in zip(images, plans))
+        batch = self.bufs.get('batch', (len(images), hp, wp, 4))
+        if _SCOPE['id'] is None or key != self.last_key:
+            for i, (img, (h, w, scale, oh, ow)) in enumerate(zip(images, plans)):
+                src = img if (img.is_contiguous() and img.dtype == torch.float32) else img.float().contiguous()
+                ops.transform_image(src, batch, i, oh, ow, 1.0 / scale, 1.0 / scale, self.mean, self.std)
+            self.last_key = key
+        self.last_scales = [p[2] for p in plans]
+        return batch, [(p[3], p[4]) for p in plans]
+
+
+# =========================================================================================== stem
+class StemEngine(object):
+    def __init__(self, conv1, bn1):
+        self.conv1, self.fbn = conv1, FrozenAffine(bn1)
+        self.wc = WeightCache(conv1.weight)
+        self.bufs = None
+        self.plan_key = None
+        self.flops_fwd = self.flops_bwd = 0
+
+    def forward(self, x4, keep):
+        n, hp, wp, _ = x4.shape
+        if self.bufs is None:
+            self.bufs = Buffers(x4.device)
+        scale, shift = self.fbn.get()
+        pk = self.wc.get(False, 4)
+        self.wc.refresh(force=self.conv1.weight.requires_grad)
+        oh, ow = ops.conv_out_size(hp, 7, 2, 3), ops.conv_out_size(wp, 7, 2, 3)
+        ph, pw_ = ops.conv_out_size(oh, 3, 2, 1), ops.conv_out_size(ow, 3, 2, 1)
+        key = (x4.data_ptr(), tuple(x4.shape), scale.data_ptr())
+        if key != self.plan_key:
+            b = self.bufs
+            self.a0 = b.get('a0', (n, oh, ow, 64))
+            self.x0 = b.get('x0', (n, ph, pw_, 64))
+            self.idx = b.get('idx', (n, ph, pw_, 64), torch.uint8)
+            self.l_conv = ops.conv_forward(x4, pk, self.a0, 7, 2, 3, epi_scale=scale, epi_shift=shift, relu=True)
+            self.flops_fwd = 2 * n * oh * ow * 64 * 49 * 3
+            self.x4 = x4
+            self.plan_key = key
+            self.bwd = None
+        _run(self.l_conv, 'stem.conv1')
+        ops.maxpool_fwd(self.a0, self.x0, self.idx)
+        return self.x0
+
+    def backward(self, g_x0, dw):
+        """g_x0: grad wrt the pooled stem output; dw: destination of d conv1.weight (or None when frozen)."""
+        if dw is None:
+            return
+        scale, _ = self.fbn.get()
+        key = (g_x0.data_ptr(), dw.data_ptr())
+        if self.bwd is None or self.bwd[0] != key:
+            dconv = self.bufs.get('dconv', self.a0.shape)
+            wl = ops.conv_wgrad(self.x4, dconv, dw, 7, 2, 3)
+            self.bwd = (key, dconv, wl)
+            n, oh, ow, _ = self.a0.shape
+            self.flops_bwd = 2 * n * oh * ow * 64 * 49 * 3
+        _, dconv, wl = self.bwd
+        ops.maxpool_bwd_relu_scale(g_x0, self.idx, self.a0, scale, dconv)
+        _run(wl, 'stem.wgrad')
+
+
+# =========================================================================================== frozen layers
+class _Block(object):
+    __slots__ = ('mod', 'stride', 'has_ds', 'planes', 'cin', 'w1', 'w2', 'w3', 'wd', 'f1', 'f2', 'f3', 'fd')
+
+
+class FrozenLayerEngine(object):
+    """A run of torchvision Bottleneck blocks whose convs and FrozenBatchNorm2d are frozen."""
+
+    def __init__(self, blocks, name):
+        self.name = name
+        self.blocks = []
+        for m in blocks:
+            b = _Block()
+            b.mod, b.stride = m, m.stride
+            b.has_ds = m.downsample is not None
+            b.planes, b.cin = m.conv1.weight.shape[0], m.conv1.weight.shape[1]
+            b.w1, b.w2, b.w3 = WeightCache(m.conv1.weight), WeightCache(m.conv2.weight), WeightCache(m.conv3.weight)
+            b.f1, b.f2, b.f3 = FrozenAffine(m.bn1), FrozenAffine(m.bn2), FrozenAffine(m.bn3)
+            b.wd = WeightCache(m.downsample[0].weight) if b.has_ds else None
+            b.fd = FrozenAffine(m.downsample[1]) if b.has_ds else None
+            self.blocks.append(b)
+        self.bufs = None
+        self.plan_key = None
+        self.bwd_key = None
+        self.flops_fwd = self.flops_bwd = 0
+
+    def _check_frozen(self):
+        for b in self.blocks:
+            for p in b.mod.parameters():
+                if p.requires_grad:
+                    raise NotImplementedError(
+                        '%s has trainable parameters: the HIP path implements the reference distillation '
+                        'configs, which freeze layer2-4/FPN (yaml student_model.frozen_modules)' % self.name)
+
+    def forward(self, x, keep):
+        """x: NHWC input. keep=True retains every activation for backward (student), else buffers ping-pong."""
+        if self.bufs is None:
+            self.bufs = Buffers(x.device)
+        affs = [(b.f1.get(), b.f2.get(), b.f3.get(), b.fd.get() if b.has_ds else None) for b in self.blocks]
+        for b in self.blocks:
+            for wc in (b.w1, b.w2, b.w3, b.wd):
+                if wc is not None:
+                    wc.get()
+                    wc.refresh()
+        key = (x.data_ptr(), tuple(x.shape), keep, tuple(a[0][0].data_ptr() for a in affs))
+        if key != self.plan_key:
+            self._build_forward(x, keep, affs)
+            self.plan_key = key
+            self.bwd_key = None
+        for l, tag in self.fwd:
+            _run(l, tag)
+        return self.out
+
+    def _build_forward(self, x, keep, affs):
+        self.fwd, self.acts = [], []
+        n = x.shape[0]
+        cur = x
+        flops = 0
+        for i, (b, (a1f, a2f, a3f, adf)) in enumerate(zip(self.blocks, affs)):
+            h, w = cur.shape[1], cur.shape[2]
+            oh, ow = ops.conv_out_size(h, 3, b.stride, 1), ops.conv_out_size(w, 3, b.stride, 1)
+            tagp = '%s.%d' % (self.name, i)
+            sfx = str(i) if keep else str(i & 1)
+            a1 = self.bufs.get('a1_' + sfx, (n, h, w, b.planes))
+            a2 = self.bufs.get('a2_' + sfx, (n, oh, ow, b.planes))
+            out = self.bufs.get('out_' + sfx, (n, oh, ow, b.planes * 4))
+            self.fwd.append((ops.conv_forward(cur, b.w1.get(), a1, 1, 1, 0, epi_scale=a1f[0], epi_shift=a1f[1],
+                                              relu=True), tagp + '.conv1'))
+            self.fwd.append((ops.conv_forward(a1, b.w2.get(), a2, 3, b.stride, 1, epi_scale=a2f[0], epi_shift=a2f[1],
+                                              relu=True), tagp + '.conv2'))
+            if b.has_ds:
+                ds = self.bufs.get('ds_' + sfx, (n, oh, ow, b.planes * 4))
+                self.fwd.append((ops.conv_forward(cur, b.wd.get(), ds, 1, b.stride, 0, epi_scale=adf[0],
+                                                  epi_shift=adf[1]), tagp + '.downsample'))
+                ident = ds
+                flops += 2 * n * oh * ow * b.planes * 4 * b.cin
+            else:
+                ident = cur
+            self.fwd.append((ops.conv_forward(a2, b.w3.get(), out, 1, 1, 0, epi_scale=a3f[0], epi_shift=a3f[1],
+                                              res1=ident, relu=True), tagp + '.conv3'))
+            flops += 2 * n * (h * w * b.planes * b.cin + oh * ow * b.planes * b.planes * 9
+                              + oh * ow * b.planes * 4 * b.planes)
+            self.acts.append((cur, a1, a2, out))
+            cur = out
+        self.out = cur
+        self.flops_fwd = flops
+
+    # ---- backward: self.g_out holds the gradient w.r.t. this layer's output, already masked by out > 0
+    def grad_out_buffer(self):
+        self.g_out = self.bufs.get('g_out', self.out.shape)
+        return self.g_out
+
+    def backward(self, dst, dst_mask, res2):
+        """Propagate self.g_out to `dst` (grad w.r.t. this layer's input):
+        dst = [dst_mask > 0] * (dgrad + res2).  res2 (the loss gradient of the previous layer) may be None."""
+        self._check_frozen()
+        key = (dst.data_ptr(), dst_mask.data_ptr(), None if res2 is None else res2.data_ptr(), self.g_out.data_ptr())
+        if key != self.bwd_key:
+            self._build_backward(dst, dst_mask, res2)
+            self.bwd_key = key
+        for l, tag in self.bwd:
+            _run(l, tag)
+
+    def _build_backward(self, dst, dst_mask, res2):
+        self.bwd = []
+        flops = 0
+        g = self.g_out
+        nb = len(self.blocks)
+        for i in range(nb - 1, -1, -1):
+            b = self.blocks[i]
+            x_in, a1, a2, out = self.acts[i]
+            s1, s2, s3 = b.f1.get()[0], b.f2.get()[0], b.f3.get()[0]
+            tagp = '%s.%d' % (self.name, i)
+            n, h, w, _ = x_in.shape
+            oh, ow = a2.shape[1], a2.shape[2]
+            g_a2 = self.bufs.get('g_a2_%d_%d' % (oh, b.planes), a2.shape)
+            g_a1 = self.bufs.get('g_a1_%d_%d' % (h, b.planes), a1.shape)
+            # conv3 (1x1): g_a2 = [a2>0] * W3^T (g * s3)
+            ls, _ = ops.conv_dgrad(g, b.w3, g_a2, 1, 1, 0, pro_scale=s3, mask=a2)
+            self.bwd += [(l, tagp + '.conv3.dgrad') for l in ls]
+            # conv2 (3x3, stride s): g_a1 = [a1>0] * dgrad(g_a2 * s2)
+            ls, _ = ops.conv_dgrad(g_a2, b.w2, g_a1, 3, b.stride, 1, pro_scale=s2, mask=a1)
+            self.bwd += [(l, tagp + '.conv2.dgrad') for l in ls]
+            # conv1 (1x1) + identity / downsample fan-in, masked by the previous block's ReLU
+            if i > 0:
+                g_prev = self.bufs.get('g_blk_%d' % ((i - 1) & 1), x_in.shape)
+                tgt, tmask, tres2 = g_prev, x_in, None
+            else:
+                tgt, tmask, tres2 = dst, dst_mask, res2
+            if b.has_ds:
+                ls, _ = ops.conv_dgrad(g_a1, b.w1, tgt, 1, 1, 0, pro_scale=s1, res2=tres2, mask=tmask)
+                self.bwd += [(l, tagp + '.conv1.dgrad') for l in ls]
+                ls, _ = ops.conv_dgrad(g, b.wd, tgt, 1, b.stride, 0, accumulate=True, pro_scale=b.fd.get()[0],
+                                       mask=tmask)
+                self.bwd += [(l, tagp + '.downsample.dgrad') for l in ls]
+                flops += 2 * n * oh * ow * b.planes * 4 * b.cin
+            else:
+                ls, _ = ops.conv_dgrad(g_a1, b.w1, tgt, 1, 1, 0, pro_scale=s1, res1=g, res2=tres2, mask=tmask)
+                self.bwd += [(l, tagp + '.conv1.dgrad') for l in ls]
+            flops += 2 * n * (h * w * b.planes * b.cin + oh * ow * b.planes * b.planes * 9
+                              + oh * ow * b.planes * 4 * b.planes)
+            g = tgt
+        self.flops_bwd = flops
+
+
+# =========================================================================================== student head
+class _HeadConv(object):
+    __slots__ = ('conv', 'bn', 'pad', 'relu', 'cin', 'cout', 'cs_in', 'cs_out', 'wc')
+
+
+class HeadEngine(object):
+    """Bottleneck4LargeResNet: eight bias-free 2x2 convs, each followed by a BatchNorm2d (+ReLU on four of them).
+    Conv i reads the RAW output of conv i-1 and applies BN(+ReLU) i-1 on load; its epilogue emits the batch
+    statistics of its own raw output (train mode) for hnd_bn_finalize."""
+
+    def __init__(self, convs_bns):
+        """convs_bns: list of (conv module, pad, following bn module, relu_after_bn)."""
+        self.layers = []
+        for conv, pad, bn, relu in convs_bns:
+            hc = _HeadConv()
+            hc.conv, hc.bn, hc.pad, hc.relu = conv, bn, pad, relu
+            hc.cout, hc.cin = conv.weight.shape[0], conv.weight.shape[1]
+            hc.cs_in, hc.cs_out = ops.chan_pad_of(hc.cin), ops.chan_pad_of(hc.cout)
+            hc.wc = WeightCache(conv.weight)
+            self.layers.append(hc)
+        self.bufs = None
+        self.plan_key = None
+        self.bwd_key = None
+        self.flops_fwd = self.flops_bwd = 0
+
+    def forward(self, x, training):
+        if self.bufs is None:
+            self.bufs = Buffers(x.device)
+        for hc in self.layers:
+            hc.wc.get(False, hc.cs_in)
+            hc.wc.refresh(force=training)
+        ptrs = tuple(t.data_ptr() for hc in self.layers
+                     for t in (hc.bn.weight, hc.bn.bias, hc.bn.running_mean, hc.bn.running_var))
+        key = (x.data_ptr(), tuple(x.shape), training, ptrs)
+        if key != self.plan_key:
+            self._build_forward(x, training)
+            self.plan_key = key
+            self.bwd_key = None
+        b = self.bufs
+        for i, hc in enumerate(self.layers):
+            if not training:
+                # eval-mode BN: fold running statistics (eps 1e-5) into the next prologue
+                bn = hc.bn
+                ops.fbn_fold(bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
+                             eps=BN_EPS, cs=hc.cs_out, out=(self.scale[i], self.shift[i]))
+            _run(self.convs[i], 'layer1.conv%d' % i)
+            if training:
+                bn = hc.bn
+                m = self.count[i]
+                ops.bn_finalize(self.stats[i], ops.stats_tiles(m), hc.cout, hc.cs_out, m, bn.weight.detach(),
+                                bn.bias.detach(), bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                                BN_MOMENTUM, BN_EPS, self.scale[i], self.shift[i], self.mean[i], self.rstd[i])
+        ops.affine_relu(self.y[-1], self.scale[-1], self.shift[-1], self.out, self.layers[-1].relu)
+        return self.out
+
+    def _build_forward(self, x, training):
+        n, h, w, c = x.shape
+        assert c == self.layers[0].cs_in
+        b = self.bufs
+        self.x = x
+        self.y, self.stats, self.scale, self.shift, self.mean, self.rstd = [], [], [], [], [], []
+        self.convs, self.count = [], []
+        cur, cur_scale, cur_shift, cur_relu = x, None, None, False
+        flops = 0
+        for i, hc in enumerate(self.layers):
+            oh, ow = ops.conv_out_size(h, 2, 1, hc.pad), ops.conv_out_size(w, 2, 1, hc.pad)
+            y = b.get('y%d' % i, (n, oh, ow, hc.cs_out))
+            m = n * oh * ow
+            st = b.get('stats%d' % i, (ops.stats_tiles(m), 2, hc.cs_out)) if training else None
+            sc, sh = b.get('scale%d' % i, (hc.cs_out,)), b.get('shift%d' % i, (hc.cs_out,))
+            mu, rs = b.get('mean%d' % i, (hc.cs_out,)), b.get('rstd%d' % i, (hc.cs_out,))
+            self.convs.append(ops.conv_forward(cur, hc.wc.get(False, hc.cs_in), y, 2, 1, hc.pad,
+                                               pro_scale=cur_scale, pro_shift=cur_shift, pro_relu=cur_relu,
+                                               stats=st))
+            flops += 2 * m * hc.cout * 4 * hc.cin
+            self.y.append(y)
+            self.stats.append(st)
+            self.scale.append(sc)
+            self.shift.append(sh)
+            self.mean.append(mu)
+            self.rstd.append(rs)
+            self.count.append(m)
+            cur, cur_scale, cur_shift, cur_relu = y, sc, sh, hc.relu
+            h, w = oh, ow
+        self.out = b.get('out', (n, h, w, self.layers[-1].cs_out))
+        self.flops_fwd = flops
+
+    def bottleneck(self):
+        """(raw conv output, scale, shift, relu) of the encoder's last conv = the bottleneck tensor z."""
+        return self.y[3]
+
+    def grad_out_buffer(self):
+        self.g_out = self.bufs.get('g_out', self.out.shape)
+        return self.g_out
+
+    def backward(self, grad_dst, need_input_grad):
+        """self.g_out = grad w.r.t. the layer output. grad_dst: dict param -> destination tensor (or missing).
+        Returns the buffer holding the gradient w.r.t. the layer input (stem output) if need_input_grad."""
+        key = (self.g_out.data_ptr(), need_input_grad, tuple(sorted((id(p), t.data_ptr()) for p, t in grad_dst.items())))
+        if key != self.bwd_key:
+            self._build_backward(grad_dst, need_input_grad)
+            self.bwd_key = key
+        b = self.bufs
+        for i in range(len(self.layers) - 1, -1, -1):
+            hc, st = self.layers[i], self.bsteps[i]
+            g = st['g']
+            ops.bn_bwd_reduce(g, self.y[i], self.scale[i], self.shift[i], self.mean[i], self.rstd[i], hc.relu,
+                              st['part'])
+            ops.bn_bwd_finalize(st['part'], st['ntiles'], hc.cout, hc.cs_out, self.count[i], hc.bn.weight.detach(),
+                                self.mean[i], self.rstd[i], st['dgamma'], st['dbeta'], st['k123'])
+            ops.bn_bwd_apply(g, self.y[i], self.scale[i], self.shift[i], st['k123'], hc.relu, g)   # in place -> dy
+            if st['wgrad'] is not None:
+                _run(st['wgrad'], 'layer1.conv%d.wgrad' % i)
+            for l in st['dgrad']:
+                _run(l, 'layer1.conv%d.dgrad' % i)
+        return self.g_in if need_input_grad else None
+
+    def _build_backward(self, grad_dst, need_input_grad):
+        b = self.bufs
+        self.bsteps = [None] * len(self.layers)
+        flops = 0
+        nl = len(self.layers)
+        # gradient buffers: g[i] = grad w.r.t. BN_i output (then, in place, w.r.t. raw conv_i output)
+        gbuf = [b.get('g%d' % i, self.y[i].shape) for i in range(nl - 1)] + [self.g_out]
+        self.g_in = b.get('g_in', self.x.shape) if need_input_grad else None
+        slab_bytes = 0
+        for i, hc in enumerate(self.layers):
+            src = self.x if i == 0 else self.y[i - 1]
+            n, h, w, _ = src.shape
+            oh, ow = self.y[i].shape[1], self.y[i].shape[2]
+            slab_bytes = max(slab_bytes, ops.wgrad_workspace_bytes(n, h, w, hc.cs_in, oh, ow, hc.cout, 2, 1, hc.pad))
+        slabs = b.get('slabs', ((slab_bytes + 3) // 4,))
+        for i, hc in enumerate(self.layers):
+            st = {}
+            npix = self.count[i]
+            st['g'] = gbuf[i]
+            st['ntiles'] = ops.bn_bwd_ntiles(npix)
+            st['part'] = b.get('bpart%d' % i, (st['ntiles'], 2, hc.cs_out))
+            st['k123'] = b.get('k123_%d' % i, (3, hc.cs_out))
+            st['dgamma'] = grad_dst.get(hc.bn.weight, None)
+            st['dbeta'] = grad_dst.get(hc.bn.bias, None)
+            if st['dgamma'] is None:
+                st['dgamma'] = b.get('dgamma_scratch%d' % i, (hc.cout,))
+            if st['dbeta'] is None:
+                st['dbeta'] = b.get('dbeta_scratch%d' % i, (hc.cout,))
+            src = self.x if i == 0 else self.y[i - 1]
+            pro = (None, None, False) if i == 0 else (self.scale[i - 1], self.shift[i - 1], self.layers[i - 1].relu)
+            dw = grad_dst.get(hc.conv.weight, None)
+            st['wgrad'] = None
+            if dw is not None:
+                st['wgrad'] = ops.conv_wgrad(src, gbuf[i], dw, 2, 1, hc.pad, pro_scale=pro[0], pro_shift=pro[1],
+                                             pro_relu=pro[2], slabs=slabs)
+                flops += 2 * npix * hc.cout * 4 * hc.cin
+            st['dgrad'] = []
+            tgt = gbuf[i - 1] if i > 0 else self.g_in
+            if tgt is not None:
+                pk = hc.wc.get(True, hc.cs_out)
+                ls, _ = _dgrad_with_pack(gbuf[i], hc, tgt, pk)
+                st['dgrad'] = ls
+                flops += 2 * npix * hc.cout * 4 * hc.cin
+            self.bsteps[i] = st
+        self.flops_bwd = flops
+
+
+def _dgrad_with_pack(dy, hc, dx, pk):
+    """stride-1 dgrad of a head conv using the cached transposed pack (re-packed every training step)."""
+    n, h, w, ldc = dx.shape
+    l = ops.conv_desc(dy, pk, dx, kh=2, kw=2, oh=h, ow=w, sh=1, dh=-1, bh=hc.pad, sw=1, dw=-1, bw=hc.pad, cout=ldc)
+    return [l], [pk]
+
+
+# =========================================================================================== FPN
+class FpnEngine(object):
+    def __init__(self, inner_blocks, layer_blocks):
+        self.inner = [(m, WeightCache(m.weight)) for m in inner_blocks]
+        self.layer = [(m, WeightCache(m.weight)) for m in layer_blocks]
+        self.bufs = None
+        self.plan_key = None
+        self.flops_fwd = 0
+
+    def forward(self, feats):
+        """feats: list of NHWC layer outputs (fine -> coarse).  Returns list of NHWC pyramid maps + 'pool'."""
+        if self.bufs is None:
+            self.bufs = Buffers(feats[0].device)
+        for m, wc in self.inner + self.layer:
+            wc.get()
+            wc.refresh()
+        key = tuple((f.data_ptr(), tuple(f.shape)) for f in feats) + \
+            tuple(m.bias.data_ptr() for m, _ in self.inner + self.layer)
+        if key != self.plan_key:
+            self.fwd = []
+            nlev = len(feats)
+            inner = [None] * nlev
+            self.results = [None] * nlev
+            flops = 0
+            for i in range(nlev - 1, -1, -1):
+                f = feats[i]
+                n, h, w, c = f.shape
+                m, wc = self.inner[i]
+                inner[i] = self.bufs.get('inner%d' % i, (n, h, w, m.weight.shape[0]))
+                up = inner[i + 1] if i + 1 < nlev else None
+                self.fwd.append((ops.conv_forward(f, wc.get(), inner[i], 1, 1, 0, epi_shift=m.bias.detach(),
+                                                  res1=up, res1_up=up is not None), 'fpn.inner%d' % i))
+                ml, wl = self.layer[i]
+                self.results[i] = self.bufs.get('p%d' % i, (n, h, w, ml.weight.shape[0]))
+                self.fwd.append((ops.conv_forward(inner[i], wl.get(), self.results[i], 3, 1, 1,
+                                                  epi_shift=ml.bias.detach()), 'fpn.layer%d' % i))
+                flops += 2 * n * h * w * 256 * (c + 256 * 9)
+            last = self.results[-1]
+            n, h, w, c = last.shape
+            self.pool = self.bufs.get('pool', (n, (h + 1) // 2, (w + 1) // 2, c))
+            self.flops_fwd = flops
+            self.plan_key = key
+        for l, tag in self.fwd:
+            _run(l, tag)
+        ops.subsample2(self.results[-1], self.pool)
+        return self.results + [self.pool]

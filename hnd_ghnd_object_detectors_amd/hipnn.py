@@ -1,0 +1,388 @@
+"""nn.Module building blocks whose forward runs on libhnd_hip.so.
+
+Two kinds of classes:
+  * parameter holders (Conv2d, BatchNorm2d, FrozenBatchNorm2d, ...) that keep the reference's
+    state_dict layout and initialisation but execute only fused inside their
+    parent (calling them directly raises: there is deliberately no eager/torch compute path);
+  * composite modules (IntermediateLayerGetter, ResLayer, FeaturePyramidNetwork, BackboneWithFPN)
+    that own an engine from ``engine.py`` and run its prebuilt HIP launch plan.
+
+They play the role torchvision 0.4.2 plays for the reference (src/models/org/rcnn.py:6-17).
+"""
+from collections import OrderedDict
+
+import torch
+from torch import nn
+
+from . import engine as E
+from . import ops
+
+
+class _FusedOnly(object):
+    def forward(self, *args, **kwargs):
+        raise RuntimeError('%s is a parameter holder: it executes fused inside its parent module on the HIP path '
+                           '(no eager fallback exists)' % type(self).__name__)
+
+
+class Conv2d(_FusedOnly, nn.Conv2d):
+    pass
+
+
+class ConvTranspose2d(_FusedOnly, nn.ConvTranspose2d):
+    pass
+
+
+class Linear(_FusedOnly, nn.Linear):
+    pass
+
+
+class BatchNorm2d(_FusedOnly, nn.BatchNorm2d):
+    pass
+
+
+class ReLU(_FusedOnly, nn.ReLU):
+    pass
+
+
+class MaxPool2d(_FusedOnly, nn.MaxPool2d):
+    pass
+
+
+class AdaptiveAvgPool2d(_FusedOnly, nn.AdaptiveAvgPool2d):
+    pass
+
+
+class FrozenBatchNorm2d(_FusedOnly, nn.Module):
+    """torchvision 0.4.2 ops.misc.FrozenBatchNorm2d: four buffers, no eps, no num_batches_tracked."""
+
+    def __init__(self, n):
+        super().__init__()
+        self.register_buffer('weight', torch.ones(n))
+        self.register_buffer('bias', torch.zeros(n))
+        self.register_buffer('running_mean', torch.zeros(n))
+        self.register_buffer('running_var', torch.ones(n))
+
+
+def attach(t, buf, src=None):
+    """tag a logical NCHW view with the NHWC buffer behind it (and who produced it)."""
+    t._hnd = buf
+    t._hnd_src = src
+    return t
+
+
+def to_nhwc(x, pad_to=None):
+    """logical NCHW tensor -> NHWC buffer.  Tensors produced by this package carry their buffer; foreign
+    tensors are re-laid out once with torch copies (plumbing, off the distillation hot path)."""
+    buf = getattr(x, '_hnd', None)
+    if buf is not None:
+        return buf
+    if x.dim() != 4 or not x.is_cuda:
+        raise RuntimeError('HIP modules take 4-d device tensors, got %s on %s' % (tuple(x.shape), x.device))
+    c = x.shape[1]
+    cs = pad_to or ops.chan_pad_of(c)
+    buf = torch.zeros(x.shape[0], x.shape[2], x.shape[3], cs, dtype=torch.float32, device=x.device)
+    buf[..., :c].copy_(x.permute(0, 2, 3, 1))
+    return buf
+
+
+# ------------------------------------------------------------------------------------------ resnet pieces
+def conv3x3(in_planes, out_planes, stride=1):
+    return Conv2d(in_planes, out_planes, kernel_size=3, stride=stride, padding=1, bias=False)
+
+
+def conv1x1(in_planes, out_planes, stride=1):
+    return Conv2d(in_planes, out_planes, kernel_size=1, stride=stride, bias=False)
+
+
+class Bottleneck(_FusedOnly, nn.Module):
+    """Holder with torchvision's Bottleneck attribute names (stride on conv2, v1.5)."""
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, groups=1, base_width=64, dilation=1,
+                 norm_layer=None):
+        super().__init__()
+        if groups != 1 or base_width != 64 or dilation != 1:
+            raise NotImplementedError('HIP path implements the plain ResNet bottleneck (groups=1, width 64)')
+        norm_layer = norm_layer or FrozenBatchNorm2d
+        self.conv1 = conv1x1(inplanes, planes)
+        self.bn1 = norm_layer(planes)
+        self.conv2 = conv3x3(planes, planes, stride)
+        self.bn2 = norm_layer(planes)
+        self.conv3 = conv1x1(planes, planes * self.expansion)
+        self.bn3 = norm_layer(planes * self.expansion)
+        self.relu = ReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+
+
+class BasicBlock(_FusedOnly, nn.Module):
+    expansion = 1
+
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        raise NotImplementedError('BasicBlock backbones (resnet18/34) are outside the HIP path (ResNet-50 configs)')
+
+
+class ResLayer(nn.Sequential):
+    """One ResNet stage (nn.Sequential of Bottleneck) executed by a FrozenLayerEngine."""
+
+    def __init__(self, *blocks):
+        super().__init__(*blocks)
+        self._engine = None
+        self._keep = False
+        self._name = 'layer'
+
+    def engine(self):
+        if self._engine is None:
+            for m in self:
+                for bn in (m.bn1, m.bn2, m.bn3):
+                    if not isinstance(bn, FrozenBatchNorm2d):
+                        raise NotImplementedError('ResNet stages run with FrozenBatchNorm2d on the HIP path '
+                                                  '(as built by rcnn.get_base_backbone)')
+            self._engine = E.FrozenLayerEngine(list(self), self._name)
+        return self._engine
+
+    def forward(self, x):
+        eng = self.engine()
+        out = eng.forward(to_nhwc(x), self._keep)
+        return attach(E.logical(out), out)
+
+
+class IntermediateLayerGetter(nn.ModuleDict):
+    """torchvision models._utils.IntermediateLayerGetter: the stem (conv1, bn1, relu, maxpool children) runs as
+    one fused engine; layer1..4 are called as modules so forward hooks registered on them fire
+    (src/distillation/tool.py:25-35) and observe logical NCHW tensors."""
+
+    def __init__(self, model, return_layers):
+        if not set(return_layers).issubset([name for name, _ in model.named_children()]):
+            raise ValueError('return_layers are not present in model')
+        remaining = dict(return_layers)
+        layers = OrderedDict()
+        for name, module in model.named_children():
+            layers[name] = module
+            remaining.pop(name, None)
+            if not remaining:
+                break
+        super().__init__(layers)
+        self.return_layers = dict(return_layers)
+        self._stem = None
+        for name, module in self.items():
+            if isinstance(module, ResLayer):
+                module._name = name
+
+    def stem(self):
+        if self._stem is None:
+            self._stem = E.StemEngine(self['conv1'], self['bn1'])
+        return self._stem
+
+    def needs_backward(self):
+        return self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+
+    def forward(self, x):
+        x4 = to_nhwc(x, 4)
+        if x4.shape[3] != 4:
+            raise RuntimeError('the stem expects the 3-channel image batch stored as NHWC4')
+        keep = self.needs_backward()
+        x0 = self.stem().forward(x4, keep)
+        cur = attach(E.logical(x0), x0)
+        out = OrderedDict()
+        for name, module in self.items():
+            if name in ('conv1', 'bn1', 'relu', 'maxpool'):
+                continue
+            if isinstance(module, ResLayer):
+                module._keep = keep
+            cur = module(cur)
+            if isinstance(cur, torch.Tensor):
+                cur._hnd_src = (self, name)
+            if name in self.return_layers:
+                out[self.return_layers[name]] = cur
+        self._last_keep = keep
+        return out
+
+    # ------------------------------------------------------------------ manual backward (student)
+    def trainable_plan(self):
+        """(parameters that receive gradients, in state-dict order)."""
+        return [p for _, p in self.named_parameters() if p.requires_grad]
+
+    def hnd_backward(self, top, loss_grads, grad_dst):
+        """Run the hand-written backward.
+        top: name of the highest layer that carries a loss term (its engine's g_out already holds the masked
+        loss gradient).  loss_grads: {layer name: unmasked loss-gradient buffer} for lower layers with a term.
+        grad_dst: {parameter: destination tensor} for every trainable parameter."""
+        order = ['layer4', 'layer3', 'layer2', 'layer1']
+        start = order.index(top)
+        for name in order[start:-1]:
+            layer = self[name]
+            prev_name = order[order.index(name) + 1]
+            prev = self[prev_name]
+            prev_eng = prev.engine() if isinstance(prev, ResLayer) else prev.head_engine()
+            dst = prev_eng.grad_out_buffer()
+            layer.engine().backward(dst, prev_eng.out, loss_grads.get(prev_name))
+        l1 = self['layer1']
+        conv1_w = self['conv1'].weight
+        dw1 = grad_dst.get(conv1_w)
+        if isinstance(l1, ResLayer):
+            raise NotImplementedError('backward through a plain ResNet layer1 (teacher architecture) is not on the '
+                                      'distillation path')
+        g_x0 = l1.head_engine().backward(grad_dst, need_input_grad=dw1 is not None)
+        self.stem().backward(g_x0, dw1)
+
+
+class LastLevelMaxPool(nn.Module):
+    """marker module (torchvision ops.feature_pyramid_network.LastLevelMaxPool); fused into the FPN engine."""
+
+    def forward(self, x, names):
+        raise RuntimeError('LastLevelMaxPool runs fused inside FeaturePyramidNetwork on the HIP path')
+
+
+class FeaturePyramidNetwork(nn.Module):
+    def __init__(self, in_channels_list, out_channels, extra_blocks=None):
+        super().__init__()
+        self.inner_blocks = nn.ModuleList()
+        self.layer_blocks = nn.ModuleList()
+        for c in in_channels_list:
+            if c == 0:
+                continue
+            self.inner_blocks.append(Conv2d(c, out_channels, 1))
+            self.layer_blocks.append(Conv2d(out_channels, out_channels, 3, padding=1))
+        self.extra_blocks = extra_blocks
+        self._engine = None
+
+    def forward(self, x):
+        names, feats = list(x.keys()), [to_nhwc(v) for v in x.values()]
+        if self._engine is None:
+            self._engine = E.FpnEngine(list(self.inner_blocks), list(self.layer_blocks))
+        outs = self._engine.forward(feats)
+        if self.extra_blocks is None:
+            outs = outs[:-1]
+        else:
+            names = names + ['pool']
+        return OrderedDict((k, attach(E.logical(v), v)) for k, v in zip(names, outs))
+
+
+class BackboneWithFPN(nn.Sequential):
+    def __init__(self, backbone, return_layers, in_channels_list, out_channels):
+        body = IntermediateLayerGetter(backbone, return_layers=return_layers)
+        fpn = FeaturePyramidNetwork(in_channels_list, out_channels, extra_blocks=LastLevelMaxPool())
+        super().__init__(OrderedDict([('body', body), ('fpn', fpn)]))
+        self.out_channels = out_channels
+        self.run_fpn = True      # the pyramid is dead w.r.t. the distillation loss; kept on for drop-in fidelity
+
+    def forward(self, x):
+        feats = self.body(x)
+        if not self.run_fpn:
+            return feats
+        return self.fpn(feats)
+
+
+class ImageList(object):
+    def __init__(self, tensors, image_sizes):
+        self.tensors = tensors
+        self.image_sizes = image_sizes
+
+    def to(self, *args, **kwargs):
+        return ImageList(self.tensors.to(*args, **kwargs), self.image_sizes)
+
+
+# ------------------------------------------------------------------------------------------ detector heads
+class _NotOnPath(nn.Module):
+    """RPN / RoI heads: parameter holders with torchvision 0.4.2 names and shapes so reference checkpoints load.
+    They never execute on the distillation step (src/models/org/rcnn.py:109-110 returns before them)."""
+
+    def forward(self, *args, **kwargs):
+        raise NotImplementedError('%s: detector heads are outside the distillation hot path of this build '
+                                  '(SURVEY.md section 8f, row f4)' % type(self).__name__)
+
+
+class AnchorGenerator(_NotOnPath):
+    def __init__(self, sizes=(128, 256, 512), aspect_ratios=(0.5, 1.0, 2.0)):
+        super().__init__()
+        if not isinstance(sizes[0], (list, tuple)):
+            sizes = tuple((s,) for s in sizes)
+        if not isinstance(aspect_ratios[0], (list, tuple)):
+            aspect_ratios = (aspect_ratios,) * len(sizes)
+        self.sizes, self.aspect_ratios = sizes, aspect_ratios
+
+    def num_anchors_per_location(self):
+        return [len(s) * len(a) for s, a in zip(self.sizes, self.aspect_ratios)]
+
+
+class RPNHead(_NotOnPath):
+    def __init__(self, in_channels, num_anchors):
+        super().__init__()
+        self.conv = Conv2d(in_channels, in_channels, kernel_size=3, stride=1, padding=1)
+        self.cls_logits = Conv2d(in_channels, num_anchors, kernel_size=1, stride=1)
+        self.bbox_pred = Conv2d(in_channels, num_anchors * 4, kernel_size=1, stride=1)
+        for m in self.children():
+            nn.init.normal_(m.weight, std=0.01)
+            nn.init.constant_(m.bias, 0)
+
+
+class RegionProposalNetwork(_NotOnPath):
+    def __init__(self, anchor_generator, head, *args, **kwargs):
+        super().__init__()
+        self.anchor_generator, self.head = anchor_generator, head
+
+
+class MultiScaleRoIAlign(_NotOnPath):
+    def __init__(self, featmap_names, output_size, sampling_ratio):
+        super().__init__()
+        if isinstance(output_size, int):
+            output_size = (output_size, output_size)
+        self.featmap_names, self.output_size, self.sampling_ratio = featmap_names, tuple(output_size), sampling_ratio
+
+
+class TwoMLPHead(_NotOnPath):
+    def __init__(self, in_channels, representation_size):
+        super().__init__()
+        self.fc6 = Linear(in_channels, representation_size)
+        self.fc7 = Linear(representation_size, representation_size)
+
+
+class FastRCNNPredictor(_NotOnPath):
+    def __init__(self, in_channels, num_classes):
+        super().__init__()
+        self.cls_score = Linear(in_channels, num_classes)
+        self.bbox_pred = Linear(in_channels, num_classes * 4)
+
+
+class MaskRCNNHeads(nn.Sequential):
+    def __init__(self, in_channels, layers, dilation):
+        d, nxt = OrderedDict(), in_channels
+        for i, feat in enumerate(layers, 1):
+            d['mask_fcn%d' % i] = Conv2d(nxt, feat, kernel_size=3, stride=1, padding=dilation, dilation=dilation)
+            d['relu%d' % i] = ReLU(inplace=True)
+            nxt = feat
+        super().__init__(d)
+
+
+class MaskRCNNPredictor(nn.Sequential):
+    def __init__(self, in_channels, dim_reduced, num_classes):
+        super().__init__(OrderedDict([('conv5_mask', ConvTranspose2d(in_channels, dim_reduced, 2, 2, 0)),
+                                      ('relu', ReLU(inplace=True)),
+                                      ('mask_fcn_logits', Conv2d(dim_reduced, num_classes, 1, 1, 0))]))
+
+
+class KeypointRCNNHeads(nn.Sequential):
+    def __init__(self, in_channels, layers):
+        d, nxt = [], in_channels
+        for feat in layers:
+            d.append(Conv2d(nxt, feat, 3, stride=1, padding=1))
+            d.append(ReLU(inplace=True))
+            nxt = feat
+        super().__init__(*d)
+
+
+class KeypointRCNNPredictor(_NotOnPath):
+    def __init__(self, in_channels, num_keypoints):
+        super().__init__()
+        self.kps_score_lowres = ConvTranspose2d(in_channels, num_keypoints, 4, stride=2, padding=1)
+        self.up_scale, self.out_channels = 2, num_keypoints
+
+
+class RoIHeads(_NotOnPath):
+    def __init__(self, box_roi_pool, box_head, box_predictor, *args, **kwargs):
+        super().__init__()
+        self.box_roi_pool, self.box_head, self.box_predictor = box_roi_pool, box_head, box_predictor
+        self.mask_roi_pool = self.mask_head = self.mask_predictor = None
+        self.keypoint_roi_pool = self.keypoint_head = self.keypoint_predictor = None

@@ -71,11 +71,15 @@ def pack_weights(w, transposed=False, chan_pad=None, taps=None):
     return pw
 
 
-def fbn_fold(weight, bias, mean, var, eps=0.0, cs=None):
+def fbn_fold(weight, bias, mean, var, eps=0.0, cs=None, out=None):
     c = weight.numel()
     cs = cs or c
-    scale = torch.empty(cs, dtype=torch.float32, device=weight.device)
-    shift = torch.empty(cs, dtype=torch.float32, device=weight.device)
+    if out is not None:
+        scale, shift = out
+        assert scale.numel() == cs and shift.numel() == cs
+    else:
+        scale = torch.empty(cs, dtype=torch.float32, device=weight.device)
+        shift = torch.empty(cs, dtype=torch.float32, device=weight.device)
     check(_L.hnd_fbn_fold(ptr(weight), ptr(bias), ptr(mean), ptr(var), ptr(scale), ptr(shift), c, cs, float(eps),
                           stream_ptr()), 'hnd_fbn_fold')
     return scale, shift
@@ -166,9 +170,14 @@ def dgrad_tap_classes(k, stride, pad):
 
 def conv_dgrad(dy, w_param, dx, k, stride=1, pad=0, accumulate=False, **kw_):
     """Data gradient of nn.Conv2d(k, stride, pad): dy [N,OH,OW,Cout] -> dx [N,H,W,Cin_pad].
+    w_param: the OIHW weight tensor, or an object with .weight and .get(transposed, chan_pad, taps) (engine
+    WeightCache) so the transposed operands are cached and refreshed with the parameter.
     Returns (launches, packed_weights).  Stride 2 is decomposed into one dense launch per output parity.
     With accumulate=True each launch adds into dx (res1 = dx), which also lets tap-less parities be skipped."""
     n, h, w, ldc = dx.shape
+    cache = None
+    if not isinstance(w_param, torch.Tensor):
+        cache, w_param = w_param, w_param.weight
     cout_w, cin_w, kh, kwid = w_param.shape
     assert kh == k and kwid == k and dy.shape[3] == chan_pad_of(cout_w)
     launches, packs = [], []
@@ -181,7 +190,11 @@ def conv_dgrad(dy, w_param, dx, k, stride=1, pad=0, accumulate=False, **kw_):
             ohv, owv = len(range(ph, h, stride)), len(range(pw_, w, stride))
             if ohv == 0 or owv == 0:
                 continue
-            pk = pack_weights(w_param, transposed=True, chan_pad=dy.shape[3], taps=(i0, istep, ni, j0, jstep, nj))
+            taps = (i0, istep, ni, j0, jstep, nj)
+            if cache is not None:
+                pk = cache.get(True, dy.shape[3], taps)
+            else:
+                pk = pack_weights(w_param, transposed=True, chan_pad=dy.shape[3], taps=taps)
             packs.append(pk)
             extra = dict(kw_)
             if accumulate:

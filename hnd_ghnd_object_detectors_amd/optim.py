@@ -1,0 +1,97 @@
+"""Fused Adam over one flat parameter arena (replaces torch.optim.Adam created at src/mimic_runner.py:67-68).
+
+Subclasses torch.optim.Adam so ``state_dict()`` / ``load_state_dict()`` keep the torch format the reference
+checkpoints store under 'optimizer' (src/models/__init__.py:15-17) and LambdaLR / MultiStepLR drive
+``param_groups[i]['lr']`` as usual.  ``step()`` is one hnd_adam_step_flat launch when the trainable tensors
+and their gradients sit in flat arenas (the normal case), else one launch per tensor -- never torch math.
+"""
+import torch
+
+from . import ops
+
+
+class FusedAdam(torch.optim.Adam):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False, **kwargs):
+        if weight_decay != 0 or amsgrad:
+            raise NotImplementedError('FusedAdam: weight_decay / amsgrad are not used by the hnd/ghnd configs')
+        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False)
+        self.grad_scale = 1.0          # set to 1/world_size by parallel.DistributedStudent (sum all-reduce)
+        self._flat = None
+
+    # ---------------------------------------------------------------- flat arenas
+    def _flatten(self, group, plist):
+        """move the trainable tensors (and their Adam moments) into contiguous arenas; parameters keep their
+        identity (only .data is re-pointed), so optimizers / DDP / state_dict are unaffected."""
+        offsets, total = [], 0
+        for p in plist:
+            offsets.append(total)
+            total += (p.numel() + 63) // 64 * 64
+        dev = plist[0].device
+        flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
+        flat_m, flat_v = torch.zeros_like(flat_p), torch.zeros_like(flat_p)
+        steps = set()
+        for o, p in zip(offsets, plist):
+            n = p.numel()
+            flat_p[o:o + n].copy_(p.data.reshape(-1))
+            p.data = flat_p[o:o + n].view(p.shape)
+            st = self.state[p]
+            if 'exp_avg' in st:                       # resumed from a checkpoint
+                flat_m[o:o + n].copy_(st['exp_avg'].reshape(-1))
+                flat_v[o:o + n].copy_(st['exp_avg_sq'].reshape(-1))
+                steps.add(int(st['step']))
+            else:
+                steps.add(0)
+            st['exp_avg'] = flat_m[o:o + n].view(p.shape)
+            st['exp_avg_sq'] = flat_v[o:o + n].view(p.shape)
+            if 'step' not in st:
+                st['step'] = torch.tensor(0.0)
+        if len(steps) != 1:
+            return None
+        return {'ids': [id(p) for p in plist], 'offsets': offsets, 'total': total, 'p': flat_p, 'm': flat_m,
+                'v': flat_v}
+
+    def _grads_are_flat(self, flat, plist):
+        base = plist[0].grad.data_ptr()
+        for o, p in zip(flat['offsets'], plist):
+            if p.grad.data_ptr() != base + o * 4 or not p.grad.is_contiguous():
+                return None
+        g0 = plist[0].grad
+        span = g0.untyped_storage().nbytes() // 4 - (base - g0.untyped_storage().data_ptr()) // 4
+        if span < flat['total']:
+            return None
+        return torch.as_strided(g0, (flat['total'],), (1,), g0.storage_offset())
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        if closure is not None:
+            raise NotImplementedError('FusedAdam.step(closure) is not supported')
+        for group in self.param_groups:
+            plist = [p for p in group['params'] if p.grad is not None]
+            if not plist:
+                continue
+            beta1, beta2 = group['betas']
+            flat = self._flat
+            if flat is None or flat['ids'] != [id(p) for p in plist]:
+                flat = self._flatten(group, plist)
+                self._flat = flat
+            flat_g = self._grads_are_flat(flat, plist) if flat is not None else None
+            if flat_g is not None and all(p.data_ptr() == flat['p'].data_ptr() + o * 4
+                                          for o, p in zip(flat['offsets'], plist)):
+                step = int(self.state[plist[0]]['step']) + 1
+                ops.adam_step_flat(flat['p'], flat_g, flat['m'], flat['v'], group['lr'], beta1, beta2, group['eps'],
+                                   step, self.grad_scale)
+                for p in plist:
+                    self.state[p]['step'] = torch.tensor(float(step))
+            else:
+                for p in plist:
+                    st = self.state[p]
+                    if 'exp_avg' not in st:
+                        st['step'] = torch.tensor(0.0)
+                        st['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                        st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    step = int(st['step']) + 1
+                    g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                    ops.adam_step_flat(p.data, g, st['exp_avg'], st['exp_avg_sq'], group['lr'], beta1, beta2,
+                                       group['eps'], step, self.grad_scale)
+                    st['step'] = torch.tensor(float(step))
+        return None

@@ -1,0 +1,63 @@
+"""Data parallelism for the distillation step: one process per GPU, RCCL over xGMI.
+
+The reference wraps the student in torch DistributedDataParallel (src/mimic_runner.py:141-143): per step one
+gradient-averaging all-reduce of the 25 trainable tensors (586 566 floats) plus a broadcast of every buffer.
+Here the gradients already live in ONE flat arena, so the exchange is a single in-place ``all_reduce`` of that
+arena (torch.distributed backend 'nccl' == RCCL on ROCm); the 1/world factor is folded into the fused Adam
+launch.  BatchNorm statistics stay local to each rank exactly like the reference (no SyncBN); running stats
+are broadcast from rank 0 only when asked (``sync_buffers``: before evaluation / checkpointing) instead of at
+every forward -- training-mode outputs do not depend on them.
+"""
+import torch
+import torch.distributed as dist
+from torch import nn
+
+
+class DistributedStudent(nn.Module):
+    """Drop-in for DistributedDataParallel(student): ``.module`` is the wrapped model."""
+
+    def __init__(self, module, optimizer=None):
+        super().__init__()
+        self.module = module
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.optimizer = optimizer
+        if self.world > 1:
+            for p in module.parameters():          # same start on every rank (DDP broadcasts at construction)
+                dist.broadcast(p.data, 0)
+            self.sync_buffers()
+
+    def attach_optimizer(self, optimizer):
+        self.optimizer = optimizer
+        if hasattr(optimizer, 'grad_scale'):
+            optimizer.grad_scale = 1.0 / self.world
+
+    def sync_buffers(self):
+        if self.world > 1:
+            for b in self.module.buffers():
+                dist.broadcast(b, 0)
+
+    def forward(self, *args, **kwargs):
+        return self.module(*args, **kwargs)
+
+    def reduce_gradients(self):
+        """call between loss.backward() and optimizer.step(): sums the flat gradient arena across ranks."""
+        if self.world == 1:
+            return
+        body = self.module.backbone.body
+        arena = getattr(body, '_grad_arena', None)
+        if arena is not None:
+            flat = arena.flat[arena.cur]
+            dist.all_reduce(flat)
+        else:
+            for p in self.module.parameters():
+                if p.grad is not None:
+                    dist.all_reduce(p.grad)
+        if self.optimizer is None or not hasattr(self.optimizer, 'grad_scale'):
+            raise RuntimeError('attach_optimizer(FusedAdam) first: the 1/world factor is applied in the Adam launch')
+
+
+def all_reduce_flat_(flat, world):
+    """helper used by tests: in-place sum all-reduce (+ host-side mean factor returned)."""
+    if world > 1:
+        dist.all_reduce(flat)
+    return 1.0 / world
