@@ -31,6 +31,67 @@ constexpr size_t lds_bytes() {
   return (size_t)(2 * BM * LDK + 2 * BN * LDK) * sizeof(float) + 2 * BM * sizeof(int);
 }
 
+// Epilogue of one 32x32 accumulator tile.  FULL = the block's whole 128 x BN tile is in range (every tile of a
+// BN=128 launch but the last pixel tile): then there is no per-element control flow, hipcc issues the 8..24
+// residual / mask loads of a row group back to back (uniform branches only) and the stores stream behind counted
+// waits.  A divergent `if` per element would instead make every store wait vmcnt(0) for the previous one -- one
+// HBM round trip per element, which is what small-K 1x1 convs with a residual were bound by.
+template <bool FULL>
+__device__ __forceinline__ void epilogue_tile(const hnd_conv_desc& d, const f32x16& a, const int* rowoff,
+                                              const int* resoff, int rbase, int col, bool col_ok, float es, float eb,
+                                              float& s1, float& s2) {
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    unsigned off[8];
+    float r1v[8], r2v[8], mkv[8];
+    unsigned okbits = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int r = c * 8 + q;
+      const int po = rowoff[rbase + (r & 3) + 8 * (r >> 2)];
+      const bool ok = FULL || (po >= 0 && col_ok);
+      okbits |= (ok ? 1u : 0u) << q;
+      off[q] = ok ? (unsigned)po * (unsigned)d.ldc + (unsigned)col : 0u;      // 0 = a safe address to read
+      r1v[q] = 0.f; r2v[q] = 0.f; mkv[q] = 1.f;
+    }
+    if (d.res1) {
+      if (d.res1_mode == 1) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int r = c * 8 + q;
+          const int pr = resoff[rbase + (r & 3) + 8 * (r >> 2)];
+          r1v[q] = d.res1[(size_t)(pr < 0 ? 0 : pr) * d.ldc + (((okbits >> q) & 1) ? col : 0)];
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) r1v[q] = d.res1[off[q]];
+      }
+    }
+    if (d.res2) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) r2v[q] = d.res2[off[q]];
+    }
+    if (d.mask) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) mkv[q] = d.mask[off[q]];
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      float v = a[c * 8 + q] * es + eb + r1v[q] + r2v[q];
+      v = mkv[q] > 0.f ? v : 0.f;
+      v = d.relu ? fmaxf(v, 0.f) : v;
+      if (FULL) {
+        d.y[off[q]] = v;
+      } else {
+        if ((okbits >> q) & 1) d.y[off[q]] = v; else v = 0.f;
+      }
+      s1 += v;
+      s2 += v * v;
+    }
+    asm volatile("" ::: "memory");
+  }
+}
+
 template <int BN, bool CIN4>
 __global__ void __launch_bounds__(256, 2) igemm_kernel(const hnd_conv_desc d, const int ntiles) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -194,6 +255,7 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const hnd_conv_desc d, co
 
   // ---------------------------------------------------------------- epilogue
   float* red = As;   // [2 (wm)][2 (sum,sumsq)][BN], reused after the final barrier
+  const bool tile_full = (m0 + BM <= M) && (n0 + BN <= d.cout);
 #pragma unroll
   for (int ni = 0; ni < BN / 64; ++ni) {
     const int ct = wn * (BN / 2) + ni * 32 + (lane & 31);
@@ -204,22 +266,9 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const hnd_conv_desc d, co
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int rit = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const int po = rowoff[rit];
-        if (po >= 0 && col_ok) {
-          const size_t o = (size_t)po * d.ldc + col;
-          float v = acc[mi][ni][r] * es + eb;
-          if (d.res1) v += d.res1[d.res1_mode == 1 ? (size_t)resoff[rit] * d.ldc + col : o];
-          if (d.res2) v += d.res2[o];
-          if (d.mask) v = d.mask[o] > 0.f ? v : 0.f;
-          if (d.relu) v = fmaxf(v, 0.f);
-          d.y[o] = v;
-          s1 += v;
-          s2 += v * v;
-        }
-      }
+      const int rbase = wm * 64 + mi * 32 + 4 * (lane >> 5);
+      if (tile_full) epilogue_tile<true>(d, acc[mi][ni], rowoff, resoff, rbase, col, col_ok, es, eb, s1, s2);
+      else epilogue_tile<false>(d, acc[mi][ni], rowoff, resoff, rbase, col, col_ok, es, eb, s1, s2);
     }
     if (d.stats) {
       s1 += __shfl_xor(s1, 32);
@@ -278,6 +327,7 @@ extern "C" int hnd_conv2d_igemm(const hnd_conv_desc* desc, void* stream) {
                   (long long)d.n * d.h * d.w_ < (1ll << 31),
               "hnd_conv2d_igemm: pixel count exceeds int32");
   HND_REQUIRE(d.res1_mode == 0 || (d.res1_h > 0 && d.res1_w > 0), "hnd_conv2d_igemm: res1 upsample needs dims");
+  HND_REQUIRE((long long)d.n * d.yh * d.yw * d.ldc < (1ll << 32) - 1, "hnd_conv2d_igemm: output exceeds 2^32 elements");
   hipStream_t s = hnd::as_stream(stream);
   if (d.cin == 4) {
     return launch<64, true>(d, s);   // stem (cout 64) and the 3->64 decoder conv

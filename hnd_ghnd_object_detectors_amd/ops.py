@@ -44,7 +44,7 @@ def device_arch():
 # --------------------------------------------------------------------------------------- weights
 class PackedWeight(object):
     """K-contiguous GEMM operand made by hnd_pack_weights."""
-    __slots__ = ('buf', 'rows', 'kdim', 'ni', 'nj', 'chan_pad', 'src', 'args')
+    __slots__ = ('buf', 'rows', 'kdim', 'ni', 'nj', 'chan_pad', 'chan_real', 'src', 'args')
 
     def repack(self):
         check(_L.hnd_pack_weights(self.src.data_ptr(), self.buf.data_ptr(), *self.args, stream_ptr()),
@@ -63,7 +63,7 @@ def pack_weights(w, transposed=False, chan_pad=None, taps=None):
     if chan_pad is None:
         chan_pad = chan_pad_of(chans)
     pw = PackedWeight()
-    pw.rows, pw.ni, pw.nj, pw.chan_pad, pw.src = rows, ni, nj, chan_pad, w
+    pw.rows, pw.ni, pw.nj, pw.chan_pad, pw.chan_real, pw.src = rows, ni, nj, chan_pad, chans, w
     pw.kdim = round_up(ni * nj * chan_pad, 32)
     pw.buf = torch.empty(round_up(rows, 64) * pw.kdim, dtype=torch.float32, device=w.device)
     pw.args = (cout, cin, kh, kw, int(transposed), chan_pad, i0, istep, ni, j0, jstep, nj)
@@ -88,11 +88,13 @@ def fbn_fold(weight, bias, mean, var, eps=0.0, cs=None, out=None):
 # --------------------------------------------------------------------------------------- conv launches
 class ConvLaunch(object):
     """One prebuilt hnd_conv2d_igemm launch (descriptor + keep-alive references)."""
-    __slots__ = ('desc', 'ref', 'keep', 'flops')
+    __slots__ = ('desc', 'ref', 'keep', 'flops', 'variant')
 
     def __init__(self, desc, keep, flops=0):
         self.desc, self.keep, self.flops = desc, keep, flops
         self.ref = C.byref(desc)
+        # which kernel instantiation hnd_conv2d_igemm dispatches to (mirrors csrc/conv_igemm.hip)
+        self.variant = 'igemm_c4_n64' if desc.cin == 4 else ('igemm_n128' if desc.cout % 128 == 0 else 'igemm_n64')
 
     def run(self, stream=None):
         rc = _L.hnd_conv2d_igemm(self.ref, stream if stream is not None else stream_ptr())
@@ -134,7 +136,7 @@ def conv_desc(x, pw, y, *, kh, kw, oh, ow, sh, dh, bh, sw, dw, bw, cout, y_sh=1,
     if stats is not None:
         assert stats.numel() >= stats_tiles(n * oh * ow) * 2 * cout
     keep = (x, pw, y, pro_scale, pro_shift, epi_scale, epi_shift, res1, res2, mask, stats)
-    return ConvLaunch(d, keep, flops=2 * n * oh * ow * cout * kh * kw * cin)
+    return ConvLaunch(d, keep, flops=2 * n * oh * ow * min(cout, pw.rows) * kh * kw * min(cin, pw.chan_real))
 
 
 def stats_tiles(m):
@@ -206,11 +208,12 @@ def conv_dgrad(dy, w_param, dx, k, stride=1, pad=0, accumulate=False, **kw_):
 
 
 class WgradLaunch(object):
-    __slots__ = ('desc', 'ref', 'keep', 'flops')
+    __slots__ = ('desc', 'ref', 'keep', 'flops', 'variant')
 
     def __init__(self, desc, keep, flops):
         self.desc, self.keep, self.flops = desc, keep, flops
         self.ref = C.byref(desc)
+        self.variant = 'wgrad_m128' if desc.cout >= 128 else 'wgrad_m64'
 
     def run(self, stream=None):
         rc = _L.hnd_conv2d_wgrad(self.ref, stream if stream is not None else stream_ptr())
