@@ -166,17 +166,18 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const hnd_conv_desc d, co
       cc = 0;
     }
     okmask = 0;
+    // Branch-free gather: out-of-range taps read element 0 of x (always mapped) and are zeroed by a select when
+    // the tile is written to LDS.  A divergent `if (ok) load` per row would make hipcc wait for each load right
+    // here (phi of loaded / zero value), i.e. expose one memory round trip per k-step instead of hiding it
+    // behind the MFMAs of the current tile.
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int ih = a_ih[i] + ti * d.dh, iw = a_iw[i] + tj * d.dw;
       const bool ok = a_ok[i] && tap_ok && (unsigned)ih < (unsigned)d.h && (unsigned)iw < (unsigned)d.w_;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (ok) {
-        const size_t off = (size_t)(a_nb[i] + ih * d.w_ + iw) * d.cin + cc;
-        v = *(const f32x4*)(d.x + off);
-        okmask |= 1u << i;
-      }
-      ra[i] = v;
+      const unsigned pix = ok ? (unsigned)(a_nb[i] + ih * d.w_ + iw) : 0u;
+      const unsigned off = pix * (unsigned)d.cin + (ok ? (unsigned)cc : 0u);
+      ra[i] = *(const f32x4*)(d.x + off);
+      okmask |= (ok ? 1u : 0u) << i;
     }
 #pragma unroll
     for (int i = 0; i < BN / 32; ++i) rb[i] = *(const f32x4*)(wrow[i] + (size_t)t * BK);
@@ -197,15 +198,21 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const hnd_conv_desc d, co
   auto lstore = [&](int buf) {
     float* Ab = As + buf * BM * LDK + arow * LDK + kq * 4;
     float* Bb = Bs + buf * BN * LDK + arow * LDK + kq * 4;
+    if (has_pro) {      // uniform branch; per-row validity is a select, not control flow
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      f32x4 v = ra[i];
-      if (has_pro && ((okmask >> i) & 1)) {
-        v = v * rps + rpb;
+      for (int i = 0; i < 4; ++i) {
+        f32x4 v = ra[i] * rps + rpb;
         if (d.pro_relu) {
           v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
         }
+        ra[i] = v;
       }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bool ok = (okmask >> i) & 1;
+      f32x4 v = ra[i];
+      v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
       *(f32x4*)(Ab + 32 * i * LDK) = v;
     }
 #pragma unroll
@@ -328,6 +335,7 @@ extern "C" int hnd_conv2d_igemm(const hnd_conv_desc* desc, void* stream) {
               "hnd_conv2d_igemm: pixel count exceeds int32");
   HND_REQUIRE(d.res1_mode == 0 || (d.res1_h > 0 && d.res1_w > 0), "hnd_conv2d_igemm: res1 upsample needs dims");
   HND_REQUIRE((long long)d.n * d.yh * d.yw * d.ldc < (1ll << 32) - 1, "hnd_conv2d_igemm: output exceeds 2^32 elements");
+  HND_REQUIRE((long long)d.n * d.h * d.w_ * d.cin < (1ll << 32) - 1, "hnd_conv2d_igemm: input exceeds 2^32 elements");
   hipStream_t s = hnd::as_stream(stream);
   if (d.cin == 4) {
     return launch<64, true>(d, s);   // stem (cout 64) and the 3->64 decoder conv

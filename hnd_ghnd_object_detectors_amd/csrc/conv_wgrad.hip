@@ -68,40 +68,45 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradArgs a) {
   }
 
   f32x4 ra[A_N], rb[4];
+  unsigned bok = 0;
+  const bool a_vec = a_cok && (r0 + a_c4 + 3 < d.cout);
+  // Branch-free loads (clamped addresses, validity applied by selects in lstore) so the global loads of tile
+  // s+1 stay in flight behind the MFMAs of tile s instead of being waited for inside divergent branches.
   auto gload = [&](int s) {
     const int mbase = (step0 + s) * BKW;
 #pragma unroll
     for (int i = 0; i < A_N; ++i) {
       const int m = mbase + a_r + i * A_RPI;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (m < a.M && a_cok) {
-        const float* p = d.dy + (size_t)m * d.ldy + r0 + a_c4;
-        if (r0 + a_c4 + 3 < d.cout) v = *(const f32x4*)p;
-        else { v.x = p[0]; if (r0 + a_c4 + 1 < d.cout) v.y = p[1]; if (r0 + a_c4 + 2 < d.cout) v.z = p[2]; }
+      const bool ok = m < a.M && a_cok;
+      const float* p = d.dy + (size_t)(ok ? m : 0) * d.ldy + (ok ? r0 + a_c4 : 0);
+      f32x4 v;
+      if (a_vec) {                       // thread-constant: the whole float4 lies inside [0, cout)
+        v = *(const f32x4*)p;
+      } else {                           // channel tail (cout = 3 stored as 4): scalar loads of the valid part
+        v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (ok) {
+          v.x = p[0];
+          if (r0 + a_c4 + 1 < d.cout) v.y = p[1];
+          if (r0 + a_c4 + 2 < d.cout) v.z = p[2];
+        }
       }
+      if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
       ra[i] = v;
     }
+    bok = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int m = mbase + b_r + i * 8;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (m < a.M && b_cok) {
-        const unsigned t = fdiv((unsigned)m, a.div_ow);
-        const int ow_ = m - (int)t * d.ow;
-        const unsigned n_ = fdiv(t, a.div_oh);
-        const int oh_ = (int)t - (int)n_ * d.oh;
-        const int ih = oh_ * d.stride - d.pad + ti, iw = ow_ * d.stride - d.pad + tj;
-        if ((unsigned)ih < (unsigned)d.h && (unsigned)iw < (unsigned)d.w_) {
-          v = *(const f32x4*)(d.x + ((size_t)((int)n_ * d.h + ih) * d.w_ + iw) * d.cin + ci);
-          if (has_pro) {
-            v = v * ps + pb;
-            if (d.pro_relu) {
-              v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-            }
-          }
-        }
-      }
-      rb[i] = v;
+      const int mm = m < a.M ? m : 0;
+      const unsigned t = fdiv((unsigned)mm, a.div_ow);
+      const int ow_ = mm - (int)t * d.ow;
+      const unsigned n_ = fdiv(t, a.div_oh);
+      const int oh_ = (int)t - (int)n_ * d.oh;
+      const int ih = oh_ * d.stride - d.pad + ti, iw = ow_ * d.stride - d.pad + tj;
+      const bool ok = m < a.M && b_cok && (unsigned)ih < (unsigned)d.h && (unsigned)iw < (unsigned)d.w_;
+      const size_t off = ok ? ((size_t)((int)n_ * d.h + ih) * d.w_ + iw) * d.cin + ci : 0;
+      rb[i] = *(const f32x4*)(d.x + off);
+      bok |= (ok ? 1u : 0u) << i;
     }
   };
   auto lstore = [&](int buf) {
@@ -109,7 +114,18 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradArgs a) {
     for (int i = 0; i < A_N; ++i)
       *(f32x4*)(As + (buf * BKW + a_r + i * A_RPI) * BMW + a_c4) = ra[i];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) *(f32x4*)(Bs + (buf * BKW + b_r + i * 8) * BNW + b_c4) = rb[i];
+    for (int i = 0; i < 4; ++i) {
+      f32x4 v = rb[i];
+      if (has_pro) {
+        v = v * ps + pb;
+        if (d.pro_relu) {
+          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+      }
+      const bool ok = (bok >> i) & 1;
+      v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+      *(f32x4*)(Bs + (buf * BKW + b_r + i * 8) * BNW + b_c4) = v;
+    }
   };
 
   constexpr int MI = BMW / 64;   // 32-row MFMA tiles per wave along co
