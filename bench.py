@@ -164,6 +164,13 @@ def main():
                 'unit': 'TFLOP/s', 'frac': round(ach / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
                 'launches_per_step': per[dom]['n'], 'avg_launch_ms': round(per[dom]['ms'] / per[dom]['n'], 4),
                 'algorithmic_gflop_per_launch': round(per[dom]['flop'] / per[dom]['n'] / 1e9, 3)}
+    try:        # HBM bytes per launch of the dominant kernel from the committed PMC pass (profiles/rNN_traffic.json)
+        import glob
+        tf = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_traffic.json')))[-1]
+        roofline['traffic'] = json.load(open(tf))['kernels'][dom]['traffic_bytes_per_launch']
+        roofline['traffic_source'] = os.path.basename(tf)
+    except Exception:
+        pass
     conv_ms = sum(v['ms'] for v in per.values())
     if args.detail:
         agg = {}

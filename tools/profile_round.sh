@@ -1,0 +1,17 @@
+#!/bin/bash
+# Run on the GPU box (via gpurun): rocprofv3 kernel trace + HBM traffic counters of the bench step.
+# usage: tools/profile_round.sh r01
+set -u
+R=${1:-r01}
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+OUT=gpurun_out/prof_$R
+mkdir -p $OUT
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python3 bench.py --steps 2 --warmup 1 --no_cpu_baseline > $OUT/bench_trace.json 2> $OUT/trace.err
+# PMC passes: counters only with --kernel-trace (FETCH_SIZE needs 3 TCC slots, WRITE_SIZE 2: separate passes)
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o bench -- python3 bench.py --steps 1 --warmup 1 --no_cpu_baseline > $OUT/bench_fetch.json 2> $OUT/fetch.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o bench -- python3 bench.py --steps 1 --warmup 1 --no_cpu_baseline > $OUT/bench_write.json 2> $OUT/write.err
+python3 tools/summarize_profile.py $OUT $R > $OUT/summary.md 2> $OUT/summary.err
+ls -la $OUT $OUT/* | head -40
+# keep the merged-back payload small
+rm -f $OUT/trace/bench_kernel_trace.csv $OUT/pmc_fetch/bench_kernel_trace.csv $OUT/pmc_write/bench_kernel_trace.csv
+find $OUT -name "*counter_collection.csv" -size +20M -delete
