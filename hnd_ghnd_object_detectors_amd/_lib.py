@@ -43,6 +43,7 @@ _SIGNATURES = {
     'hnd_sync_check': (C.c_int, [vp]),
     'hnd_device_arch': (C.c_char_p, []),
     'hnd_conv2d_igemm': (C.c_int, [C.POINTER(ConvDesc), vp]),
+    'hnd_conv2d_igemm_tile': (C.c_int, [C.POINTER(ConvDesc)]),
     'hnd_conv2d_wgrad_workspace': (C.c_size_t, [C.POINTER(WgradDesc)]),
     'hnd_conv2d_wgrad': (C.c_int, [C.POINTER(WgradDesc), vp]),
     'hnd_pack_weights': (C.c_int, [vp, vp] + [C.c_int] * 12 + [vp]),

@@ -2,8 +2,10 @@
 //
 //   C[m][co] = sum_k A[m][k] * W[co][k],   m = output pixel, k = (tap, ci)
 //
-// Block tile 128 (pixels) x BN (channels, 128 or 64) x 32 (k); 256 threads = 4 waves in a 2x2
-// grid, each wave owns 64 x BN/2 as 2 x (BN/64) accumulators of v_mfma_f32_32x32x2_f32.
+// Block tile BM (pixels, 128 or 64) x BN (channels, 128 or 64) x 32 (k); 256 threads = 4 waves in a 2x2
+// grid, each wave owns BM/2 x BN/2 as (BM/64) x (BN/64) accumulators of v_mfma_f32_32x32x2_f32.  The host
+// picks the tile per launch: 128x128 where there are many tiles, smaller tiles where the grid would otherwise
+// fill the 256 CUs x 2 resident blocks unevenly (layer3/layer4: M = 67k / 17k pixels at batch 16).
 // Both operands are staged K-contiguous in LDS ([row][32+4 floats]; the 4-float pad makes the
 // ds_read_b128 fragment reads conflict-free) so a lane reads 4 consecutive k of its row with one
 // ds_read_b128 and feeds 4 MFMAs.  The reduction order inside a 8-wide k group is permuted
@@ -17,16 +19,17 @@
 // flop vs (128+BN)*32*4 B staged => 64 flop/B at BN=128.
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace {
 
 using hnd::f32x16;
 using hnd::f32x4;
 
-constexpr int BM = 128;
 constexpr int BK = 32;
 constexpr int LDK = BK + 4;   // padded LDS row (floats)
 
-template <int BN>
+template <int BM, int BN>
 constexpr size_t lds_bytes() {
   return (size_t)(2 * BM * LDK + 2 * BN * LDK) * sizeof(float) + 2 * BM * sizeof(int);
 }
@@ -92,8 +95,12 @@ __device__ __forceinline__ void epilogue_tile(const hnd_conv_desc& d, const f32x
   }
 }
 
-template <int BN, bool CIN4>
-__global__ void __launch_bounds__(256, 2) igemm_kernel(const hnd_conv_desc d, const int ntiles) {
+template <int BM, int BN, bool CIN4>
+__global__ void __launch_bounds__(256, (BM == 64 && BN == 64) ? 4 : 2)
+igemm_kernel(const hnd_conv_desc d, const int ntiles) {
+  constexpr int RA = BM / 32;            // A rows gathered per thread
+  constexpr int WTM = BM / 2;            // rows per wave
+  constexpr int MI = WTM / 32, NI = BN / 64;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                          // [2][BM][LDK]
   float* Bs = smem + 2 * BM * LDK;           // [2][BN][LDK]
@@ -129,10 +136,10 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const hnd_conv_desc d, co
   }
 
   // per-thread gather rows (4 rows of the pixel tile, fixed for the whole k loop)
-  int a_nb[4], a_ih[4], a_iw[4];
-  bool a_ok[4];
+  int a_nb[RA], a_ih[RA], a_iw[RA];
+  bool a_ok[RA];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < RA; ++i) {
     const int m = m0 + arow + 32 * i;
     a_ok[i] = m < M;
     const int mm = a_ok[i] ? m : 0;
@@ -150,7 +157,7 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const hnd_conv_desc d, co
   const unsigned kw_inv = (65536u + d.kw - 1) / d.kw;
   const int T = d.kdim / BK;
 
-  f32x4 ra[4], rb[BN / 32], rps, rpb;
+  f32x4 ra[RA], rb[BN / 32], rps, rpb;
   unsigned okmask = 0;
   // uniform tap state of the NEXT tile to load (CIN_VEC mode)
   int c0 = 0, khi = 0, kwi = 0;
@@ -171,7 +178,7 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const hnd_conv_desc d, co
     // here (phi of loaded / zero value), i.e. expose one memory round trip per k-step instead of hiding it
     // behind the MFMAs of the current tile.
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < RA; ++i) {
       const int ih = a_ih[i] + ti * d.dh, iw = a_iw[i] + tj * d.dw;
       const bool ok = a_ok[i] && tap_ok && (unsigned)ih < (unsigned)d.h && (unsigned)iw < (unsigned)d.w_;
       const unsigned pix = ok ? (unsigned)(a_nb[i] + ih * d.w_ + iw) : 0u;
@@ -200,7 +207,7 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const hnd_conv_desc d, co
     float* Bb = Bs + buf * BN * LDK + arow * LDK + kq * 4;
     if (has_pro) {      // uniform branch; per-row validity is a select, not control flow
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < RA; ++i) {
         f32x4 v = ra[i] * rps + rpb;
         if (d.pro_relu) {
           v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
@@ -209,7 +216,7 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const hnd_conv_desc d, co
       }
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < RA; ++i) {
       const bool ok = (okmask >> i) & 1;
       f32x4 v = ra[i];
       v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
@@ -219,30 +226,30 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const hnd_conv_desc d, co
     for (int i = 0; i < BN / 32; ++i) *(f32x4*)(Bb + 32 * i * LDK) = rb[i];
   };
 
-  f32x16 acc[2][BN / 64];
+  f32x16 acc[MI][NI];
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
+  for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-    for (int ni = 0; ni < BN / 64; ++ni)
+    for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
   auto compute = [&](int buf) {
-    const float* Ap = As + buf * BM * LDK + (wm * 64 + (lane & 31)) * LDK + (lane >> 5) * 4;
+    const float* Ap = As + buf * BM * LDK + (wm * WTM + (lane & 31)) * LDK + (lane >> 5) * 4;
     const float* Bp = Bs + buf * BN * LDK + (wn * (BN / 2) + (lane & 31)) * LDK + (lane >> 5) * 4;
 #pragma unroll
     for (int kk = 0; kk < BK / 8; ++kk) {
-      f32x4 a[2], b[BN / 64];
-      a[0] = *(const f32x4*)(Ap + kk * 8);
-      a[1] = *(const f32x4*)(Ap + 32 * LDK + kk * 8);
+      f32x4 a[MI], b[NI];
 #pragma unroll
-      for (int ni = 0; ni < BN / 64; ++ni) b[ni] = *(const f32x4*)(Bp + ni * 32 * LDK + kk * 8);
+      for (int mi = 0; mi < MI; ++mi) a[mi] = *(const f32x4*)(Ap + mi * 32 * LDK + kk * 8);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) b[ni] = *(const f32x4*)(Bp + ni * 32 * LDK + kk * 8);
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-          for (int ni = 0; ni < BN / 64; ++ni)
+          for (int ni = 0; ni < NI; ++ni)
             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][s], b[ni][s], acc[mi][ni], 0, 0, 0);
     }
   };
@@ -264,7 +271,7 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const hnd_conv_desc d, co
   float* red = As;   // [2 (wm)][2 (sum,sumsq)][BN], reused after the final barrier
   const bool tile_full = (m0 + BM <= M) && (n0 + BN <= d.cout);
 #pragma unroll
-  for (int ni = 0; ni < BN / 64; ++ni) {
+  for (int ni = 0; ni < NI; ++ni) {
     const int ct = wn * (BN / 2) + ni * 32 + (lane & 31);
     const int col = n0 + ct;
     const bool col_ok = col < d.cout;
@@ -272,8 +279,8 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const hnd_conv_desc d, co
     const float eb = (d.epi_shift && col_ok) ? d.epi_shift[col] : 0.f;
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-      const int rbase = wm * 64 + mi * 32 + 4 * (lane >> 5);
+    for (int mi = 0; mi < MI; ++mi) {
+      const int rbase = wm * WTM + mi * 32 + 4 * (lane >> 5);
       if (tile_full) epilogue_tile<true>(d, acc[mi][ni], rowoff, resoff, rbase, col, col_ok, es, eb, s1, s2);
       else epilogue_tile<false>(d, acc[mi][ni], rowoff, resoff, rbase, col, col_ok, es, eb, s1, s2);
     }
@@ -296,15 +303,15 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const hnd_conv_desc d, co
   }
 }
 
-template <int BN, bool CIN4>
+template <int BM, int BN, bool CIN4>
 int launch(const hnd_conv_desc& d, hipStream_t stream) {
   static bool attr_set = false;
-  auto kern = igemm_kernel<BN, CIN4>;
+  auto kern = igemm_kernel<BM, BN, CIN4>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lds_bytes<BN>());
+                                       (int)lds_bytes<BM, BN>());
     if (e != hipSuccess) {
-      hnd::set_error("hipFuncSetAttribute(igemm<%d>) failed: %s", BN, hipGetErrorString(e));
+      hnd::set_error("hipFuncSetAttribute(igemm<%d,%d>) failed: %s", BM, BN, hipGetErrorString(e));
       return HND_ERR_LAUNCH;
     }
     attr_set = true;
@@ -312,8 +319,45 @@ int launch(const hnd_conv_desc& d, hipStream_t stream) {
   const long long M = (long long)d.n * d.oh * d.ow;
   const int mtiles = (int)((M + BM - 1) / BM);
   const int ntiles = (d.cout + BN - 1) / BN;
-  hipLaunchKernelGGL(kern, dim3(mtiles * ntiles), dim3(256), lds_bytes<BN>(), stream, d, ntiles);
+  const size_t lds = lds_bytes<BM, BN>();
+  hipLaunchKernelGGL(kern, dim3(mtiles * ntiles), dim3(256), lds, stream, d, ntiles);
   return hnd::check_launch("hnd_conv2d_igemm");
+}
+
+// Tile choice.  Resident blocks: 2 per CU for every tile but 64x64 (4 per CU).  A launch runs in
+// ceil(blocks / slots) rounds, so a grid of e.g. 1050 128x128 tiles (layer3, 512 slots) wastes a third of its
+// last round; smaller tiles quantise better at a lower per-tile efficiency (factors measured with
+// tools/bench_conv.py on MI355X).
+int pick_tile(const hnd_conv_desc& d) {
+  if (const char* f = getenv("HND_IGEMM_TILE")) {       // testing / tuning override: 0..3
+    const int t = atoi(f);
+    if (t >= 0 && t <= 3) {
+      if ((t == 0 || t == 2) && d.cout % 128 != 0) return t + 1;
+      if (d.stats && (t == 2 || t == 3)) return t - 2;
+      return t;
+    }
+  }
+  const long long M = (long long)d.n * d.oh * d.ow;
+  const bool n128 = d.cout % 128 == 0;
+  // eff: large-grid throughput relative to 128x128 (124 / 113 / 115 / 114 TFLOP/s on a 16800-tile 3x3 conv);
+  // lone: cost of a block that has a CU to itself, in units of a full round of `bpc` co-resident blocks
+  // (fitted to the 3x3 512->512 @25x42 and 256->256 @50x84 convs: 0.57 at 2 blocks/CU, 0.34 at 4).
+  struct Cand { int id, bm, bn, bpc; double eff, lone; };
+  const Cand cands[4] = {{0, 128, 128, 2, 1.00, 0.57}, {1, 128, 64, 2, 0.91, 0.57}, {2, 64, 128, 2, 0.93, 0.57},
+                         {3, 64, 64, 4, 0.915, 0.34}};
+  int best = n128 ? 0 : 1;
+  double best_t = 1e300;
+  for (const Cand& c : cands) {
+    if (c.bn == 128 && !n128) continue;
+    if (d.stats && c.bm != 128) continue;          // BN statistics partials are per 128-pixel tile
+    const long long blocks = ((M + c.bm - 1) / c.bm) * ((d.cout + c.bn - 1) / c.bn);
+    const long long slots = 256ll * c.bpc;
+    const long long full = blocks / slots, rem = blocks % slots;
+    const double last = rem == 0 ? 0.0 : c.lone + (1.0 - c.lone) * (double)rem / (double)slots;
+    const double t = ((double)full + last) * c.bpc * c.bm * c.bn / c.eff;
+    if (t < best_t) { best_t = t; best = c.id; }
+  }
+  return best;
 }
 
 }  // namespace
@@ -338,8 +382,18 @@ extern "C" int hnd_conv2d_igemm(const hnd_conv_desc* desc, void* stream) {
   HND_REQUIRE((long long)d.n * d.h * d.w_ * d.cin < (1ll << 32) - 1, "hnd_conv2d_igemm: input exceeds 2^32 elements");
   hipStream_t s = hnd::as_stream(stream);
   if (d.cin == 4) {
-    return launch<64, true>(d, s);   // stem (cout 64) and the 3->64 decoder conv
+    return launch<128, 64, true>(d, s);   // stem (cout 64) and the 3->64 decoder conv
   }
-  if (d.cout % 128 == 0) return launch<128, false>(d, s);
-  return launch<64, false>(d, s);
+  switch (pick_tile(d)) {
+    case 0: return launch<128, 128, false>(d, s);
+    case 1: return launch<128, 64, false>(d, s);
+    case 2: return launch<64, 128, false>(d, s);
+    default: return launch<64, 64, false>(d, s);
+  }
+}
+
+extern "C" int hnd_conv2d_igemm_tile(const hnd_conv_desc* desc) {
+  if (!desc) return -1;
+  if (desc->cin == 4) return 1;
+  return pick_tile(*desc);
 }

@@ -96,6 +96,8 @@ typedef struct hnd_conv_desc {
 } hnd_conv_desc;
 
 int hnd_conv2d_igemm(const hnd_conv_desc* desc, void* stream);
+/* which block tile the launch above would use: 0 = 128x128, 1 = 128x64, 2 = 64x128, 3 = 64x64 (pixels x channels) */
+int hnd_conv2d_igemm_tile(const hnd_conv_desc* desc);
 
 /* Weight gradient (autograd conv backward(weight), src/mimic_runner.py:53) of the trainable convs:
  * student stem conv1 (custom/resnet.py:26) and the eight 2x2 convs (resnet_layer.py:43-62).

@@ -36,6 +36,7 @@ def main():
     ap.add_argument('--iters', type=int, default=10)
     ap.add_argument('--batch', type=int, default=16)
     ap.add_argument('--only', default='')
+    ap.add_argument('--tiles', default='', help="comma list of HND_IGEMM_TILE overrides to sweep, e.g. '0,1,2,3'")
     args = ap.parse_args()
     dev = 'cuda:0'
     only = [s for s in args.only.split(',') if s]
@@ -50,20 +51,30 @@ def main():
         y = torch.empty(n, oh, ow, cout, device=dev)
         sc, sh = torch.rand(cout, device=dev) + 0.5, torch.randn(cout, device=dev)
         r = torch.randn(n, oh, ow, cout, device=dev) if res else None
-        l = ops.conv_forward(x, ops.pack_weights(wt), y, k, s, p, epi_scale=sc, epi_shift=sh, res1=r, relu=True)
-        for _ in range(2):
-            l.run()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(args.iters):
-            l.run()
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / args.iters
-        tot_ms += ms
-        tot_fl += l.flops
-        print('%-26s %-10s %8.3f ms  %7.1f TFLOP/s' % (name, l.variant, ms, l.flops / ms / 1e9), flush=True)
-    print('%-26s %-10s %8.3f ms  %7.1f TFLOP/s' % ('TOTAL', '', tot_ms, tot_fl / tot_ms / 1e9))
+        pk = ops.pack_weights(wt)
+        line = '%-26s' % name
+        for tile in ([t for t in args.tiles.split(',') if t] or [None]):
+            if tile is None:
+                os.environ.pop('HND_IGEMM_TILE', None)
+            else:
+                os.environ['HND_IGEMM_TILE'] = tile
+            l = ops.conv_forward(x, pk, y, k, s, p, epi_scale=sc, epi_shift=sh, res1=r, relu=True)
+            for _ in range(2):
+                l.run()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(args.iters):
+                l.run()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / args.iters
+            line += '  %-14s %7.3f ms %6.1f TF' % (l.variant, ms, l.flops / ms / 1e9)
+        if not args.tiles:
+            tot_ms += ms
+            tot_fl += l.flops
+        print(line, flush=True)
+    if tot_ms:
+        print('%-26s %-10s %8.3f ms  %7.1f TFLOP/s' % ('TOTAL', '', tot_ms, tot_fl / tot_ms / 1e9))
 
 
 if __name__ == '__main__':
