@@ -45,6 +45,9 @@ def parse():
     ap.add_argument('--cpu_batch', type=int, default=2)
     ap.add_argument('--cpu_steps', type=int, default=1)
     ap.add_argument('--cpu_threads', type=int, default=32)
+    ap.add_argument('--dist_backend', default='nccl', help="'nccl' (= RCCL); 'gloo' only to exercise the multi-rank "
+                    "code path on a single-GPU box together with --share_device")
+    ap.add_argument('--share_device', action='store_true', help='testing: every rank uses cuda:0')
     ap.add_argument('--detail', default=None, help='write the per-launch table of the profiled step to this file')
     return ap.parse_args()
 
@@ -81,10 +84,12 @@ def main():
         raise SystemExit('WORLD_SIZE=%d but --gpus %d' % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the HIP path has no CPU fallback')
+    if args.share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1:
-        dist.init_process_group('nccl', init_method='env://')      # 'nccl' is RCCL on ROCm
+        dist.init_process_group(args.dist_backend, init_method='env://')      # 'nccl' is RCCL on ROCm
 
     from hnd_ghnd_object_detectors_amd import engine as E
     from hnd_ghnd_object_detectors_amd.configs import make_config
@@ -147,6 +152,7 @@ def main():
     if rank != 0:
         if world > 1:
             dist.barrier()
+            dist.destroy_process_group()
         return
 
     # ---- roofline of the dominant kernel from the per-launch HIP events of the last timed step
@@ -210,6 +216,7 @@ def main():
     _print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == '__main__':
