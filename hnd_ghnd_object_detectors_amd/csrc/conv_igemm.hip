@@ -26,12 +26,17 @@ namespace {
 using hnd::f32x16;
 using hnd::f32x4;
 
-constexpr int BK = 32;
-constexpr int LDK = BK + 4;   // padded LDS row (floats)
 
-template <int BM, int BN>
+template <int BM, int BN, int BK>
 constexpr size_t lds_bytes() {
-  return (size_t)(2 * BM * LDK + 2 * BN * LDK) * sizeof(float) + 2 * BM * sizeof(int);
+  return (size_t)(2 * BM * (BK + 4) + 2 * BN * (BK + 4)) * sizeof(float) + 2 * BM * sizeof(int);
+}
+
+// resident blocks per CU the launch bounds ask for (LDS and VGPR budgets both allow it)
+template <int BM, int BN, int BK>
+constexpr int blocks_per_cu() {
+  return BK == 16 ? ((BM == 64 && BN == 64) ? 5 : ((BM == 128 && BN == 128) ? 3 : 4))
+                  : ((BM == 64 && BN == 64) ? 4 : 2);
 }
 
 // Epilogue of one 32x32 accumulator tile.  FULL = the block's whole 128 x BN tile is in range (every tile of a
@@ -95,10 +100,14 @@ __device__ __forceinline__ void epilogue_tile(const hnd_conv_desc& d, const f32x
   }
 }
 
-template <int BM, int BN, bool CIN4>
-__global__ void __launch_bounds__(256, (BM == 64 && BN == 64) ? 4 : 2)
+template <int BM, int BN, int BK, bool CIN4>
+__global__ void __launch_bounds__(256, (blocks_per_cu<BM, BN, BK>()))
 igemm_kernel(const hnd_conv_desc d, const int ntiles) {
-  constexpr int RA = BM / 32;            // A rows gathered per thread
+  constexpr int LDK = BK + 4;            // padded LDS row (floats): conflict-free ds_read_b128 at 144 B and 80 B
+  constexpr int TPR = BK / 4;            // threads per staged row (one float4 each)
+  constexpr int RPP = 256 / TPR;         // rows staged per pass
+  constexpr int RA = BM / RPP;           // A rows gathered per thread
+  constexpr int RB = BN / RPP;           // B rows loaded per thread
   constexpr int WTM = BM / 2;            // rows per wave
   constexpr int MI = WTM / 32, NI = BN / 64;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -119,7 +128,7 @@ igemm_kernel(const hnd_conv_desc d, const int ntiles) {
   const int M = d.n * d.oh * d.ow;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 1, wn = wave >> 1;
-  const int arow = tid >> 3, kq = tid & 7;
+  const int arow = tid / TPR, kq = tid % TPR;
 
   if (tid < BM) {
     const int m = m0 + tid;
@@ -140,7 +149,7 @@ igemm_kernel(const hnd_conv_desc d, const int ntiles) {
   bool a_ok[RA];
 #pragma unroll
   for (int i = 0; i < RA; ++i) {
-    const int m = m0 + arow + 32 * i;
+    const int m = m0 + arow + RPP * i;
     a_ok[i] = m < M;
     const int mm = a_ok[i] ? m : 0;
     const int ow_ = mm % d.ow, t = mm / d.ow, oh_ = t % d.oh, n_ = t / d.oh;
@@ -148,16 +157,16 @@ igemm_kernel(const hnd_conv_desc d, const int ntiles) {
     a_ih[i] = oh_ * d.sh + d.bh;
     a_iw[i] = ow_ * d.sw + d.bw;
   }
-  const float* wrow[BN / 32];
+  const float* wrow[RB];
 #pragma unroll
-  for (int i = 0; i < BN / 32; ++i) wrow[i] = d.w + (size_t)(n0 + arow + 32 * i) * d.kdim + kq * 4;
+  for (int i = 0; i < RB; ++i) wrow[i] = d.w + (size_t)(n0 + arow + RPP * i) * d.kdim + kq * 4;
 
   const bool has_pro = d.pro_scale != nullptr;
   const int ntaps = d.kh * d.kw;
   const unsigned kw_inv = (65536u + d.kw - 1) / d.kw;
   const int T = d.kdim / BK;
 
-  f32x4 ra[RA], rb[BN / 32], rps, rpb;
+  f32x4 ra[RA], rb[RB], rps, rpb;
   unsigned okmask = 0;
   // uniform tap state of the NEXT tile to load (CIN_VEC mode)
   int c0 = 0, khi = 0, kwi = 0;
@@ -166,7 +175,7 @@ igemm_kernel(const hnd_conv_desc d, const int ntiles) {
     int ti = khi, tj = kwi, cc = c0 + kq * 4;
     bool tap_ok = true;
     if (CIN4) {
-      const int tap = t * 8 + kq;
+      const int tap = t * TPR + kq;
       ti = (int)((tap * kw_inv) >> 16);
       tj = tap - ti * d.kw;
       tap_ok = tap < ntaps;
@@ -187,7 +196,7 @@ igemm_kernel(const hnd_conv_desc d, const int ntiles) {
       okmask |= (ok ? 1u : 0u) << i;
     }
 #pragma unroll
-    for (int i = 0; i < BN / 32; ++i) rb[i] = *(const f32x4*)(wrow[i] + (size_t)t * BK);
+    for (int i = 0; i < RB; ++i) rb[i] = *(const f32x4*)(wrow[i] + (size_t)t * BK);
     if (has_pro) {
       rps = *(const f32x4*)(d.pro_scale + cc);
       if (d.pro_shift) rpb = *(const f32x4*)(d.pro_shift + cc);
@@ -220,10 +229,10 @@ igemm_kernel(const hnd_conv_desc d, const int ntiles) {
       const bool ok = (okmask >> i) & 1;
       f32x4 v = ra[i];
       v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
-      *(f32x4*)(Ab + 32 * i * LDK) = v;
+      *(f32x4*)(Ab + RPP * i * LDK) = v;
     }
 #pragma unroll
-    for (int i = 0; i < BN / 32; ++i) *(f32x4*)(Bb + 32 * i * LDK) = rb[i];
+    for (int i = 0; i < RB; ++i) *(f32x4*)(Bb + RPP * i * LDK) = rb[i];
   };
 
   f32x16 acc[MI][NI];
@@ -303,13 +312,13 @@ igemm_kernel(const hnd_conv_desc d, const int ntiles) {
   }
 }
 
-template <int BM, int BN, bool CIN4>
+template <int BM, int BN, int BK, bool CIN4>
 int launch(const hnd_conv_desc& d, hipStream_t stream) {
   static bool attr_set = false;
-  auto kern = igemm_kernel<BM, BN, CIN4>;
+  auto kern = igemm_kernel<BM, BN, BK, CIN4>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lds_bytes<BM, BN>());
+                                       (int)lds_bytes<BM, BN, BK>());
     if (e != hipSuccess) {
       hnd::set_error("hipFuncSetAttribute(igemm<%d,%d>) failed: %s", BM, BN, hipGetErrorString(e));
       return HND_ERR_LAUNCH;
@@ -319,7 +328,7 @@ int launch(const hnd_conv_desc& d, hipStream_t stream) {
   const long long M = (long long)d.n * d.oh * d.ow;
   const int mtiles = (int)((M + BM - 1) / BM);
   const int ntiles = (d.cout + BN - 1) / BN;
-  const size_t lds = lds_bytes<BM, BN>();
+  const size_t lds = lds_bytes<BM, BN, BK>();
   hipLaunchKernelGGL(kern, dim3(mtiles * ntiles), dim3(256), lds, stream, d, ntiles);
   return hnd::check_launch("hnd_conv2d_igemm");
 }
@@ -328,6 +337,12 @@ int launch(const hnd_conv_desc& d, hipStream_t stream) {
 // ceil(blocks / slots) rounds, so a grid of e.g. 1050 128x128 tiles (layer3, 512 slots) wastes a third of its
 // last round; smaller tiles quantise better at a lower per-tile efficiency (factors measured with
 // tools/bench_conv.py on MI355X).
+// bit t set: tile t runs its 16-deep k-step build (smaller LDS footprint -> more resident blocks per CU)
+int bk16_mask() {
+  static const int m = getenv("HND_IGEMM_BK16") ? atoi(getenv("HND_IGEMM_BK16")) : 7;
+  return m;
+}
+
 int pick_tile(const hnd_conv_desc& d) {
   if (const char* f = getenv("HND_IGEMM_TILE")) {       // testing / tuning override: 0..3
     const int t = atoi(f);
@@ -339,12 +354,18 @@ int pick_tile(const hnd_conv_desc& d) {
   }
   const long long M = (long long)d.n * d.oh * d.ow;
   const bool n128 = d.cout % 128 == 0;
-  // eff: large-grid throughput relative to 128x128 (124 / 113 / 115 / 114 TFLOP/s on a 16800-tile 3x3 conv);
-  // lone: cost of a block that has a CU to itself, in units of a full round of `bpc` co-resident blocks
-  // (fitted to the 3x3 512->512 @25x42 and 256->256 @50x84 convs: 0.57 at 2 blocks/CU, 0.34 at 4).
+  // eff: large-grid throughput relative to the 128x128 tile (128.6 / 115.6 / 117.1 / 113.8 TFLOP/s measured on a
+  // 16800-tile 3x3 conv with tools/bench_conv.py); bpc: resident blocks per CU of the build in use.
+  // A launch takes `full` rounds of 256*bpc blocks plus a last partial round in which the busiest CU holds
+  // b = ceil(rem / 256) blocks; a CU with b of bpc blocks needs lone + (1 - lone)(b - 1)/(bpc - 1) of a round
+  // (a block alone on a CU does not run bpc times faster: 0.57 of a round at bpc 2, 0.34 at bpc 4 -- fitted to
+  // the 512->512 @25x42 and 256->256 @50x84 3x3 convs, which the model then predicts within 3 %).
   struct Cand { int id, bm, bn, bpc; double eff, lone; };
-  const Cand cands[4] = {{0, 128, 128, 2, 1.00, 0.57}, {1, 128, 64, 2, 0.91, 0.57}, {2, 64, 128, 2, 0.93, 0.57},
-                         {3, 64, 64, 4, 0.915, 0.34}};
+  const int b16 = bk16_mask();
+  const Cand cands[4] = {{0, 128, 128, (b16 & 1) ? 3 : 2, (b16 & 1) ? 1.00 : 0.97, (b16 & 1) ? 0.45 : 0.57},
+                         {1, 128, 64, (b16 & 2) ? 4 : 2, (b16 & 2) ? 0.90 : 0.88, (b16 & 2) ? 0.34 : 0.57},
+                         {2, 64, 128, (b16 & 4) ? 4 : 2, (b16 & 4) ? 0.91 : 0.895, (b16 & 4) ? 0.34 : 0.57},
+                         {3, 64, 64, (b16 & 8) ? 5 : 4, (b16 & 8) ? 0.86 : 0.885, (b16 & 8) ? 0.30 : 0.34}};
   int best = n128 ? 0 : 1;
   double best_t = 1e300;
   for (const Cand& c : cands) {
@@ -353,7 +374,8 @@ int pick_tile(const hnd_conv_desc& d) {
     const long long blocks = ((M + c.bm - 1) / c.bm) * ((d.cout + c.bn - 1) / c.bn);
     const long long slots = 256ll * c.bpc;
     const long long full = blocks / slots, rem = blocks % slots;
-    const double last = rem == 0 ? 0.0 : c.lone + (1.0 - c.lone) * (double)rem / (double)slots;
+    const long long b = (rem + 255) / 256;
+    const double last = rem == 0 ? 0.0 : c.lone + (1.0 - c.lone) * (double)(b - 1) / (double)(c.bpc - 1);
     const double t = ((double)full + last) * c.bpc * c.bm * c.bn / c.eff;
     if (t < best_t) { best_t = t; best = c.id; }
   }
@@ -382,13 +404,14 @@ extern "C" int hnd_conv2d_igemm(const hnd_conv_desc* desc, void* stream) {
   HND_REQUIRE((long long)d.n * d.h * d.w_ * d.cin < (1ll << 32) - 1, "hnd_conv2d_igemm: input exceeds 2^32 elements");
   hipStream_t s = hnd::as_stream(stream);
   if (d.cin == 4) {
-    return launch<128, 64, true>(d, s);   // stem (cout 64) and the 3->64 decoder conv
+    return launch<128, 64, 32, true>(d, s);   // stem (cout 64) and the 3->64 decoder conv
   }
+  const int bk16 = bk16_mask();
   switch (pick_tile(d)) {
-    case 0: return launch<128, 128, false>(d, s);
-    case 1: return launch<128, 64, false>(d, s);
-    case 2: return launch<64, 128, false>(d, s);
-    default: return launch<64, 64, false>(d, s);
+    case 0: return (bk16 & 1) ? launch<128, 128, 16, false>(d, s) : launch<128, 128, 32, false>(d, s);
+    case 1: return (bk16 & 2) ? launch<128, 64, 16, false>(d, s) : launch<128, 64, 32, false>(d, s);
+    case 2: return (bk16 & 4) ? launch<64, 128, 16, false>(d, s) : launch<64, 128, 32, false>(d, s);
+    default: return (bk16 & 8) ? launch<64, 64, 16, false>(d, s) : launch<64, 64, 32, false>(d, s);
   }
 }
 
