@@ -12,6 +12,8 @@
 // torch OIHW layout -> bitwise reproducible, no float atomics.
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace {
 
 using hnd::FastDiv;
@@ -20,7 +22,6 @@ using hnd::f32x4;
 using hnd::fdiv;
 
 constexpr int BNW = 128;
-constexpr int BKW = 32;
 
 struct WgradArgs {
   hnd_wgrad_desc d;
@@ -28,8 +29,8 @@ struct WgradArgs {
   int ncols, ncols_pad, co_pad, rtiles, ctiles, steps_per_split, M;
 };
 
-template <int BMW>
-__global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradArgs a) {
+template <int BMW, int BKW>
+__global__ void __launch_bounds__(256, (BKW == 16 ? 4 : 2)) wgrad_kernel(const WgradArgs a) {
   __shared__ __attribute__((aligned(16))) float smem[2 * BKW * (BMW + BNW)];
   float* As = smem;                       // [2][BKW][BMW]   dy tile
   float* Bs = smem + 2 * BKW * BMW;       // [2][BKW][BNW]   gathered activation tile
@@ -67,7 +68,8 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradArgs a) {
     if (d.pro_shift) pb = *(const f32x4*)(d.pro_shift + ci);
   }
 
-  f32x4 ra[A_N], rb[4];
+  constexpr int B_N = BKW / 8;             // passes of 8 pixel rows for the activation tile
+  f32x4 ra[A_N], rb[B_N];
   unsigned bok = 0;
   const bool a_vec = a_cok && (r0 + a_c4 + 3 < d.cout);
   // Branch-free loads (clamped addresses, validity applied by selects in lstore) so the global loads of tile
@@ -95,7 +97,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradArgs a) {
     }
     bok = 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < B_N; ++i) {
       const int m = mbase + b_r + i * 8;
       const int mm = m < a.M ? m : 0;
       const unsigned t = fdiv((unsigned)mm, a.div_ow);
@@ -114,7 +116,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradArgs a) {
     for (int i = 0; i < A_N; ++i)
       *(f32x4*)(As + (buf * BKW + a_r + i * A_RPI) * BMW + a_c4) = ra[i];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < B_N; ++i) {
       f32x4 v = rb[i];
       if (has_pro) {
         v = v * ps + pb;
@@ -199,7 +201,13 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __re
   dw[(((size_t)co * cin_real + ci) * kh + i) * kw + j] = s;
 }
 
-int plan(const hnd_wgrad_desc& d, WgradArgs& a) {
+// k-step depth of the build in use: 16 (32 KB LDS, 4 resident blocks per CU) unless HND_WGRAD_BK=32
+int wgrad_bk() {
+  static const int bk = (getenv("HND_WGRAD_BK") && atoi(getenv("HND_WGRAD_BK")) == 32) ? 32 : 16;
+  return bk;
+}
+
+int plan(const hnd_wgrad_desc& d, WgradArgs& a, int BKW) {
   a.d = d;
   a.M = d.n * d.oh * d.ow;
   a.ncols = d.kh * d.kw * d.cin;
@@ -233,7 +241,7 @@ extern "C" size_t hnd_conv2d_wgrad_workspace(const hnd_wgrad_desc* desc) {
   WgradArgs a;
   hnd_wgrad_desc d = *desc;
   if (d.cin <= 0 || d.cout <= 0 || d.kh <= 0 || d.kw <= 0 || d.oh <= 0 || d.ow <= 0 || d.n <= 0) return 0;
-  plan(d, a);
+  plan(d, a, wgrad_bk());
   return (size_t)a.d.splitk * a.co_pad * a.ncols_pad * sizeof(float);
 }
 
@@ -250,11 +258,17 @@ extern "C" int hnd_conv2d_wgrad(const hnd_wgrad_desc* desc, void* stream) {
   HND_REQUIRE((long long)d.n * d.oh * d.ow < (1ll << 31) && (long long)d.n * d.h * d.w_ < (1ll << 31),
               "hnd_conv2d_wgrad: pixel count exceeds int32");
   WgradArgs a;
-  const int bmw = plan(d, a);
+  const int bk = wgrad_bk();
+  const int bmw = plan(d, a, bk);
   hipStream_t s = hnd::as_stream(stream);
   const int grid = a.rtiles * a.ctiles * a.d.splitk;
-  if (bmw == 128) hipLaunchKernelGGL(wgrad_kernel<128>, dim3(grid), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(wgrad_kernel<64>, dim3(grid), dim3(256), 0, s, a);
+  if (bk == 16) {
+    if (bmw == 128) hipLaunchKernelGGL((wgrad_kernel<128, 16>), dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((wgrad_kernel<64, 16>), dim3(grid), dim3(256), 0, s, a);
+  } else {
+    if (bmw == 128) hipLaunchKernelGGL((wgrad_kernel<128, 32>), dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((wgrad_kernel<64, 32>), dim3(grid), dim3(256), 0, s, a);
+  }
   int rc = hnd::check_launch("hnd_conv2d_wgrad");
   if (rc) return rc;
   const int total = d.cout * d.kh * d.kw * d.cin_real;
