@@ -21,6 +21,10 @@
 
 #include <stdlib.h>
 
+#ifndef HND_BPC_128
+#define HND_BPC_128 3
+#endif
+
 namespace {
 
 using hnd::f32x16;
@@ -29,13 +33,13 @@ using hnd::f32x4;
 
 template <int BM, int BN, int BK>
 constexpr size_t lds_bytes() {
-  return (size_t)(2 * BM * (BK + 4) + 2 * BN * (BK + 4)) * sizeof(float) + 2 * BM * sizeof(int);
+  return (size_t)(2 * BM * (BK + 4) + 2 * BN * (BK + 4)) * sizeof(float);
 }
 
 // resident blocks per CU the launch bounds ask for (LDS and VGPR budgets both allow it)
 template <int BM, int BN, int BK>
 constexpr int blocks_per_cu() {
-  return BK == 16 ? ((BM == 64 && BN == 64) ? 5 : ((BM == 128 && BN == 128) ? 3 : 4))
+  return BK == 16 ? ((BM == 64 && BN == 64) ? 5 : ((BM == 128 && BN == 128) ? HND_BPC_128 : 4))
                   : ((BM == 64 && BN == 64) ? 4 : 2);
 }
 
@@ -113,8 +117,8 @@ igemm_kernel(const hnd_conv_desc d, const int ntiles) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                          // [2][BM][LDK]
   float* Bs = smem + 2 * BM * LDK;           // [2][BN][LDK]
-  int* rowoff = (int*)(Bs + 2 * BN * LDK);   // [BM] output pixel index (or -1)
-  int* resoff = rowoff + BM;                 // [BM] res1 pixel index (mode 1)
+  int* rowoff = (int*)Bs;                    // [BM] output pixel index (or -1); aliases the B staging buffer,
+  int* resoff = rowoff + BM;                 // [BM] res1 pixel index (mode 1)  -- filled after the k loop
 
   // XCD-aware bijective remap: blocks b and b+8 share an XCD/L2, give each XCD a contiguous run
   // of logical tiles so the N-tiles of one pixel tile hit the same L2.
@@ -129,20 +133,6 @@ igemm_kernel(const hnd_conv_desc d, const int ntiles) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 1, wn = wave >> 1;
   const int arow = tid / TPR, kq = tid % TPR;
-
-  if (tid < BM) {
-    const int m = m0 + tid;
-    int po = -1, pr = -1;
-    if (m < M) {
-      const int ow_ = m % d.ow, t = m / d.ow, oh_ = t % d.oh, n_ = t / d.oh;
-      const int yr = oh_ * d.y_sh + d.y_oh, yc = ow_ * d.y_sw + d.y_ow;
-      po = (n_ * d.yh + yr) * d.yw + yc;
-      if (d.res1_mode == 1)
-        pr = (n_ * d.res1_h + (yr * d.res1_h) / d.yh) * d.res1_w + (yc * d.res1_w) / d.yw;
-    }
-    rowoff[tid] = po;
-    resoff[tid] = pr;
-  }
 
   // per-thread gather rows (4 rows of the pixel tile, fixed for the whole k loop)
   int a_nb[RA], a_ih[RA], a_iw[RA];
@@ -277,6 +267,22 @@ igemm_kernel(const hnd_conv_desc d, const int ntiles) {
   }
 
   // ---------------------------------------------------------------- epilogue
+  // (the k loop ended with a barrier: the staging buffers are free; As becomes the stats scratch, Bs the row tables)
+  if (tid < BM) {
+    const int m = m0 + tid;
+    int po = -1, pr = -1;
+    if (m < M) {
+      const int ow_ = m % d.ow, t = m / d.ow, oh_ = t % d.oh, n_ = t / d.oh;
+      const int yr = oh_ * d.y_sh + d.y_oh, yc = ow_ * d.y_sw + d.y_ow;
+      po = (n_ * d.yh + yr) * d.yw + yc;
+      if (d.res1_mode == 1)
+        pr = (n_ * d.res1_h + (yr * d.res1_h) / d.yh) * d.res1_w + (yc * d.res1_w) / d.yw;
+    }
+    rowoff[tid] = po;
+    resoff[tid] = pr;
+  }
+
+  __syncthreads();
   float* red = As;   // [2 (wm)][2 (sum,sumsq)][BN], reused after the final barrier
   const bool tile_full = (m0 + BM <= M) && (n0 + BN <= d.cout);
 #pragma unroll
