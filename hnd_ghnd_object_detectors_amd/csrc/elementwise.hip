@@ -4,6 +4,7 @@
 // per-wave shuffle reductions then per-block partials (no float atomics -> deterministic).
 #include "common.h"
 
+#include <hip/hip_fp16.h>
 #include <math.h>
 
 namespace {
@@ -432,6 +433,83 @@ __global__ void fill_kernel(float* x, long long n, float v) {
     x[e] = v;
 }
 
+// ------------------------------------------------------------------------------------ bottleneck codec
+constexpr int kMinMaxBlocks = 512;
+
+__global__ void minmax_kernel(const float* __restrict__ x, long long npix, int c, int cs, float* __restrict__ part) {
+  __shared__ float smin[4], smax[4];
+  float lo = INFINITY, hi = -INFINITY;
+  const long long total = npix * cs;
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    if ((int)(e % cs) < c) {
+      const float v = x[e];
+      lo = fminf(lo, v);
+      hi = fmaxf(hi, v);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    lo = fminf(lo, __shfl_xor(lo, o));
+    hi = fmaxf(hi, __shfl_xor(hi, o));
+  }
+  if ((threadIdx.x & 63) == 0) { smin[threadIdx.x >> 6] = lo; smax[threadIdx.x >> 6] = hi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    part[blockIdx.x * 2 + 0] = fminf(fminf(smin[0], smin[1]), fminf(smin[2], smin[3]));
+    part[blockIdx.x * 2 + 1] = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
+  }
+}
+
+__global__ void qparams_kernel(const float* __restrict__ part, int nblocks, float qmax, float* __restrict__ qp) {
+  float lo = INFINITY, hi = -INFINITY;
+  for (int i = threadIdx.x; i < nblocks; i += 64) {
+    lo = fminf(lo, part[i * 2]);
+    hi = fmaxf(hi, part[i * 2 + 1]);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    lo = fminf(lo, __shfl_xor(lo, o));
+    hi = fmaxf(hi, __shfl_xor(hi, o));
+  }
+  if (threadIdx.x == 0) {
+    const float scale = (hi - lo) / (qmax - 0.f);
+    float zp = 0.f - lo / scale;
+    zp = zp < 0.f ? 0.f : (zp > qmax ? qmax : zp);
+    qp[0] = lo; qp[1] = hi; qp[2] = scale; qp[3] = truncf(zp);
+  }
+}
+
+__global__ void quantize_kernel(const float* __restrict__ x, long long npix, int c, int cs,
+                                const float* __restrict__ qp, float qmax, uint8_t* __restrict__ q) {
+  const float scale = qp[2], zp = qp[3];
+  const long long total = npix * cs;
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    float v = 0.f;
+    if ((int)(e % cs) < c) {
+      v = zp + x[e] / scale;
+      v = v < 0.f ? 0.f : (v > qmax ? qmax : v);
+      v = rintf(v);
+    }
+    q[e] = (uint8_t)v;
+  }
+}
+
+__global__ void dequantize_kernel(const uint8_t* __restrict__ q, const float* __restrict__ qp, float* __restrict__ x,
+                                  long long npix, int c, int cs) {
+  const float scale = qp[2], zp = qp[3];
+  const long long total = npix * cs;
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x)
+    x[e] = ((int)(e % cs) < c) ? scale * ((float)q[e] - zp) : 0.f;
+}
+
+__global__ void roundtrip_f16_kernel(float* x, long long n) {
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x)
+    x[e] = __half2float(__float2half(x[e]));
+}
+
 }  // namespace
 
 // ======================================================================================== C ABI
@@ -604,6 +682,35 @@ int hnd_subsample2(const float* x, float* y, int n, int h, int w, int c, int oh,
   hipLaunchKernelGGL(subsample2_kernel, dim3(grid_for((long long)n * oh * ow * (c / 4))), dim3(256), 0,
                      hnd::as_stream(stream), x, y, n, h, w, c, oh, ow);
   return hnd::check_launch("hnd_subsample2");
+}
+
+size_t hnd_minmax_scratch_elems(void) { return 2 * kMinMaxBlocks; }
+
+int hnd_quantize_u8(const float* x, int64_t npix, int c, int cs, uint8_t* q, float* qparams, float* scratch,
+                    void* stream) {
+  HND_REQUIRE(x && q && qparams && scratch && npix > 0 && c > 0 && cs >= c, "hnd_quantize_u8: bad arguments");
+  hipStream_t s = hnd::as_stream(stream);
+  int nb = grid_for((long long)npix * cs);
+  if (nb > kMinMaxBlocks) nb = kMinMaxBlocks;
+  hipLaunchKernelGGL(minmax_kernel, dim3(nb), dim3(256), 0, s, x, (long long)npix, c, cs, scratch);
+  hipLaunchKernelGGL(qparams_kernel, dim3(1), dim3(64), 0, s, scratch, nb, 255.f, qparams);
+  hipLaunchKernelGGL(quantize_kernel, dim3(grid_for((long long)npix * cs)), dim3(256), 0, s, x, (long long)npix, c, cs,
+                     qparams, 255.f, q);
+  return hnd::check_launch("hnd_quantize_u8");
+}
+
+int hnd_dequantize_u8(const uint8_t* q, const float* qparams, float* x, int64_t npix, int c, int cs, void* stream) {
+  HND_REQUIRE(q && qparams && x && npix > 0 && c > 0 && cs >= c, "hnd_dequantize_u8: bad arguments");
+  hipLaunchKernelGGL(dequantize_kernel, dim3(grid_for((long long)npix * cs)), dim3(256), 0, hnd::as_stream(stream), q,
+                     qparams, x, (long long)npix, c, cs);
+  return hnd::check_launch("hnd_dequantize_u8");
+}
+
+int hnd_roundtrip_f16(float* x, int64_t numel, void* stream) {
+  HND_REQUIRE(x && numel > 0, "hnd_roundtrip_f16: bad arguments");
+  hipLaunchKernelGGL(roundtrip_f16_kernel, dim3(grid_for(numel)), dim3(256), 0, hnd::as_stream(stream), x,
+                     (long long)numel);
+  return hnd::check_launch("hnd_roundtrip_f16");
 }
 
 int hnd_fill(float* x, int64_t numel, float value, void* stream) {

@@ -400,8 +400,9 @@ class HeadEngine(object):
         self.plan_key = None
         self.bwd_key = None
         self.flops_fwd = self.flops_bwd = 0
+        self.encoder_len = 4          # convs 0..3 form the encoder, 4..7 the decoder (resnet_layer.py:42-65)
 
-    def forward(self, x, training):
+    def forward(self, x, training, codec=None):
         if self.bufs is None:
             self.bufs = Buffers(x.device)
         for hc in self.layers:
@@ -422,6 +423,14 @@ class HeadEngine(object):
                 ops.fbn_fold(bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
                              eps=BN_EPS, cs=hc.cs_out, out=(self.scale[i], self.shift[i]))
             _run(self.convs[i], 'layer1.conv%d' % i)
+            if codec is not None and i == self.encoder_len - 1:
+                # eval-time bottleneck transformer on z = encoder output (logical [N, bch, H, W]); the codec
+                # writes the dequantised tensor back into the same buffer, which the decoder plan reads
+                z = logical(self.y[i], hc.cout)
+                z._hnd = self.y[i]
+                z2, _ = codec(z, None)
+                if getattr(z2, '_hnd', None) is not self.y[i]:
+                    raise RuntimeError('bottleneck transformer must return the (de)quantised tensor in place')
             if training:
                 bn = hc.bn
                 m = self.count[i]

@@ -1,8 +1,9 @@
 """Encoder/decoder container of the bottleneck-injected layer1 (mirror of src/models/mimic/base.py).
 
-``BottleneckBase4Ext.forward`` (reference :50-58) = decoder(encoder(x)); the eval-only bottleneck
-transformer (:54-57) and the neural-filter branch (:13-19, :38-48) are not on the distillation step
-(mimic_runner.py:90 forces use_bottleneck_transformer False) and raise until built.
+``BottleneckBase4Ext.forward`` (reference :50-58) = decoder(encoder(x)), with the eval-only bottleneck
+transformer (:54-57: quantise / dequantise the bottleneck tensor) applied between the two when
+``use_bottleneck_transformer`` is set; the neural-filter branch (:13-19, :38-48) belongs to ext_runner
+and raises.
 """
 from torch import nn
 
@@ -47,10 +48,11 @@ class BottleneckBase4Ext(nn.Module):
         return self._engine
 
     def forward(self, x):
+        codec = None
         if (not self.training) and self.bottleneck_transformer is not None and self.use_bottleneck_transformer:
-            raise NotImplementedError('eval-time bottleneck quantisation is not built yet (SURVEY.md 8f, row f1)')
+            codec = self.bottleneck_transformer            # reference base.py:54-57 (eval only)
         eng = self.head_engine()
-        out = eng.forward(to_nhwc(x), self.training)
+        out = eng.forward(to_nhwc(x), self.training, codec=codec)
         return attach(E.logical(out), out)
 
     def get_ext_classifier(self):

@@ -348,6 +348,26 @@ def fill(x, value):
     check(_L.hnd_fill(ptr(x), x.numel(), float(value), stream_ptr()), 'hnd_fill')
 
 
+def quantize_u8(x, c, q, qparams, scratch):
+    cs = x.shape[-1]
+    check(_L.hnd_quantize_u8(ptr(x), x.numel() // cs, c, cs, ptr(q), ptr(qparams), ptr(scratch), stream_ptr()),
+          'hnd_quantize_u8')
+
+
+def dequantize_u8(q, qparams, x, c):
+    cs = x.shape[-1]
+    check(_L.hnd_dequantize_u8(ptr(q), ptr(qparams), ptr(x), x.numel() // cs, c, cs, stream_ptr()),
+          'hnd_dequantize_u8')
+
+
+def minmax_scratch_elems():
+    return _L.hnd_minmax_scratch_elems()
+
+
+def roundtrip_f16(x):
+    check(_L.hnd_roundtrip_f16(ptr(x), x.numel(), stream_ptr()), 'hnd_roundtrip_f16')
+
+
 def interp_out_size(size, scale):
     """F.interpolate(scale_factor=scale) output size: floor(size * scale) in double (torch semantics)."""
     return int(math.floor(float(size) * scale))

@@ -210,6 +210,19 @@ int hnd_adam_step_flat(float* param, const float* grad, float* exp_avg, float* e
 int hnd_subsample2(const float* x, float* y, int n, int h, int w, int c, int oh, int ow, void* stream);
 int hnd_fill(float* x, int64_t numel, float value, void* stream);
 
+/* Eval-time bottleneck codec: Quantizer / Dequantizer of src/structure/transformer.py:131-153
+ * over myutils tensor_util.quantize_tensor / dequantize_tensor (un-vendored; semantics as used at :139,:152):
+ *   scale = (max - min) / (2^bits - 1);  zero_point = trunc(clamp(0 - min/scale, 0, 2^bits - 1));
+ *   q = round_half_even(clamp(zero_point + x/scale, 0, 2^bits - 1));   x' = scale * (q - zero_point)
+ * x is NHWC with channel stride cs; only the first c channels take part (pad channels stay 0).
+ * qparams (device float[4]) = {min, max, scale, zero_point}; scratch: device float[hnd_minmax_scratch_elems()]. */
+size_t hnd_minmax_scratch_elems(void);
+int hnd_quantize_u8(const float* x, int64_t npix, int c, int cs, uint8_t* q, float* qparams, float* scratch,
+                    void* stream);
+int hnd_dequantize_u8(const uint8_t* q, const float* qparams, float* x, int64_t npix, int c, int cs, void* stream);
+/* Quantizer(num_bits=16): z.half() then .float() (transformer.py:136-137,149-150) as one round trip */
+int hnd_roundtrip_f16(float* x, int64_t numel, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

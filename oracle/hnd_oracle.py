@@ -246,10 +246,20 @@ def _train_bn(x, sd, p, training, update_buffers):
     return y
 
 
-def student_layer1(x, sd, training=True, update_buffers=True, intermediates=None):
+def quantize_dequantize(z, num_bits=8):
+    """Quantizer -> Dequantizer of src/structure/transformer.py:131-153 (myutils tensor_util semantics)."""
+    if num_bits == 16:
+        return z.half().float()
+    from oracle.myutils_r import quantize_tensor, dequantize_tensor
+    return dequantize_tensor(quantize_tensor(z, num_bits=num_bits))
+
+
+def student_layer1(x, sd, training=True, update_buffers=True, intermediates=None, codec_bits=None):
     """Bottleneck4LargeResNet.forward == decoder(encoder(x)) (base.py:50-58 with
     use_bottleneck_transformer False, as mimic_runner.py:90 forces during distillation)."""
     for prefix, spec in ((B + 'layer1.encoder.encoder.', ENCODER_SPEC), (B + 'layer1.decoder.', DECODER_SPEC)):
+        if spec is DECODER_SPEC and codec_bits is not None and not training:
+            x = quantize_dequantize(x, codec_bits)        # base.py:54-57: eval only, between encoder and decoder
         for op in spec:
             name = '%s%d' % (prefix, op[1])
             if op[0] == 'conv':
@@ -276,14 +286,15 @@ def fpn(feats, sd):
     return OrderedDict(zip((0, 1, 2, 3, 'pool'), outs))
 
 
-def backbone_forward(x, sd, student, training=True, update_buffers=True, with_fpn=True, intermediates=None):
+def backbone_forward(x, sd, student, training=True, update_buffers=True, with_fpn=True, intermediates=None,
+                     codec_bits=None):
     """body (IntermediateLayerGetter) + fpn; returns (hooked layer outputs, fpn features)."""
     hooked = OrderedDict()
     x = stem(x, sd)
     if intermediates is not None:
         intermediates['stem'] = x
     if student:
-        x = student_layer1(x, sd, training, update_buffers, intermediates)
+        x = student_layer1(x, sd, training, update_buffers, intermediates, codec_bits)
     else:
         x = resnet_layer(x, sd, 1)
     hooked['layer1'] = x

@@ -209,6 +209,44 @@ def run_case(name, case):
     print('   wrote %s (%.1f KB)' % (path, os.path.getsize(path) / 1024.0))
 
 
+def run_eval_codec_case(name='tiny_eval_quantized'):
+    """student.eval() with the bottleneck transformer ON (reference base.py:54-57 + structure/transformer.py)."""
+    print('== %s' % name)
+    case = dict(yaml='ghnd/faster_rcnn-backbone_resnet50-b3ch.yaml', model='faster_rcnn', sizes=[(64, 96), (60, 90)],
+                min_size=64, max_size=128, steps=0, seed=21)
+    t_sd = O.init_teacher_state(case['seed'])
+    s_sd = O.init_student_state(t_sd, case['seed'] + 1000)
+    for k in list(s_sd):                        # non-trivial running statistics for the eval-mode BatchNorms
+        if 'layer1' in k and k.endswith('running_var'):
+            s_sd[k] = s_sd[k] * 1.7 + 0.1
+        if 'layer1' in k and k.endswith('running_mean'):
+            s_sd[k] = s_sd[k] + 0.05
+    config, teacher, student = build_reference_models(case)
+    student.load_state_dict(s_sd, strict=True)
+    student.eval()
+    student.distill_backbone_only = True
+    images, _ = make_inputs(case)
+    out = OrderedDict()
+    out['meta'] = np.array(json.dumps(case))
+    worst = 0.0
+    for tag, use in (('plain', False), ('quantized', True)):
+        student.backbone.body.layer1.use_bottleneck_transformer = use
+        with torch.no_grad():
+            feats = student([im.clone() for im in images])
+        x, _ = O.transform_images(images, (64,), 128)
+        o_h, o_f = O.backbone_forward(x, O.cast_state(s_sd, torch.float32), student=True, training=False,
+                                      codec_bits=8 if use else None)
+        for k, v in feats.items():
+            put(out, '%s/fpn/%s' % (tag, k), v, full_limit=30000)
+            worst = max(worst, float((v - o_f[k]).abs().max()))
+    out['oracle_vs_reference_maxabs'] = np.float64(worst)
+    print('   oracle-vs-reference worst abs=%.3e' % worst)
+    assert worst < 1e-5
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **out)
+    print('   wrote %s (%.1f KB)' % (path, os.path.getsize(path) / 1024.0))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--only')
@@ -218,6 +256,8 @@ def main():
         if args.only and args.only != name:
             continue
         run_case(name, case)
+    if not args.only or args.only == 'tiny_eval_quantized':
+        run_eval_codec_case()
 
 
 if __name__ == '__main__':

@@ -117,7 +117,7 @@ def test_distill_steps_match_reference_golden(name):
     sd = student.state_dict()
     for n in O.trainable_keys(s_sd):
         if not n.endswith(G.ZERO_GRAD_SUFFIXES):
-            G.compare(z, 'after/param/' + n, sd[n], 2e-3, atol=1e-6)
+            G.compare(z, 'after/param/' + n, sd[n], 2e-2 if gtol else 2e-3, atol=1e-6)
     for n in z.files:
         if n.startswith('after/buffer/'):
             key = n[len('after/buffer/'):]
@@ -204,6 +204,39 @@ def test_student_eval_mode_uses_running_statistics():
     for k in (0, 1, 2, 3, 'pool'):
         rel = float((feats[k].cpu() - ref_f[k]).abs().max() / ref_f[k].abs().max())
         assert rel < FEAT_TOL, (k, rel)
+
+
+def test_eval_with_quantized_bottleneck_matches_reference_golden():
+    """student.eval() + use_bottleneck_transformer (the reference's -transform_bottleneck path, base.py:54-57)."""
+    z, meta = G.load('tiny_eval_quantized')
+    cfg = MU.config_for(meta)
+    t_sd, s_sd = MU.oracle_states(meta['seed'])
+    for k in list(s_sd):
+        if 'layer1' in k and k.endswith('running_var'):
+            s_sd[k] = s_sd[k] * 1.7 + 0.1
+        if 'layer1' in k and k.endswith('running_mean'):
+            s_sd[k] = s_sd[k] + 0.05
+    teacher, student = MU.build_pair(cfg, t_sd, s_sd, DEV)
+    student.eval()
+    images, _ = G.case_inputs(meta)
+    ims = [im.to(DEV) for im in images]
+    for tag, use, tol in (('plain', False, FEAT_TOL), ('quantized', True, 2e-2)):
+        student.backbone.body.layer1.use_bottleneck_transformer = use
+        with torch.no_grad():
+            feats = student(ims)
+        for k, v in feats.items():
+            # a bottleneck value within rounding of a quantisation boundary may land in the neighbouring bin
+            # (one step = 1/255 of the range), which moves a few downstream features visibly: hence 2e-2 there
+            G.compare(z, '%s/fpn/%s' % (tag, k), v.contiguous(), tol)
+    # the codec is eval-only: in train mode the same flag must not change anything (mimic_runner.py:90 sets it False)
+    student.train()
+    student.backbone.body.layer1.use_bottleneck_transformer = True
+    a = student(ims, [{'boxes': torch.zeros(1, 4, device=DEV), 'labels': torch.ones(1, dtype=torch.int64, device=DEV)}
+                      for _ in ims])[0].clone()
+    student.backbone.body.layer1.use_bottleneck_transformer = False
+    b = student(ims, [{'boxes': torch.zeros(1, 4, device=DEV), 'labels': torch.ones(1, dtype=torch.int64, device=DEV)}
+                      for _ in ims])[0]
+    assert torch.equal(a, b)
 
 
 def test_full_size_step_matches_reference_checksums():

@@ -399,6 +399,41 @@ def test_subsample_and_fill(ops):
     assert float(y.min()) == 3.5 and float(y.max()) == 3.5
 
 
+@pytest.mark.parametrize('c,shift', [(3, 0.0), (3, 5.0), (6, -2.0)])
+def test_bottleneck_codec_matches_myutils_semantics(ops, c, shift):
+    """uint8 quantise / dequantise vs the restated myutils tensor_util (oracle/myutils_r.py)."""
+    from oracle.myutils_r import quantize_tensor, dequantize_tensor
+    g = gen(15 + c)
+    z = torch.randn(2, c, 13, 17, generator=g) * 3 + shift        # all-positive when shifted: pad zeros must not count
+    ref_q = quantize_tensor(z.clone(), num_bits=8)
+    ref = dequantize_tensor(ref_q)
+    cs = ops.chan_pad_of(c)
+    buf = nhwc(z, cs)
+    q = torch.empty(buf.shape, dtype=torch.uint8, device=DEV)
+    qp = torch.empty(4, device=DEV)
+    scratch = torch.empty(ops.minmax_scratch_elems(), device=DEV)
+    ops.quantize_u8(buf, c, q, qp, scratch)
+    out = torch.full(buf.shape, float('nan'), device=DEV)
+    ops.dequantize_u8(q, qp, out, c)
+    ops.sync_check()
+    lo, hi, scale, zp = [float(v) for v in qp.cpu()]
+    assert lo == float(z.min()) and hi == float(z.max())
+    assert abs(scale - float(ref_q.scale)) <= 1e-7 * abs(scale) and zp == float(ref_q.zero_point)
+    got_q = q.cpu()[..., :c].permute(0, 3, 1, 2)
+    assert int((got_q.int() - ref_q.tensor.int()).abs().max()) <= 1          # ties of x/scale may round either way
+    assert float((got_q != ref_q.tensor).float().mean()) < 1e-3
+    assert float((nchw(out, c) - ref).abs().max()) <= scale * 1.0001
+    if cs != c:
+        assert float(out[..., c:].abs().max()) == 0.0 and int(q[..., c:].max()) == 0
+
+
+def test_f16_roundtrip(ops):
+    x = torch.randn(5000, generator=gen(16)) * 100
+    d = x.to(DEV)
+    ops.roundtrip_f16(d)
+    assert torch.equal(d.cpu(), x.half().float())
+
+
 def test_bad_arguments_raise(ops):
     x = torch.zeros(1, 4, 4, 48, device=DEV)      # cin 48: neither 4 nor a multiple of 32
     w = torch.zeros(64, 48, 1, 1, device=DEV)
