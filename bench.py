@@ -207,6 +207,7 @@ def main():
         'conv_kernel_ms_per_step': round(conv_ms, 2),
         'kernels': kernels,
         'last_loss': last,
+        'max_mem_gb': round(torch.cuda.max_memory_allocated() / 1e9, 2),
     }
     if world == 1 and not args.no_cpu_baseline:
         terms = {k: v['factor'] for k, v in config['train']['criterion']['terms'].items()}
