@@ -21,6 +21,8 @@
 
 #include <stdlib.h>
 
+#include <type_traits>
+
 #ifndef HND_BPC_128
 #define HND_BPC_128 3
 #endif
@@ -31,9 +33,9 @@ using hnd::f32x16;
 using hnd::f32x4;
 
 
-template <int BM, int BN, int BK>
+template <int BM, int BN, int BK, bool PRO>
 constexpr size_t lds_bytes() {
-  return (size_t)(2 * BM * (BK + 4) + 2 * BN * (BK + 4)) * sizeof(float);
+  return (size_t)(2 * (BM + BN) * BK) * sizeof(float);
 }
 
 // resident blocks per CU the launch bounds ask for (LDS and VGPR budgets both allow it)
@@ -104,10 +106,14 @@ __device__ __forceinline__ void epilogue_tile(const hnd_conv_desc& d, const f32x
   }
 }
 
-template <int BM, int BN, int BK, bool CIN4>
+template <int BM, int BN, int BK, bool CIN4, bool PRO>
 __global__ void __launch_bounds__(256, (blocks_per_cu<BM, BN, BK>()))
 igemm_kernel(const hnd_conv_desc d, const int ntiles) {
-  constexpr int LDK = BK + 4;            // padded LDS row (floats): conflict-free ds_read_b128 at 144 B and 80 B
+  // LDS rows are BK floats, unpadded, with the 16-byte chunks of a row XOR-swizzled by f(row) so that the
+  // ds_read_b128 fragment reads (16 rows per lane group) and the staging writes are both bank-conflict free:
+  // chunk c of row r lives at position c ^ f(r), f(r) = (r >> 2) & 3 for 64-byte rows, (r >> 1) & 7 for 128-byte.
+  constexpr int LDK = BK;
+  constexpr int CH = BK / 4;
   constexpr int TPR = BK / 4;            // threads per staged row (one float4 each)
   constexpr int RPP = 256 / TPR;         // rows staged per pass
   constexpr int RA = BM / RPP;           // A rows gathered per thread
@@ -115,8 +121,9 @@ igemm_kernel(const hnd_conv_desc d, const int ntiles) {
   constexpr int WTM = BM / 2;            // rows per wave
   constexpr int MI = WTM / 32, NI = BN / 64;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* As = smem;                          // [2][BM][LDK]
-  float* Bs = smem + 2 * BM * LDK;           // [2][BN][LDK]
+  constexpr int NST = 2;                     // LDS stages (double buffer)
+  float* As = smem;                          // [NST][BM][BK]
+  float* Bs = smem + NST * BM * BK;          // [NST][BN][BK]
   int* rowoff = (int*)Bs;                    // [BM] output pixel index (or -1); aliases the B staging buffer,
   int* resoff = rowoff + BM;                 // [BM] res1 pixel index (mode 1)  -- filled after the k loop
 
@@ -133,6 +140,8 @@ igemm_kernel(const hnd_conv_desc d, const int ntiles) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 1, wn = wave >> 1;
   const int arow = tid / TPR, kq = tid % TPR;
+  const int fa = (CH == 4 ? (arow >> 2) : (arow >> 1)) & (CH - 1);     // swizzle of this thread's staged rows
+  const int fl = (CH == 4 ? (lane >> 2) : (lane >> 1)) & (CH - 1);     // swizzle of this lane's fragment rows
 
   // per-thread gather rows (4 rows of the pixel tile, fixed for the whole k loop)
   int a_nb[RA], a_ih[RA], a_iw[RA];
@@ -151,47 +160,48 @@ igemm_kernel(const hnd_conv_desc d, const int ntiles) {
 #pragma unroll
   for (int i = 0; i < RB; ++i) wrow[i] = d.w + (size_t)(n0 + arow + RPP * i) * d.kdim + kq * 4;
 
-  const bool has_pro = d.pro_scale != nullptr;
   const int ntaps = d.kh * d.kw;
   const unsigned kw_inv = (65536u + d.kw - 1) / d.kw;
   const int T = d.kdim / BK;
+  const float relu_floor = d.pro_relu ? 0.f : -INFINITY;
 
-  f32x4 ra[RA], rb[RB], rps, rpb;
+  // ---- staging pieces.  Tile `tnext` is gathered into registers (ra/rb), later written to LDS.  The pieces are
+  // interleaved one by one between groups of MFMAs (see step()): issued in the shadow of the matrix pipe they
+  // cost no time, whereas issued as one block before / after the MFMAs they cost 13 % (measured by ablation).
+  f32x4 ra[RA], rb[RB];
+  f32x4 rps = {1.f, 1.f, 1.f, 1.f}, rpb = {0.f, 0.f, 0.f, 0.f};
   unsigned okmask = 0;
-  // uniform tap state of the NEXT tile to load (CIN_VEC mode)
-  int c0 = 0, khi = 0, kwi = 0;
+  int c0 = 0, khi = 0, kwi = 0, tnext = 0;      // tap state / index of the next tile to gather
+  int g_ti = 0, g_tj = 0, g_cc = 0;
+  bool g_tapok = true;
 
-  auto gload = [&](int t) {
-    int ti = khi, tj = kwi, cc = c0 + kq * 4;
-    bool tap_ok = true;
+  auto load_begin = [&]() {
+    g_ti = khi; g_tj = kwi; g_cc = c0 + kq * 4; g_tapok = true;
     if (CIN4) {
-      const int tap = t * TPR + kq;
-      ti = (int)((tap * kw_inv) >> 16);
-      tj = tap - ti * d.kw;
-      tap_ok = tap < ntaps;
-      cc = 0;
+      const int tap = tnext * TPR + kq;
+      g_ti = (int)((tap * kw_inv) >> 16);
+      g_tj = tap - g_ti * d.kw;
+      g_tapok = tap < ntaps;
+      g_cc = 0;
     }
     okmask = 0;
-    // Branch-free gather: out-of-range taps read element 0 of x (always mapped) and are zeroed by a select when
-    // the tile is written to LDS.  A divergent `if (ok) load` per row would make hipcc wait for each load right
-    // here (phi of loaded / zero value), i.e. expose one memory round trip per k-step instead of hiding it
-    // behind the MFMAs of the current tile.
-#pragma unroll
-    for (int i = 0; i < RA; ++i) {
-      const int ih = a_ih[i] + ti * d.dh, iw = a_iw[i] + tj * d.dw;
-      const bool ok = a_ok[i] && tap_ok && (unsigned)ih < (unsigned)d.h && (unsigned)iw < (unsigned)d.w_;
-      const unsigned pix = ok ? (unsigned)(a_nb[i] + ih * d.w_ + iw) : 0u;
-      const unsigned off = pix * (unsigned)d.cin + (ok ? (unsigned)cc : 0u);
-      ra[i] = *(const f32x4*)(d.x + off);
-      okmask |= (ok ? 1u : 0u) << i;
+    if (PRO) {
+      rps = *(const f32x4*)(d.pro_scale + g_cc);
+      rpb = *(const f32x4*)(d.pro_shift + g_cc);
     }
-#pragma unroll
-    for (int i = 0; i < RB; ++i) rb[i] = *(const f32x4*)(wrow[i] + (size_t)t * BK);
-    if (has_pro) {
-      rps = *(const f32x4*)(d.pro_scale + cc);
-      if (d.pro_shift) rpb = *(const f32x4*)(d.pro_shift + cc);
-      else rpb = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+  };
+  // Branch-free gather: out-of-range taps read element 0 of x (always mapped) and are zeroed by a select when the
+  // tile is written to LDS (a divergent `if (ok) load` would make hipcc wait for the load inside the branch).
+  auto load_a = [&](int i) {
+    const int ih = a_ih[i] + g_ti * d.dh, iw = a_iw[i] + g_tj * d.dw;
+    const bool ok = a_ok[i] && g_tapok && (unsigned)ih < (unsigned)d.h && (unsigned)iw < (unsigned)d.w_;
+    const unsigned pix = ok ? (unsigned)(a_nb[i] + ih * d.w_ + iw) : 0u;
+    const unsigned off = pix * (unsigned)d.cin + (ok ? (unsigned)g_cc : 0u);
+    ra[i] = *(const f32x4*)(d.x + off);
+    okmask |= (ok ? 1u : 0u) << i;
+  };
+  auto load_b = [&](int i) { rb[i] = *(const f32x4*)(wrow[i] + (size_t)tnext * BK); };
+  auto load_end = [&]() {
     if (!CIN4) {   // advance the uniform tap state
       c0 += BK;
       if (c0 >= d.cin) {
@@ -199,30 +209,35 @@ igemm_kernel(const hnd_conv_desc d, const int ntiles) {
         if (++kwi == d.kw) { kwi = 0; ++khi; }
       }
     }
+    ++tnext;
   };
-
-  auto lstore = [&](int buf) {
-    float* Ab = As + buf * BM * LDK + arow * LDK + kq * 4;
-    float* Bb = Bs + buf * BN * LDK + arow * LDK + kq * 4;
-    if (has_pro) {      // uniform branch; per-row validity is a select, not control flow
-#pragma unroll
-      for (int i = 0; i < RA; ++i) {
-        f32x4 v = ra[i] * rps + rpb;
-        if (d.pro_relu) {
-          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-        }
-        ra[i] = v;
-      }
+  auto store_a = [&](int buf, int i) {
+    f32x4 v = ra[i];
+    if (PRO) {
+      v = v * rps + rpb;
+      v.x = fmaxf(v.x, relu_floor); v.y = fmaxf(v.y, relu_floor);
+      v.z = fmaxf(v.z, relu_floor); v.w = fmaxf(v.w, relu_floor);
     }
+    const bool ok = (okmask >> i) & 1;       // padding is a zero of the NORMALISED tensor: select after the prologue
+    v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+    *(f32x4*)(As + buf * BM * LDK + (arow + RPP * i) * LDK + ((kq ^ fa) * 4)) = v;
+  };
+  auto store_b = [&](int buf, int i) {
+    *(f32x4*)(Bs + buf * BN * LDK + (arow + RPP * i) * LDK + ((kq ^ fa) * 4)) = rb[i];
+  };
+  auto load_tile = [&]() {
+    load_begin();
 #pragma unroll
-    for (int i = 0; i < RA; ++i) {
-      const bool ok = (okmask >> i) & 1;
-      f32x4 v = ra[i];
-      v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
-      *(f32x4*)(Ab + RPP * i * LDK) = v;
-    }
+    for (int i = 0; i < RA; ++i) load_a(i);
 #pragma unroll
-    for (int i = 0; i < RB; ++i) *(f32x4*)(Bb + RPP * i * LDK) = rb[i];
+    for (int i = 0; i < RB; ++i) load_b(i);
+    load_end();
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < RA; ++i) store_a(buf, i);
+#pragma unroll
+    for (int i = 0; i < RB; ++i) store_b(buf, i);
   };
 
   f32x16 acc[MI][NI];
@@ -233,37 +248,82 @@ igemm_kernel(const hnd_conv_desc d, const int ntiles) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-  auto compute = [&](int buf) {
-    const float* Ap = As + buf * BM * LDK + (wm * WTM + (lane & 31)) * LDK + (lane >> 5) * 4;
-    const float* Bp = Bs + buf * BN * LDK + (wn * (BN / 2) + (lane & 31)) * LDK + (lane >> 5) * 4;
+  // One k-step: MFMAs on LDS buffer `buf`; if ST the register tile is written to the other buffer piece by piece
+  // during the first half of the MFMA groups, if LD the following tile is gathered during the second half.
+  constexpr int KK = BK / 8, G = KK * 4, NP = RA + RB;
+  static_assert(NP <= G / 2, "staging pieces must fit in half of the MFMA groups");
+  auto step = [&](int buf, auto st_tag, auto ld_tag) {
+    constexpr bool ST = decltype(st_tag)::value, LD = decltype(ld_tag)::value;
+    const float* Ap = As + buf * BM * LDK + (wm * WTM + (lane & 31)) * LDK;
+    const float* Bp = Bs + buf * BN * LDK + (wn * (BN / 2) + (lane & 31)) * LDK;
+    const int hh = lane >> 5;
+    f32x4 a[MI], b[NI], an[MI], bn[NI];
+    {
+      const int o = ((0 * 2 + hh) ^ fl) * 4;
 #pragma unroll
-    for (int kk = 0; kk < BK / 8; ++kk) {
-      f32x4 a[MI], b[NI];
+      for (int mi = 0; mi < MI; ++mi) a[mi] = *(const f32x4*)(Ap + mi * 32 * LDK + o);
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) a[mi] = *(const f32x4*)(Ap + mi * 32 * LDK + kk * 8);
+      for (int ni = 0; ni < NI; ++ni) b[ni] = *(const f32x4*)(Bp + ni * 32 * LDK + o);
+    }
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) b[ni] = *(const f32x4*)(Bp + ni * 32 * LDK + kk * 8);
+    for (int kk = 0; kk < KK; ++kk) {
 #pragma unroll
-      for (int s = 0; s < 4; ++s)
+      for (int s = 0; s < 4; ++s) {
+        const int g = kk * 4 + s;
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni)
             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][s], b[ni][s], acc[mi][ni], 0, 0, 0);
+        if (ST && g < NP) {
+          if (g < RA) store_a(buf ^ 1, g);
+          else store_b(buf ^ 1, g - RA);
+        }
+        if (LD && g >= G / 2) {
+          const int q = g - G / 2;
+          if (q == 0) load_begin();
+          if (q < RA) load_a(q);
+          else if (q < NP) load_b(q - RA);
+          if (q == NP - 1) load_end();
+        }
+        if (s == 1 && kk + 1 < KK) {      // next k-group's fragments: two MFMA groups ahead of their first use
+          const int o = (((kk + 1) * 2 + hh) ^ fl) * 4;
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) an[mi] = *(const f32x4*)(Ap + mi * 32 * LDK + o);
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) bn[ni] = *(const f32x4*)(Bp + ni * 32 * LDK + o);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (kk + 1 < KK) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) a[mi] = an[mi];
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) b[ni] = bn[ni];
+      }
     }
   };
+  using std::true_type;
+  using std::false_type;
 
-  gload(0);
-  lstore(0);
-  __syncthreads();
-  int cur = 0;
-  for (int t = 0; t < T; ++t) {
-    const bool more = (t + 1) < T;
-    if (more) gload(t + 1);
-    compute(cur);
-    if (more) lstore(cur ^ 1);
+  int cur = 0, t = 0;
+  {
+    load_tile();           // tile 0 -> registers -> LDS buffer 0
+    store_tile(0);
+    if (T > 1) load_tile();   // tile 1 -> registers
     __syncthreads();
-    cur ^= 1;
+    for (; t + 2 < T; ++t) {  // steady state: compute t | write t+1 | gather t+2
+      step(cur, true_type{}, true_type{});
+      __syncthreads();
+      cur ^= 1;
+    }
+    if (t + 1 < T) {
+      step(cur, true_type{}, false_type{});
+      __syncthreads();
+      cur ^= 1;
+    }
+    step(cur, false_type{}, false_type{});
+    __syncthreads();
   }
 
   // ---------------------------------------------------------------- epilogue
@@ -318,13 +378,13 @@ igemm_kernel(const hnd_conv_desc d, const int ntiles) {
   }
 }
 
-template <int BM, int BN, int BK, bool CIN4>
-int launch(const hnd_conv_desc& d, hipStream_t stream) {
+template <int BM, int BN, int BK, bool CIN4, bool PRO>
+int launch_pro(const hnd_conv_desc& d, hipStream_t stream) {
   static bool attr_set = false;
-  auto kern = igemm_kernel<BM, BN, BK, CIN4>;
+  auto kern = igemm_kernel<BM, BN, BK, CIN4, PRO>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lds_bytes<BM, BN, BK>());
+                                       (int)lds_bytes<BM, BN, BK, PRO>());
     if (e != hipSuccess) {
       hnd::set_error("hipFuncSetAttribute(igemm<%d,%d>) failed: %s", BM, BN, hipGetErrorString(e));
       return HND_ERR_LAUNCH;
@@ -334,7 +394,7 @@ int launch(const hnd_conv_desc& d, hipStream_t stream) {
   const long long M = (long long)d.n * d.oh * d.ow;
   const int mtiles = (int)((M + BM - 1) / BM);
   const int ntiles = (d.cout + BN - 1) / BN;
-  const size_t lds = lds_bytes<BM, BN, BK>();
+  const size_t lds = lds_bytes<BM, BN, BK, PRO>();
   hipLaunchKernelGGL(kern, dim3(mtiles * ntiles), dim3(256), lds, stream, d, ntiles);
   return hnd::check_launch("hnd_conv2d_igemm");
 }
@@ -343,6 +403,11 @@ int launch(const hnd_conv_desc& d, hipStream_t stream) {
 // ceil(blocks / slots) rounds, so a grid of e.g. 1050 128x128 tiles (layer3, 512 slots) wastes a third of its
 // last round; smaller tiles quantise better at a lower per-tile efficiency (factors measured with
 // tools/bench_conv.py on MI355X).
+template <int BM, int BN, int BK, bool CIN4>
+int launch(const hnd_conv_desc& d, hipStream_t stream) {
+  return d.pro_scale ? launch_pro<BM, BN, BK, CIN4, true>(d, stream) : launch_pro<BM, BN, BK, CIN4, false>(d, stream);
+}
+
 // bit t set: tile t runs its 16-deep k-step build (smaller LDS footprint -> more resident blocks per CU)
 int bk16_mask() {
   static const int m = getenv("HND_IGEMM_BK16") ? atoi(getenv("HND_IGEMM_BK16")) : 7;
@@ -406,6 +471,7 @@ extern "C" int hnd_conv2d_igemm(const hnd_conv_desc* desc, void* stream) {
                   (long long)d.n * d.h * d.w_ < (1ll << 31),
               "hnd_conv2d_igemm: pixel count exceeds int32");
   HND_REQUIRE(d.res1_mode == 0 || (d.res1_h > 0 && d.res1_w > 0), "hnd_conv2d_igemm: res1 upsample needs dims");
+  HND_REQUIRE(d.pro_scale == nullptr || d.pro_shift != nullptr, "hnd_conv2d_igemm: pro_shift is required with pro_scale");
   HND_REQUIRE((long long)d.n * d.yh * d.yw * d.ldc < (1ll << 32) - 1, "hnd_conv2d_igemm: output exceeds 2^32 elements");
   HND_REQUIRE((long long)d.n * d.h * d.w_ * d.cin < (1ll << 32) - 1, "hnd_conv2d_igemm: input exceeds 2^32 elements");
   hipStream_t s = hnd::as_stream(stream);

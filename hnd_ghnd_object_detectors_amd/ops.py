@@ -115,6 +115,8 @@ def conv_desc(x, pw, y, *, kh, kw, oh, ow, sh, dh, bh, sw, dw, bw, cout, y_sh=1,
     n, h, w, cin = _nhwc(x)
     ny, yh, yw, ldc = _nhwc(y)
     assert ny == n and pw.kdim >= kh * kw * cin and pw.chan_pad == cin, (pw.kdim, kh, kw, cin, pw.chan_pad)
+    if pro_scale is not None and pro_shift is None:
+        pro_shift = _zeros(cin, x.device)
     d = ConvDesc()
     d.x, d.w, d.y = ptr(x), ptr(pw.buf), ptr(y)
     d.pro_scale, d.pro_shift = ptr(pro_scale), ptr(pro_shift)
@@ -138,6 +140,16 @@ def conv_desc(x, pw, y, *, kh, kw, oh, ow, sh, dh, bh, sw, dw, bw, cout, y_sh=1,
         assert stats.numel() >= stats_tiles(n * oh * ow) * 2 * cout
     keep = (x, pw, y, pro_scale, pro_shift, epi_scale, epi_shift, res1, res2, mask, stats)
     return ConvLaunch(d, keep, flops=2 * n * oh * ow * min(cout, pw.rows) * kh * kw * min(cin, pw.chan_real))
+
+
+_ZEROS = {}
+
+
+def _zeros(n, device):
+    key = (n, str(device))
+    if key not in _ZEROS:
+        _ZEROS[key] = torch.zeros(n, dtype=torch.float32, device=device)
+    return _ZEROS[key]
 
 
 def stats_tiles(m):

@@ -77,7 +77,7 @@ typedef struct hnd_conv_desc {
   const float* w;          /* packed weights [round_up(cout,64)][kdim], K contiguous (hnd_pack_weights) */
   float* y;                /* output [n][yh][yw][ldc]                                              */
   const float* pro_scale;  /* [cin] or NULL                                                        */
-  const float* pro_shift;  /* [cin] or NULL (treated as 0)                                         */
+  const float* pro_shift;  /* [cin]; required whenever pro_scale is given                           */
   const float* epi_scale;  /* [cout] or NULL                                                       */
   const float* epi_shift;  /* [cout] or NULL                                                       */
   const float* res1;       /* same geometry as y (mode 0) or [n][res1_h][res1_w][ldc] (mode 1), or NULL */
