@@ -10,7 +10,19 @@ from collections import defaultdict
 out, tag = sys.argv[1], sys.argv[2]
 
 
+import re
+
+FULLNAMES = True
+
+
 def short(name):
+    m = re.search(r'igemm_kernel<(\d+), (\d+), (\d+), (true|false), (true|false)>', name)
+    if m:
+        base = ('igemm_c4_%sx%s' if m.group(4) == 'true' else 'igemm_%sx%s') % (m.group(1), m.group(2))
+        return base + ('[bn-prologue]' if m.group(5) == 'true' and FULLNAMES else '')
+    m = re.search(r'wgrad_kernel<(\d+), (\d+)>', name)
+    if m:
+        return 'wgrad_m%s' % m.group(1)
     for key, lab in (('igemm_kernel<128, false>', 'igemm_n128'), ('igemm_kernel<64, false>', 'igemm_n64'),
                      ('igemm_kernel<64, true>', 'igemm_c4_n64'), ('wgrad_kernel<128>', 'wgrad_m128'),
                      ('wgrad_kernel<64>', 'wgrad_m64'), ('igemm_kernelILi128ELb0', 'igemm_n128'),
@@ -26,12 +38,14 @@ print('# rocprofv3 summary %s (bench.py GHND Faster R-CNN b3ch, batch 16, 1 x MI
 stats = glob.glob(os.path.join(out, 'trace', '*kernel_stats.csv'))
 if stats:
     rows = list(csv.DictReader(open(stats[0])))
-    print('## kernel-trace --stats (2 timed + 1 warm-up steps)\n')
+    print('## kernel-trace --stats (6 timed + 2 warm-up steps, teacher/student stream overlap off)\n')
     print('| kernel | calls | total ms | avg us | % |')
     print('|---|---|---|---|---|')
     for r in rows[:24]:
         print('| %s | %s | %.2f | %.1f | %s |' % (short(r['Name']), r['Calls'], float(r['TotalDurationNs']) / 1e6,
                                                    float(r['AverageNs']) / 1e3, r['Percentage']))
+FULLNAMES = False      # traffic is keyed by the bench variant names
+traffic = {}
 for label, sub, col in (('FETCH_SIZE', 'pmc_fetch', 'FETCH_SIZE'), ('WRITE_SIZE', 'pmc_write', 'WRITE_SIZE')):
     files = glob.glob(os.path.join(out, sub, '*counter_collection.csv'))
     if not files:
@@ -44,6 +58,7 @@ for label, sub, col in (('FETCH_SIZE', 'pmc_fetch', 'FETCH_SIZE'), ('WRITE_SIZE'
             a[1] += 1
     print('\n## %s per kernel (one warm-up + one timed step; counter unit KiB; on gfx950 FETCH_SIZE counts half '
           'the bytes of wide coalesced reads -> double it, MI355X_MICROARCH.md HBM section)\n' % label)
+    traffic.setdefault(label, agg)
     print('| kernel | dispatches | sum KiB | avg MiB / dispatch |')
     print('|---|---|---|---|')
     for k, (v, n) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:12]:
@@ -56,3 +71,14 @@ for f in ('bench_trace.json',):
             print('\n## bench line under the profiler\n\n```\n%s\n```' % json.dumps({k: d[k] for k in ('value', 'ms_per_step', 'roofline', 'kernels')}))
         except Exception as e:      # noqa
             print('\n(bench json unreadable: %s)' % e)
+
+if 'FETCH_SIZE' in traffic and 'WRITE_SIZE' in traffic:
+    tj = {'source': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `bench.py --steps 1 '
+                    '--warmup 1`, summed over both steps; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts '
+                    '64 B per 128-B request)', 'unit': 'bytes per launch', 'kernels': {}}
+    for k, (fv, fn) in traffic['FETCH_SIZE'].items():
+        if k in traffic['WRITE_SIZE'] and ('igemm' in k or 'wgrad' in k):
+            wv, wn = traffic['WRITE_SIZE'][k]
+            tj['kernels'][k] = {'dispatches': fn, 'fetch_kib_raw': fv, 'write_kib': wv,
+                                'traffic_bytes_per_launch': int((2 * fv + wv) * 1024 / fn)}
+    json.dump(tj, open(os.path.join(out, 'traffic.json'), 'w'), indent=1)
