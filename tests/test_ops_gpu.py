@@ -434,6 +434,81 @@ def test_f16_roundtrip(ops):
     assert torch.equal(d.cpu(), x.half().float())
 
 
+def test_conv_random_geometries_all_tiles(ops, monkeypatch):
+    """seeded sweep over kernel size / stride / padding / odd extents / channel counts / fused options, on every
+    block-tile build (HND_IGEMM_TILE override), forward and data-gradient, vs torch CPU."""
+    import random
+    rnd = random.Random(1234)
+    worst = 0.0
+    for it in range(36):
+        k = rnd.choice([1, 1, 2, 3, 3, 5, 7])
+        s = rnd.choice([1, 1, 2])
+        p = rnd.randint(0, k // 2 + (1 if k == 2 else 0))
+        cin = rnd.choice([3, 32, 64, 96, 160])
+        cout = rnd.choice([3, 5, 32, 64, 100, 128, 192, 256])
+        n = rnd.randint(1, 3)
+        h, w = rnd.randint(k + 1, 29), rnd.randint(k + 1, 33)
+        if k == 7 and cin != 3:
+            cin = 32
+        g = gen(5000 + it)
+        x = torch.randn(n, cin, h, w, generator=g, requires_grad=True)
+        wt = torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k)
+        out = F.conv2d(x, wt, None, s, p)
+        use_res, use_relu, use_scale = rnd.random() < 0.5, rnd.random() < 0.5, rnd.random() < 0.5
+        es, eb = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
+        res = torch.randn(out.shape, generator=g)
+        ref = out.detach()
+        if use_scale:
+            ref = ref * es[None, :, None, None] + eb[None, :, None, None]
+        if use_res:
+            ref = ref + res
+        if use_relu:
+            ref = F.relu(ref)
+        dy = torch.randn(out.shape, generator=g)
+        out.backward(dy)
+        cp_in, cp_out = ops.chan_pad_of(cin), ops.chan_pad_of(cout)
+        monkeypatch.setenv('HND_IGEMM_TILE', str(it % 4))
+        xd, wd = nhwc(x.detach(), cp_in), wt.to(DEV).contiguous()
+        y = torch.full((n, out.shape[2], out.shape[3], cp_out), float('nan'), device=DEV)
+        pad_c = lambda v: F.pad(v, (0, cp_out - cout)).to(DEV)
+        ops.conv_forward(xd, ops.pack_weights(wd, chan_pad=cp_in), y, k, s, p,
+                         epi_scale=pad_c(es) if use_scale else None, epi_shift=pad_c(eb) if use_scale else None,
+                         res1=nhwc(res, cp_out) if use_res else None, relu=use_relu).run()
+        dx = torch.full((n, h, w, cp_in), float('nan'), device=DEV)
+        if s == 2 and k == 1:
+            ops.fill(dx, 0.0)
+        launches, _ = ops.conv_dgrad(nhwc(dy, cp_out), wd, dx, k, s, p, accumulate=(s == 2 and k == 1))
+        for l in launches:
+            l.run()
+        ops.sync_check()
+        e1, e2 = relerr(nchw(y, cout), ref), relerr(nchw(dx, cin), x.grad)
+        worst = max(worst, e1, e2)
+        assert e1 < 1e-4 and e2 < 1e-4, (it, k, s, p, cin, cout, n, h, w, e1, e2)
+    monkeypatch.delenv('HND_IGEMM_TILE')
+
+
+def test_conv_linearity_at_full_size(ops):
+    """size-independent property at the benchmark's extent (3x3 256->256 on 200x336, batch 2): conv(a*x + b*z) ==
+    a*conv(x) + b*conv(z) to fp32 rounding, and a checksum against a strided torch reference of a few output rows."""
+    g = gen(17)
+    n, c, h, w = 2, 256, 200, 336
+    x, z = torch.randn(n, h, w, c, generator=g), torch.randn(n, h, w, c, generator=g)
+    wt = torch.randn(256, 256, 3, 3, generator=g) / math.sqrt(256 * 9)
+    pw = ops.pack_weights(wt.to(DEV).contiguous())
+    outs = []
+    for inp in (x, z, 1.5 * x - 0.25 * z):
+        y = torch.empty(n, h, w, 256, device=DEV)
+        ops.conv_forward(inp.to(DEV), pw, y, 3, 1, 1).run()
+        outs.append(y)
+    ops.sync_check()
+    lin = 1.5 * outs[0] - 0.25 * outs[1]
+    assert float((outs[2] - lin).abs().max() / lin.abs().max()) < 1e-5
+    rows = slice(97, 103)
+    ref = F.conv2d(x[:1, 96:104].permute(0, 3, 1, 2), wt, None, 1, 1)[:, :, 1:-1]      # output rows 97..102
+    got = outs[0][:1, rows].cpu().permute(0, 3, 1, 2)
+    assert relerr(got, ref) < 1e-4
+
+
 def test_bad_arguments_raise(ops):
     x = torch.zeros(1, 4, 4, 48, device=DEV)      # cin 48: neither 4 nor a multiple of 32
     w = torch.zeros(64, 48, 1, 1, device=DEV)
