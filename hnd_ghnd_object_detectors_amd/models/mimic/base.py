@@ -12,30 +12,33 @@ from ...hipnn import attach, to_nhwc
 
 
 class ExtEncoder(nn.Module):
+    """container that keeps the reference's ``encoder.encoder.N`` state-dict prefix; the optional neural-filter
+    classifier (``ext_config``) belongs to ext_runner and is not built here."""
+
     def __init__(self, encoder, ext_classifier=None, ext_config=None):
         super().__init__()
-        self.encoder = encoder
-        self.ext_classifier = ext_classifier
-        self.threshold = ext_config['threshold'] if ext_config is not None else None
         if ext_classifier is not None:
             raise NotImplementedError('neural filter (ext_config) belongs to ext_runner, outside this build')
-
-    def forward(self, x):
-        raise RuntimeError('ExtEncoder executes fused inside Bottleneck4LargeResNet on the HIP path')
+        self.encoder, self.ext_classifier = encoder, None
+        self.threshold = None if ext_config is None else ext_config['threshold']
 
     def get_ext_classifier(self):
         return self.ext_classifier
 
+    def forward(self, x):
+        raise RuntimeError('ExtEncoder executes fused inside Bottleneck4LargeResNet on the HIP path')
+
 
 class BottleneckBase4Ext(nn.Module):
+    """encoder -> [eval-only bottleneck transformer] -> decoder, executed as one HeadEngine plan."""
+
     def __init__(self, encoder, decoder, bottleneck_transformer=None):
         super().__init__()
-        self.encoder = encoder
-        self.decoder = decoder
+        self.encoder, self.decoder = encoder, decoder
         self.bottleneck_transformer = bottleneck_transformer
-        self.data_logging = False
-        self.uses_ext_encoder = isinstance(encoder, ExtEncoder) and encoder.ext_classifier is not None
         self.use_bottleneck_transformer = False
+        self.uses_ext_encoder = False
+        self.data_logging = False
         self._engine = None
 
     def head_layers(self):
@@ -48,11 +51,9 @@ class BottleneckBase4Ext(nn.Module):
         return self._engine
 
     def forward(self, x):
-        codec = None
-        if (not self.training) and self.bottleneck_transformer is not None and self.use_bottleneck_transformer:
-            codec = self.bottleneck_transformer            # reference base.py:54-57 (eval only)
-        eng = self.head_engine()
-        out = eng.forward(to_nhwc(x), self.training, codec=codec)
+        use_codec = self.use_bottleneck_transformer and not self.training and self.bottleneck_transformer is not None
+        out = self.head_engine().forward(to_nhwc(x), self.training,
+                                         codec=self.bottleneck_transformer if use_codec else None)   # base.py:54-57
         return attach(E.logical(out), out)
 
     def get_ext_classifier(self):

@@ -19,35 +19,41 @@ def overwrite_config(config, json_str):
 
 
 def setup_for_distributed(is_master):
-    """silence print on non-master ranks (pass force=True to override)."""
-    builtin_print = __builtin__.print
+    """after this call plain print() is silent on non-master ranks; print(..., force=True) always prints."""
+    original = __builtin__.print
 
-    def print(*args, **kwargs):
-        force = kwargs.pop('force', False)
-        if is_master or force:
-            builtin_print(*args, **kwargs)
+    def rank_aware_print(*args, force=False, **kwargs):
+        if force or is_master:
+            original(*args, **kwargs)
 
-    __builtin__.print = print
+    __builtin__.print = rank_aware_print
+
+
+def _rank_from_env():
+    env = os.environ
+    if 'RANK' in env and 'WORLD_SIZE' in env:
+        return int(env['RANK']), int(env['WORLD_SIZE']), int(env.get('LOCAL_RANK', 0))
+    if 'SLURM_PROCID' in env:
+        rank = int(env['SLURM_PROCID'])
+        return rank, None, rank % max(torch.cuda.device_count(), 1)
+    return None
 
 
 def init_distributed_mode(world_size=1, dist_url='env://', backend=None):
-    """One process per GPU; backend 'nccl' is RCCL on ROCm (reference main_util.py:43-62).  `backend` may be set
-    to 'gloo' for CPU tests."""
-    if 'RANK' in os.environ and 'WORLD_SIZE' in os.environ:
-        rank = int(os.environ['RANK'])
-        world_size = int(os.environ['WORLD_SIZE'])
-        device_id = int(os.environ.get('LOCAL_RANK', 0))
-    elif 'SLURM_PROCID' in os.environ:
-        rank = int(os.environ['SLURM_PROCID'])
-        device_id = rank % max(torch.cuda.device_count(), 1)
-    else:
+    """One process per GPU (reference main_util.py:43-62).  Backend 'nccl' is RCCL on ROCm; 'gloo' is accepted for
+    CPU tests.  Returns (distributed, [device_id])."""
+    found = _rank_from_env()
+    if found is None:
         print('Not using distributed mode')
         return False, None
-    backend = backend or ('nccl' if torch.cuda.is_available() else 'gloo')
-    if torch.cuda.is_available():
+    rank, env_world, device_id = found
+    world_size = env_world or world_size
+    has_gpu = torch.cuda.is_available()
+    if has_gpu:
         torch.cuda.set_device(device_id)
     print('| distributed init (rank {}): {}'.format(rank, dist_url), flush=True)
-    torch.distributed.init_process_group(backend=backend, init_method=dist_url, world_size=world_size, rank=rank)
+    torch.distributed.init_process_group(backend=backend or ('nccl' if has_gpu else 'gloo'), init_method=dist_url,
+                                         world_size=world_size, rank=rank)
     torch.distributed.barrier()
     setup_for_distributed(rank == 0)
     return True, [device_id]
