@@ -50,6 +50,8 @@ _SIGNATURES = {
     'hnd_fbn_fold': (C.c_int, [vp] * 6 + [C.c_int, C.c_int, C.c_float, vp]),
     'hnd_transform_image': (C.c_int, [vp, C.c_int, C.c_int, vp] + [C.c_int] * 5 + [C.c_float, C.c_float,
                                                                                     c_float_p, c_float_p, vp]),
+    'hnd_transform_image_u8': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp] + [C.c_int] * 5 +
+                               [C.c_float, C.c_float, c_float_p, c_float_p, vp]),
     'hnd_maxpool3x3s2_fwd': (C.c_int, [vp, vp, vp] + [C.c_int] * 6 + [vp]),
     'hnd_maxpool3x3s2_bwd_relu_scale': (C.c_int, [vp] * 5 + [C.c_int] * 6 + [vp]),
     'hnd_bn_finalize': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int64, vp, vp, vp, vp, vp,

@@ -65,12 +65,15 @@ __global__ void fbn_fold_kernel(const float* w, const float* b, const float* mea
 // ------------------------------------------------------------------------------------ transform
 struct TransformArgs {
   const float* src;
+  const uint8_t* src8;     // U8 kernels: decoded image, value / 255 first (ToTensor)
+  int hwc, flip;           // uint8 layout [h][w][3] vs [3][h][w]; horizontal flip of the source
   float* dst;
   int h, w, out_h, out_w, hp, wp;
   float rh, rw;
   float mean[3], inv_unused[3], std[3];
 };
 
+template <bool U8>
 __global__ void transform_kernel(const TransformArgs a) {
   const int total = a.hp * a.wp;
   const size_t plane = (size_t)a.h * a.w;
@@ -89,14 +92,24 @@ __global__ void transform_kernel(const TransformArgs a) {
       const float ly = sy - (float)y0, lx = sx - (float)x0;
       const float hy = 1.f - ly, hx = 1.f - lx;
       float v[3];
+      // U8 only: image.flip(-1) happens before the resize, i.e. on source columns
+      const int fx0 = (U8 && a.flip) ? a.w - 1 - x0 : x0, fx1 = (U8 && a.flip) ? a.w - 1 - x1 : x1;
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        const float* s = a.src + c * plane;
+        float q00, q01, q10, q11;
+        if (!U8) {
+          const float* s = a.src + c * plane;
+          q00 = s[(size_t)y0 * a.w + fx0]; q01 = s[(size_t)y0 * a.w + fx1];
+          q10 = s[(size_t)y1 * a.w + fx0]; q11 = s[(size_t)y1 * a.w + fx1];
+        } else {
+          const size_t cs = a.hwc ? 1 : plane, ps = a.hwc ? 3 : 1;      // channel / pixel strides
+          const uint8_t* s = a.src8 + c * cs;
+          q00 = (float)s[((size_t)y0 * a.w + fx0) * ps] / 255.f; q01 = (float)s[((size_t)y0 * a.w + fx1) * ps] / 255.f;
+          q10 = (float)s[((size_t)y1 * a.w + fx0) * ps] / 255.f; q11 = (float)s[((size_t)y1 * a.w + fx1) * ps] / 255.f;
+        }
         // normalise first ((x-mean)/std, rcnn.py:74), then interpolate (rcnn.py:75)
-        const float p00 = (s[(size_t)y0 * a.w + x0] - a.mean[c]) / a.std[c];
-        const float p01 = (s[(size_t)y0 * a.w + x1] - a.mean[c]) / a.std[c];
-        const float p10 = (s[(size_t)y1 * a.w + x0] - a.mean[c]) / a.std[c];
-        const float p11 = (s[(size_t)y1 * a.w + x1] - a.mean[c]) / a.std[c];
+        const float p00 = (q00 - a.mean[c]) / a.std[c], p01 = (q01 - a.mean[c]) / a.std[c];
+        const float p10 = (q10 - a.mean[c]) / a.std[c], p11 = (q11 - a.mean[c]) / a.std[c];
         v[c] = hy * (hx * p00 + lx * p01) + ly * (hx * p10 + lx * p11);
       }
       o.x = v[0]; o.y = v[1]; o.z = v[2];
@@ -547,12 +560,36 @@ int hnd_transform_image(const float* src, int h, int w, float* dst, int index, i
               "hnd_transform_image: bad geometry (out %dx%d, padded %dx%d)", out_h, out_w, hp, wp);
   TransformArgs a;
   a.src = src;
+  a.src8 = nullptr;
+  a.hwc = 0;
+  a.flip = 0;
   a.dst = dst + (size_t)index * hp * wp * 4;
   a.h = h; a.w = w; a.out_h = out_h; a.out_w = out_w; a.hp = hp; a.wp = wp;
   a.rh = scale_h; a.rw = scale_w;
   for (int i = 0; i < 3; ++i) { a.mean[i] = mean[i]; a.std[i] = std[i]; a.inv_unused[i] = 0.f; }
-  hipLaunchKernelGGL(transform_kernel, dim3(grid_for((long long)hp * wp)), dim3(256), 0, hnd::as_stream(stream), a);
+  hipLaunchKernelGGL(transform_kernel<false>, dim3(grid_for((long long)hp * wp)), dim3(256), 0,
+                     hnd::as_stream(stream), a);
   return hnd::check_launch("hnd_transform_image");
+}
+
+int hnd_transform_image_u8(const uint8_t* src, int h, int w, int hwc, int flip, float* dst, int index, int out_h,
+                           int out_w, int hp, int wp, float scale_h, float scale_w, const float mean[3],
+                           const float std[3], void* stream) {
+  HND_REQUIRE(src && dst && mean && std, "hnd_transform_image_u8: null pointer");
+  HND_REQUIRE(h > 0 && w > 0 && out_h > 0 && out_w > 0 && out_h <= hp && out_w <= wp && index >= 0,
+              "hnd_transform_image_u8: bad geometry (out %dx%d, padded %dx%d)", out_h, out_w, hp, wp);
+  TransformArgs a;
+  a.src = nullptr;
+  a.src8 = src;
+  a.hwc = hwc != 0;
+  a.flip = flip != 0;
+  a.dst = dst + (size_t)index * hp * wp * 4;
+  a.h = h; a.w = w; a.out_h = out_h; a.out_w = out_w; a.hp = hp; a.wp = wp;
+  a.rh = scale_h; a.rw = scale_w;
+  for (int i = 0; i < 3; ++i) { a.mean[i] = mean[i]; a.std[i] = std[i]; a.inv_unused[i] = 0.f; }
+  hipLaunchKernelGGL(transform_kernel<true>, dim3(grid_for((long long)hp * wp)), dim3(256), 0,
+                     hnd::as_stream(stream), a);
+  return hnd::check_launch("hnd_transform_image_u8");
 }
 
 int hnd_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* idx, int n, int h, int w, int c, int oh, int ow,

@@ -147,6 +147,11 @@ def transform_scope_end():
     _SCOPE['id'] = None
 
 
+def _image_key(im):
+    t = im.data if hasattr(im, 'hwc') else im
+    return (id(im), t.data_ptr(), t._version, bool(getattr(im, 'flip', False)))
+
+
 class TransformEngine(object):
     def __init__(self, mean, std):
         self.mean, self.std = [float(m) for m in mean], [float(s) for s in std]
@@ -154,7 +159,9 @@ class TransformEngine(object):
         self.last_key = None
 
     def run(self, images, sizes, max_size):
-        """images: list of CHW device tensors; sizes: per-image target min side. Returns (NHWC4 batch, image_sizes)."""
+        """images: list of CHW device tensors (or uint8 DecodedImage of structure.transformer: /255 and the
+        pending flip are fused into the same kernel); sizes: per-image target min side.
+        Returns (NHWC4 batch, image_sizes)."""
         dev = images[0].device
         if self.bufs is None:
             self.bufs = Buffers(dev)
@@ -170,10 +177,14 @@ class TransformEngine(object):
             plans.append((h, w, scale, ops.interp_out_size(h, scale), ops.interp_out_size(w, scale)))
         hp = int(math.ceil(max(p[3] for p in plans) / 32.0) * 32)
         wp = int(math.ceil(max(p[4] for p in plans) / 32.0) * 32)
-        key = (_SCOPE['id'],) + tuple((id(im), im.data_ptr(), im._version) + p for im, p in zip(images, plans))
+        key = (_SCOPE['id'],) + tuple(_image_key(im) + p for im, p in zip(images, plans))
         batch = self.bufs.get('batch', (len(images), hp, wp, 4))
         if _SCOPE['id'] is None or key != self.last_key:
             for i, (img, (h, w, scale, oh, ow)) in enumerate(zip(images, plans)):
+                if hasattr(img, 'hwc'):         # DecodedImage
+                    ops.transform_image_u8(img.data if img.data.is_contiguous() else img.data.contiguous(), batch, i,
+                                           oh, ow, 1.0 / scale, 1.0 / scale, self.mean, self.std, img.hwc, img.flip)
+                    continue
                 src = img if (img.is_contiguous() and img.dtype == torch.float32) else img.float().contiguous()
                 ops.transform_image(src, batch, i, oh, ow, 1.0 / scale, 1.0 / scale, self.mean, self.std)
             self.last_key = key

@@ -37,6 +37,8 @@ _FLAGS = (  # (flag, kwargs): the reference's CLI first, this build's additions 
     ('--dist_url', dict(default='env://', help='url used to set up distributed training')),
     ('--synthetic_batches', dict(default=0, type=int, help='batches per epoch of synthetic COCO-shaped data')),
     ('--image_size', dict(default='800x1333', help='HxW of the synthetic images')),
+    ('-decoded_input', dict(action='store_true', help='feed decoded uint8 HWC images; ToTensor / flip / normalise / '
+                                                      'resize run as one device kernel')),
     ('--num_epochs', dict(default=None, type=int, help='override train.num_epochs')),
 )
 
@@ -133,7 +135,8 @@ def main(args):
         data_util.get_coco_data_loaders(config['dataset'], batch_size, distributed)     # raises: COCO out of scope
     height, width = (int(v) for v in args.image_size.split('x'))
     train_loader = data_util.SyntheticDetectionLoader(args.synthetic_batches, batch_size, height, width,
-                                                      student_config['name'], rank=misc_util.get_rank())
+                                                      student_config['name'], rank=misc_util.get_rank(),
+                                                      decoded=args.decoded_input)
     if distributed:
         student_model = DistributedStudent(student_model)
     if args.distill:

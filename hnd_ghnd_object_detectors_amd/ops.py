@@ -272,6 +272,19 @@ def transform_image(src, dst, index, out_h, out_w, rscale_h, rscale_w, mean, std
                                  float(rscale_h), float(rscale_w), m, s, stream_ptr()), 'hnd_transform_image')
 
 
+def transform_image_u8(src, dst, index, out_h, out_w, rscale_h, rscale_w, mean, std, hwc, flip=False):
+    """src uint8 [H,W,3] (hwc) or [3,H,W] -> image `index` of dst [N,Hp,Wp,4]: /255, optional horizontal flip,
+    normalise, bilinear resize, zero pad -- one pass."""
+    assert src.dtype == torch.uint8 and src.is_contiguous() and src.dim() == 3 and dst.shape[3] == 4
+    h, w = (src.shape[0], src.shape[1]) if hwc else (src.shape[1], src.shape[2])
+    assert src.shape[2 if hwc else 0] == 3
+    m = (C.c_float * 3)(*mean)
+    s = (C.c_float * 3)(*std)
+    check(_L.hnd_transform_image_u8(ptr(src), h, w, int(bool(hwc)), int(bool(flip)), ptr(dst), index, out_h, out_w,
+                                    dst.shape[1], dst.shape[2], float(rscale_h), float(rscale_w), m, s, stream_ptr()),
+          'hnd_transform_image_u8')
+
+
 def maxpool_fwd(x, y, idx):
     n, h, w, c = x.shape
     check(_L.hnd_maxpool3x3s2_fwd(ptr(x), ptr(y), ptr(idx), n, h, w, c, y.shape[1], y.shape[2], stream_ptr()),

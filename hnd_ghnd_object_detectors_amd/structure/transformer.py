@@ -4,7 +4,15 @@ The reference applies them ONLY at evaluation time with ``-transform_bottleneck`
 mimic_runner.py:90 disables them while distilling).  ``Quantizer`` / ``Dequantizer`` run as fused HIP kernels
 (global min/max -> affine uint8 quantise; dequantise) on the NHWC bottleneck buffer; the 16-bit variants are a
 half round trip.  JPEG codecs and the DataLogger of the reference are deployment/analysis tools outside the path.
+
+Input pipeline (reference :32-55): ``ToTensor`` keeps the decoded uint8 image as a
+``DecodedImage`` instead of materialising a float CHW copy on the host, ``RandomHorizontalFlip`` only flips the
+(tiny) targets and marks the image; the /255, the flip and the model's normalise/resize/pad then run as ONE HIP
+kernel inside ``CustomRCNNTransform`` (hnd_transform_image_u8): 4x fewer host->device bytes, no host float work.
 """
+import random
+
+import numpy as np
 import torch
 
 from .. import ops
@@ -19,6 +27,90 @@ class Compose(object):
         for t in self.transforms:
             image, target = t(image, target)
         return image, target
+
+
+class DecodedImage(object):
+    """A decoded image waiting for the device: uint8 [H, W, 3] (``hwc``) or [3, H, W], plus a pending horizontal
+    flip.  Quacks like the float CHW tensor the reference's dataset yields where the host looks at it
+    (``.shape``, ``.to(device)``, ``.device``); the float values only ever exist inside the transform kernel."""
+
+    def __init__(self, data, hwc, flip=False):
+        assert data.dtype == torch.uint8 and data.dim() == 3 and data.shape[2 if hwc else 0] == 3
+        self.data, self.hwc, self.flip = data, hwc, flip
+
+    @property
+    def shape(self):
+        d = self.data.shape
+        return torch.Size((3, d[0], d[1]) if self.hwc else tuple(d))
+
+    @property
+    def device(self):
+        return self.data.device
+
+    @property
+    def is_cuda(self):
+        return self.data.is_cuda
+
+    def dim(self):
+        return 3
+
+    def to(self, *args, **kwargs):
+        kwargs = {k: v for k, v in kwargs.items() if k != 'dtype'}
+        args = tuple(a for a in args if not isinstance(a, torch.dtype))
+        return DecodedImage(self.data.to(*args, **kwargs), self.hwc, self.flip)
+
+    def float_chw(self):
+        """What the reference's ToTensor (+ flip) would have produced -- for checks, not used by the product path."""
+        x = self.data.permute(2, 0, 1) if self.hwc else self.data
+        x = x.float() / 255
+        return x.flip(-1) if self.flip else x
+
+
+def flip_coco_person_keypoints(kps, width):
+    """COCO left/right joint swap + x mirror, zeroing invisible joints (reference :12-20)."""
+    order = [0, 2, 1, 4, 3, 6, 5, 8, 7, 10, 9, 12, 11, 14, 13, 16, 15]
+    out = kps[:, order]
+    out[..., 0] = width - out[..., 0]
+    out[out[..., 2] == 0] = 0
+    return out
+
+
+class RandomHorizontalFlip(object):
+    """reference :32-49.  A DecodedImage is flipped lazily (inside the device kernel); tensors are flipped here."""
+
+    def __init__(self, prob):
+        self.prob = prob
+
+    def __call__(self, image, target):
+        if random.random() >= self.prob:
+            return image, target
+        width = image.shape[-1]
+        if isinstance(image, DecodedImage):
+            image = DecodedImage(image.data, image.hwc, not image.flip)
+        else:
+            image = image.flip(-1)
+        boxes = target['boxes']
+        boxes[:, [0, 2]] = width - boxes[:, [2, 0]]
+        target['boxes'] = boxes
+        if 'masks' in target:
+            target['masks'] = target['masks'].flip(-1)
+        if 'keypoints' in target:
+            target['keypoints'] = flip_coco_person_keypoints(target['keypoints'], width)
+        return image, target
+
+
+class ToTensor(object):
+    """reference :52-55 (functional.to_tensor).  PIL images / uint8 arrays stay uint8 (DecodedImage)."""
+
+    def __call__(self, image, target):
+        if isinstance(image, DecodedImage) or (torch.is_tensor(image) and image.dtype != torch.uint8):
+            return image, target
+        if torch.is_tensor(image):          # uint8 tensor: [H, W, 3] unless it is unambiguously [3, H, W]
+            return DecodedImage(image.contiguous(), hwc=image.shape[0] != 3), target
+        arr = np.asarray(image)
+        if arr.dtype != np.uint8 or arr.ndim != 3 or arr.shape[2] != 3:
+            raise TypeError('ToTensor expects an RGB uint8 image, got %s %s' % (arr.dtype, arr.shape))
+        return DecodedImage(torch.from_numpy(np.ascontiguousarray(arr)), hwc=True), target
 
 
 class DataLogger(object):

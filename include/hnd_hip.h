@@ -144,6 +144,15 @@ int hnd_transform_image(const float* src, int h, int w, float* dst, int index, i
                         int hp, int wp, float scale_h, float scale_w, const float mean[3], const float std[3],
                         void* stream);
 
+/* On-device input pipeline: the same transform fed by the DECODED image, uint8, HWC
+ * ([h][w][3], as PIL / numpy hand it over; hwc != 0) or CHW ([3][h][w]): fuses structure.transformer.ToTensor
+ * (src/structure/transformer.py:52-55, value / 255), RandomHorizontalFlip (:32-49, when flip != 0) and the
+ * normalise / resize / pad of hnd_transform_image into one pass -- a quarter of the host->device bytes and no
+ * float image on the host. */
+int hnd_transform_image_u8(const uint8_t* src, int h, int w, int hwc, int flip, float* dst, int index, int out_h,
+                           int out_w, int hp, int wp, float scale_h, float scale_w, const float mean[3],
+                           const float std[3], void* stream);
+
 /* nn.MaxPool2d(3, 2, 1) (custom/resnet.py:30,99) NHWC; idx (uint8 tap 0..8) kept for backward. */
 int hnd_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* idx, int n, int h, int w, int c, int oh, int ow,
                          void* stream);

@@ -208,6 +208,33 @@ def transform_images(images, min_size=(800,), max_size=1333, training=False, fix
     return batch, sizes
 
 
+# ----------------------------------------------------------------------------- dataset-side transforms
+def to_tensor_u8(image_hwc):
+    """structure/transformer.py:52-55 -> torchvision functional.to_tensor: uint8 [H,W,3] -> float [3,H,W] / 255."""
+    return image_hwc.permute(2, 0, 1).contiguous().float().div(255)
+
+
+_KP_FLIP = [0, 2, 1, 4, 3, 6, 5, 8, 7, 10, 9, 12, 11, 14, 13, 16, 15]
+
+
+def horizontal_flip(image, target):
+    """structure/transformer.py:12-20,36-49 (the branch RandomHorizontalFlip takes when it flips)."""
+    width = image.shape[-1]
+    image = image.flip(-1)
+    target = dict(target)
+    b = target['boxes'].clone()
+    b[:, [0, 2]] = width - b[:, [2, 0]]
+    target['boxes'] = b
+    if 'masks' in target:
+        target['masks'] = target['masks'].flip(-1)
+    if 'keypoints' in target:
+        k = target['keypoints'][:, _KP_FLIP].clone()
+        k[..., 0] = width - k[..., 0]
+        k[k[..., 2] == 0] = 0
+        target['keypoints'] = k
+    return image, target
+
+
 # ----------------------------------------------------------------------------- network pieces
 def frozen_bn(x, sd, p):
     scale = sd[p + 'weight'] * sd[p + 'running_var'].rsqrt()          # no eps (0.4.2)

@@ -247,6 +247,52 @@ def run_eval_codec_case(name='tiny_eval_quantized'):
     print('   wrote %s (%.1f KB)' % (path, os.path.getsize(path) / 1024.0))
 
 
+def run_input_pipeline_case(name='tiny_input_pipeline'):
+    """Decoded uint8 image -> reference ToTensor -> RandomHorizontalFlip (forced on / off) -> CustomRCNNTransform."""
+    print('== %s' % name)
+    from PIL import Image
+    from structure.transformer import RandomHorizontalFlip, ToTensor       # the reference's classes
+    from models.org.rcnn import CustomRCNNTransform
+    g = torch.Generator().manual_seed(33)
+    out = OrderedDict()
+    images, worst = [], 0.0
+    for i, (h, w, flip) in enumerate([(40, 56, True), (48, 44, False), (37, 61, True)]):
+        u8 = torch.randint(0, 256, (h, w, 3), generator=g, dtype=torch.uint8)
+        kp = torch.rand(2, 17, 3, generator=g) * torch.tensor([w, h, 1.0])
+        kp[..., 2] = (kp[..., 2] > 0.4).float()
+        target = {'boxes': torch.tensor([[3.0, 4.0, 0.5 * w, 0.75 * h], [1.0, 2.0, w - 2.0, h - 1.0]]),
+                  'masks': (torch.rand(2, h, w, generator=g) > 0.5).to(torch.uint8), 'keypoints': kp}
+        before = {k: v.clone() for k, v in target.items()}
+        img, tgt = ToTensor()(Image.fromarray(u8.numpy()), target)
+        img, tgt = RandomHorizontalFlip(1.0 if flip else 0.0)(img, tgt)
+        o_img = O.to_tensor_u8(u8)
+        o_tgt = before
+        if flip:
+            o_img, o_tgt = O.horizontal_flip(o_img, before)
+        worst = max(worst, float((img - o_img).abs().max()),
+                    *[float((tgt[k].float() - o_tgt[k].float()).abs().max()) for k in tgt])
+        out['u8/%d' % i] = u8.numpy()
+        out['flip/%d' % i] = np.array(flip)
+        for k in before:
+            out['target_in/%d/%s' % (i, k)] = before[k].numpy()
+            out['target_out/%d/%s' % (i, k)] = tgt[k].numpy()
+        images.append(img)
+    tr = CustomRCNNTransform(64, 128, O.IMAGE_MEAN, O.IMAGE_STD)
+    tr.eval()
+    il, _ = tr([im.clone() for im in images], None)
+    o_batch, o_sizes = O.transform_images(images, (64,), 128)
+    worst = max(worst, float((il.tensors - o_batch).abs().max()))
+    assert [tuple(s) for s in il.image_sizes] == o_sizes
+    out['batch'] = il.tensors.numpy()
+    out['image_sizes'] = np.array(o_sizes)
+    out['oracle_vs_reference_maxabs'] = np.float64(worst)
+    print('   oracle-vs-reference worst abs=%.3e' % worst)
+    assert worst < 1e-6
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **out)
+    print('   wrote %s (%.1f KB)' % (path, os.path.getsize(path) / 1024.0))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--only')
@@ -258,6 +304,8 @@ def main():
         run_case(name, case)
     if not args.only or args.only == 'tiny_eval_quantized':
         run_eval_codec_case()
+    if not args.only or args.only == 'tiny_input_pipeline':
+        run_input_pipeline_case()
 
 
 if __name__ == '__main__':

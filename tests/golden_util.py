@@ -15,6 +15,21 @@ def load(name):
     return z, meta
 
 
+def load_raw(name):
+    return np.load(os.path.join(GOLDEN_DIR, name + '.npz'), allow_pickle=False)
+
+
+def pipeline_case(z):
+    """(uint8 HWC image, flip flag, targets before, targets after) per image of tiny_input_pipeline.npz"""
+    out = []
+    n = len([k for k in z.files if k.startswith('u8/')])
+    for i in range(n):
+        tin = {k: torch.from_numpy(z['target_in/%d/%s' % (i, k)]) for k in ('boxes', 'masks', 'keypoints')}
+        tout = {k: torch.from_numpy(z['target_out/%d/%s' % (i, k)]) for k in ('boxes', 'masks', 'keypoints')}
+        out.append((torch.from_numpy(z['u8/%d' % i]), bool(z['flip/%d' % i]), tin, tout))
+    return out
+
+
 def case_inputs(meta):
     """Re-create the seeded inputs of make_golden.make_inputs (kept in sync by test_oracle_golden)."""
     g = torch.Generator().manual_seed(1234 + meta['seed'])

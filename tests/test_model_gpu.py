@@ -144,6 +144,27 @@ def test_transform_and_fpn_match_golden():
         G.compare(z, 'student_fpn/%s' % k, v.contiguous(), FEAT_TOL)
 
 
+def test_decoded_input_pipeline_matches_reference_fixture():
+    """uint8 HWC images through this build's ToTensor / RandomHorizontalFlip and the model's transform (one fused
+    kernel per image) == the reference's ToTensor -> flip -> CustomRCNNTransform (tiny_input_pipeline.npz)."""
+    from hnd_ghnd_object_detectors_amd.structure.transformer import RandomHorizontalFlip, ToTensor
+    z, meta = G.load('tiny_ghnd_faster')
+    cfg, t_sd, s_sd, teacher, student, box, opt, warm = _setup(meta)
+    zp = G.load_raw('tiny_input_pipeline')
+    images, targets = [], []
+    for u8, flip, tin, tout in G.pipeline_case(zp):
+        img, tgt = ToTensor()(u8, {k: v.clone() for k, v in tin.items()})
+        img, tgt = RandomHorizontalFlip(1.0 if flip else 0.0)(img, tgt)
+        images.append(img.to(DEV, non_blocking=True))
+        targets.append({k: v.to(DEV) for k, v in tgt.items()})
+    teacher.eval()
+    il, out_t = teacher.transform(images, targets, None)
+    assert [list(s) for s in il.image_sizes] == zp['image_sizes'].tolist()
+    ref = torch.from_numpy(zp['batch'])
+    assert float((il.tensors.cpu() - ref).abs().max()) < 2e-5
+    assert out_t[0]['masks'].shape[-2:] == tuple(il.image_sizes[0])
+
+
 def test_against_oracle_on_fresh_inputs_with_resume_of_buffers():
     """three steps on new seeded inputs (batch 3, odd sizes) vs the CPU oracle run side by side."""
     from hnd_ghnd_object_detectors_amd.distillation.tool import DistillationBox
@@ -328,6 +349,6 @@ def test_mimic_runner_cli_end_to_end(tmp_path, capsys):
     assert ck['lr_scheduler']['last_epoch'] == 1 or ck['lr_scheduler']['last_epoch'] == 0
     assert len(ck['model']) == 293 and len(ck['optimizer']['state']) == 25
     # resume: the checkpoint is picked up (model via get_model, optimizer/scheduler via distill)
-    mimic_runner.main(mimic_runner.get_argparser().parse_args(argv[:-1] + ['1']))
+    mimic_runner.main(mimic_runner.get_argparser().parse_args(argv[:-1] + ['1', '-decoded_input']))
     out = capsys.readouterr().out
     assert 'Loading model parameters' in out and 'Loading optimizer parameters' in out

@@ -274,6 +274,29 @@ def test_transform_matches_oracle(ops, shape, size, max_size):
     assert float(dst[..., 3].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize('hwc', [True, False])
+@pytest.mark.parametrize('flip', [False, True])
+@pytest.mark.parametrize('shape,size,max_size', [((37, 61), 64, 128), ((120, 50), 64, 100), ((64, 64), 64, 128)])
+def test_transform_u8_matches_oracle(ops, shape, size, max_size, hwc, flip):
+    """decoded uint8 image: /255 (ToTensor) + flip + normalise + resize + pad in one kernel"""
+    from oracle import hnd_oracle as O
+    u8 = torch.randint(0, 256, (shape[0], shape[1], 3), generator=gen(19), dtype=torch.uint8)
+    img = O.to_tensor_u8(u8)
+    if flip:
+        img = img.flip(-1)
+    ref, sizes = O.transform_images([img], min_size=(size,), max_size=max_size)
+    scale = size / float(min(shape))
+    if float(max(shape)) * scale > max_size:
+        scale = max_size / float(max(shape))
+    oh, ow = sizes[0]
+    dst = torch.full((1, ref.shape[2], ref.shape[3], 4), float('nan'), device=DEV)
+    src = u8 if hwc else u8.permute(2, 0, 1).contiguous()
+    ops.transform_image_u8(src.to(DEV), dst, 0, oh, ow, 1.0 / scale, 1.0 / scale, O.IMAGE_MEAN, O.IMAGE_STD, hwc, flip)
+    ops.sync_check()
+    assert float((nchw(dst, 3) - ref).abs().max()) < 2e-5
+    assert float(dst[..., 3].abs().max()) == 0.0
+
+
 def test_maxpool_fwd_bwd(ops):
     g = gen(10)
     n, c, h, w = 2, 64, 21, 30

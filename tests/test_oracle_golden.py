@@ -80,3 +80,20 @@ def test_fp64_gradient_noise_floor():
             continue
         rel = float((g32[n].double() - g64[n]).norm() / g64[n].norm())
         assert rel < 1e-4, (n, rel)
+
+
+def test_oracle_input_pipeline_matches_reference_fixture():
+    """ToTensor -> RandomHorizontalFlip -> CustomRCNNTransform of the reference on decoded uint8 images."""
+    z = G.load_raw('tiny_input_pipeline')
+    assert float(z['oracle_vs_reference_maxabs']) < 1e-6
+    images = []
+    for u8, flip, tin, tout in G.pipeline_case(z):
+        img, tgt = O.to_tensor_u8(u8), tin
+        if flip:
+            img, tgt = O.horizontal_flip(img, tin)
+        for k in tout:
+            assert torch.equal(tgt[k], tout[k]), k
+        images.append(img)
+    batch, sizes = O.transform_images(images, (64,), 128)
+    assert [list(s) for s in sizes] == z['image_sizes'].tolist()
+    assert float((batch - torch.from_numpy(z['batch'])).abs().max()) < 1e-6
