@@ -89,7 +89,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1:
-        dist.init_process_group(args.dist_backend, init_method='env://')      # 'nccl' is RCCL on ROCm
+        kw = {'device_id': dev} if args.dist_backend == 'nccl' else {}
+        dist.init_process_group(args.dist_backend, init_method='env://', **kw)        # 'nccl' is RCCL on ROCm
 
     from hnd_ghnd_object_detectors_amd import engine as E
     from hnd_ghnd_object_detectors_amd.configs import make_config

@@ -71,6 +71,13 @@ _SIGNATURES = {
     'hnd_quantize_u8': (C.c_int, [vp, C.c_int64, C.c_int, C.c_int, vp, vp, vp, vp]),
     'hnd_dequantize_u8': (C.c_int, [vp, vp, vp, C.c_int64, C.c_int, C.c_int, vp]),
     'hnd_roundtrip_f16': (C.c_int, [vp, C.c_int64, vp]),
+    'hnd_adaptive_avgpool_fwd': (C.c_int, [vp, vp] + [C.c_int] * 6 + [vp]),
+    'hnd_adaptive_avgpool_bwd': (C.c_int, [vp, vp] + [C.c_int] * 6 + [vp]),
+    'hnd_linear_fwd': (C.c_int, [vp] * 4 + [C.c_int] * 5 + [vp]),
+    'hnd_linear_bwd': (C.c_int, [vp] * 6 + [C.c_int] * 5 + [vp]),
+    'hnd_softmax_rows': (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),
+    'hnd_channel_sum': (C.c_int, [vp, vp, C.c_int64, C.c_int, C.c_int, vp]),
+    'hnd_sgd_step_flat': (C.c_int, [vp, vp, vp, C.c_int64] + [C.c_float] * 4 + [C.c_int, C.c_int, C.c_float, vp]),
 }
 
 EXPORTED_SYMBOLS = tuple(sorted(_SIGNATURES))

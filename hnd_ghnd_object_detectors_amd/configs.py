@@ -62,3 +62,23 @@ def make_config(model='faster_rcnn', method='ghnd', bch=3, batch_size=4, pretrai
                                 'params': {'milestones': [9, 27] if keypoint else [5, 15], 'gamma': 0.1}}},
         'test': {'batch_size': 1},
     }
+
+
+def make_ext_config(bch=3, batch_size=2, pretrained=True, min_size=None, max_size=None, threshold=0.01,
+                    ckpt_root='./resource/ckpt'):
+    """the neural-filter schema of the reference's config/ext/keypoint_rcnn-backbone_ext_resnet50-b3ch.yaml"""
+    base = make_config('keypoint_rcnn', 'ghnd', bch, batch_size, pretrained, min_size, max_size, ckpt_root)
+    for split in base['dataset']['splits'].values():
+        split['remove_non_annotated_imgs'] = False          # the filter needs the person-free images
+    model = base['student_model']
+    for key in ('distill_backbone_only', 'frozen_modules'):
+        del model[key]
+    model['backbone']['params']['freeze_layers'] = True
+    model['backbone']['ext_config'] = {
+        'backbone_frozen': True, 'threshold': threshold,
+        'ckpt': '%s/ext/coco2017-keypoint_rcnn-backbone_ext_custom_resnet50-b%dch.pt' % (ckpt_root, bch)}
+    return {'dataset': base['dataset'], 'model': model,
+            'train': {'num_epochs': 30, 'batch_size': batch_size, 'log_freq': 10000,
+                      'optimizer': {'type': 'SGD', 'params': {'lr': 0.001, 'momentum': 0.9, 'weight_decay': 0.0001}},
+                      'scheduler': {'type': 'MultiStepLR', 'params': {'milestones': [15, 25], 'gamma': 0.1}}},
+            'test': {'batch_size': 1}}

@@ -17,6 +17,8 @@
 //
 // Roofline: compute bound on the fp32 matrix pipe (157.3 TFLOP/s): per block k-step 128*BN*32*2
 // flop vs (128+BN)*32*4 B staged => 64 flop/B at BN=128.
+#include <atomic>
+
 #include "common.h"
 
 #include <stdlib.h>
@@ -380,16 +382,19 @@ igemm_kernel(const hnd_conv_desc d, const int ntiles) {
 
 template <int BM, int BN, int BK, bool CIN4, bool PRO>
 int launch_pro(const hnd_conv_desc& d, hipStream_t stream) {
-  static bool attr_set = false;
+  static std::atomic<unsigned long long> attr_set{0};    // per device: the attribute lives on the device's function
   auto kern = igemm_kernel<BM, BN, BK, CIN4, PRO>;
-  if (!attr_set) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (!(attr_set.load(std::memory_order_relaxed) & bit)) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds_bytes<BM, BN, BK, PRO>());
     if (e != hipSuccess) {
       hnd::set_error("hipFuncSetAttribute(igemm<%d,%d>) failed: %s", BM, BN, hipGetErrorString(e));
       return HND_ERR_LAUNCH;
     }
-    attr_set = true;
+    attr_set.fetch_or(bit, std::memory_order_relaxed);
   }
   const long long M = (long long)d.n * d.oh * d.ow;
   const int mtiles = (int)((M + BM - 1) / BM);

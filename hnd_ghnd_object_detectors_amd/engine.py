@@ -613,3 +613,168 @@ class FpnEngine(object):
             _run(l, tag)
         ops.subsample2(self.results[-1], self.pool)
         return self.results + [self.pool]
+
+
+# =========================================================================================== neural filter
+class _FilterConv(object):
+    __slots__ = ('conv', 'bn', 'k', 'stride', 'cin', 'cout', 'cs_in', 'cs_out', 'wc')
+
+
+class FilterEngine(object):
+    """Ext4ResNet (reference src/models/ext/classifier.py:16-37): AdaptiveAvgPool(64x64) -> three biased convs,
+    each followed by BatchNorm + ReLU (applied on load by the next consumer) -> AdaptiveAvgPool(8x8) -> Linear.
+    Convolutions, BatchNorm statistics and their backward reuse the distillation kernels; the bias rides in the
+    conv epilogue (epi_shift) so the BN statistics emitted by the same epilogue include it."""
+
+    def __init__(self, extractor, linear):
+        mods = list(extractor)
+        self.pool0, self.pool1 = tuple(mods[0].output_size), tuple(mods[-1].output_size)
+        self.layers = []
+        for i, m in enumerate(mods):
+            if isinstance(m, torch.nn.Conv2d):
+                fc = _FilterConv()
+                fc.conv, fc.bn = m, mods[i + 1]
+                assert isinstance(fc.bn, torch.nn.BatchNorm2d) and isinstance(mods[i + 2], torch.nn.ReLU)
+                assert m.kernel_size[0] == m.kernel_size[1] and m.padding == (0, 0) and m.bias is not None
+                fc.k, fc.stride = m.kernel_size[0], m.stride[0]
+                fc.cout, fc.cin = m.weight.shape[0], m.weight.shape[1]
+                fc.cs_in, fc.cs_out = ops.chan_pad_of(fc.cin), ops.chan_pad_of(fc.cout)
+                fc.wc = WeightCache(m.weight)
+                self.layers.append(fc)
+        self.linear = linear
+        self.bufs = None
+        self.plan_key = None
+        self.bwd_key = None
+
+    def params(self):
+        out = []
+        for fc in self.layers:
+            out += [fc.conv.weight, fc.conv.bias, fc.bn.weight, fc.bn.bias]
+        return out + [self.linear.weight, self.linear.bias]
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x, training):
+        """x: stem output, NHWC [N, H, W, 64].  Returns [N, 2] logits (training) or softmax probabilities."""
+        if self.bufs is None:
+            self.bufs = Buffers(x.device)
+        for fc in self.layers:
+            fc.wc.get(False, fc.cs_in)
+            fc.wc.refresh(force=training)
+        ptrs = tuple(t.data_ptr() for fc in self.layers
+                     for t in (fc.conv.bias, fc.bn.weight, fc.bn.bias, fc.bn.running_mean, fc.bn.running_var))
+        key = (x.data_ptr(), tuple(x.shape), training, ptrs)
+        if key != self.plan_key:
+            self._build_forward(x, training)
+            self.plan_key = key
+            self.bwd_key = None
+        ops.adaptive_avgpool_fwd(x, self.p0)
+        for i, fc in enumerate(self.layers):
+            self.bias[i][:fc.cout].copy_(fc.conv.bias.detach())          # pad channels keep bias 0
+            if not training:
+                bn = fc.bn
+                ops.fbn_fold(bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, eps=BN_EPS,
+                             cs=fc.cs_out, out=(self.scale[i], self.shift[i]))
+            _run(self.convs[i], 'ext.conv%d' % i)
+            if training:
+                bn, m = fc.bn, self.count[i]
+                ops.bn_finalize(self.stats[i], ops.stats_tiles(m), fc.cout, fc.cs_out, m, bn.weight.detach(),
+                                bn.bias.detach(), bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                                BN_MOMENTUM, BN_EPS, self.scale[i], self.shift[i], self.mean[i], self.rstd[i])
+        ops.affine_relu(self.y[-1], self.scale[-1], self.shift[-1], self.a_last, True)
+        ops.adaptive_avgpool_fwd(self.a_last, self.p1)
+        ops.linear_fwd(self.p1, self.layers[-1].cout, self.linear.weight.detach(), self.linear.bias.detach(),
+                       self.logits)
+        if training:
+            return self.logits
+        ops.softmax_rows(self.logits, self.probs)
+        return self.probs
+
+    def _build_forward(self, x, training):
+        n, h, w, c = x.shape
+        assert c == self.layers[0].cs_in, (c, self.layers[0].cs_in)
+        b = self.bufs
+        self.x = x
+        self.p0 = b.get('p0', (n, self.pool0[0], self.pool0[1], c))
+        self.y, self.stats, self.scale, self.shift, self.mean, self.rstd = [], [], [], [], [], []
+        self.convs, self.count, self.bias = [], [], []
+        cur, cur_scale, cur_shift, cur_relu = self.p0, None, None, False
+        h, w = self.pool0
+        for i, fc in enumerate(self.layers):
+            oh, ow = ops.conv_out_size(h, fc.k, fc.stride, 0), ops.conv_out_size(w, fc.k, fc.stride, 0)
+            y = b.get('y%d' % i, (n, oh, ow, fc.cs_out))
+            m = n * oh * ow
+            st = b.get('stats%d' % i, (ops.stats_tiles(m), 2, fc.cs_out)) if training else None
+            bias = b.get('bias%d' % i, (fc.cs_out,))
+            bias.zero_()
+            sc, sh = b.get('scale%d' % i, (fc.cs_out,)), b.get('shift%d' % i, (fc.cs_out,))
+            mu, rs = b.get('mean%d' % i, (fc.cs_out,)), b.get('rstd%d' % i, (fc.cs_out,))
+            self.convs.append(ops.conv_forward(cur, fc.wc.get(False, fc.cs_in), y, fc.k, fc.stride, 0,
+                                               pro_scale=cur_scale, pro_shift=cur_shift, pro_relu=cur_relu,
+                                               epi_shift=bias, stats=st))
+            self.y.append(y)
+            self.stats.append(st)
+            self.bias.append(bias)
+            self.scale.append(sc)
+            self.shift.append(sh)
+            self.mean.append(mu)
+            self.rstd.append(rs)
+            self.count.append(m)
+            cur, cur_scale, cur_shift, cur_relu = y, sc, sh, True
+            h, w = oh, ow
+        last = self.layers[-1]
+        self.a_last = b.get('a_last', (n, h, w, last.cs_out))
+        self.p1 = b.get('p1', (n, self.pool1[0], self.pool1[1], last.cs_out))
+        nout = self.linear.weight.shape[0]
+        self.logits = b.get('logits', (n, nout))
+        self.probs = b.get('probs', (n, nout))
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, dlogits, grad_dst):
+        """dlogits [N, nout] (contiguous); grad_dst: {parameter: destination tensor}."""
+        key = (dlogits.data_ptr(), tuple(sorted((id(p), t.data_ptr()) for p, t in grad_dst.items())))
+        if key != self.bwd_key:
+            self._build_backward(grad_dst)
+            self.bwd_key = key
+        last = self.layers[-1]
+        ops.linear_bwd(self.p1, last.cout, self.linear.weight.detach(), dlogits, grad_dst[self.linear.weight],
+                       grad_dst[self.linear.bias], self.dp1)
+        ops.adaptive_avgpool_bwd(self.dp1, self.g[-1])
+        for i in range(len(self.layers) - 1, -1, -1):
+            fc, st, g = self.layers[i], self.bsteps[i], self.g[i]
+            ops.bn_bwd_reduce(g, self.y[i], self.scale[i], self.shift[i], self.mean[i], self.rstd[i], True, st['part'])
+            ops.bn_bwd_finalize(st['part'], st['ntiles'], fc.cout, fc.cs_out, self.count[i], fc.bn.weight.detach(),
+                                self.mean[i], self.rstd[i], grad_dst[fc.bn.weight], grad_dst[fc.bn.bias], st['k123'])
+            ops.bn_bwd_apply(g, self.y[i], self.scale[i], self.shift[i], st['k123'], True, g)     # in place -> dy
+            ops.channel_sum(g, fc.cout, grad_dst[fc.conv.bias])
+            _run(st['wgrad'], 'ext.conv%d.wgrad' % i)
+            for l in st['dgrad']:
+                _run(l, 'ext.conv%d.dgrad' % i)
+
+    def _build_backward(self, grad_dst):
+        b = self.bufs
+        missing = [p for p in self.params() if p not in grad_dst]
+        if missing:
+            raise RuntimeError('the neural filter trains all of its %d tensors together (ext_runner.py:196-197); '
+                               '%d have requires_grad=False' % (len(self.params()), len(missing)))
+        self.dp1 = b.get('dp1', self.p1.shape)
+        self.g = [b.get('g%d' % i, self.y[i].shape) for i in range(len(self.layers))]
+        slab_bytes = 0
+        for i, fc in enumerate(self.layers):
+            src = self.p0 if i == 0 else self.y[i - 1]
+            n, h, w, _ = src.shape
+            slab_bytes = max(slab_bytes, ops.wgrad_workspace_bytes(n, h, w, fc.cs_in, self.y[i].shape[1],
+                                                                   self.y[i].shape[2], fc.cout, fc.k, fc.stride, 0))
+        slabs = b.get('slabs', ((slab_bytes + 3) // 4,))
+        self.bsteps = []
+        for i, fc in enumerate(self.layers):
+            st = {'ntiles': ops.bn_bwd_ntiles(self.count[i])}
+            st['part'] = b.get('bpart%d' % i, (st['ntiles'], 2, fc.cs_out))
+            st['k123'] = b.get('k123_%d' % i, (3, fc.cs_out))
+            src = self.p0 if i == 0 else self.y[i - 1]
+            pro = (None, None, False) if i == 0 else (self.scale[i - 1], self.shift[i - 1], True)
+            st['wgrad'] = ops.conv_wgrad(src, self.g[i], grad_dst[fc.conv.weight], fc.k, fc.stride, 0,
+                                         pro_scale=pro[0], pro_shift=pro[1], pro_relu=pro[2], slabs=slabs)
+            st['dgrad'] = []
+            if i > 0:
+                st['dgrad'], _ = ops.conv_dgrad(self.g[i], fc.wc, self.g[i - 1], fc.k, fc.stride, 0)
+            self.bsteps.append(st)

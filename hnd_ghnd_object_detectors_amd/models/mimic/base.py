@@ -2,8 +2,9 @@
 
 ``BottleneckBase4Ext.forward`` (reference :50-58) = decoder(encoder(x)), with the eval-only bottleneck
 transformer (:54-57: quantise / dequantise the bottleneck tensor) applied between the two when
-``use_bottleneck_transformer`` is set; the neural-filter branch (:13-19, :38-48) belongs to ext_runner
-and raises.
+``use_bottleneck_transformer`` is set.  With a neural filter (``ext_config``; :13-19, :38-48) the
+layer returns ``(features or None, ext_z)``: the filter runs first on the stem output and, for batch-1 inference
+below ``threshold``, the encoder/decoder are skipped (early exit).
 """
 from torch import nn
 
@@ -12,18 +13,23 @@ from ...hipnn import attach, to_nhwc
 
 
 class ExtEncoder(nn.Module):
-    """container that keeps the reference's ``encoder.encoder.N`` state-dict prefix; the optional neural-filter
-    classifier (``ext_config``) belongs to ext_runner and is not built here."""
+    """container that keeps the reference's ``encoder.encoder.N`` / ``encoder.ext_classifier.*`` state-dict
+    prefixes; the convolutions execute inside the parent's HeadEngine, the classifier through its FilterEngine."""
 
     def __init__(self, encoder, ext_classifier=None, ext_config=None):
         super().__init__()
-        if ext_classifier is not None:
-            raise NotImplementedError('neural filter (ext_config) belongs to ext_runner, outside this build')
-        self.encoder, self.ext_classifier = encoder, None
+        self.encoder, self.ext_classifier = encoder, ext_classifier
         self.threshold = None if ext_config is None else ext_config['threshold']
 
     def get_ext_classifier(self):
         return self.ext_classifier
+
+    def filter(self, x):
+        """reference forward_with_ext (:13-19) up to the gate: (run the encoder?, ext_z)."""
+        ext_z = self.ext_classifier(x)
+        if not self.training and ext_z.shape[0] == 1 and float(ext_z[0][1]) < self.threshold:
+            return False, ext_z
+        return True, ext_z
 
     def forward(self, x):
         raise RuntimeError('ExtEncoder executes fused inside Bottleneck4LargeResNet on the HIP path')
@@ -37,7 +43,7 @@ class BottleneckBase4Ext(nn.Module):
         self.encoder, self.decoder = encoder, decoder
         self.bottleneck_transformer = bottleneck_transformer
         self.use_bottleneck_transformer = False
-        self.uses_ext_encoder = False
+        self.uses_ext_encoder = isinstance(encoder, ExtEncoder) and encoder.ext_classifier is not None
         self.data_logging = False
         self._engine = None
 
@@ -51,10 +57,16 @@ class BottleneckBase4Ext(nn.Module):
         return self._engine
 
     def forward(self, x):
+        ext_z = None
+        if self.uses_ext_encoder:                       # reference :38-48 via ExtEncoder.forward_with_ext
+            go_on, ext_z = self.encoder.filter(x)
+            if not go_on:
+                return None, ext_z
         use_codec = self.use_bottleneck_transformer and not self.training and self.bottleneck_transformer is not None
         out = self.head_engine().forward(to_nhwc(x), self.training,
                                          codec=self.bottleneck_transformer if use_codec else None)   # base.py:54-57
-        return attach(E.logical(out), out)
+        out = attach(E.logical(out), out)
+        return (out, ext_z) if self.uses_ext_encoder else out
 
     def get_ext_classifier(self):
         raise NotImplementedError('get_ext_classifier function is not implemented')

@@ -7,6 +7,7 @@ BatchNorm2d, four ReLU.  Execution is one fused HIP plan (engine.HeadEngine).
 from torch import nn
 
 from ... import hipnn
+from ..ext.classifier import Ext4ResNet
 from .base import BottleneckBase4Ext, ExtEncoder
 
 
@@ -28,9 +29,8 @@ class Bottleneck4LargeResNet(BottleneckBase4Ext):
             _conv(64, 128, 0), bn(128), relu(inplace=True),
             _conv(128, 256, 0), bn(256),
             _conv(256, 256, 0), bn(256), relu(inplace=True))
-        if ext_config is not None:
-            raise NotImplementedError('neural filter (ext_config) belongs to ext_runner, outside this build')
-        super().__init__(encoder=ExtEncoder(encoder, None, ext_config), decoder=decoder,
+        ext_classifier = Ext4ResNet(64) if ext_config is not None else None          # reference :66
+        super().__init__(encoder=ExtEncoder(encoder, ext_classifier, ext_config), decoder=decoder,
                          bottleneck_transformer=bottleneck_transformer)
 
     def head_layers(self):

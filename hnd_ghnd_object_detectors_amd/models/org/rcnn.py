@@ -88,10 +88,11 @@ class CustomRCNN(nn.Module):
         self.distill_backbone_only = False
 
     def train_ext(self):
-        raise NotImplementedError('neural-filter training is outside this build (SURVEY.md 8f-f2)')
+        self.ext_training = True
+        self.backbone.body.ext_training = True
 
     def get_ext_classifier(self):
-        return None
+        return self.backbone.body.get_ext_classifier()
 
     def forward(self, images, targets=None, fixed_sizes=None):
         if self.training and targets is None:
@@ -100,6 +101,15 @@ class CustomRCNN(nn.Module):
         features = self.backbone(images.tensors)
         if self.distill_backbone_only:
             return features
+        if hasattr(self.backbone.body, 'ext_training'):         # ExtIntermediateLayerGetter, reference :113-122
+            features, ext_logits = features
+            if self.ext_training:
+                return ext_logits
+            if not self.training and features is None:          # the filter rejected the image: empty prediction
+                ch, height, width = images.tensors.shape[1:]
+                return [{'boxes': torch.empty(0, 4), 'labels': torch.empty(0, dtype=torch.int64),
+                         'scores': torch.empty(0), 'masks': torch.zeros(100, ch, height, width),
+                         'keypoints': torch.empty(0, 17, 3), 'keypoints_scores': torch.empty(0, 17)}]
         raise NotImplementedError('RPN / RoI heads (full detection forward) are outside the distillation hot path of '
                                   'this build; set distill_backbone_only=True (SURVEY.md section 8f, row f4)')
 

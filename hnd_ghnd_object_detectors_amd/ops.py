@@ -393,6 +393,56 @@ def roundtrip_f16(x):
     check(_L.hnd_roundtrip_f16(ptr(x), x.numel(), stream_ptr()), 'hnd_roundtrip_f16')
 
 
+# ------------------------------------------------------------------------------ neural filter (Ext4ResNet)
+def adaptive_avgpool_fwd(x, y):
+    n, h, w, c = _nhwc(x)
+    assert y.shape[0] == n and y.shape[3] == c
+    check(_L.hnd_adaptive_avgpool_fwd(ptr(x), ptr(y), n, h, w, c, y.shape[1], y.shape[2], stream_ptr()),
+          'hnd_adaptive_avgpool_fwd')
+
+
+def adaptive_avgpool_bwd(dy, dx):
+    n, h, w, c = _nhwc(dx)
+    assert dy.shape[0] == n and dy.shape[3] == c
+    check(_L.hnd_adaptive_avgpool_bwd(ptr(dy), ptr(dx), n, h, w, c, dy.shape[1], dy.shape[2], stream_ptr()),
+          'hnd_adaptive_avgpool_bwd')
+
+
+def linear_fwd(x, c, weight, bias, out):
+    """x NHWC [n, h, w, cs] holding logical [n, c, h, w]; weight [nout, c*h*w] (NCHW flatten order)."""
+    n, h, w, cs = _nhwc(x)
+    nout = weight.shape[0]
+    assert weight.is_contiguous() and weight.shape[1] == c * h * w and tuple(out.shape) == (n, nout)
+    check(_L.hnd_linear_fwd(ptr(x), ptr(weight), ptr(bias), ptr(out), n, h * w, c, cs, nout, stream_ptr()),
+          'hnd_linear_fwd')
+
+
+def linear_bwd(x, c, weight, dout, dweight, dbias, dx):
+    n, h, w, cs = _nhwc(x)
+    nout = weight.shape[0]
+    assert dout.is_contiguous() and tuple(dout.shape) == (n, nout)
+    assert dweight is None or (dweight.is_contiguous() and dweight.shape == weight.shape)
+    assert dx is None or tuple(dx.shape) == tuple(x.shape)
+    check(_L.hnd_linear_bwd(ptr(x), ptr(weight), ptr(dout), ptr(dweight), ptr(dbias), ptr(dx), n, h * w, c, cs, nout,
+                            stream_ptr()), 'hnd_linear_bwd')
+
+
+def softmax_rows(x, y):
+    assert x.dim() == 2 and x.is_contiguous() and y.shape == x.shape
+    check(_L.hnd_softmax_rows(ptr(x), ptr(y), x.shape[0], x.shape[1], stream_ptr()), 'hnd_softmax_rows')
+
+
+def channel_sum(x, c, out):
+    cs = x.shape[-1]
+    check(_L.hnd_channel_sum(ptr(x), ptr(out), x.numel() // cs, c, cs, stream_ptr()), 'hnd_channel_sum')
+
+
+def sgd_step_flat(param, grad, buf, lr, momentum, dampening, weight_decay, nesterov, first_step, grad_scale=1.0):
+    check(_L.hnd_sgd_step_flat(ptr(param), ptr(grad), ptr(buf), param.numel(), float(lr), float(momentum),
+                               float(dampening), float(weight_decay), int(bool(nesterov)), int(bool(first_step)),
+                               float(grad_scale), stream_ptr()), 'hnd_sgd_step_flat')
+
+
 def interp_out_size(size, scale):
     """F.interpolate(scale_factor=scale) output size: floor(size * scale) in double (torch semantics)."""
     return int(math.floor(float(size) * scale))

@@ -1,4 +1,6 @@
-"""Fused Adam over one flat parameter arena (replaces torch.optim.Adam created at src/mimic_runner.py:67-68).
+"""Fused optimizers over one flat parameter arena: Adam (replaces torch.optim.Adam created at
+src/mimic_runner.py:67-68) and SGD with momentum / weight decay (the neural filter's optimizer,
+src/ext_runner.py:118-120 with config/ext/*.yaml).
 
 Subclasses torch.optim.Adam so ``state_dict()`` / ``load_state_dict()`` keep the torch format the reference
 checkpoints store under 'optimizer' (src/models/__init__.py:15-17) and LambdaLR / MultiStepLR drive
@@ -94,4 +96,72 @@ class FusedAdam(torch.optim.Adam):
                     ops.adam_step_flat(p.data, g, st['exp_avg'], st['exp_avg_sq'], group['lr'], beta1, beta2,
                                        group['eps'], step, self.grad_scale)
                     st['step'] = torch.tensor(float(step))
+        return None
+
+
+class FusedSGD(torch.optim.SGD):
+    """torch.optim.SGD (momentum, dampening, weight_decay, nesterov) as one hnd_sgd_step_flat launch over flat
+    parameter / gradient / momentum arenas; ``state_dict()`` keeps torch's ``momentum_buffer`` entries."""
+
+    def __init__(self, params, lr=1e-3, momentum=0, dampening=0, weight_decay=0, nesterov=False, **kwargs):
+        super().__init__(params, lr=lr, momentum=momentum, dampening=dampening, weight_decay=weight_decay,
+                         nesterov=nesterov)
+        self.grad_scale = 1.0
+        self._flat = None
+
+    def _flatten(self, plist):
+        offsets, total = [], 0
+        for p in plist:
+            offsets.append(total)
+            total += (p.numel() + 63) // 64 * 64
+        dev = plist[0].device
+        flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
+        flat_b = torch.zeros_like(flat_p)
+        started = set()
+        for o, p in zip(offsets, plist):
+            n = p.numel()
+            flat_p[o:o + n].copy_(p.data.reshape(-1))
+            p.data = flat_p[o:o + n].view(p.shape)
+            st = self.state[p]
+            buf = st.get('momentum_buffer')
+            started.add(buf is not None)
+            if buf is not None:                       # resumed from a checkpoint
+                flat_b[o:o + n].copy_(buf.reshape(-1))
+            st['momentum_buffer'] = flat_b[o:o + n].view(p.shape) if buf is not None else None
+        if len(started) != 1:
+            return None
+        return {'ids': [id(p) for p in plist], 'offsets': offsets, 'total': total, 'p': flat_p, 'b': flat_b,
+                'started': started.pop()}
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        if closure is not None:
+            raise NotImplementedError('FusedSGD.step(closure) is not supported')
+        for group in self.param_groups:
+            plist = [p for p in group['params'] if p.grad is not None]
+            if not plist:
+                continue
+            hyper = (group['lr'], group['momentum'], group['dampening'], group['weight_decay'], group['nesterov'])
+            flat = self._flat
+            if flat is None or flat['ids'] != [id(p) for p in plist]:
+                flat = self._flatten(plist)
+                self._flat = flat
+            flat_g = FusedAdam._grads_are_flat(self, flat, plist) if flat is not None else None
+            if flat_g is not None and all(p.data_ptr() == flat['p'].data_ptr() + o * 4
+                                          for o, p in zip(flat['offsets'], plist)):
+                ops.sgd_step_flat(flat['p'], flat_g, flat['b'], *hyper, first_step=not flat['started'],
+                                  grad_scale=self.grad_scale)
+                if not flat['started'] and group['momentum'] != 0:
+                    for o, p in zip(flat['offsets'], plist):
+                        self.state[p]['momentum_buffer'] = flat['b'][o:o + p.numel()].view(p.shape)
+                flat['started'] = True
+            else:
+                for p in plist:
+                    st = self.state[p]
+                    first = st.get('momentum_buffer') is None
+                    if first and group['momentum'] != 0:
+                        st['momentum_buffer'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                    ops.sgd_step_flat(p.data, g, st.get('momentum_buffer'), *hyper, first_step=first,
+                                      grad_scale=self.grad_scale)
         return None

@@ -44,16 +44,21 @@ class DistributedStudent(nn.Module):
         if self.world == 1:
             return
         body = self.module.backbone.body
-        arena = getattr(body, '_grad_arena', None)
-        if arena is not None:
-            flat = arena.flat[arena.cur]
-            dist.all_reduce(flat)
+        arenas = [getattr(body, '_grad_arena', None)]
+        ext = body.get_ext_classifier() if hasattr(body, 'get_ext_classifier') else None
+        if ext is not None:                        # neural-filter training: its 14 tensors have their own arena
+            arenas = [getattr(ext, '_arena', None)]
+        arenas = [a for a in arenas if a is not None]
+        if arenas:
+            for arena in arenas:
+                dist.all_reduce(arena.flat[arena.cur])
         else:
             for p in self.module.parameters():
                 if p.grad is not None:
                     dist.all_reduce(p.grad)
         if self.optimizer is None or not hasattr(self.optimizer, 'grad_scale'):
-            raise RuntimeError('attach_optimizer(FusedAdam) first: the 1/world factor is applied in the Adam launch')
+            raise RuntimeError('attach_optimizer(FusedAdam / FusedSGD) first: the 1/world factor is applied in the '
+                               'optimizer launch')
 
 
 def all_reduce_flat_(flat, world):

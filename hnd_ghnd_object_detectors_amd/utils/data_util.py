@@ -29,10 +29,11 @@ class SyntheticDetectionLoader(object):
     """len()-able iterable of (images, targets) tuples, sharded by rank through the seed."""
 
     def __init__(self, num_batches, batch_size, height=800, width=1333, model_name='faster_rcnn', seed=1234, rank=0,
-                 device='cpu', decoded=False, train=True):
+                 device='cpu', decoded=False, train=True, positive_every=0):
         self.num_batches, self.batch_size, self.h, self.w = num_batches, batch_size, height, width
         self.model_name, self.seed, self.rank, self.device = model_name, seed, rank, device
         self.decoded, self.transform = decoded, get_transform(train)
+        self.positive_every = positive_every       # neural filter: every k-th person has 17 visible keypoints
         self.epoch = 0
 
     def set_epoch(self, epoch):
@@ -44,13 +45,16 @@ class SyntheticDetectionLoader(object):
     def make_targets(self):
         h, w = self.h, self.w
         out = []
-        for _ in range(self.batch_size):
+        self._count = getattr(self, '_count', 0) + 1
+        for i in range(self.batch_size):
             t = {'boxes': torch.tensor([[0.125 * w, 0.125 * h, 0.5 * w, 0.5 * h]], dtype=torch.float32),
                  'labels': torch.tensor([1], dtype=torch.int64)}
             if self.model_name == 'mask_rcnn':
                 t['masks'] = torch.zeros(1, h, w, dtype=torch.uint8)
             if self.model_name == 'keypoint_rcnn':
                 t['keypoints'] = torch.zeros(1, 17, 3, dtype=torch.float32)
+                if self.positive_every and (i + self._count) % self.positive_every == 0:
+                    t['keypoints'][..., 2] = 1
             out.append(t)
         return out
 

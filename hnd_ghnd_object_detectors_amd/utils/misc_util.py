@@ -129,3 +129,17 @@ def is_main_process():
 def save_on_master(*args, **kwargs):
     if is_main_process():
         torch.save(*args, **kwargs)
+
+
+def reduce_dict(input_dict, average=True):
+    """mean (or sum) of every value over the ranks, for logging (reference src/utils/misc_util.py:115-139)."""
+    world = get_world_size()
+    if world < 2:
+        return input_dict
+    keys = sorted(input_dict)
+    with torch.no_grad():
+        packed = torch.stack([input_dict[k].detach().float() for k in keys])
+        dist.all_reduce(packed)
+        if average:
+            packed /= world
+    return dict(zip(keys, packed))

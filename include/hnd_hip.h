@@ -232,6 +232,30 @@ int hnd_dequantize_u8(const uint8_t* q, const float* qparams, float* x, int64_t 
 /* Quantizer(num_bits=16): z.half() then .float() (transformer.py:136-137,149-150) as one round trip */
 int hnd_roundtrip_f16(float* x, int64_t numel, void* stream);
 
+/* ---- neural filter: Ext4ResNet, src/models/ext/classifier.py:16-37 --------------------
+ * Its three convolutions (+bias via epi_shift) and train-mode BatchNorms reuse hnd_conv2d_igemm / _wgrad / hnd_bn_*.
+ * nn.AdaptiveAvgPool2d((oh, ow)) (classifier.py:20,30) on NHWC, c % 4 == 0; window o = [floor(o*in/out),
+ * ceil((o+1)*in/out)); the backward is the gather form (deterministic). */
+int hnd_adaptive_avgpool_fwd(const float* x, float* y, int n, int h, int w, int c, int oh, int ow, void* stream);
+int hnd_adaptive_avgpool_bwd(const float* dy, float* dx, int n, int h, int w, int c, int oh, int ow, void* stream);
+/* nn.Linear on z.flatten(1) (classifier.py:32,36): x is NHWC [n][hw][cs] holding logical [n][c][hw]; weight is
+ * torch's [nout][c*hw] (NCHW flatten order), out [n][nout].  hnd_linear_bwd writes dweight [nout][c*hw], dbias [nout]
+ * (either may be NULL together) and dx [n][hw][cs] (NULL to skip; pad channels written as 0). */
+int hnd_linear_fwd(const float* x, const float* weight, const float* bias, float* out, int n, int hw, int c, int cs,
+                   int nout, void* stream);
+int hnd_linear_bwd(const float* x, const float* weight, const float* dout, float* dweight, float* dbias, float* dx,
+                   int n, int hw, int c, int cs, int nout, void* stream);
+/* z.softmax(dim=1) of the eval-mode classifier (classifier.py:37) */
+int hnd_softmax_rows(const float* x, float* y, int rows, int cols, void* stream);
+/* per-channel sum over pixels of x [npix][cs] -> out[c]: the bias gradient of nn.Conv2d (autograd, ext_runner.py:72) */
+int hnd_channel_sum(const float* x, float* out, int64_t npix, int c, int cs, void* stream);
+/* torch.optim.SGD.step (ext_runner.py:118-120; config/ext: lr 1e-3, momentum 0.9, weight_decay 1e-4) over a flat
+ * arena: d = grad*grad_scale + weight_decay*p; buf = first_step ? d : momentum*buf + (1-dampening)*d;
+ * p -= lr * (nesterov ? d + momentum*buf : buf).  momentum_buf may be NULL when momentum == 0. */
+int hnd_sgd_step_flat(float* param, const float* grad, float* momentum_buf, int64_t numel, float lr, float momentum,
+                      float dampening, float weight_decay, int nesterov, int first_step, float grad_scale,
+                      void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -398,6 +398,115 @@ class DistillOracle(object):
         return float(loss.detach()), OrderedDict((k, float(v.detach())) for k, v in per_term.items()), grads, lr
 
 
+# ----------------------------------------------------------------------------- neural filter
+EXT = B + 'layer1.encoder.ext_classifier.'
+# Ext4ResNet.extractor (src/models/ext/classifier.py:19-31): index -> (kind, ...)
+EXT_CONVS = ((1, 64, 64, 4, 2), (4, 64, 32, 3, 2), (7, 32, 16, 2, 1))      # (idx, cin, cout, k, stride)
+EXT_BNS = ((2, 64), (5, 32), (8, 16))
+
+
+def init_ext_state(seed, dtype=torch.float32):
+    """Seeded init of Ext4ResNet(64) with torch's default nn.Conv2d / nn.Linear distributions; BatchNorm buffers
+    are perturbed away from (0, 1) so that eval mode is a non-trivial check."""
+    gen = torch.Generator().manual_seed(seed)
+    sd = OrderedDict()
+    for (ci, cin, cout, k, _), (bi, c) in zip(EXT_CONVS, EXT_BNS):
+        _conv_b(gen, sd, '%sextractor.%d.' % (EXT, ci), cin, cout, k, dtype)
+        p = '%sextractor.%d.' % (EXT, bi)
+        sd[p + 'weight'] = (torch.rand(c, generator=gen) * 0.5 + 0.75).to(dtype)
+        sd[p + 'bias'] = (torch.randn(c, generator=gen) * 0.1).to(dtype)
+        sd[p + 'running_mean'] = (torch.randn(c, generator=gen) * 0.1).to(dtype)
+        sd[p + 'running_var'] = (torch.rand(c, generator=gen) * 0.5 + 0.75).to(dtype)
+        sd[p + 'num_batches_tracked'] = torch.tensor(0, dtype=torch.int64)
+    _linear(gen, sd, EXT + 'linear.', 16 * 8 * 8, 2, dtype)
+    return sd
+
+
+def ext_trainable_keys(sd):
+    return [k for k in sd if k.startswith(EXT) and 'running_' not in k and 'num_batches' not in k]
+
+
+def ext_classifier(x, sd, training=True, update_buffers=True, intermediates=None):
+    """Ext4ResNet.forward (classifier.py:34-37) on the stem output x [N, 64, H, W]: logits in training mode,
+    softmax probabilities in eval mode."""
+    z = F.adaptive_avg_pool2d(x, (64, 64))
+    for (ci, _, _, _, stride), (bi, _) in zip(EXT_CONVS, EXT_BNS):
+        p = '%sextractor.%d.' % (EXT, ci)
+        z = F.conv2d(z, sd[p + 'weight'], sd[p + 'bias'], stride=stride)
+        z = F.relu(_train_bn(z, sd, '%sextractor.%d.' % (EXT, bi), training, update_buffers))
+        if intermediates is not None:
+            intermediates['extractor.%d' % (bi + 1)] = z
+    z = F.adaptive_avg_pool2d(z, (8, 8))
+    z = F.linear(z.flatten(1), sd[EXT + 'linear.weight'], sd[EXT + 'linear.bias'])
+    return z if training else z.softmax(dim=1)
+
+
+def valid_target(target, min_keypoints_per_image=10):
+    """check_if_valid_target, src/models/ext/backbone.py:11-36: the image-level label of the neural filter."""
+    if len(target) == 0:
+        return False
+    if all(any(float(o) <= 1 for o in box[2:]) for box in target['boxes']):
+        return False
+    if 'keypoints' not in target:
+        return True
+    return sum(sum(1 for row in kp if float(row[2]) > 0) for kp in target['keypoints']) >= min_keypoints_per_image
+
+
+class FilterOracle(object):
+    """ext_runner.train_model (:39-76) for a frozen student + trainable Ext4ResNet on CPU: cross entropy on the
+    classifier logits, SGD(momentum, weight decay) and the epoch-0 warm-up.  As written in the reference, layer1's
+    encoder/decoder also run in train mode (base.py:13-19,38-48) and so update their BatchNorm running statistics."""
+
+    def __init__(self, student_sd, ext_sd, lr=1e-3, momentum=0.9, weight_decay=1e-4, min_size=(800,), max_size=1333,
+                 warmup_iters=0, warmup_factor=1e-3, dtype=torch.float32):
+        self.dtype = dtype
+        self.s = cast_state(student_sd, dtype)
+        self.s.update(cast_state(ext_sd, dtype))
+        self.min_size, self.max_size = min_size, max_size
+        self.keys = ext_trainable_keys(self.s)
+        for k in self.keys:
+            self.s[k] = self.s[k].clone().requires_grad_(True)
+        self.opt = torch.optim.SGD([self.s[k] for k in self.keys], lr=lr, momentum=momentum,
+                                   weight_decay=weight_decay)
+        self.sched = None
+        if warmup_iters > 0:
+            def f(x):
+                if x >= warmup_iters:
+                    return 1
+                a = float(x) / warmup_iters
+                return warmup_factor * (1 - a) + a
+            self.sched = torch.optim.lr_scheduler.LambdaLR(self.opt, f)
+
+    def forward(self, images, training=True, fixed_sizes=None, update_buffers=True, intermediates=None):
+        images = [im.to(self.dtype) for im in images]
+        x, _ = transform_images(images, self.min_size, self.max_size, training=False, fixed_sizes=fixed_sizes)
+        with torch.no_grad():
+            x0 = stem(x, self.s)
+        out = ext_classifier(x0, self.s, training, update_buffers, intermediates)
+        gated = (not training) and out.shape[0] == 1          # base.py:15: early exit for batch-1 inference
+        if training or not gated:
+            with torch.no_grad():                             # frozen, but executed (and BN buffers updated)
+                student_layer1(x0, self.s, training=training, update_buffers=update_buffers)
+        return out
+
+    def step(self, images, targets, fixed_sizes=None):
+        logits = self.forward(images, True, fixed_sizes)
+        labels = torch.tensor([1 if valid_target(t) else 0 for t in targets], dtype=torch.int64)
+        loss = F.cross_entropy(logits, labels)
+        self.opt.zero_grad()
+        loss.backward()
+        grads = OrderedDict((k, self.s[k].grad.detach().clone()) for k in self.keys)
+        self.opt.step()
+        lr = self.opt.param_groups[0]['lr']
+        if self.sched is not None:
+            self.sched.step()
+        return float(loss.detach()), logits.detach().clone(), grads, lr
+
+
+# conv biases in front of a train-mode BatchNorm: their true gradient is 0 (the batch mean absorbs them)
+EXT_ZERO_GRAD_KEYS = tuple('%sextractor.%d.bias' % (EXT, ci) for ci, *_ in EXT_CONVS)
+
+
 def synthetic_batch(batch, h=800, w=1333, seed=1234, rank=0, model_name='faster_rcnn'):
     """SURVEY.md section 8(d) synthetic inputs: uniform [0,1) images, one box per image."""
     g = torch.Generator().manual_seed(seed + rank)

@@ -293,6 +293,110 @@ def run_input_pipeline_case(name='tiny_input_pipeline'):
     print('   wrote %s (%.1f KB)' % (path, os.path.getsize(path) / 1024.0))
 
 
+def run_ext_filter_case(name='tiny_ext_filter'):
+    """Neural filter: the reference's ext model (config/ext/*.yaml) trained the way
+    ext_runner.train_model does -- cross entropy on Ext4ResNet logits, SGD(momentum, wd), epoch-0 warm-up -- then
+    evaluated (softmax probabilities)."""
+    print('== %s' % name)
+    import ext_runner                                              # reference
+    case = dict(yaml='ext/keypoint_rcnn-backbone_ext_resnet50-b3ch.yaml', model='keypoint_rcnn', seed=41,
+                sizes=[(60, 90), (64, 72), (52, 100)], min_size=64, max_size=128, steps=3, num_classes=2,
+                loader_len=5)
+    config = yaml_util.load_yaml_file(os.path.join(REF_CONFIG, case['yaml']))
+    override = {'model': {'backbone': {'params': {'pretrained': False},
+                                       'ext_config': {'ckpt': '/nonexistent/ext.pt'}},
+                          'params': {'pretrained': False, 'min_size': case['min_size'], 'max_size': case['max_size']},
+                          'ckpt': '/nonexistent/student.pt'}}
+    main_util.overwrite_config(config, json.dumps(override))
+    device = torch.device('cpu')
+    model = get_model(config['model'], device, strict=False)       # ext_runner.py:193-194
+    t_sd = O.init_teacher_state(case['seed'], 'keypoint_rcnn', num_classes=2)
+    s_sd = O.init_student_state(t_sd, case['seed'] + 1000)
+    e_sd = O.init_ext_state(case['seed'] + 2000)
+    full = OrderedDict(s_sd)
+    full.update(e_sd)
+    model.load_state_dict(full, strict=True)
+    module_util.freeze_module_params(model)                        # ext_runner.py:195-199
+    ext_classifier = model.get_ext_classifier()
+    module_util.unfreeze_module_params(ext_classifier)
+    names = module_util.get_updatable_param_names(model)
+    model.train_ext()
+    opt_cfg = config['train']['optimizer']
+    optimizer = func_util.get_optimizer(ext_classifier, opt_cfg['type'], opt_cfg['params'])
+    warm = main_util.warmup_lr_scheduler(optimizer, min(1000, case['loader_len'] - 1), 1.0 / 1000.0)
+    orc = O.FilterOracle(s_sd, e_sd, lr=opt_cfg['params']['lr'], momentum=opt_cfg['params']['momentum'],
+                         weight_decay=opt_cfg['params']['weight_decay'], min_size=(case['min_size'],),
+                         max_size=case['max_size'], warmup_iters=case['loader_len'] - 1)
+
+    g = torch.Generator().manual_seed(1234 + case['seed'])
+    images, targets = [], []
+    for i, (h, w) in enumerate(case['sizes']):
+        images.append(torch.rand(3, h, w, generator=g))
+        kp = torch.rand(1, 17, 3, generator=g) * torch.tensor([w, h, 1.0])
+        kp[..., 2] = 1.0 if i != 2 else 0.0                         # image 2: no visible keypoints -> negative
+        if i == 2:
+            kp[0, :5, 2] = 1.0
+        box = [[0.125 * w, 0.125 * h, 0.5 * w, 0.5 * h]] if i != 1 else [[3.0, 4.0, 0.5, 20.0]]   # image 1: empty box
+        targets.append({'boxes': torch.tensor(box), 'labels': torch.tensor([1]), 'keypoints': kp})
+    out = OrderedDict()
+    out['meta'] = np.array(json.dumps(case))
+    out['param_names'] = np.array(json.dumps(names))
+    worst, worst_grad = 0.0, 0.0
+    pref = 'backbone.body.layer1.encoder.ext_classifier.'
+    model.train()                                                  # train_model, ext_runner.py:40
+    for step in range(case['steps']):
+        ims = [im.clone() for im in images]
+        tgs = [{k: v.clone() for k, v in t.items()} for t in targets]
+        ext_logits = model(ims, tgs)
+        ext_targets = ext_runner.convert_target2ext_targets(tgs, device)
+        loss = torch.nn.functional.cross_entropy(ext_logits, ext_targets)
+        optimizer.zero_grad()
+        loss.backward()
+        lr = optimizer.param_groups[0]['lr']
+        grads = OrderedDict((n, p.grad.detach().clone()) for n, p in model.named_parameters() if p.requires_grad)
+        optimizer.step()
+        warm.step()
+        o_loss, o_logits, o_grads, o_lr = orc.step(images, targets)
+        out['step%d/logits' % step] = ext_logits.detach().numpy()
+        out['step%d/labels' % step] = ext_targets.numpy()
+        out['step%d/loss' % step] = np.float64(float(loss.detach()))
+        out['step%d/lr' % step] = np.float64(lr)
+        worst = max(worst, float((ext_logits.detach() - o_logits).abs().max()), abs(float(loss) - o_loss))
+        assert abs(lr - o_lr) < 1e-15
+        for n, gr in grads.items():
+            put(out, 'step%d/grad/%s' % (step, n[len(pref):]), gr, full_limit=4000)
+            if n in O.EXT_ZERO_GRAD_KEYS:
+                continue
+            den = float(gr.norm()) + 1e-30
+            worst_grad = max(worst_grad, float((gr - o_grads[n]).norm()) / den)
+        for n, p in model.named_parameters():
+            if p.requires_grad:
+                put(out, 'step%d/param_after/%s' % (step, n[len(pref):]), p.detach().clone(), full_limit=4000)
+                worst = max(worst, float((p.detach() - orc.s[n].detach()).abs().max()))
+    sd = model.state_dict()
+    for k, v in sd.items():                                        # every BatchNorm buffer the ext training touched
+        if 'layer1' in k and ('running_' in k or 'num_batches' in k):
+            out['buffers/' + k] = v.numpy().copy()
+            worst = max(worst, float((v.double() - orc.s[k].double()).abs().max()))
+    model.eval()                                                   # evaluate, ext_runner.py:80
+    with torch.no_grad():
+        probs = model([im.clone() for im in images], [dict(t) for t in targets])
+        probs1 = model([images[0].clone()], [dict(targets[0])])
+    out['eval/probs'] = probs.numpy()
+    out['eval/probs_single'] = probs1.numpy()
+    with torch.no_grad():
+        worst = max(worst, float((probs - orc.forward(images, training=False)).abs().max()),
+                    float((probs1 - orc.forward(images[:1], training=False)).abs().max()))
+    out['oracle_vs_reference_maxabs'] = np.float64(worst)
+    out['oracle_vs_reference_grad_rel'] = np.float64(worst_grad)
+    print('   labels=%s loss0=%.6f oracle-vs-reference worst abs=%.3e grad rel=%.3e'
+          % (out['step0/labels'].tolist(), float(out['step0/loss']), worst, worst_grad))
+    assert worst < 1e-5 and worst_grad < 1e-4
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **out)
+    print('   wrote %s (%.1f KB)' % (path, os.path.getsize(path) / 1024.0))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--only')
@@ -306,6 +410,8 @@ def main():
         run_eval_codec_case()
     if not args.only or args.only == 'tiny_input_pipeline':
         run_input_pipeline_case()
+    if not args.only or args.only == 'tiny_ext_filter':
+        run_ext_filter_case()
 
 
 if __name__ == '__main__':

@@ -30,6 +30,21 @@ def pipeline_case(z):
     return out
 
 
+def ext_case_inputs(meta):
+    """Re-create the seeded inputs of make_golden.run_ext_filter_case (kept in sync by test_oracle_golden)."""
+    g = torch.Generator().manual_seed(1234 + meta['seed'])
+    images, targets = [], []
+    for i, (h, w) in enumerate(meta['sizes']):
+        images.append(torch.rand(3, h, w, generator=g))
+        kp = torch.rand(1, 17, 3, generator=g) * torch.tensor([w, h, 1.0])
+        kp[..., 2] = 1.0 if i != 2 else 0.0
+        if i == 2:
+            kp[0, :5, 2] = 1.0
+        box = [[0.125 * w, 0.125 * h, 0.5 * w, 0.5 * h]] if i != 1 else [[3.0, 4.0, 0.5, 20.0]]
+        targets.append({'boxes': torch.tensor(box), 'labels': torch.tensor([1]), 'keypoints': kp})
+    return images, targets
+
+
 def case_inputs(meta):
     """Re-create the seeded inputs of make_golden.make_inputs (kept in sync by test_oracle_golden)."""
     g = torch.Generator().manual_seed(1234 + meta['seed'])

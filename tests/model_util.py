@@ -43,3 +43,26 @@ def build_pair(config, t_sd, s_sd, device):
 
 def terms_of(config):
     return OrderedDict((k, v['factor']) for k, v in config['train']['criterion']['terms'].items())
+
+
+def ext_states(seed):
+    t_sd = O.init_teacher_state(seed, 'keypoint_rcnn', num_classes=2)
+    return O.init_student_state(t_sd, seed + 1000), O.init_ext_state(seed + 2000)
+
+
+def build_ext_model(s_sd, e_sd, device, min_size, max_size, threshold=0.01):
+    """the neural-filter model prepared exactly like ext_runner.main"""
+    from hnd_ghnd_object_detectors_amd.configs import make_ext_config
+    from hnd_ghnd_object_detectors_amd.models import get_model
+    from hnd_ghnd_object_detectors_amd.myutils.pytorch import module_util
+    cfg = make_ext_config(3, pretrained=False, min_size=min_size, max_size=max_size, threshold=threshold,
+                          ckpt_root='/nonexistent')
+    model = get_model(cfg['model'], device, strict=False)
+    full = OrderedDict(s_sd)
+    full.update(e_sd)
+    model.load_state_dict(full, strict=True)
+    module_util.freeze_module_params(model)
+    ext = model.get_ext_classifier()
+    module_util.unfreeze_module_params(ext)
+    model.train_ext()
+    return cfg, model, ext

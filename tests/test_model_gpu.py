@@ -352,3 +352,110 @@ def test_mimic_runner_cli_end_to_end(tmp_path, capsys):
     mimic_runner.main(mimic_runner.get_argparser().parse_args(argv[:-1] + ['1', '-decoded_input']))
     out = capsys.readouterr().out
     assert 'Loading model parameters' in out and 'Loading optimizer parameters' in out
+
+
+# ------------------------------------------------------------------------------------------ neural filter (8f-f2)
+def _ext_sync(orc, model):
+    sd = model.state_dict()
+    with torch.no_grad():
+        for k, v in orc.s.items():
+            if k in sd:
+                v.copy_(sd[k].detach().cpu().to(v.dtype))
+
+
+def test_neural_filter_training_matches_reference_golden():
+    """ext_runner-style steps (frozen detector, Ext4ResNet on the stem output, cross entropy, SGD momentum + wd,
+    warm-up) against the fixture the reference's own ext model produced; gradients judged against the fp64 oracle."""
+    from hnd_ghnd_object_detectors_amd import ext_runner
+    from hnd_ghnd_object_detectors_amd.myutils.pytorch import func_util
+    from hnd_ghnd_object_detectors_amd.utils import main_util
+    z, meta = G.load('tiny_ext_filter')
+    s_sd, e_sd = MU.ext_states(meta['seed'])
+    cfg, model, ext = MU.build_ext_model(s_sd, e_sd, DEV, meta['min_size'], meta['max_size'])
+    opt_cfg = cfg['train']['optimizer']
+    opt = func_util.get_optimizer(ext, opt_cfg['type'], opt_cfg['params'])
+    warm = main_util.warmup_lr_scheduler(opt, meta['loader_len'] - 1, 1e-3)
+    kw = dict(min_size=(meta['min_size'],), max_size=meta['max_size'])
+    orc64 = O.FilterOracle(s_sd, e_sd, dtype=torch.float64, **kw)
+    orc32 = O.FilterOracle(s_sd, e_sd, **kw)
+    images, targets = G.ext_case_inputs(meta)
+    model.train()
+    names = {n: p for n, p in model.named_parameters() if p.requires_grad}
+    assert len(names) == 14
+    for step in range(meta['steps']):
+        for orc in (orc64, orc32):
+            _ext_sync(orc, model)
+        ims, tgs = _to_dev(images, [{k: v.clone() for k, v in t.items()} for t in targets])
+        logits = model(ims, tgs)
+        labels = ext_runner.convert_target2ext_targets(tgs, DEV)
+        assert labels.tolist() == z['step%d/labels' % step].tolist()
+        loss = torch.nn.functional.cross_entropy(logits, labels)
+        opt.zero_grad()
+        loss.backward()
+        assert abs(opt.param_groups[0]['lr'] - float(z['step%d/lr' % step])) < 1e-15
+        G.compare(z, 'step%d/logits' % step, logits.detach(), FEAT_TOL)
+        assert abs(float(loss.detach()) - float(z['step%d/loss' % step])) <= LOSS_TOL * float(z['step%d/loss' % step])
+        _, _, g64, _ = orc64.step(images, targets)
+        _, _, g32, _ = orc32.step(images, targets)
+        for n, p in names.items():
+            if n in O.EXT_ZERO_GRAD_KEYS:       # true gradient 0: compare magnitudes only
+                assert float(p.grad.abs().max()) < 1e-5
+                continue
+            _grad_check(n, p.grad, g32[n], g64[n])
+            G.compare(z, 'step%d/grad/%s' % (step, n[len(O.EXT):]), p.grad, 5e-3)
+        opt.step()
+        warm.step()
+        for n, p in names.items():
+            G.compare(z, 'step%d/param_after/%s' % (step, n[len(O.EXT):]), p.detach(), 1e-4)
+    sd = model.state_dict()
+    for k in z.files:                           # BatchNorm buffers of the filter AND of layer1 (updated as written)
+        if k.startswith('buffers/'):
+            # atol: running means that are analytically 0 (a bias-free conv of a zero-mean BN output) are fp32 noise
+            G.compare(z, k, sd[k[len('buffers/'):]].float(), 1e-3, atol=1e-4)
+    assert int(sd[O.EXT + 'extractor.2.num_batches_tracked']) == meta['steps']
+    assert int(sd[O.B + 'layer1.decoder.0.num_batches_tracked']) == meta['steps']
+    # eval: softmax probabilities; batch-1 gate of ExtEncoder
+    model.eval()
+    with torch.no_grad():
+        ims, tgs = _to_dev(images, targets)
+        probs = model(ims, tgs)
+        single = model(ims[:1], tgs[:1])
+    G.compare(z, 'eval/probs', probs, FEAT_TOL)
+    G.compare(z, 'eval/probs_single', single, FEAT_TOL)
+    layer1 = model.backbone.body.layer1
+    x0 = model.backbone.body.stem().forward(model.transform(ims[:1], None, None)[0].tensors._hnd, False)
+    from hnd_ghnd_object_detectors_amd.hipnn import attach
+    from hnd_ghnd_object_detectors_amd import engine as E
+    layer1.encoder.threshold = 0.999            # reject: the encoder/decoder are skipped
+    out, ext_z = layer1(attach(E.logical(x0), x0))
+    assert out is None and tuple(ext_z.shape) == (1, 2)
+    layer1.encoder.threshold = 0.0              # accept: features come back with the probabilities
+    out, ext_z = layer1(attach(E.logical(x0), x0))
+    assert out is not None and out.shape[1] == 256 and abs(float(ext_z.sum()) - 1.0) < 1e-5
+
+
+def test_ext_runner_cli_end_to_end(tmp_path, capsys):
+    """reference CLI (--config / --json / -train) on synthetic batches: one epoch of filter training, ROC-AUC
+    validation, checkpoint with the classifier only, resume on the second invocation."""
+    import json
+    import os
+    from hnd_ghnd_object_detectors_amd import ext_runner
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg_path = os.path.join(root, 'config', 'ext', 'keypoint_rcnn-backbone_ext_resnet50-b3ch.yaml')
+    ckpt = str(tmp_path / 'ext.pt')
+    override = {'model': {'backbone': {'params': {'pretrained': False}, 'ext_config': {'ckpt': ckpt}},
+                          'params': {'pretrained': False, 'min_size': 64, 'max_size': 128},
+                          'ckpt': str(tmp_path / 'none.pt')},
+                'train': {'batch_size': 4, 'log_freq': 1}, 'test': {'batch_size': 2}}
+    argv = ['--config', cfg_path, '--json', json.dumps(override), '-train', '--synthetic_batches', '3',
+            '--image_size', '64x96', '--num_epochs', '1']
+    torch.manual_seed(0)
+    ext_runner.main(ext_runner.get_argparser().parse_args(argv))
+    out = capsys.readouterr().out
+    assert 'Updatable parameters' in out and 'ROC-AUC' in out and 'Updating ckpt' in out and '[Test]' in out
+    ck = torch.load(ckpt, weights_only=False)
+    assert len(ck['model']) == 23 and all(not k.startswith('backbone') for k in ck['model'])
+    assert len(ck['optimizer']['state']) == 14
+    ext_runner.main(ext_runner.get_argparser().parse_args(argv))
+    out = capsys.readouterr().out
+    assert 'Loading model parameters' in out and 'Loading optimizer parameters' in out

@@ -60,6 +60,9 @@ CONV_CASES = [
     (2, 256, 8, 10, 512, 1, 2, 0),     # stride-2 1x1 downsample
     (1, 512, 7, 9, 128, 1, 1, 0),      # 1x1
     (3, 64, 33, 41, 64, 1, 1, 0),      # M not a multiple of 128
+    (2, 64, 64, 64, 64, 4, 2, 0),      # neural filter conv 4x4 stride 2
+    (3, 64, 31, 31, 32, 3, 2, 0),      # neural filter conv 3x3 stride 2, unpadded
+    (2, 32, 15, 15, 16, 2, 1, 0),      # neural filter conv 2x2, cout 16 stored as 32
 ]
 
 
@@ -136,6 +139,9 @@ DGRAD_CASES = [
     (2, 128, 17, 21, 128, 3, 2, 1),    # stride 2, odd input
     (2, 128, 16, 20, 128, 3, 2, 1),    # stride 2, even input
     (1, 512, 7, 9, 128, 1, 1, 0),
+    (3, 64, 31, 31, 32, 3, 2, 0),      # neural filter: stride 2 without padding
+    (2, 64, 64, 64, 64, 4, 2, 0),      # even kernel, stride 2
+    (2, 32, 15, 15, 16, 2, 1, 0),
 ]
 
 
@@ -189,6 +195,9 @@ WGRAD_CASES = [
     (2, 3, 12, 14, 64, 2, 1, 0),
     (2, 128, 11, 13, 256, 2, 1, 0),
     (2, 3, 37, 45, 64, 7, 2, 3),
+    (2, 64, 64, 64, 64, 4, 2, 0),      # neural filter
+    (3, 64, 31, 31, 32, 3, 2, 0),
+    (2, 32, 15, 15, 16, 2, 1, 0),
 ]
 
 
@@ -410,6 +419,94 @@ def test_adam_matches_torch(ops):
         ops.adam_step_flat(p, (grad * 4).to(DEV), m, v, 1e-3, 0.9, 0.999, 1e-8, step, grad_scale=0.25)
     ops.sync_check()
     assert float((p.cpu() - ref_p.detach()).abs().max()) < 1e-6
+
+
+@pytest.mark.parametrize('shape,out', [((2, 64, 50, 84), (64, 64)), ((1, 64, 64, 64), (64, 64)),
+                                       ((3, 32, 14, 14), (8, 8)), ((2, 64, 23, 100), (64, 64))])
+def test_adaptive_avgpool_fwd_bwd(ops, shape, out):
+    """nn.AdaptiveAvgPool2d incl. up-sampling windows (input smaller than output) and overlapping windows"""
+    g = gen(31)
+    x = torch.randn(*shape, generator=g, requires_grad=True)
+    y = F.adaptive_avg_pool2d(x, out)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    yd = torch.full((shape[0], out[0], out[1], shape[1]), float('nan'), device=DEV)
+    ops.adaptive_avgpool_fwd(nhwc(x.detach()), yd)
+    dx = torch.full((shape[0], shape[2], shape[3], shape[1]), float('nan'), device=DEV)
+    ops.adaptive_avgpool_bwd(nhwc(dy), dx)
+    ops.sync_check()
+    assert relerr(nchw(yd), y.detach()) < 1e-6
+    assert relerr(nchw(dx), x.grad) < 1e-6
+
+
+def test_linear_on_nchw_flatten_fwd_bwd(ops):
+    """nn.Linear(16*8*8, 2) on z.flatten(1) with the activations stored NHWC, 16 channels padded to 32"""
+    g = gen(32)
+    n, c, h, w, nout = 5, 16, 8, 8, 2
+    x = torch.randn(n, c, h, w, generator=g, requires_grad=True)
+    wt = (torch.randn(nout, c * h * w, generator=g) / 32).requires_grad_(True)
+    b = torch.randn(nout, generator=g).requires_grad_(True)
+    out = F.linear(x.flatten(1), wt, b)
+    do = torch.randn(out.shape, generator=g)
+    out.backward(do)
+    xd = nhwc(x.detach(), 32)
+    od = torch.empty(n, nout, device=DEV)
+    ops.linear_fwd(xd, c, wt.detach().to(DEV), b.detach().to(DEV), od)
+    dw, db = torch.empty(nout, c * h * w, device=DEV), torch.empty(nout, device=DEV)
+    dx = torch.full((n, h, w, 32), float('nan'), device=DEV)
+    ops.linear_bwd(xd, c, wt.detach().to(DEV), do.to(DEV), dw, db, dx)
+    ops.sync_check()
+    assert relerr(od.cpu(), out.detach()) < 1e-6
+    assert relerr(dw.cpu(), wt.grad) < 1e-6 and relerr(db.cpu(), b.grad) < 1e-6
+    assert relerr(nchw(dx, c), x.grad) < 1e-6 and float(dx[..., c:].abs().max()) == 0.0
+
+
+def test_softmax_rows_and_channel_sum(ops):
+    g = gen(33)
+    x = torch.randn(7, 2, generator=g) * 5
+    y = torch.empty(7, 2, device=DEV)
+    ops.softmax_rows(x.to(DEV), y)
+    assert float((y.cpu() - x.softmax(dim=1)).abs().max()) < 1e-6
+    t = torch.randn(3, 16, 14, 14, generator=g)
+    out = torch.empty(16, device=DEV)
+    ops.channel_sum(nhwc(t, 32), 16, out)
+    ops.sync_check()
+    assert relerr(out.cpu(), t.sum(dim=(0, 2, 3))) < 1e-5
+
+
+@pytest.mark.parametrize('momentum,wd,nesterov', [(0.9, 1e-4, False), (0.0, 0.0, False), (0.9, 0.0, True)])
+def test_sgd_matches_torch(ops, momentum, wd, nesterov):
+    g = gen(34)
+    p0 = torch.randn(10007, generator=g)
+    ref_p = p0.clone().requires_grad_(True)
+    opt = torch.optim.SGD([ref_p], lr=1e-2, momentum=momentum, weight_decay=wd, nesterov=nesterov)
+    p, buf = p0.to(DEV), torch.zeros(10007, device=DEV)
+    for step in range(4):
+        grad = torch.randn(10007, generator=g)
+        ref_p.grad = grad.clone()
+        opt.step()
+        ops.sgd_step_flat(p, (grad * 2).to(DEV), buf, 1e-2, momentum, 0.0, wd, nesterov, step == 0, grad_scale=0.5)
+    ops.sync_check()
+    assert float((p.cpu() - ref_p.detach()).abs().max()) < 1e-6
+
+
+def test_conv_bias_in_epilogue_feeds_bn_statistics(ops):
+    """neural-filter conv: bias added by epi_shift; the same epilogue's (sum, sum^2) partials include it"""
+    g = gen(35)
+    n, cin, h, w, cout, k, s = 3, 64, 31, 31, 32, 3, 2
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k)
+    b = torch.randn(cout, generator=g)
+    ref = F.conv2d(x, wt, b, s, 0)
+    y = torch.empty(n, ref.shape[2], ref.shape[3], cout, device=DEV)
+    m = n * ref.shape[2] * ref.shape[3]
+    st = torch.zeros(ops.stats_tiles(m), 2, cout, device=DEV)
+    ops.conv_forward(nhwc(x), ops.pack_weights(wt.to(DEV).contiguous(), chan_pad=cin), y, k, s, 0,
+                     epi_shift=b.to(DEV), stats=st).run()
+    ops.sync_check()
+    assert relerr(nchw(y), ref) < 1e-4
+    tot = st.sum(dim=0).cpu()
+    assert relerr(tot[0], ref.sum(dim=(0, 2, 3))) < 1e-4 and relerr(tot[1], (ref * ref).sum(dim=(0, 2, 3))) < 1e-4
 
 
 def test_subsample_and_fill(ops):

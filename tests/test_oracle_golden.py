@@ -97,3 +97,29 @@ def test_oracle_input_pipeline_matches_reference_fixture():
     batch, sizes = O.transform_images(images, (64,), 128)
     assert [list(s) for s in sizes] == z['image_sizes'].tolist()
     assert float((batch - torch.from_numpy(z['batch'])).abs().max()) < 1e-6
+
+
+def test_filter_oracle_matches_reference_fixture():
+    """neural filter: ext_runner-style training steps + eval probabilities of the reference's ext model"""
+    z, meta = G.load('tiny_ext_filter')
+    assert float(z['oracle_vs_reference_maxabs']) < 1e-5 and float(z['oracle_vs_reference_grad_rel']) < 1e-4
+    t_sd = O.init_teacher_state(meta['seed'], 'keypoint_rcnn', num_classes=2)
+    s_sd, e_sd = O.init_student_state(t_sd, meta['seed'] + 1000), O.init_ext_state(meta['seed'] + 2000)
+    orc = O.FilterOracle(s_sd, e_sd, min_size=(meta['min_size'],), max_size=meta['max_size'],
+                         warmup_iters=meta['loader_len'] - 1)
+    images, targets = G.ext_case_inputs(meta)
+    for step in range(meta['steps']):
+        loss, logits, grads, lr = orc.step(images, targets)
+        assert [1 if O.valid_target(t) else 0 for t in targets] == z['step%d/labels' % step].tolist()
+        assert abs(loss - float(z['step%d/loss' % step])) < 1e-6 and abs(lr - float(z['step%d/lr' % step])) < 1e-15
+        G.compare(z, 'step%d/logits' % step, logits, 1e-6)
+        for k, g in grads.items():
+            if k not in O.EXT_ZERO_GRAD_KEYS:
+                G.compare(z, 'step%d/grad/%s' % (step, k[len(O.EXT):]), g, 1e-5)
+        for k in orc.keys:
+            G.compare(z, 'step%d/param_after/%s' % (step, k[len(O.EXT):]), orc.s[k], 1e-6)
+    for k in z.files:
+        if k.startswith('buffers/'):
+            G.compare(z, k, orc.s[k[len('buffers/'):]].float(), 1e-6)
+    G.compare(z, 'eval/probs', orc.forward(images, training=False), 1e-6)
+    G.compare(z, 'eval/probs_single', orc.forward(images[:1], training=False), 1e-6)
