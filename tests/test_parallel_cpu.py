@@ -74,3 +74,54 @@ def test_world2_gloo_gradient_allreduce_and_parameter_broadcast():
     assert gs0 == gs1 == 0.5                          # mean folded into the Adam launch
     assert n0 == n1 == 25 and tot0 == tot1 >= 586566
     assert main0 and not main1
+
+
+def _ext_worker(rank, world, port, q):
+    os.environ.update({'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(port), 'RANK': str(rank),
+                       'WORLD_SIZE': str(world), 'LOCAL_RANK': str(rank)})
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from tests import model_util as MU
+    from hnd_ghnd_object_detectors_amd.distillation.hip_loss import GradArena
+    from hnd_ghnd_object_detectors_amd.parallel import DistributedStudent
+    from hnd_ghnd_object_detectors_amd.utils import main_util, misc_util
+    main_util.init_distributed_mode(backend='gloo')
+    s_sd, e_sd = MU.ext_states(3)
+    _, model, ext = MU.build_ext_model(s_sd, e_sd, torch.device('cpu'), 64, 128)
+    with torch.no_grad():
+        for p in ext.parameters():
+            p.add_(float(rank))
+    wrapped = DistributedStudent(model)
+    w0 = ext.linear.weight.detach().clone()
+
+    class _Opt(object):
+        grad_scale = 1.0
+    opt = _Opt()
+    wrapped.attach_optimizer(opt)
+    params = ext.engine().params()
+    ext._arena = GradArena(params)
+    flat = ext._arena.pick()
+    flat.fill_(float(rank + 1))
+    wrapped.reduce_gradients()
+    red = misc_util.reduce_dict({'loss_ext_classifier': torch.tensor(float(rank + 1))})
+    q.put((rank, float(w0.sum()), float(flat.min()), float(flat.max()), opt.grad_scale, len(params),
+           float(red['loss_ext_classifier'])))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world2_gloo_neural_filter_gradient_allreduce():
+    """the filter's 14 tensors have their own flat arena: one all-reduce, mean folded into the SGD launch"""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ext_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, w0, lo0, hi0, gs0, n0, l0), (_, w1, lo1, hi1, gs1, n1, l1) = res
+    assert w0 == w1 and lo0 == hi0 == lo1 == hi1 == 3.0 and gs0 == gs1 == 0.5 and n0 == n1 == 14
+    assert l0 == l1 == 1.5

@@ -13,6 +13,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- p
 # PMC passes: counters only with --kernel-trace (FETCH_SIZE needs 3 TCC slots, WRITE_SIZE 2: separate passes)
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o bench -- python3 bench.py --steps 1 --warmup 1 --no_cpu_baseline > $OUT/bench_fetch.json 2> $OUT/fetch.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o bench -- python3 bench.py --steps 1 --warmup 1 --no_cpu_baseline > $OUT/bench_write.json 2> $OUT/write.err
+# neural filter training step, batch 16: kernel stats only
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/filter -o filter -- python3 tools/bench_filter.py --batch 16 --steps 10 --cpu_steps 0 > $OUT/bench_filter.json 2> $OUT/filter.err
+rm -f $OUT/filter/filter_kernel_trace.csv
 python3 tools/summarize_profile.py $OUT $R > $OUT/summary.md 2> $OUT/summary.err
 ls -la $OUT $OUT/* | head -40
 # keep the merged-back payload small
