@@ -487,6 +487,56 @@ class HeadEngine(object):
         """(raw conv output, scale, shift, relu) of the encoder's last conv = the bottleneck tensor z."""
         return self.y[3]
 
+    # ------------------------------------------------------------------ split deployment (inference only)
+    def forward_part(self, x, part):
+        """Head/tail split (reference src/models/mimic/split_rcnn.py:13-37,162-185), eval-mode BatchNorm:
+        part 'encoder': stem output -> raw bottleneck z (what crosses the link);
+        part 'decoder': z -> layer1 output.  Each part has its own buffers and prebuilt launches."""
+        lo, hi = (0, self.encoder_len) if part == 'encoder' else (self.encoder_len, len(self.layers))
+        if self.bufs is None:
+            self.bufs = Buffers(x.device)
+        if not hasattr(self, 'parts'):
+            self.parts = {}
+        for hc in self.layers[lo:hi]:
+            hc.wc.get(False, hc.cs_in)
+            hc.wc.refresh()
+        b = self.bufs
+        first = max(lo - 1, 0)               # the decoder's first conv applies decoder.0 (BN of layer lo-1) on load
+        ptrs = tuple(t.data_ptr() for hc in self.layers[first:hi] for t in (hc.bn.running_mean, hc.bn.weight))
+        key = (x.data_ptr(), tuple(x.shape), ptrs)
+        plan = self.parts.get(part)
+        if plan is None or plan['key'] != key:
+            n, h, w, c = x.shape
+            assert c == self.layers[lo].cs_in, (c, self.layers[lo].cs_in)
+            plan = {'key': key, 'convs': [], 'y': [], 'fold': {}}
+            for i in range(first, hi):
+                hc = self.layers[i]
+                plan['fold'][i] = (b.get('%s.scale%d' % (part, i), (hc.cs_out,)),
+                                   b.get('%s.shift%d' % (part, i), (hc.cs_out,)))
+            cur = x
+            pro = (None, None, False) if lo == 0 else plan['fold'][lo - 1] + (self.layers[lo - 1].relu,)
+            for i in range(lo, hi):
+                hc = self.layers[i]
+                oh, ow = ops.conv_out_size(h, 2, 1, hc.pad), ops.conv_out_size(w, 2, 1, hc.pad)
+                y = b.get('%s.y%d' % (part, i), (n, oh, ow, hc.cs_out))
+                plan['convs'].append(ops.conv_forward(cur, hc.wc.get(False, hc.cs_in), y, 2, 1, hc.pad,
+                                                      pro_scale=pro[0], pro_shift=pro[1], pro_relu=pro[2]))
+                plan['y'].append(y)
+                cur, pro, h, w = y, plan['fold'][i] + (hc.relu,), oh, ow
+            plan['out'] = b.get('%s.out' % part, cur.shape) if part == 'decoder' else cur
+            self.parts[part] = plan
+        for i, (sc, sh) in plan['fold'].items():
+            bn = self.layers[i].bn
+            ops.fbn_fold(bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, eps=BN_EPS,
+                         cs=self.layers[i].cs_out, out=(sc, sh))
+        for i, l in enumerate(plan['convs']):
+            _run(l, 'layer1.%s.conv%d' % (part, lo + i))
+        if part == 'decoder':
+            last = len(self.layers) - 1
+            ops.affine_relu(plan['y'][-1], plan['fold'][last][0], plan['fold'][last][1], plan['out'],
+                            self.layers[last].relu)
+        return plan['out']
+
     def grad_out_buffer(self):
         self.g_out = self.bufs.get('g_out', self.out.shape)
         return self.g_out

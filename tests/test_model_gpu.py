@@ -4,6 +4,7 @@
 Bar (north_star): feature maps and losses within 1e-3 relative fp32; gradients within 2e-3 rel-L2
 (SURVEY.md hard parts: the two zero-gradient BN biases are excluded)."""
 import random
+from collections import OrderedDict
 
 import pytest
 import torch
@@ -258,6 +259,51 @@ def test_eval_with_quantized_bottleneck_matches_reference_golden():
     b = student(ims, [{'boxes': torch.zeros(1, 4, device=DEV), 'labels': torch.ones(1, dtype=torch.int64, device=DEV)}
                       for _ in ims])[0]
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('quantization,tag,tol', [(None, 'plain', FEAT_TOL), (8, 'quantized', 2e-2)])
+def test_head_tail_split_matches_reference_golden(quantization, tag, tol):
+    """split_rcnn_model: RcnnHead (transform + stem + encoder [+ uint8 quantiser]) -> z -> RcnnTail ([dequantiser]
+    + decoder + layer2-4 + FPN) reproduces the reference's unsplit eval features (the same arithmetic, base.py:54-57
+    vs split_rcnn.py:13-37,162-185) and the unsplit HIP model bit for bit."""
+    from hnd_ghnd_object_detectors_amd.models.mimic.split_rcnn import split_rcnn_model
+    from hnd_ghnd_object_detectors_amd.structure.transformer import QuantizedTensor
+    z, meta = G.load('tiny_eval_quantized')
+    cfg = MU.config_for(meta)
+    t_sd, s_sd = MU.oracle_states(meta['seed'])
+    for k in list(s_sd):
+        if 'layer1' in k and k.endswith('running_var'):
+            s_sd[k] = s_sd[k] * 1.7 + 0.1
+        if 'layer1' in k and k.endswith('running_mean'):
+            s_sd[k] = s_sd[k] + 0.05
+    _, student = MU.build_pair(cfg, t_sd, s_sd, DEV)
+    student.eval()
+    images, _ = G.case_inputs(meta)
+    ims = [im.to(DEV) for im in images]
+    student.backbone.body.layer1.use_bottleneck_transformer = quantization is not None
+    with torch.no_grad():
+        whole = OrderedDict((k, v.clone()) for k, v in student(ims).items())
+    head, tail = split_rcnn_model(student, quantization)
+    head.eval()
+    tail.eval()
+    tail.features_only = True
+    with torch.no_grad():
+        zq, tensors_shape, image_sizes, original_sizes = head(ims)
+        if quantization is not None:
+            assert isinstance(zq, QuantizedTensor) and zq.tensor.dtype == torch.uint8 and zq.tensor.shape[1] == 3
+            # what crosses the link: the uint8 tensor + (scale, zero_point); rebuild it as the tail's side would
+            zq = QuantizedTensor(zq.tensor, zq.scale, zq.zero_point, zq.qparams.clone(), origin=None,
+                                 channels=zq.channels)
+        else:
+            assert zq.shape[1] == 3
+        feats = tail(zq, tensors_shape, image_sizes, original_sizes)
+    assert original_sizes == [tuple(im.shape[-2:]) for im in images] and len(tensors_shape) == 4
+    for k, v in feats.items():
+        G.compare(z, '%s/fpn/%s' % (tag, k), v.contiguous(), tol)
+        assert torch.equal(v, whole[k]), k
+    with pytest.raises(NotImplementedError):
+        tail.features_only = False
+        tail(zq, tensors_shape, image_sizes, original_sizes)
 
 
 def test_full_size_step_matches_reference_checksums():
