@@ -182,14 +182,21 @@ def main():
     if args.detail:
         agg = {}
         for tag, launch, e0, e1 in E.PROFILE['records']:
-            a = agg.setdefault((tag, launch.variant), [0.0, 0.0, 0])
+            a = agg.setdefault((tag, launch.variant), [0.0, 0.0, 0, ''])
             a[0] += e0.elapsed_time(e1)
             a[1] += launch.flops
             a[2] += 1
+            d = launch.desc
+            if launch.variant.startswith('igemm'):           # GEMM extent and grid fill: tiles / resident slots
+                bm, bn = (int(v) for v in launch.variant.split('_')[-1].split('x'))
+                m = d.n * d.oh * d.ow
+                tiles = -(-m // bm) * -(-d.cout // bn)
+                slots = 256 * (3 if (bm, bn) == (128, 128) else 4)
+                a[3] = 'M=%-8d N=%-5d K=%-5d tiles=%-6d rounds=%.2f' % (m, d.cout, d.kdim, tiles, tiles / slots)
         with open(args.detail, 'w') as fp:
-            fp.write('%-34s %-14s %3s %9s %9s %8s\n' % ('launch', 'kernel', 'n', 'ms', 'GFLOP', 'TFLOP/s'))
-            for (tag, var), (ms, fl, n) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
-                fp.write('%-34s %-14s %3d %9.3f %9.2f %8.2f\n' % (tag, var, n, ms, fl / 1e9, fl / ms / 1e9))
+            fp.write('%-34s %-14s %3s %9s %9s %8s  %s\n' % ('launch', 'kernel', 'n', 'ms', 'GFLOP', 'TFLOP/s', 'shape'))
+            for (tag, var), (ms, fl, n, shape) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
+                fp.write('%-34s %-14s %3d %9.3f %9.2f %8.2f  %s\n' % (tag, var, n, ms, fl / 1e9, fl / ms / 1e9, shape))
     ms_per_step = elapsed / args.steps * 1e3
     value = args.batch * world * args.steps / elapsed
     gflop_img = GFLOP_PER_IMAGE[args.method] - (243.6 if args.no_fpn else 0.0)

@@ -6,8 +6,10 @@ runs the teacher without targets, then the student with targets (Keypoint R-CNN:
 drawn ``fixed_sizes``, :45-48), collects ``{loss_name: ((teacher_path, out), (student_path, out))}`` (:53-58) and
 returns ``criterion(output_dict, org_loss_dict)``.
 MI355X specifics: the frozen teacher forward is issued on a second HIP stream (it is independent of the student
-forward, so the tails of one network's launches are filled by the other's), and both models share one transformed
-batch inside a transform scope.
+forward, so the tails of one network's launches are filled by the other's); both feature pyramids -- executed as
+written, but read by nobody when ``org_loss_factor`` is 0 -- are issued on a third stream so they trail into the
+backward pass and fill the last-round gaps of its dgrad launches (joined before the next forward); both models
+share one transformed batch inside a transform scope.
 """
 import os
 import random
@@ -44,6 +46,10 @@ class DistillationBox(nn.Module):
         self.require_adjustment = isinstance(unwrap(student_model), KeypointRCNN)
         self.overlap_teacher = os.environ.get('HND_TEACHER_STREAM', '1') != '0'
         self._side_stream = None
+        # the criterion ignores the models' own outputs (org_loss_factor 0): their FPNs may trail into the backward
+        self.defer_fpn = (os.environ.get('HND_DEFER_FPN', '1') != '0' and
+                          getattr(self.criterion, 'org_loss_factor', 1) == 0)
+        self._fpn_stream = None
 
     def _run_models(self, images, targets, extra):
         teacher = unwrap(self.teacher_model)
@@ -54,11 +60,19 @@ class DistillationBox(nn.Module):
         if self._side_stream is None:
             self._side_stream = torch.cuda.Stream(device=images[0].device)
         main = torch.cuda.current_stream()
+        if self.defer_fpn:
+            if self._fpn_stream is None:
+                self._fpn_stream = torch.cuda.Stream(device=images[0].device)
+            main.wait_stream(self._fpn_stream)       # last step's pyramids are done before their inputs are rewritten
+            E.DEFER_FPN['stream'] = self._fpn_stream
         teacher.transform(images, None, extra.get('fixed_sizes'))   # shared batch, produced once on the main stream
         self._side_stream.wait_stream(main)
         with torch.cuda.stream(self._side_stream):
             self.teacher_model(images, **extra)
-        student_out = self.student_model(images, targets, **extra)
+        try:
+            student_out = self.student_model(images, targets, **extra)
+        finally:
+            E.DEFER_FPN['stream'] = None
         main.wait_stream(self._side_stream)
         return student_out
 

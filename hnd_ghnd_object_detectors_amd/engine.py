@@ -22,6 +22,9 @@ from . import ops
 
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1
 PROFILE = {'enabled': False, 'records': []}     # bench.py: per-launch HIP events on the launch stream
+# DistillationBox sets 'stream' while it runs teacher + student: their feature pyramids (whose outputs the
+# distillation criterion never reads) are then issued on that stream and overlap the backward pass
+DEFER_FPN = {'stream': None}
 
 
 def _run(launch, tag=None):

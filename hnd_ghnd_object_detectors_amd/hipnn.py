@@ -272,7 +272,14 @@ class BackboneWithFPN(nn.Sequential):
         feats = self.body(x)
         if not self.run_fpn:
             return feats
-        return self.fpn(feats)
+        side = E.DEFER_FPN['stream']
+        if side is None or E.PROFILE['enabled'] or not x.is_cuda:
+            return self.fpn(feats)
+        # inside DistillationBox: the pyramid only depends on the layer outputs just produced on this stream and is
+        # consumed by nobody during the step -> issue it on the side stream (joined before the next forward)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            return self.fpn(feats)
 
 
 class ImageList(object):

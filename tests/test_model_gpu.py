@@ -166,6 +166,39 @@ def test_decoded_input_pipeline_matches_reference_fixture():
     assert out_t[0]['masks'].shape[-2:] == tuple(il.image_sizes[0])
 
 
+def test_deferred_fpn_stream_changes_nothing(monkeypatch):
+    """inside DistillationBox both pyramids are issued on a side stream that overlaps the backward pass
+    (HND_DEFER_FPN): loss, gradients, updated parameters and the pyramid outputs are bit-identical to the
+    in-order run."""
+    from hnd_ghnd_object_detectors_amd.distillation.tool import DistillationBox
+    from hnd_ghnd_object_detectors_amd.myutils.pytorch import func_util
+    z, meta = G.load('tiny_ghnd_faster')
+    images, targets = G.case_inputs(meta)
+    results = []
+    for defer in ('0', '1'):
+        monkeypatch.setenv('HND_DEFER_FPN', defer)
+        cfg = MU.config_for(meta)
+        t_sd, s_sd = MU.oracle_states(meta['seed'])
+        teacher, student = MU.build_pair(cfg, t_sd, s_sd, DEV)
+        box = DistillationBox(teacher, student, cfg['train']['criterion'])
+        assert box.defer_fpn == (defer == '1')
+        opt = func_util.get_optimizer(student, 'Adam', {'lr': 1e-3})
+        seen = {}
+        student.backbone.fpn.register_forward_hook(lambda m, i, o: seen.update(fpn=o))
+        for _ in range(3):
+            ims, tgs = _to_dev(images, targets)
+            loss = box(ims, tgs)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+        torch.cuda.synchronize()
+        results.append((float(loss.detach()), [p.detach().clone() for p in student.parameters() if p.requires_grad],
+                        [v.clone() for v in seen['fpn'].values()]))
+    (l0, p0, f0), (l1, p1, f1) = results
+    assert l0 == l1 and all(torch.equal(a, b) for a, b in zip(p0, p1))
+    assert len(f0) == 5 and all(torch.equal(a, b) for a, b in zip(f0, f1))
+
+
 def test_against_oracle_on_fresh_inputs_with_resume_of_buffers():
     """three steps on new seeded inputs (batch 3, odd sizes) vs the CPU oracle run side by side."""
     from hnd_ghnd_object_detectors_amd.distillation.tool import DistillationBox
