@@ -76,7 +76,8 @@ _SIGNATURES = {
     'hnd_linear_fwd': (C.c_int, [vp] * 4 + [C.c_int] * 5 + [vp]),
     'hnd_linear_bwd': (C.c_int, [vp] * 6 + [C.c_int] * 5 + [vp]),
     'hnd_softmax_rows': (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),
-    'hnd_channel_sum': (C.c_int, [vp, vp, C.c_int64, C.c_int, C.c_int, vp]),
+    'hnd_channel_sum_scratch_elems': (C.c_size_t, [C.c_int]),
+    'hnd_channel_sum': (C.c_int, [vp, vp, C.c_int64, C.c_int, C.c_int, vp, vp]),
     'hnd_sgd_step_flat': (C.c_int, [vp, vp, vp, C.c_int64] + [C.c_float] * 4 + [C.c_int, C.c_int, C.c_float, vp]),
 }
 

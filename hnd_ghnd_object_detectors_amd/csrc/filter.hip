@@ -149,17 +149,31 @@ __global__ void softmax_rows_kernel(const float* __restrict__ x, float* __restri
 }
 
 // ---------------------------------------------------------------------------- per-channel sum (conv bias gradient)
-// block = 64 channels x 4 pixel stripes; fixed summation order
-__global__ void channel_sum_kernel(const float* __restrict__ x, float* __restrict__ out, long long npix, int c, int cs) {
+// two passes, fixed summation order: grid (pixel chunk, 64-channel group) -> scratch[chunk][c]; then over chunks
+constexpr int kSumChunks = 128;
+
+__global__ void channel_sum_partial_kernel(const float* __restrict__ x, float* __restrict__ scratch, long long npix,
+                                           int c, int cs, int nchunks) {
   __shared__ float red[256];
   const int lane = threadIdx.x & 63, stripe = threadIdx.x >> 6;
-  const int ch = blockIdx.x * 64 + lane;
+  const int chunk = blockIdx.x, ch = blockIdx.y * 64 + lane;
+  const long long per = (npix + nchunks - 1) / nchunks;
+  const long long p0 = chunk * per, p1 = (p0 + per < npix) ? p0 + per : npix;
   float acc = 0.f;
   if (ch < c)
-    for (long long p = stripe; p < npix; p += 4) acc += x[(size_t)p * cs + ch];
+    for (long long p = p0 + stripe; p < p1; p += 4) acc += x[(size_t)p * cs + ch];
   red[threadIdx.x] = acc;
   __syncthreads();
-  if (stripe == 0 && ch < c) out[ch] = (red[lane] + red[64 + lane]) + (red[128 + lane] + red[192 + lane]);
+  if (stripe == 0 && ch < c)
+    scratch[(size_t)chunk * c + ch] = (red[lane] + red[64 + lane]) + (red[128 + lane] + red[192 + lane]);
+}
+
+__global__ void channel_sum_final_kernel(const float* __restrict__ scratch, float* __restrict__ out, int c, int nchunks) {
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= c) return;
+  float acc = 0.f;
+  for (int k = 0; k < nchunks; ++k) acc += scratch[(size_t)k * c + ch];
+  out[ch] = acc;
 }
 
 // ---------------------------------------------------------------------------- torch.optim.SGD (momentum, weight decay)
@@ -231,10 +245,16 @@ int hnd_softmax_rows(const float* x, float* y, int rows, int cols, void* stream)
   return hnd::check_launch("hnd_softmax_rows");
 }
 
-int hnd_channel_sum(const float* x, float* out, int64_t npix, int c, int cs, void* stream) {
-  HND_REQUIRE(x && out && npix > 0 && c > 0 && cs >= c, "hnd_channel_sum: bad arguments");
-  hipLaunchKernelGGL(channel_sum_kernel, dim3((c + 63) / 64), dim3(256), 0, hnd::as_stream(stream), x, out,
-                     (long long)npix, c, cs);
+size_t hnd_channel_sum_scratch_elems(int c) { return (size_t)kSumChunks * (size_t)(c > 0 ? c : 0); }
+
+int hnd_channel_sum(const float* x, float* out, int64_t npix, int c, int cs, float* scratch, void* stream) {
+  HND_REQUIRE(x && out && scratch && npix > 0 && c > 0 && cs >= c, "hnd_channel_sum: bad arguments");
+  int nchunks = (int)((npix + 255) / 256);
+  if (nchunks > kSumChunks) nchunks = kSumChunks;
+  hipLaunchKernelGGL(channel_sum_partial_kernel, dim3(nchunks, (c + 63) / 64), dim3(256), 0, hnd::as_stream(stream), x,
+                     scratch, (long long)npix, c, cs, nchunks);
+  hipLaunchKernelGGL(channel_sum_final_kernel, dim3((c + 63) / 64), dim3(64), 0, hnd::as_stream(stream), scratch, out,
+                     c, nchunks);
   return hnd::check_launch("hnd_channel_sum");
 }
 

@@ -798,7 +798,7 @@ class FilterEngine(object):
             ops.bn_bwd_finalize(st['part'], st['ntiles'], fc.cout, fc.cs_out, self.count[i], fc.bn.weight.detach(),
                                 self.mean[i], self.rstd[i], grad_dst[fc.bn.weight], grad_dst[fc.bn.bias], st['k123'])
             ops.bn_bwd_apply(g, self.y[i], self.scale[i], self.shift[i], st['k123'], True, g)     # in place -> dy
-            ops.channel_sum(g, fc.cout, grad_dst[fc.conv.bias])
+            ops.channel_sum(g, fc.cout, grad_dst[fc.conv.bias], self.sum_scratch)
             _run(st['wgrad'], 'ext.conv%d.wgrad' % i)
             for l in st['dgrad']:
                 _run(l, 'ext.conv%d.dgrad' % i)
@@ -810,6 +810,7 @@ class FilterEngine(object):
             raise RuntimeError('the neural filter trains all of its %d tensors together (ext_runner.py:196-197); '
                                '%d have requires_grad=False' % (len(self.params()), len(missing)))
         self.dp1 = b.get('dp1', self.p1.shape)
+        self.sum_scratch = b.get('sum_scratch', (ops.channel_sum_scratch_elems(max(fc.cout for fc in self.layers)),))
         self.g = [b.get('g%d' % i, self.y[i].shape) for i in range(len(self.layers))]
         slab_bytes = 0
         for i, fc in enumerate(self.layers):

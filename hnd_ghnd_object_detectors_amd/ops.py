@@ -432,9 +432,16 @@ def softmax_rows(x, y):
     check(_L.hnd_softmax_rows(ptr(x), ptr(y), x.shape[0], x.shape[1], stream_ptr()), 'hnd_softmax_rows')
 
 
-def channel_sum(x, c, out):
+def channel_sum(x, c, out, scratch=None):
     cs = x.shape[-1]
-    check(_L.hnd_channel_sum(ptr(x), ptr(out), x.numel() // cs, c, cs, stream_ptr()), 'hnd_channel_sum')
+    need = _L.hnd_channel_sum_scratch_elems(c)
+    if scratch is None or scratch.numel() < need:
+        scratch = torch.empty(need, dtype=torch.float32, device=x.device)
+    check(_L.hnd_channel_sum(ptr(x), ptr(out), x.numel() // cs, c, cs, ptr(scratch), stream_ptr()), 'hnd_channel_sum')
+
+
+def channel_sum_scratch_elems(c):
+    return _L.hnd_channel_sum_scratch_elems(c)
 
 
 def sgd_step_flat(param, grad, buf, lr, momentum, dampening, weight_decay, nesterov, first_step, grad_scale=1.0):

@@ -247,8 +247,10 @@ int hnd_linear_bwd(const float* x, const float* weight, const float* dout, float
                    int n, int hw, int c, int cs, int nout, void* stream);
 /* z.softmax(dim=1) of the eval-mode classifier (classifier.py:37) */
 int hnd_softmax_rows(const float* x, float* y, int rows, int cols, void* stream);
-/* per-channel sum over pixels of x [npix][cs] -> out[c]: the bias gradient of nn.Conv2d (autograd, ext_runner.py:72) */
-int hnd_channel_sum(const float* x, float* out, int64_t npix, int c, int cs, void* stream);
+/* per-channel sum over pixels of x [npix][cs] -> out[c]: the bias gradient of nn.Conv2d (autograd, ext_runner.py:72).
+ * Two passes in a fixed order (bit-reproducible); scratch: device float[hnd_channel_sum_scratch_elems(c)]. */
+size_t hnd_channel_sum_scratch_elems(int c);
+int hnd_channel_sum(const float* x, float* out, int64_t npix, int c, int cs, float* scratch, void* stream);
 /* torch.optim.SGD.step (ext_runner.py:118-120; config/ext: lr 1e-3, momentum 0.9, weight_decay 1e-4) over a flat
  * arena: d = grad*grad_scale + weight_decay*p; buf = first_step ? d : momentum*buf + (1-dampening)*d;
  * p -= lr * (nesterov ? d + momentum*buf : buf).  momentum_buf may be NULL when momentum == 0. */

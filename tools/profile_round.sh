@@ -9,6 +9,7 @@ mkdir -p $OUT
 # teacher/student stream overlap off for the trace so per-kernel durations are those of kernels running alone
 # (bench.py measures its roofline step the same way); the PMC passes do not depend on it
 export HND_TEACHER_STREAM=0
+export HND_DEFER_FPN=0
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python3 bench.py --steps 6 --warmup 2 --no_cpu_baseline > $OUT/bench_trace.json 2> $OUT/trace.err
 # PMC passes: counters only with --kernel-trace (FETCH_SIZE needs 3 TCC slots, WRITE_SIZE 2: separate passes)
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o bench -- python3 bench.py --steps 1 --warmup 1 --no_cpu_baseline > $OUT/bench_fetch.json 2> $OUT/fetch.err

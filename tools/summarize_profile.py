@@ -82,3 +82,16 @@ if 'FETCH_SIZE' in traffic and 'WRITE_SIZE' in traffic:
             tj['kernels'][k] = {'dispatches': fn, 'fetch_kib_raw': fv, 'write_kib': wv,
                                 'traffic_bytes_per_launch': int((2 * fv + wv) * 1024 / fn)}
     json.dump(tj, open(os.path.join(out, 'traffic.json'), 'w'), indent=1)
+
+fstats = glob.glob(os.path.join(out, 'filter', '*kernel_stats.csv'))
+if fstats:
+    rows = list(csv.DictReader(open(fstats[0])))
+    print('\n## neural filter (SURVEY 8f-f2): kernel-trace --stats of tools/bench_filter.py --batch 16 (10 + 5 steps)\n')
+    print('| kernel | calls | total ms | avg us | % |')
+    print('|---|---|---|---|---|')
+    for r in rows[:16]:
+        print('| %s | %s | %.2f | %.1f | %s |' % (short(r['Name']), r['Calls'], float(r['TotalDurationNs']) / 1e6,
+                                                   float(r['AverageNs']) / 1e3, r['Percentage']))
+    p = os.path.join(out, 'bench_filter.json')
+    if os.path.exists(p) and os.path.getsize(p):
+        print('\n```\n%s\n```' % open(p).read().strip().splitlines()[-1])
