@@ -49,6 +49,10 @@ def init_distributed_mode(world_size=1, dist_url='env://', backend=None):
     rank, env_world, device_id = found
     world_size = env_world or world_size
     has_gpu = torch.cuda.is_available()
+    # test knobs: exercise the multi-rank runner on a single-GPU box (every rank on cuda:0, gloo instead of RCCL)
+    backend = backend or os.environ.get('HND_DIST_BACKEND')
+    if os.environ.get('HND_SHARE_DEVICE', '0') != '0':
+        device_id = 0
     if has_gpu:
         torch.cuda.set_device(device_id)
     print('| distributed init (rank {}): {}'.format(rank, dist_url), flush=True)
