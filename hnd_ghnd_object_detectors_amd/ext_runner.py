@@ -162,16 +162,20 @@ def main(args):
     device = torch.device(args.device)
     print(args)
     train_config, model_config = config['train'], config['model']
-    if args.synthetic_batches <= 0:
-        data_util.get_coco_data_loaders(config['dataset'], train_config['batch_size'], distributed)   # raises
-    height, width = (int(v) for v in args.image_size.split('x'))
-    rank = misc_util.get_rank()
+    if args.synthetic_batches > 0:
+        height, width = (int(v) for v in args.image_size.split('x'))
+        rank = misc_util.get_rank()
 
-    def loader(batch_size, seed):
-        return data_util.SyntheticDetectionLoader(args.synthetic_batches, batch_size, height, width,
-                                                  model_config['name'], seed=seed, rank=rank, positive_every=2)
-    train_loader = loader(train_config['batch_size'], 1234)
-    val_loader = loader(config['test']['batch_size'], 4321)
+        def loader(batch_size, seed):
+            return data_util.SyntheticDetectionLoader(args.synthetic_batches, batch_size, height, width,
+                                                      model_config['name'], seed=seed, rank=rank, positive_every=2)
+        train_loader = loader(train_config['batch_size'], 1234)
+        val_loader = test_loader = loader(config['test']['batch_size'], 4321)
+    else:
+        train_sampler, train_loader, val_loader, test_loader = data_util.get_coco_data_loaders(
+            config['dataset'], train_config['batch_size'], distributed)
+        if hasattr(train_sampler, 'set_epoch'):
+            train_loader.set_epoch = train_sampler.set_epoch
     print('Creating model')
     model = get_model(model_config, device, strict=False)
     module_util.freeze_module_params(model)
@@ -186,7 +190,7 @@ def main(args):
         ckpt_file_path = model_config['backbone']['ext_config']['ckpt']
         train(model, ext_classifier, train_loader, val_loader, device, distributed, config, args, ckpt_file_path)
         load_ckpt(ckpt_file_path, model=ext_classifier)
-    evaluate(model, val_loader, device=device, min_recall=args.min_recall, split_name='Test')
+    evaluate(model, test_loader, device=device, min_recall=args.min_recall, split_name='Test')
 
 
 if __name__ == '__main__':

@@ -5,8 +5,9 @@
 Kept from the reference: the command-line flags (:17-29), the YAML schema, ``--json`` overrides, the checkpoint
 dictionary, and the per-batch order of operations of ``distill_model`` (:48-58): device upload, DistillationBox,
 ``zero_grad`` / ``backward`` / ``step``, the epoch-0 linear warm-up, one logged ``loss.item()`` per iteration.
-Different, and outside the hot path: batches come from a seeded synthetic COCO-shaped loader
-(``--synthetic_batches``; neither COCO nor pycocotools exist here) and checkpoints are kept on the lowest mean
+Different, and outside the hot path: without ``--synthetic_batches N`` (seeded synthetic COCO-shaped batches, used
+by the tests and benchmarks) batches come from the COCO-format folders of the yaml through utils/coco_util.py
+(no pycocotools), decoded images travel as uint8 to the device; checkpoints are kept on the lowest mean
 training loss instead of validation mAP (:94-100 needs RPN / RoI heads / NMS, out of this build's scope).
 One process per GPU (torchrun / torch.distributed.run); RANK / LOCAL_RANK / WORLD_SIZE come from the environment
 exactly as in the reference's ``init_distributed_mode``.
@@ -39,6 +40,8 @@ _FLAGS = (  # (flag, kwargs): the reference's CLI first, this build's additions 
     ('--image_size', dict(default='800x1333', help='HxW of the synthetic images')),
     ('-decoded_input', dict(action='store_true', help='feed decoded uint8 HWC images; ToTensor / flip / normalise / '
                                                       'resize run as one device kernel')),
+    ('-host_float_input', dict(action='store_true', help='COCO loaders: convert images to float CHW on the host like '
+                                                         'the reference instead of shipping uint8 to the device')),
     ('--num_epochs', dict(default=None, type=int, help='override train.num_epochs')),
 )
 
@@ -131,12 +134,17 @@ def main(args):
     freeze_modules(student_model, student_config)
     print('Updatable parameters: {}'.format(module_util.get_updatable_param_names(student_model)))
     batch_size = config['train']['batch_size']
-    if args.synthetic_batches <= 0:
-        data_util.get_coco_data_loaders(config['dataset'], batch_size, distributed)     # raises: COCO out of scope
-    height, width = (int(v) for v in args.image_size.split('x'))
-    train_loader = data_util.SyntheticDetectionLoader(args.synthetic_batches, batch_size, height, width,
-                                                      student_config['name'], rank=misc_util.get_rank(),
-                                                      decoded=args.decoded_input)
+    if args.synthetic_batches > 0:
+        height, width = (int(v) for v in args.image_size.split('x'))
+        train_sampler = None
+        train_loader = data_util.SyntheticDetectionLoader(args.synthetic_batches, batch_size, height, width,
+                                                          student_config['name'], rank=misc_util.get_rank(),
+                                                          decoded=args.decoded_input)
+    else:       # COCO-format folders named by the yaml (reference :128-129); uint8 images unless -host_float_input
+        train_sampler, train_loader, _, _ = data_util.get_coco_data_loaders(
+            config['dataset'], batch_size, distributed, decoded=not args.host_float_input)
+        if train_sampler is not None and hasattr(train_sampler, 'set_epoch'):
+            train_loader.set_epoch = train_sampler.set_epoch        # distill() advances the shard per epoch
     if distributed:
         student_model = DistributedStudent(student_model)
     if args.distill:

@@ -100,9 +100,20 @@ class RandomHorizontalFlip(object):
 
 
 class ToTensor(object):
-    """reference :52-55 (functional.to_tensor).  PIL images / uint8 arrays stay uint8 (DecodedImage)."""
+    """reference :52-55 (functional.to_tensor).  With ``decoded`` (default) PIL images / uint8 arrays stay uint8
+    (DecodedImage: the /255 happens inside the device transform kernel); ``decoded=False`` returns the float CHW
+    tensor on the host exactly like the reference."""
+
+    def __init__(self, decoded=True):
+        self.decoded = decoded
 
     def __call__(self, image, target):
+        image, target = self._defer(image, target)
+        if not self.decoded and isinstance(image, DecodedImage):
+            image = image.float_chw().contiguous()
+        return image, target
+
+    def _defer(self, image, target):
         if isinstance(image, DecodedImage) or (torch.is_tensor(image) and image.dtype != torch.uint8):
             return image, target
         if torch.is_tensor(image):          # uint8 tensor: [H, W, 3] unless it is unambiguously [3, H, W]
@@ -110,7 +121,7 @@ class ToTensor(object):
         arr = np.asarray(image)
         if arr.dtype != np.uint8 or arr.ndim != 3 or arr.shape[2] != 3:
             raise TypeError('ToTensor expects an RGB uint8 image, got %s %s' % (arr.dtype, arr.shape))
-        return DecodedImage(torch.from_numpy(np.ascontiguousarray(arr)), hwc=True), target
+        return DecodedImage(torch.from_numpy(np.array(arr, order="C")), hwc=True), target       # copy: PIL memory is read-only
 
 
 class DataLogger(object):

@@ -1,15 +1,17 @@
-"""Input feeding for the distillation runner.
+"""Input feeding for the runners.
 
-The reference builds COCO loaders (src/utils/data_util.py:18-48: pycocotools datasets, aspect-ratio grouped
-batches, DistributedSampler).  Dataset I/O is outside this build's hot path and neither COCO nor pycocotools
-exist in the image, so the runner is fed by seeded synthetic COCO-shaped batches:
-uniform [0,1) images 3xHxW, one box per image (+ a mask / 17 keypoints for Mask / Keypoint R-CNN).
+``get_coco_data_loaders`` mirrors the reference (src/utils/data_util.py:18-48: COCO datasets, aspect-ratio grouped
+batches, DistributedSampler) over utils/coco_util.py, which reads COCO-format folders without pycocotools.
+COCO itself is not in the image, so benchmarks and tests are fed by seeded synthetic COCO-shaped batches
+(SURVEY.md section 8d): uniform [0,1) images 3xHxW, one box per image (+ a mask / 17 keypoints for Mask /
+Keypoint R-CNN).
 
 ``decoded=True`` feeds what a JPEG decoder hands over instead -- uint8 [H, W, 3] -- through this build's
 ``ToTensor`` / ``RandomHorizontalFlip`` (structure/transformer.py; the reference's training pipeline,
 src/utils/data_util.py:9-15 ``get_coco_dataset``: ToTensor then RandomHorizontalFlip(0.5)), so the float conversion
 and the flip run inside the device transform kernel.
 """
+import os
 import random
 
 import torch
@@ -17,9 +19,10 @@ import torch
 from ..structure.transformer import Compose, RandomHorizontalFlip, ToTensor
 
 
-def get_transform(train=False):
-    """the transform chain of reference src/utils/data_util.py:10-12"""
-    transforms = [ToTensor()]
+def get_transform(train=False, decoded=True):
+    """the transform chain of reference src/utils/data_util.py:10-12; ``decoded`` keeps the image uint8 for the
+    fused device kernel (False: float CHW tensor on the host, exactly like the reference)"""
+    transforms = [ToTensor(decoded)]
     if train:
         transforms.append(RandomHorizontalFlip(0.5))
     return Compose(transforms)
@@ -72,6 +75,47 @@ class SyntheticDetectionLoader(object):
             yield tuple(p[0] for p in pairs), tuple(p[1] for p in pairs)
 
 
-def get_coco_data_loaders(dataset_config, batch_size, distributed):
-    raise NotImplementedError('COCO dataset loading (pycocotools) is outside the distillation hot path of this '
-                              'build; run mimic_runner with --synthetic_batches N (SURVEY.md section 8d)')
+def get_coco_dataset(split_dict, is_train, decoded=True):
+    from .coco_util import get_coco
+    return get_coco(img_dir_path=split_dict['images'], ann_file_path=split_dict['annotations'],
+                    transforms=get_transform(is_train, decoded),
+                    remove_non_annotated_imgs=split_dict['remove_non_annotated_imgs'],
+                    jpeg_quality=split_dict['jpeg_quality'])
+
+
+def get_coco_data_loaders(dataset_config, batch_size, distributed, decoded=True):
+    """(train_sampler, train_loader, val_loader, test_loader) over COCO-format folders (reference :18-48):
+    aspect-ratio grouped training batches, batch-1 validation / test, DistributedSampler shards per rank."""
+    from torch.utils.data import DataLoader, RandomSampler, SequentialSampler, BatchSampler
+    from torch.utils.data.distributed import DistributedSampler
+    from ..structure.sampler import GroupedBatchSampler, create_aspect_ratio_groups
+    from . import misc_util
+    splits = dataset_config['splits']
+    for split in splits.values():
+        if not os.path.isfile(os.path.expanduser(split['annotations'])):
+            raise FileNotFoundError('COCO annotation file `{}` is not found: point the yaml at a COCO-format dataset or '
+                                    'run with --synthetic_batches N'.format(split['annotations']))
+    train_dataset = get_coco_dataset(splits['train'], True, decoded)
+    val_dataset = get_coco_dataset(splits['val'], False, decoded)
+    test_dataset = get_coco_dataset(splits['test'], False, decoded)
+    print('Creating data loaders')
+    if distributed:
+        train_sampler, val_sampler, test_sampler = (DistributedSampler(d) for d in
+                                                    (train_dataset, val_dataset, test_dataset))
+    else:
+        train_sampler = RandomSampler(train_dataset)
+        val_sampler, test_sampler = SequentialSampler(val_dataset), SequentialSampler(test_dataset)
+    factor = dataset_config['aspect_ratio_group_factor']
+    if factor >= 0:
+        group_ids = create_aspect_ratio_groups(train_dataset, k=factor)
+        train_batch_sampler = GroupedBatchSampler(train_sampler, group_ids, batch_size)
+    else:
+        train_batch_sampler = BatchSampler(train_sampler, batch_size, drop_last=True)
+    workers = dataset_config['num_workers']
+    train_loader = DataLoader(train_dataset, batch_sampler=train_batch_sampler, num_workers=workers,
+                              collate_fn=misc_util.collate_fn)
+    val_loader = DataLoader(val_dataset, batch_size=1, sampler=val_sampler, num_workers=workers,
+                            collate_fn=misc_util.collate_fn)
+    test_loader = DataLoader(test_dataset, batch_size=1, sampler=test_sampler, num_workers=workers,
+                             collate_fn=misc_util.collate_fn)
+    return train_sampler, train_loader, val_loader, test_loader

@@ -1,6 +1,7 @@
 """CPU: host logic of the drop-in surface (no GPU compute): module tree / state-dict layout, trainable set,
 YAML loading incl. the reference's own files, schedulers, synthetic loader, meters."""
 import os
+import random
 
 import pytest
 import torch
@@ -163,3 +164,54 @@ def test_neural_filter_model_layout_labels_and_config():
         assert check_if_valid_target(t) == O.valid_target(t)
     with pytest.raises(RuntimeError):           # parameter holders never compute eagerly
         ext.extractor[1](torch.zeros(1, 64, 8, 8))
+
+
+def test_coco_format_loaders_without_pycocotools(tmp_path):
+    """COCO-format folder -> datasets / aspect-ratio grouped loaders (reference data_util.py:18-48, coco_util.py):
+    targets as the reference builds them, invalid images filtered, batches of one aspect-ratio bin, uint8 images."""
+    from tests.coco_fixture import write_tiny_coco
+    from hnd_ghnd_object_detectors_amd.structure.sampler import GroupedBatchSampler, create_aspect_ratio_groups
+    from hnd_ghnd_object_detectors_amd.structure.transformer import DecodedImage
+    from hnd_ghnd_object_detectors_amd.utils import coco_util, data_util
+    img_dir, ann_file = write_tiny_coco(str(tmp_path))
+    ds = coco_util.get_coco(img_dir, ann_file, data_util.get_transform(False), remove_non_annotated_imgs=False)
+    assert len(ds) == 8 and ds.get_height_and_width(2) == (40, 80)
+    img, t = ds[0]
+    assert isinstance(img, DecodedImage) and tuple(img.shape) == (3, 48, 64) and img.data.dtype == torch.uint8
+    assert t['boxes'].tolist() == [[8.0, 12.0, 40.0, 36.0]] and t['labels'].tolist() == [1]     # crowd anno dropped
+    assert t['keypoints'].shape == (1, 17, 3) and t['image_id'].tolist() == [100]
+    assert t['masks'].shape == (1, 48, 64) and abs(int(t['masks'].sum()) - 33 * 25) <= 60        # filled rectangle
+    assert t['area'].numel() == 1 and t['iscrowd'].tolist() == [0]
+    _, t3 = ds[3]
+    assert t3['boxes'].shape == (0, 4) and t3['masks'].shape == (0, 56, 56)                      # no annotations
+    _, t6 = ds[6]
+    assert t6['boxes'].shape == (1, 4)                  # a 0.5-wide box is kept by the converter ...
+    kept = coco_util.remove_images_without_annotations(ds)
+    assert [ds.ids[i] for i in kept.indices] == [100, 101, 102, 104, 107]   # ... but 103/105/106 are not valid images
+    f_img, _ = coco_util.get_coco(img_dir, ann_file, data_util.get_transform(False, decoded=False), False)[1]
+    assert f_img.dtype == torch.float32 and tuple(f_img.shape) == (3, 64, 48) and float(f_img.max()) <= 1.0
+    groups = create_aspect_ratio_groups(ds, k=1)        # bins 0.5 | 1 | 2
+    assert groups == [2, 1, 3, 2, 3, 2, 2, 1]
+    sampler = torch.utils.data.SequentialSampler(ds)
+    batches = list(GroupedBatchSampler(sampler, groups, 2))
+    assert len(batches) == 4 and all(groups[a] == groups[b] for a, b in batches)
+    assert batches[:3] == [[0, 3], [2, 4], [5, 6]] and batches[3] == [1, 7]
+    cfg = {'num_workers': 0, 'aspect_ratio_group_factor': 1,
+           'splits': {k: {'images': img_dir, 'annotations': ann_file, 'remove_non_annotated_imgs': k == 'train',
+                          'jpeg_quality': None} for k in ('train', 'val', 'test')}}
+    random.seed(0)
+    torch.manual_seed(0)
+    train_sampler, train_loader, val_loader, test_loader = data_util.get_coco_data_loaders(cfg, 2, False)
+    assert len(train_loader) == 2 and len(val_loader) == 8
+    for images, targets in train_loader:
+        assert len(images) == 2 and all(isinstance(im, DecodedImage) for im in images)
+        assert all(t['boxes'].shape[0] == 1 for t in targets)
+        for im, t in zip(images, targets):              # RandomHorizontalFlip mirrored the box with the image
+            w = im.shape[-1]
+            x0 = float(t['boxes'][0, 0])
+            assert abs(x0 - (w - 0.625 * w if im.flip else 0.125 * w)) < 1e-4
+    with pytest.raises(FileNotFoundError):
+        bad = {'num_workers': 0, 'aspect_ratio_group_factor': 1,
+               'splits': {k: {'images': img_dir, 'annotations': '/nonexistent.json', 'remove_non_annotated_imgs': False,
+                              'jpeg_quality': None} for k in ('train', 'val', 'test')}}
+        data_util.get_coco_data_loaders(bad, 2, False)

@@ -567,3 +567,43 @@ def test_mimic_runner_two_ranks_share_one_gpu(tmp_path):
     ck = torch.load(ckpt, weights_only=False)
     assert len(ck['model']) == 293 and len(ck['optimizer']['state']) == 25
     assert all(torch.isfinite(v).all() for v in ck['model'].values() if v.is_floating_point())
+
+
+def test_mimic_runner_on_coco_format_folder(tmp_path, capsys):
+    """no --synthetic_batches: the runner reads the COCO-format folder named by the yaml (json index + PIL, no
+    pycocotools), batches by aspect ratio, ships uint8 images and runs the fused device transform."""
+    import json
+    import os
+    from tests.coco_fixture import write_tiny_coco
+    from hnd_ghnd_object_detectors_amd import mimic_runner
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    img_dir, ann_file = write_tiny_coco(str(tmp_path / 'coco'))
+    cfg_path = os.path.join(root, 'config', 'ghnd', 'keypoint_rcnn-backbone_resnet50-b3ch.yaml')
+    ckpt = str(tmp_path / 'student.pt')
+    split = {'images': img_dir, 'annotations': ann_file}
+    small = {'pretrained': False, 'min_size': [48, 56, 64], 'max_size': 128}
+    override = {'dataset': {'num_workers': 0, 'splits': {'train': split, 'val': split, 'test': split}},
+                'teacher_model': {'backbone': {'params': {'pretrained': False}}, 'params': small,
+                                  'ckpt': str(tmp_path / 'none.pt')},
+                'student_model': {'backbone': {'params': {'pretrained': False}}, 'params': small, 'ckpt': ckpt},
+                'train': {'batch_size': 2, 'log_freq': 1}}
+    argv = ['--config', cfg_path, '--json', json.dumps(override), '-distill', '--num_epochs', '2']
+    torch.manual_seed(0)
+    random.seed(0)
+    mimic_runner.main(mimic_runner.get_argparser().parse_args(argv))
+    out = capsys.readouterr().out
+    assert 'Creating data loaders' in out and 'Epoch: [1]' in out and 'Updating ckpt' in out
+    assert 'Count of instances per bin' in out
+    ck = torch.load(ckpt, weights_only=False)
+    assert all(torch.isfinite(v).all() for v in ck['model'].values() if v.is_floating_point())
+    # same data through the reference's host-side float conversion gives the same first-epoch loss trajectory
+    torch.manual_seed(0)
+    random.seed(0)
+    os.remove(ckpt)
+    mimic_runner.main(mimic_runner.get_argparser().parse_args(argv + ['-host_float_input']))
+    out2 = capsys.readouterr().out
+
+    def losses(text):
+        return [float(l.split('loss: ')[1].split(' ')[0]) for l in text.splitlines() if 'loss: ' in l and 'Epoch: [0]' in l]
+    a, b = losses(out), losses(out2)
+    assert len(a) == len(b) > 0 and all(abs(x - y) <= 1e-4 * abs(y) for x, y in zip(a, b)), (a, b)
