@@ -51,80 +51,84 @@ def convert_target2ext_targets(targets, device):
     """image-level labels from the targets AS THE MODEL'S TRANSFORM LEFT THEM (the reference labels after the
     forward pass, :55-56, i.e. on rescaled boxes); the rule walks a few numbers, so they are read back once."""
     host = [{k: t[k].cpu() for k in ('boxes', 'keypoints') if k in t} if len(t) else t for t in targets]
-    labels = [1 if check_if_valid_target(t) else 0 for t in host]
-    return torch.tensor(labels, dtype=torch.int64).to(device)
+    return torch.tensor([int(check_if_valid_target(t)) for t in host], dtype=torch.int64).to(device)
 
 
-def _to_device(images, targets, device):
-    images = [img.to(device, non_blocking=True) for img in images]
-    targets = [{k: v.to(device, non_blocking=True) for k, v in t.items()} for t in targets]
-    return images, targets
+def _upload(images, targets, device):
+    return ([img.to(device, non_blocking=True) for img in images],
+            [{k: v.to(device, non_blocking=True) for k, v in t.items()} for t in targets])
 
 
 def train_model(model, optimizer, data_loader, device, epoch, log_freq, wrapper=None):
-    """one epoch of filter training (reference :39-76)."""
+    """one epoch of filter training (reference :39-76): CE on the classifier logits, warm-up in epoch 0."""
     model.train()
     meters = misc_util.MetricLogger(delimiter='  ')
     meters.add_meter('lr', misc_util.SmoothedValue(window_size=1, fmt='{value:.6f}'))
-    warmup = None
-    if epoch == 0 and len(data_loader) > 1:
-        warmup = main_util.warmup_lr_scheduler(optimizer, min(1000, len(data_loader) - 1), 1.0 / 1000.0)
+    num_batches = len(data_loader)
+    warmup = (main_util.warmup_lr_scheduler(optimizer, min(1000, num_batches - 1), 1.0 / 1000.0)
+              if epoch == 0 and num_batches > 1 else None)
     for images, targets in meters.log_every(data_loader, log_freq, 'Epoch: [{}]'.format(epoch)):
-        images, targets = _to_device(images, targets, device)
+        images, targets = _upload(images, targets, device)
         ext_logits = model(images, targets)
         ext_targets = convert_target2ext_targets(targets, device)
         loss = nn.functional.cross_entropy(ext_logits, ext_targets)
-        loss_value = float(misc_util.reduce_dict({'loss_ext_classifier': loss.detach()})['loss_ext_classifier'])
-        if not math.isfinite(loss_value):
-            print('Loss is {}, stopping training'.format(loss_value))
+        logged = float(misc_util.reduce_dict({'loss_ext_classifier': loss.detach()})['loss_ext_classifier'])
+        if not math.isfinite(logged):
+            print('Loss is {}, stopping training'.format(logged))
             sys.exit(1)
         optimizer.zero_grad()
         loss.backward()
         if wrapper is not None:
-            wrapper.reduce_gradients()
+            wrapper.reduce_gradients()          # one flat all-reduce; the mean is folded into the SGD launch
         optimizer.step()
         if warmup is not None:
             warmup.step()
-        meters.update(loss=loss_value, loss_ext_classifier=loss_value, lr=optimizer.param_groups[0]['lr'])
+        meters.update(loss=logged, loss_ext_classifier=logged, lr=optimizer.param_groups[0]['lr'])
     return meters.loss.global_avg
 
 
-def evaluate(model, data_loader, device, min_recall, split_name='Validation'):
-    """accuracy / recall / specificity / ROC-AUC of the filter (reference :79-123); the decision-threshold table
-    for ``min_recall`` is printed for the Test split."""
-    from sklearn import metrics
+def _collect_scores(model, data_loader, device):
+    """P(positive) and label of every sample of the loader, as numpy vectors"""
     model.eval()
-    probs, labels = [], []
+    scores, labels = [], []
     with torch.no_grad():
         for images, targets in data_loader:
-            images, targets = _to_device(images, targets, device)
-            ext_probs = model(images, targets)
-            ext_targets = convert_target2ext_targets(targets, device)
-            probs.append(ext_probs[:, 1].cpu().numpy())
-            labels.append(ext_targets.cpu().numpy())
-    probs, labels = np.concatenate(probs), np.concatenate(labels)
-    preds = (probs > 0.5).astype(np.int64)            # argmax over two softmax outputs
-    num_samples, pos_count = len(labels), int(labels.sum())
-    correct, pos_correct = int((preds == labels).sum()), int(preds[labels == 1].sum())
-    roc_auc = metrics.roc_auc_score(labels, probs) if 0 < pos_count < num_samples else float('nan')
+            images, targets = _upload(images, targets, device)
+            probabilities = model(images, targets)
+            labels.append(convert_target2ext_targets(targets, device).cpu().numpy())
+            scores.append(probabilities[:, 1].cpu().numpy())
+    return np.concatenate(scores), np.concatenate(labels)
+
+
+def evaluate(model, data_loader, device, min_recall, split_name='Validation'):
+    """accuracy / recall / specificity / ROC-AUC of the filter (reference :79-123); for the Test split the table of
+    decision thresholds that keep recall >= ``min_recall`` is printed as well."""
+    from sklearn import metrics
+    scores, labels = _collect_scores(model, data_loader, device)
+    predicted = scores > 0.5                            # argmax over the two softmax outputs
+    total, positives = len(labels), int(labels.sum())
+    hits = int((predicted == (labels == 1)).sum())
+    true_pos = int(predicted[labels == 1].sum())
+    true_neg = hits - true_pos
+    both_classes = 0 < positives < total
+    roc_auc = metrics.roc_auc_score(labels, scores) if both_classes else float('nan')
     print('[{}]'.format(split_name))
-    print('\tAccuracy: {:.4f} ({} / {})'.format(correct / num_samples, correct, num_samples))
-    print('\tRecall: {:.4f} ({} / {})'.format(pos_correct / max(pos_count, 1), pos_correct, pos_count))
-    print('\tSpecificity: {:.4f} ({} / {})'.format((correct - pos_correct) / max(num_samples - pos_count, 1),
-                                                   correct - pos_correct, num_samples - pos_count))
+    for title, num, den in (('Accuracy', hits, total), ('Recall', true_pos, positives),
+                            ('Specificity', true_neg, total - positives)):
+        print('\t{}: {:.4f} ({} / {})'.format(title, num / max(den, 1), num, den))
     print('\tROC-AUC: {:.4f}'.format(roc_auc))
-    if split_name == 'Test' and 0 < pos_count < num_samples:
+    if split_name == 'Test' and both_classes:
         import pandas as pd
-        fprs, tprs, thrs = metrics.roc_curve(labels, probs, pos_label=1)
-        idx = np.searchsorted(tprs, min_recall)
-        table = pd.DataFrame(np.array([thrs[idx:], tprs[idx:], fprs[idx:]]).T,
-                             columns=['Threshold', 'TPR (Recall)', 'FPR'])
+        fprs, tprs, thresholds = metrics.roc_curve(labels, scores, pos_label=1)
+        first = int(np.searchsorted(tprs, min_recall))
+        table = pd.DataFrame({'Threshold': thresholds[first:], 'TPR (Recall)': tprs[first:], 'FPR': fprs[first:]})
         with pd.option_context('display.max_rows', None, 'display.max_columns', None):
             print(table)
     return roc_auc
 
 
 def train(model, ext_classifier, train_loader, val_loader, device, distributed, config, args, ckpt_file_path):
+    """epochs of train_model + validation; the classifier checkpoint follows the best validation ROC-AUC (:126-160)"""
     train_config = config['train']
     optimizer = func_util.get_optimizer(ext_classifier, train_config['optimizer']['type'],
                                         train_config['optimizer']['params'])
@@ -142,14 +146,47 @@ def train(model, ext_classifier, train_loader, val_loader, device, distributed, 
             train_loader.set_epoch(epoch)
         train_model(model, optimizer, train_loader, device, epoch, train_config['log_freq'], wrapper)
         lr_scheduler.step()
-        val_roc_auc = evaluate(model, val_loader, device, min_recall=args.min_recall, split_name='Validation')
-        if (val_roc_auc > best or not file_util.check_if_exists(ckpt_file_path)) and misc_util.is_main_process():
-            print('Updating ckpt (Best ROC-AUC: {:.4f} -> {:.4f})'.format(best, val_roc_auc))
-            best = max(best, float(val_roc_auc)) if math.isfinite(val_roc_auc) else best
+        score = evaluate(model, val_loader, device, min_recall=args.min_recall, split_name='Validation')
+        first_ckpt = not file_util.check_if_exists(ckpt_file_path)
+        if (score > best or first_ckpt) and misc_util.is_main_process():
+            print('Updating ckpt (Best ROC-AUC: {:.4f} -> {:.4f})'.format(best, score))
+            best = max(best, float(score)) if math.isfinite(score) else best
             save_ckpt(ext_classifier, optimizer, lr_scheduler, best, config, args, ckpt_file_path)
     if distributed:
         dist.barrier()
     print('Training time {}'.format(datetime.timedelta(seconds=int(time.time() - started))))
+
+
+def _loaders(args, config, distributed):
+    """(train, val, test) loaders: seeded synthetic batches when asked for, else the yaml's COCO-format folders"""
+    batch_train, batch_eval = config['train']['batch_size'], config['test']['batch_size']
+    if args.synthetic_batches > 0:
+        height, width = (int(v) for v in args.image_size.split('x'))
+
+        def synthetic(batch_size, seed):
+            return data_util.SyntheticDetectionLoader(args.synthetic_batches, batch_size, height, width,
+                                                      config['model']['name'], seed=seed, rank=misc_util.get_rank(),
+                                                      positive_every=2)
+        held_out = synthetic(batch_eval, 4321)
+        return synthetic(batch_train, 1234), held_out, held_out
+    sampler, train_loader, val_loader, test_loader = data_util.get_coco_data_loaders(config['dataset'], batch_train,
+                                                                                     distributed)
+    if hasattr(sampler, 'set_epoch'):
+        train_loader.set_epoch = sampler.set_epoch      # train() advances the shard per epoch
+    return train_loader, val_loader, test_loader
+
+
+def _filter_model(model_config, device):
+    """the frozen detector with only its neural filter trainable, switched to filter mode (reference :192-199)"""
+    model = get_model(model_config, device, strict=False)
+    module_util.freeze_module_params(model)
+    ext_classifier = model.get_ext_classifier()
+    if ext_classifier is None:
+        raise ValueError('the model has no neural filter: set backbone.ext_config in the yaml')
+    module_util.unfreeze_module_params(ext_classifier)
+    print('Updatable parameters: {}'.format(module_util.get_updatable_param_names(model)))
+    model.train_ext()
+    return model, ext_classifier
 
 
 def main(args):
@@ -161,35 +198,16 @@ def main(args):
         raise RuntimeError('the HIP path needs an MI355X (no CPU fallback exists)')
     device = torch.device(args.device)
     print(args)
-    train_config, model_config = config['train'], config['model']
-    if args.synthetic_batches > 0:
-        height, width = (int(v) for v in args.image_size.split('x'))
-        rank = misc_util.get_rank()
-
-        def loader(batch_size, seed):
-            return data_util.SyntheticDetectionLoader(args.synthetic_batches, batch_size, height, width,
-                                                      model_config['name'], seed=seed, rank=rank, positive_every=2)
-        train_loader = loader(train_config['batch_size'], 1234)
-        val_loader = test_loader = loader(config['test']['batch_size'], 4321)
-    else:
-        train_sampler, train_loader, val_loader, test_loader = data_util.get_coco_data_loaders(
-            config['dataset'], train_config['batch_size'], distributed)
-        if hasattr(train_sampler, 'set_epoch'):
-            train_loader.set_epoch = train_sampler.set_epoch
+    train_loader, val_loader, test_loader = _loaders(args, config, distributed)
     print('Creating model')
-    model = get_model(model_config, device, strict=False)
-    module_util.freeze_module_params(model)
-    ext_classifier = model.get_ext_classifier()
-    module_util.unfreeze_module_params(ext_classifier)
-    print('Updatable parameters: {}'.format(module_util.get_updatable_param_names(model)))
-    model.train_ext()
+    model, ext_classifier = _filter_model(config['model'], device)
     if distributed:
         model = DistributedStudent(model)
     if args.train:
         print('Start training')
-        ckpt_file_path = model_config['backbone']['ext_config']['ckpt']
+        ckpt_file_path = config['model']['backbone']['ext_config']['ckpt']
         train(model, ext_classifier, train_loader, val_loader, device, distributed, config, args, ckpt_file_path)
-        load_ckpt(ckpt_file_path, model=ext_classifier)
+        load_ckpt(ckpt_file_path, model=ext_classifier)         # evaluate the best classifier, not the last
     evaluate(model, test_loader, device=device, min_recall=args.min_recall, split_name='Test')
 
 
