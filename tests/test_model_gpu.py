@@ -607,3 +607,37 @@ def test_mimic_runner_on_coco_format_folder(tmp_path, capsys):
         return [float(l.split('loss: ')[1].split(' ')[0]) for l in text.splitlines() if 'loss: ' in l and 'Epoch: [0]' in l]
     a, b = losses(out), losses(out2)
     assert len(a) == len(b) > 0 and all(abs(x - y) <= 1e-4 * abs(y) for x, y in zip(a, b)), (a, b)
+
+
+def test_ext_model_eval_with_quantised_bottleneck_equals_plain_student():
+    """BASELINE config 5: Keypoint R-CNN b3ch + neural filter + int8 bottleneck.  In eval mode the filter model's
+    pyramid (filter accepts) equals the filter-less student's with the same weights bit for bit, with and without
+    the uint8 codec; the filter's probabilities ride along."""
+    meta = {'model': 'keypoint_rcnn', 'yaml': 'ghnd/', 'min_size': 64, 'max_size': 128, 'seed': 31, 'num_classes': 2}
+    s_sd, e_sd = MU.ext_states(meta['seed'])
+    cfg_e, ext_model, ext = MU.build_ext_model(s_sd, e_sd, DEV, 64, 128, threshold=0.0)
+    ext_model.ext_training = False
+    ext_model.backbone.body.ext_training = False
+    cfg = MU.config_for(meta)
+    t_sd = O.init_teacher_state(meta['seed'], 'keypoint_rcnn', num_classes=2)
+    _, student = MU.build_pair(cfg, t_sd, s_sd, DEV)
+    for m in (ext_model, student):
+        m.eval()
+        m.distill_backbone_only = True
+    g = torch.Generator().manual_seed(3)
+    ims = [torch.rand(3, 60, 90, generator=g).to(DEV), torch.rand(3, 64, 80, generator=g).to(DEV)]
+    assert ext_model.backbone.body.layer1.bottleneck_transformer is not None          # yaml: quantizer + dequantizer
+    for use in (False, True):
+        ext_model.backbone.body.layer1.use_bottleneck_transformer = use
+        student.backbone.body.layer1.use_bottleneck_transformer = use
+        with torch.no_grad():
+            feats_e, probs = ext_model(ims)
+            feats_e = {k: v.clone() for k, v in feats_e.items()}
+            feats_s = student(ims)
+        assert tuple(probs.shape) == (2, 2) and float((probs.sum(dim=1) - 1).abs().max()) < 1e-5
+        assert list(feats_e) == list(feats_s) and all(torch.equal(feats_e[k], feats_s[k]) for k in feats_s)
+    plain = {k: v.clone() for k, v in feats_s.items()}
+    student.backbone.body.layer1.use_bottleneck_transformer = False
+    with torch.no_grad():
+        ref = student(ims)
+    assert any(not torch.equal(plain[k], ref[k]) for k in ref)            # the codec really changed the features
