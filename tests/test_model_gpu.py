@@ -557,8 +557,12 @@ def test_mimic_runner_two_ranks_share_one_gpu(tmp_path):
                                   'params': {'pretrained': False, 'min_size': 64, 'max_size': 128}, 'ckpt': ckpt},
                 'train': {'batch_size': 2, 'log_freq': 1}}
     env = dict(os.environ, HND_DIST_BACKEND='gloo', HND_SHARE_DEVICE='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    import socket
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
-           '127.0.0.1', '--master-port', '29533', '-m', 'hnd_ghnd_object_detectors_amd.mimic_runner', '--config',
+           '127.0.0.1', '--master-port', str(port), '-m', 'hnd_ghnd_object_detectors_amd.mimic_runner', '--config',
            cfg_path, '--json', json.dumps(override), '-distill', '--synthetic_batches', '3', '--image_size', '64x96',
            '--num_epochs', '1', '--world_size', '2']
     res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
