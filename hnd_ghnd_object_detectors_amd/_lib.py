@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('HND_LIB_PATH') or os.path.join(_HERE, 'libhnd_hip.so')     # env: kernel experiments
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 c_float_p = C.POINTER(C.c_float)
 vp = C.c_void_p
@@ -21,7 +21,7 @@ class ConvDesc(C.Structure):
                [(n, C.c_int32) for n in ('n', 'h', 'w_', 'cin', 'oh', 'ow', 'yh', 'yw', 'cout', 'ldc',
                                          'y_sh', 'y_oh', 'y_sw', 'y_ow', 'kh', 'kw',
                                          'sh', 'dh', 'bh', 'sw', 'dw', 'bw', 'kdim', 'pro_relu', 'relu',
-                                         'res1_mode', 'res1_h', 'res1_w')]
+                                         'res1_mode', 'res1_h', 'res1_w', 'w_group_rows', 'w_group_stride')]
 
 
 class WgradDesc(C.Structure):
@@ -52,6 +52,10 @@ _SIGNATURES = {
                                                                                     c_float_p, c_float_p, vp]),
     'hnd_transform_image_u8': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp] + [C.c_int] * 5 +
                                [C.c_float, C.c_float, c_float_p, c_float_p, vp]),
+    'hnd_wino_tiles_pad': (C.c_int64, [C.c_int, C.c_int, C.c_int]),
+    'hnd_wino_weights': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp]),
+    'hnd_wino_input': (C.c_int, [vp, vp] + [C.c_int] * 4 + [vp, vp, C.c_int, vp]),
+    'hnd_wino_output': (C.c_int, [vp, vp] + [C.c_int] * 5 + [vp, vp, vp, vp, C.c_int, vp]),
     'hnd_maxpool3x3s2_fwd': (C.c_int, [vp, vp, vp] + [C.c_int] * 6 + [vp]),
     'hnd_maxpool3x3s2_bwd_relu_scale': (C.c_int, [vp] * 5 + [C.c_int] * 6 + [vp]),
     'hnd_bn_finalize': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int64, vp, vp, vp, vp, vp,

@@ -159,8 +159,9 @@ igemm_kernel(const hnd_conv_desc d, const int ntiles) {
     a_iw[i] = ow_ * d.sw + d.bw;
   }
   const float* wrow[RB];
+  const float* wbase = d.w + (d.w_group_rows > 0 ? (size_t)(m0 / d.w_group_rows) * (size_t)d.w_group_stride : 0);
 #pragma unroll
-  for (int i = 0; i < RB; ++i) wrow[i] = d.w + (size_t)(n0 + arow + RPP * i) * d.kdim + kq * 4;
+  for (int i = 0; i < RB; ++i) wrow[i] = wbase + (size_t)(n0 + arow + RPP * i) * d.kdim + kq * 4;
 
   const int ntaps = d.kh * d.kw;
   const unsigned kw_inv = (65536u + d.kw - 1) / d.kw;
@@ -472,6 +473,8 @@ extern "C" int hnd_conv2d_igemm(const hnd_conv_desc* desc, void* stream) {
               d.kh * d.kw * d.cin);
   HND_REQUIRE(d.cin != 4 || d.kh * d.kw <= 64, "hnd_conv2d_igemm: at most 64 taps when cin==4");
   HND_REQUIRE(d.ldc >= d.cout, "hnd_conv2d_igemm: ldc < cout");
+  HND_REQUIRE(d.w_group_rows >= 0 && d.w_group_rows % 128 == 0 && (d.w_group_rows == 0 || d.w_group_stride > 0),
+              "hnd_conv2d_igemm: w_group_rows=%d must be 0 or a multiple of 128 with a positive stride", d.w_group_rows);
   HND_REQUIRE((long long)d.n * d.oh * d.ow < (1ll << 31) && (long long)d.n * d.yh * d.yw < (1ll << 31) &&
                   (long long)d.n * d.h * d.w_ < (1ll << 31),
               "hnd_conv2d_igemm: pixel count exceeds int32");

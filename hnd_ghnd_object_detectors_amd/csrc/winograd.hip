@@ -1,0 +1,227 @@
+// Winograd F(2x2, 3x3) for the stride-1, pad-1 3x3 convolutions (frozen ResNet conv2, FPN output convs, and their
+// data gradients): Y = A^T [ (G g G^T) .* (B^T d B) ] A per 2x2 output tile, i.e. 16 multiplies per input/output
+// channel pair instead of 36.  The 16 element-wise products over channels are 16 independent GEMMs
+//     M_f [tiles x cout] = V_f [tiles x cin] * U_f^T [cin x cout]
+// which run as ONE launch of the implicit-GEMM kernel (conv_igemm.hip: a 1x1 "conv" over 16*tiles_pad pixels whose
+// weight matrix is selected per 128-row group).  This file holds the three HBM-bound transforms around it.
+// fp32 throughout; the transforms only add / halve, so the result differs from direct summation by ~1e-6 relative.
+#include "common.h"
+
+using hnd::f32x4;
+
+namespace {
+
+constexpr int kMaxBlocks = 256 * 32;
+
+inline int grid_for(long long work_items, int threads = 256) {
+  long long b = (work_items + threads - 1) / threads;
+  if (b < 1) b = 1;
+  if (b > kMaxBlocks) b = kMaxBlocks;
+  return (int)b;
+}
+
+// U_f[co][ci] = (G g G^T)[f], g = w[co][ci] (forward) or w[ci][co] flipped (data gradient), written in the packed
+// GEMM-operand layout of hnd_pack_weights: [16][rows_pad][kdim], K (= input channel of the GEMM) contiguous.
+__global__ void wino_weights_kernel(const float* __restrict__ w, float* __restrict__ u, int cout, int cin, int dgrad,
+                                    int rows, int rows_pad, int kdim) {
+  // GEMM rows = output channels of this conv direction, K = its input channels
+  const long long total = (long long)rows_pad * kdim;
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    const int r = (int)(e / kdim), k = (int)(e - (long long)r * kdim);
+    const int kreal = dgrad ? cout : cin;
+    float g[3][3];
+    const bool ok = r < rows && k < kreal;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        float v = 0.f;
+        if (ok) v = dgrad ? w[(((size_t)k * cin + r) * 3 + (2 - i)) * 3 + (2 - j)]      // w[co=k][ci=r], flipped
+                          : w[(((size_t)r * cin + k) * 3 + i) * 3 + j];
+        g[i][j] = v;
+      }
+    float t[4][3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      t[0][j] = g[0][j];
+      t[1][j] = 0.5f * (g[0][j] + g[1][j] + g[2][j]);
+      t[2][j] = 0.5f * (g[0][j] - g[1][j] + g[2][j]);
+      t[3][j] = g[2][j];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float u0 = t[i][0], u1 = 0.5f * (t[i][0] + t[i][1] + t[i][2]), u2 = 0.5f * (t[i][0] - t[i][1] + t[i][2]),
+                  u3 = t[i][2];
+      float* dst = u + ((size_t)(i * 4) * rows_pad + r) * kdim + k;
+      const size_t fs = (size_t)rows_pad * kdim;
+      dst[0] = u0; dst[fs] = u1; dst[2 * fs] = u2; dst[3 * fs] = u3;
+    }
+  }
+}
+
+struct WinoGeom {
+  int n, h, w, c;          // tensor being transformed (input: c = cin; output: c = ldc of y)
+  int th, tw;              // tiles per image
+  int tiles_pad;           // rows per component in V / M (multiple of 128)
+};
+
+// V[f][t][c] = (B^T d B)[f] of the 4x4 input patch of tile t (rows 2ty-1.., cols 2tx-1..), zero outside the image.
+// Optional prologue on in-bounds elements: a = x*scale[c] + shift[c], relu.
+__global__ void wino_input_kernel(const float* __restrict__ x, float* __restrict__ v, const WinoGeom g,
+                                  const float* __restrict__ pro_scale, const float* __restrict__ pro_shift,
+                                  int pro_relu) {
+  const int c4n = g.c >> 2;
+  const long long tiles = (long long)g.n * g.th * g.tw;
+  const long long total = tiles * c4n;
+  const size_t fs = (size_t)g.tiles_pad * g.c;           // component stride
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(e % c4n);
+    long long t = e / c4n;
+    const int tx = (int)(t % g.tw);
+    long long q = t / g.tw;
+    const int ty = (int)(q % g.th), b = (int)(q / g.th);
+    f32x4 ps = {1.f, 1.f, 1.f, 1.f}, pb = {0.f, 0.f, 0.f, 0.f};
+    if (pro_scale) {
+      ps = *(const f32x4*)(pro_scale + c4 * 4);
+      pb = *(const f32x4*)(pro_shift + c4 * 4);
+    }
+    const float floor_ = pro_relu ? 0.f : -INFINITY;
+    f32x4 d[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int iy = 2 * ty - 1 + i;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int ix = 2 * tx - 1 + j;
+        const bool ok = (unsigned)iy < (unsigned)g.h && (unsigned)ix < (unsigned)g.w;
+        const size_t off = ok ? (((size_t)b * g.h + iy) * g.w + ix) * g.c + c4 * 4 : 0;
+        f32x4 a = *(const f32x4*)(x + off);
+        if (pro_scale) {
+          a = a * ps + pb;
+          a.x = fmaxf(a.x, floor_); a.y = fmaxf(a.y, floor_); a.z = fmaxf(a.z, floor_); a.w = fmaxf(a.w, floor_);
+        }
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        d[i][j] = ok ? a : z;
+      }
+    }
+    f32x4 r[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {          // B^T d
+      r[0][j] = d[0][j] - d[2][j];
+      r[1][j] = d[1][j] + d[2][j];
+      r[2][j] = d[2][j] - d[1][j];
+      r[3][j] = d[1][j] - d[3][j];
+    }
+    float* dst = v + (size_t)t * g.c + c4 * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {          // (.) B
+      *(f32x4*)(dst + (size_t)(i * 4 + 0) * fs) = r[i][0] - r[i][2];
+      *(f32x4*)(dst + (size_t)(i * 4 + 1) * fs) = r[i][1] + r[i][2];
+      *(f32x4*)(dst + (size_t)(i * 4 + 2) * fs) = r[i][2] - r[i][1];
+      *(f32x4*)(dst + (size_t)(i * 4 + 3) * fs) = r[i][1] - r[i][3];
+    }
+  }
+}
+
+struct WinoEpilogue {
+  const float* epi_scale;
+  const float* epi_shift;
+  const float* res1;
+  const float* mask;
+  int relu;
+};
+
+// y[2ty+a][2tx+b][c] = epilogue( (A^T m A)[a][b] ), m = the 16 GEMM results of tile t; same epilogue order as the
+// implicit-GEMM kernel: scale/shift, + res1, mask (ReLU backward), ReLU.
+__global__ void wino_output_kernel(const float* __restrict__ m, float* __restrict__ y, const WinoGeom g, int cout,
+                                   const WinoEpilogue ep) {
+  const int c4n = (cout + 3) >> 2;
+  const long long tiles = (long long)g.n * g.th * g.tw;
+  const long long total = tiles * c4n;
+  const size_t fs = (size_t)g.tiles_pad * cout;
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(e % c4n);
+    long long t = e / c4n;
+    const int tx = (int)(t % g.tw);
+    long long q = t / g.tw;
+    const int ty = (int)(q % g.th), b = (int)(q / g.th);
+    const float* src = m + (size_t)t * cout + c4 * 4;
+    f32x4 s[2][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {          // A^T m
+      const f32x4 m0 = *(const f32x4*)(src + (size_t)(0 * 4 + j) * fs), m1 = *(const f32x4*)(src + (size_t)(1 * 4 + j) * fs),
+                  m2 = *(const f32x4*)(src + (size_t)(2 * 4 + j) * fs), m3 = *(const f32x4*)(src + (size_t)(3 * 4 + j) * fs);
+      s[0][j] = m0 + m1 + m2;
+      s[1][j] = m1 - m2 - m3;
+    }
+    f32x4 es = {1.f, 1.f, 1.f, 1.f}, eb = {0.f, 0.f, 0.f, 0.f};
+    if (ep.epi_scale) es = *(const f32x4*)(ep.epi_scale + c4 * 4);
+    if (ep.epi_shift) eb = *(const f32x4*)(ep.epi_shift + c4 * 4);
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const int oy = 2 * ty + a;
+#pragma unroll
+      for (int bb = 0; bb < 2; ++bb) {
+        const int ox = 2 * tx + bb;
+        if (oy >= g.h || ox >= g.w) continue;
+        f32x4 v = bb == 0 ? s[a][0] + s[a][1] + s[a][2] : s[a][1] - s[a][2] - s[a][3];
+        v = v * es + eb;
+        const size_t off = (((size_t)b * g.h + oy) * g.w + ox) * g.c + c4 * 4;
+        if (ep.res1) v += *(const f32x4*)(ep.res1 + off);
+        if (ep.mask) {
+          const f32x4 k = *(const f32x4*)(ep.mask + off);
+          v.x = k.x > 0.f ? v.x : 0.f; v.y = k.y > 0.f ? v.y : 0.f; v.z = k.z > 0.f ? v.z : 0.f; v.w = k.w > 0.f ? v.w : 0.f;
+        }
+        if (ep.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        *(f32x4*)(y + off) = v;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t hnd_wino_tiles_pad(int n, int h, int w) {
+  const long long t = (long long)n * ((h + 1) / 2) * ((w + 1) / 2);
+  return (t + 127) / 128 * 128;
+}
+
+int hnd_wino_weights(const float* weight, float* u, int cout, int cin, int dgrad, void* stream) {
+  HND_REQUIRE(weight && u && cout > 0 && cin > 0, "hnd_wino_weights: bad arguments");
+  const int rows = dgrad ? cin : cout, kreal = dgrad ? cout : cin;
+  HND_REQUIRE(kreal % 32 == 0, "hnd_wino_weights: GEMM depth %d must be a multiple of 32", kreal);
+  const int rows_pad = (rows + 63) / 64 * 64;
+  hipLaunchKernelGGL(wino_weights_kernel, dim3(grid_for((long long)rows_pad * kreal)), dim3(256), 0,
+                     hnd::as_stream(stream), weight, u, cout, cin, dgrad, rows, rows_pad, kreal);
+  return hnd::check_launch("hnd_wino_weights");
+}
+
+int hnd_wino_input(const float* x, float* v, int n, int h, int w, int c, const float* pro_scale,
+                   const float* pro_shift, int pro_relu, void* stream) {
+  HND_REQUIRE(x && v && n > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0, "hnd_wino_input: bad arguments");
+  HND_REQUIRE(pro_scale == nullptr || pro_shift != nullptr, "hnd_wino_input: pro_shift is required with pro_scale");
+  WinoGeom g{n, h, w, c, (h + 1) / 2, (w + 1) / 2, (int)hnd_wino_tiles_pad(n, h, w)};
+  const long long tiles = (long long)n * g.th * g.tw;
+  hipLaunchKernelGGL(wino_input_kernel, dim3(grid_for(tiles * (c / 4))), dim3(256), 0, hnd::as_stream(stream), x, v, g,
+                     pro_scale, pro_shift, pro_relu);
+  return hnd::check_launch("hnd_wino_input");
+}
+
+int hnd_wino_output(const float* m, float* y, int n, int h, int w, int cout, int ldc, const float* epi_scale,
+                    const float* epi_shift, const float* res1, const float* mask, int relu, void* stream) {
+  HND_REQUIRE(m && y && n > 0 && h > 0 && w > 0 && cout > 0 && cout % 4 == 0 && ldc >= cout && ldc % 4 == 0,
+              "hnd_wino_output: bad arguments");
+  WinoGeom g{n, h, w, ldc, (h + 1) / 2, (w + 1) / 2, (int)hnd_wino_tiles_pad(n, h, w)};
+  WinoEpilogue ep{epi_scale, epi_shift, res1, mask, relu};
+  const long long tiles = (long long)n * g.th * g.tw;
+  hipLaunchKernelGGL(wino_output_kernel, dim3(grid_for(tiles * (cout / 4))), dim3(256), 0, hnd::as_stream(stream), m, y,
+                     g, cout, ep);
+  return hnd::check_launch("hnd_wino_output");
+}
+
+}  // extern "C"

@@ -14,6 +14,7 @@ the ReLU mask / FrozenBN scale / residual fan-in fused into the conv kernel, tra
 dgrad+wgrad for the head, maxpool/ReLU/FBN backward and wgrad for the stem.
 """
 import math
+import os
 from collections import OrderedDict
 
 import torch
@@ -21,6 +22,7 @@ import torch
 from . import ops
 
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1
+WINOGRAD = os.environ.get('HND_WINOGRAD', '1') != '0'
 PROFILE = {'enabled': False, 'records': []}     # bench.py: per-launch HIP events on the launch stream
 # DistillationBox sets 'stream' while it runs teacher + student: their feature pyramids (whose outputs the
 # distillation criterion never reads) are then issued on that stream and overlap the backward pass
@@ -121,6 +123,34 @@ class WeightCache(object):
                 pk.src = self.weight.detach()
                 pk.repack()
             self.ver = ver
+
+
+class WinoCache(object):
+    """Winograd-domain weights (forward and transposed) of one frozen 3x3 conv, transformed once per version."""
+
+    def __init__(self, weight):
+        self.weight, self.packs, self.ver = weight, {}, None
+
+    def get(self, dgrad=False):
+        ww = self.packs.get(dgrad)
+        if ww is None:
+            ww = self.packs[dgrad] = ops.WinoWeights(self.weight.detach(), dgrad)
+            self.ver = (self.weight._version, self.weight.data_ptr())
+        return ww
+
+    def refresh(self):
+        ver = (self.weight._version, self.weight.data_ptr())
+        if ver != self.ver:
+            for ww in self.packs.values():
+                ww.src = self.weight.detach()
+                ww.repack()
+            self.ver = ver
+
+
+def use_winograd(cin, cout, stride):
+    """F(2x2,3x3) pays when the 16 GEMMs are deep enough to run at MFMA rate and the 4x inflated transformed tensors
+    stay cheap next to them: measured x1.26-1.95 for 256/512 channels, x1.04 for 128 (tools/bench_wino.py)."""
+    return WINOGRAD and stride == 1 and min(cin, cout) >= 256 and cin % 32 == 0 and cout % 4 == 0
 
 
 # =========================================================================================== transform
@@ -247,7 +277,7 @@ class StemEngine(object):
 
 # =========================================================================================== frozen layers
 class _Block(object):
-    __slots__ = ('mod', 'stride', 'has_ds', 'planes', 'cin', 'w1', 'w2', 'w3', 'wd', 'f1', 'f2', 'f3', 'fd')
+    __slots__ = ('mod', 'stride', 'has_ds', 'planes', 'cin', 'w1', 'w2', 'w3', 'wd', 'f1', 'f2', 'f3', 'fd', 'wino')
 
 
 class FrozenLayerEngine(object):
@@ -265,6 +295,7 @@ class FrozenLayerEngine(object):
             b.f1, b.f2, b.f3 = FrozenAffine(m.bn1), FrozenAffine(m.bn2), FrozenAffine(m.bn3)
             b.wd = WeightCache(m.downsample[0].weight) if b.has_ds else None
             b.fd = FrozenAffine(m.downsample[1]) if b.has_ds else None
+            b.wino = WinoCache(m.conv2.weight) if use_winograd(b.planes, b.planes, b.stride) else None
             self.blocks.append(b)
         self.bufs = None
         self.plan_key = None
@@ -286,9 +317,12 @@ class FrozenLayerEngine(object):
         affs = [(b.f1.get(), b.f2.get(), b.f3.get(), b.fd.get() if b.has_ds else None) for b in self.blocks]
         for b in self.blocks:
             for wc in (b.w1, b.w2, b.w3, b.wd):
-                if wc is not None:
+                if wc is not None and not (wc is b.w2 and b.wino is not None):
                     wc.get()
                     wc.refresh()
+            if b.wino is not None:
+                b.wino.get(False)
+                b.wino.refresh()
         key = (x.data_ptr(), tuple(x.shape), keep, tuple(a[0][0].data_ptr() for a in affs))
         if key != self.plan_key:
             self._build_forward(x, keep, affs)
@@ -313,8 +347,13 @@ class FrozenLayerEngine(object):
             out = self.bufs.get('out_' + sfx, (n, oh, ow, b.planes * 4))
             self.fwd.append((ops.conv_forward(cur, b.w1.get(), a1, 1, 1, 0, epi_scale=a1f[0], epi_shift=a1f[1],
                                               relu=True), tagp + '.conv1'))
-            self.fwd.append((ops.conv_forward(a1, b.w2.get(), a2, 3, b.stride, 1, epi_scale=a2f[0], epi_shift=a2f[1],
-                                              relu=True), tagp + '.conv2'))
+            if b.wino is not None:      # stride-1 3x3, >= 256 channels: Winograd F(2x2,3x3)
+                v, m = self._wino_scratch(n, h, w, b.planes, b.planes)
+                self.fwd += ops.WinoConv(a1, b.wino.get(False), a2, v, m, epi_scale=a2f[0], epi_shift=a2f[1],
+                                         relu=True).launches(tagp + '.conv2')
+            else:
+                self.fwd.append((ops.conv_forward(a1, b.w2.get(), a2, 3, b.stride, 1, epi_scale=a2f[0],
+                                                  epi_shift=a2f[1], relu=True), tagp + '.conv2'))
             if b.has_ds:
                 ds = self.bufs.get('ds_' + sfx, (n, oh, ow, b.planes * 4))
                 self.fwd.append((ops.conv_forward(cur, b.wd.get(), ds, 1, b.stride, 0, epi_scale=adf[0],
@@ -331,6 +370,12 @@ class FrozenLayerEngine(object):
             cur = out
         self.out = cur
         self.flops_fwd = flops
+
+    def _wino_scratch(self, n, h, w, cin, cout):
+        """V / M scratch of the Winograd launches of this engine (they run one after another on one stream)."""
+        nv, nm = ops.WinoConv.scratch_elems(n, h, w, cin, cout)
+        self._wino_need = (max(nv, getattr(self, '_wino_need', (0, 0))[0]), max(nm, getattr(self, '_wino_need', (0, 0))[1]))
+        return self.bufs.get('wino_v', (self._wino_need[0],)), self.bufs.get('wino_m', (self._wino_need[1],))
 
     # ---- backward: self.g_out holds the gradient w.r.t. this layer's output, already masked by out > 0
     def grad_out_buffer(self):
@@ -366,8 +411,13 @@ class FrozenLayerEngine(object):
             ls, _ = ops.conv_dgrad(g, b.w3, g_a2, 1, 1, 0, pro_scale=s3, mask=a2)
             self.bwd += [(l, tagp + '.conv3.dgrad') for l in ls]
             # conv2 (3x3, stride s): g_a1 = [a1>0] * dgrad(g_a2 * s2)
-            ls, _ = ops.conv_dgrad(g_a2, b.w2, g_a1, 3, b.stride, 1, pro_scale=s2, mask=a1)
-            self.bwd += [(l, tagp + '.conv2.dgrad') for l in ls]
+            if b.wino is not None:
+                v, m = self._wino_scratch(n, h, w, b.planes, b.planes)
+                self.bwd += ops.WinoConv(g_a2, b.wino.get(True), g_a1, v, m, pro_scale=s2,
+                                         mask=a1).launches(tagp + '.conv2.dgrad')
+            else:
+                ls, _ = ops.conv_dgrad(g_a2, b.w2, g_a1, 3, b.stride, 1, pro_scale=s2, mask=a1)
+                self.bwd += [(l, tagp + '.conv2.dgrad') for l in ls]
             # conv1 (1x1) + identity / downsample fan-in, masked by the previous block's ReLU
             if i > 0:
                 g_prev = self.bufs.get('g_blk_%d' % ((i - 1) & 1), x_in.shape)
@@ -625,6 +675,8 @@ class FpnEngine(object):
     def __init__(self, inner_blocks, layer_blocks):
         self.inner = [(m, WeightCache(m.weight)) for m in inner_blocks]
         self.layer = [(m, WeightCache(m.weight)) for m in layer_blocks]
+        self.wino = [WinoCache(m.weight) if use_winograd(m.weight.shape[1], m.weight.shape[0], 1) else None
+                     for m in layer_blocks]
         self.bufs = None
         self.plan_key = None
         self.flops_fwd = 0
@@ -633,7 +685,11 @@ class FpnEngine(object):
         """feats: list of NHWC layer outputs (fine -> coarse).  Returns list of NHWC pyramid maps + 'pool'."""
         if self.bufs is None:
             self.bufs = Buffers(feats[0].device)
-        for m, wc in self.inner + self.layer:
+        for i, (m, wc) in enumerate(self.inner + self.layer):
+            if i >= len(self.inner) and self.wino[i - len(self.inner)] is not None:
+                self.wino[i - len(self.inner)].get(False)
+                self.wino[i - len(self.inner)].refresh()
+                continue
             wc.get()
             wc.refresh()
         key = tuple((f.data_ptr(), tuple(f.shape)) for f in feats) + \
@@ -644,6 +700,9 @@ class FpnEngine(object):
             inner = [None] * nlev
             self.results = [None] * nlev
             flops = 0
+            # Winograd scratch sized for the finest level up front (the loop runs coarse -> fine)
+            n0, h0, w0, _ = feats[0].shape
+            need = ops.WinoConv.scratch_elems(n0, h0, w0, 256, 256) if any(w is not None for w in self.wino) else (0, 0)
             for i in range(nlev - 1, -1, -1):
                 f = feats[i]
                 n, h, w, c = f.shape
@@ -654,8 +713,15 @@ class FpnEngine(object):
                                                   res1=up, res1_up=up is not None), 'fpn.inner%d' % i))
                 ml, wl = self.layer[i]
                 self.results[i] = self.bufs.get('p%d' % i, (n, h, w, ml.weight.shape[0]))
-                self.fwd.append((ops.conv_forward(inner[i], wl.get(), self.results[i], 3, 1, 1,
-                                                  epi_shift=ml.bias.detach()), 'fpn.layer%d' % i))
+                if self.wino[i] is not None:            # 3x3 256->256 output conv: Winograd F(2x2,3x3)
+                    nv, nm = ops.WinoConv.scratch_elems(n, h, w, 256, ml.weight.shape[0])
+                    need = (max(nv, need[0]), max(nm, need[1]))
+                    v, mm = self.bufs.get('wino_v', (need[0],)), self.bufs.get('wino_m', (need[1],))
+                    self.fwd += ops.WinoConv(inner[i], self.wino[i].get(False), self.results[i], v, mm,
+                                             epi_shift=ml.bias.detach()).launches('fpn.layer%d' % i)
+                else:
+                    self.fwd.append((ops.conv_forward(inner[i], wl.get(), self.results[i], 3, 1, 1,
+                                                      epi_shift=ml.bias.detach()), 'fpn.layer%d' % i))
                 flops += 2 * n * h * w * 256 * (c + 256 * 9)
             last = self.results[-1]
             n, h, w, c = last.shape

@@ -393,6 +393,103 @@ def roundtrip_f16(x):
     check(_L.hnd_roundtrip_f16(ptr(x), x.numel(), stream_ptr()), 'hnd_roundtrip_f16')
 
 
+# ------------------------------------------------------------------------------ Winograd F(2x2, 3x3)
+def wino_tiles_pad(n, h, w):
+    return int(_L.hnd_wino_tiles_pad(n, h, w))
+
+
+class WinoWeights(object):
+    """U = G g G^T of one 3x3 conv weight in packed GEMM-operand layout [16][rows_pad][depth]; dgrad: transposed conv."""
+
+    def __init__(self, weight, dgrad=False):
+        cout, cin, kh, kw = weight.shape
+        assert kh == 3 and kw == 3 and weight.is_contiguous()
+        self.src, self.dgrad = weight, dgrad
+        self.rows, self.depth = (cin, cout) if dgrad else (cout, cin)
+        assert self.depth % 32 == 0, 'Winograd path needs a GEMM depth that is a multiple of 32'
+        self.rows_pad = round_up(self.rows, 64)
+        self.buf = torch.empty(16 * self.rows_pad * self.depth, dtype=torch.float32, device=weight.device)
+        self.repack()
+
+    def repack(self):
+        cout, cin = self.src.shape[0], self.src.shape[1]
+        check(_L.hnd_wino_weights(ptr(self.src), ptr(self.buf), cout, cin, int(self.dgrad), stream_ptr()),
+              'hnd_wino_weights')
+
+
+class WinoConv(object):
+    """One stride-1 pad-1 3x3 convolution (or its data gradient) as input transform -> 16 GEMMs in one igemm launch
+    -> output transform.  x [N,H,W,C] -> y [N,H,W,ldc]; v / m are caller-provided scratch (see scratch_elems)."""
+
+    def __init__(self, x, ww, y, v, m, pro_scale=None, pro_shift=None, pro_relu=False, epi_scale=None, epi_shift=None,
+                 res1=None, mask=None, relu=False):
+        n, h, w, c = _nhwc(x)
+        assert tuple(y.shape[:3]) == (n, h, w) and c == ww.depth
+        self.x, self.y, self.ww = x, y, ww
+        self.geom = (n, h, w, c)
+        self.tiles_pad = wino_tiles_pad(n, h, w)
+        self.cout = round_up(ww.rows, 4)
+        assert self.cout <= y.shape[3]
+        need_v, need_m = 16 * self.tiles_pad * c, 16 * self.tiles_pad * self.cout
+        assert v.numel() >= need_v and m.numel() >= need_m
+        if pro_scale is not None and pro_shift is None:
+            pro_shift = _zeros(c, x.device)
+        self.pro = (pro_scale, pro_shift, int(pro_relu))
+        self.epi = (epi_scale, epi_shift, res1, mask, int(relu))
+        for t in (res1, mask):
+            assert t is None or tuple(t.shape) == tuple(y.shape)
+        self.v = v[:need_v].view(1, 1, 16 * self.tiles_pad, c)
+        self.m = m[:need_m].view(1, 1, 16 * self.tiles_pad, self.cout)
+        pw = PackedWeight.__new__(PackedWeight)
+        pw.buf, pw.kdim, pw.rows, pw.chan_pad, pw.chan_real = ww.buf, ww.depth, ww.rows, c, c
+        self.gemm = conv_desc(self.v, pw, self.m, kh=1, kw=1, oh=1, ow=16 * self.tiles_pad, sh=1, dh=1, bh=0, sw=1,
+                              dw=1, bw=0, cout=self.cout)
+        self.gemm.desc.w_group_rows = self.tiles_pad
+        self.gemm.desc.w_group_stride = ww.rows_pad * ww.depth
+        tiles = n * ((h + 1) // 2) * ((w + 1) // 2)
+        self.gemm.flops = 2 * 16 * tiles * ww.rows * ww.depth          # multiplies actually executed
+        self.flops = self.gemm.flops
+        self.variant = self.gemm.variant
+
+    @staticmethod
+    def scratch_elems(n, h, w, cin, cout):
+        tp = wino_tiles_pad(n, h, w)
+        return 16 * tp * cin, 16 * tp * round_up(cout, 4)
+
+    def _run_input(self, stream=None):
+        n, h, w, c = self.geom
+        check(_L.hnd_wino_input(ptr(self.x), ptr(self.v), n, h, w, c, ptr(self.pro[0]), ptr(self.pro[1]), self.pro[2],
+                                stream if stream is not None else stream_ptr()), 'hnd_wino_input')
+
+    def _run_output(self, stream=None):
+        n, h, w, c = self.geom
+        es, eb, r1, mk, relu = self.epi
+        check(_L.hnd_wino_output(ptr(self.m), ptr(self.y), n, h, w, self.cout, self.y.shape[3], ptr(es), ptr(eb),
+                                 ptr(r1), ptr(mk), relu, stream if stream is not None else stream_ptr()),
+              'hnd_wino_output')
+
+    def launches(self, tag):
+        """[(launch, tag)] for an engine plan: the two transforms carry no flops (not event-timed by bench.py), the
+        GEMM launch is an ordinary igemm launch with the multiplies it really executes."""
+        return [(_Step(self._run_input), tag + '.wino_in'), (self.gemm, tag), (_Step(self._run_output), tag + '.wino_out')]
+
+    def run(self, stream=None):
+        self._run_input(stream)
+        self.gemm.run(stream)
+        self._run_output(stream)
+
+
+class _Step(object):
+    """a plan entry without MFMA work"""
+    __slots__ = ('fn', 'flops')
+
+    def __init__(self, fn):
+        self.fn, self.flops = fn, 0
+
+    def run(self, stream=None):
+        self.fn(stream)
+
+
 # ------------------------------------------------------------------------------ neural filter (Ext4ResNet)
 def adaptive_avgpool_fwd(x, y):
     n, h, w, c = _nhwc(x)

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define HND_ABI_VERSION 1
+#define HND_ABI_VERSION 2
 
 typedef enum hnd_status {
   HND_OK = 0,
@@ -93,6 +93,10 @@ typedef struct hnd_conv_desc {
   int32_t kdim;            /* row stride of w: kh*kw*cin rounded up to a multiple of 32            */
   int32_t pro_relu, relu;
   int32_t res1_mode, res1_h, res1_w;
+  /* grouped weights (0 = off): output rows [g*w_group_rows, (g+1)*w_group_rows) use the packed matrix at
+   * w + g*w_group_stride floats; w_group_rows must be a multiple of 128.  Used by the Winograd path: the 16
+   * transform components are 16 GEMMs over disjoint row groups of one launch. */
+  int32_t w_group_rows, w_group_stride;
 } hnd_conv_desc;
 
 int hnd_conv2d_igemm(const hnd_conv_desc* desc, void* stream);
@@ -152,6 +156,24 @@ int hnd_transform_image(const float* src, int h, int w, float* dst, int index, i
 int hnd_transform_image_u8(const uint8_t* src, int h, int w, int hwc, int flip, float* dst, int index, int out_h,
                            int out_w, int hp, int wp, float scale_h, float scale_w, const float mean[3],
                            const float std[3], void* stream);
+
+/* ---- Winograd F(2x2, 3x3) for stride-1 pad-1 3x3 convolutions (torchvision Bottleneck.conv2 and the FPN output
+ * convs built at src/models/org/rcnn.py:391-414; forward and data gradient) -------------------------------------
+ * y = out_transform( GEMM_f( in_transform(x), U_f ) ), f = 0..15, with the 16 GEMMs issued as ONE hnd_conv2d_igemm
+ * launch (1x1 conv over 16*tiles_pad "pixels", w_group_rows = tiles_pad, w_group_stride = rows_pad*depth).
+ * hnd_wino_tiles_pad: rows per component = n*ceil(h/2)*ceil(w/2) rounded up to 128.
+ * hnd_wino_weights:   OIHW [cout][cin][3][3] -> u [16][round_up(rows,64)][depth] (forward: rows = cout, depth = cin;
+ *                     dgrad != 0: rows = cin, depth = cout, taps flipped -- the transposed convolution).
+ * hnd_wino_input:     x [n][h][w][c] (+ optional per-channel prologue scale/shift/relu on in-bounds elements)
+ *                     -> v [16][tiles_pad][c].
+ * hnd_wino_output:    m [16][tiles_pad][cout] -> y [n][h][w][ldc], epilogue order as hnd_conv2d_igemm:
+ *                     scale/shift, + res1, mask (ReLU backward), ReLU. */
+int64_t hnd_wino_tiles_pad(int n, int h, int w);
+int hnd_wino_weights(const float* weight, float* u, int cout, int cin, int dgrad, void* stream);
+int hnd_wino_input(const float* x, float* v, int n, int h, int w, int c, const float* pro_scale,
+                   const float* pro_shift, int pro_relu, void* stream);
+int hnd_wino_output(const float* m, float* y, int n, int h, int w, int cout, int ldc, const float* epi_scale,
+                    const float* epi_shift, const float* res1, const float* mask, int relu, void* stream);
 
 /* nn.MaxPool2d(3, 2, 1) (custom/resnet.py:30,99) NHWC; idx (uint8 tap 0..8) kept for backward. */
 int hnd_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* idx, int n, int h, int w, int c, int oh, int ow,
