@@ -171,8 +171,10 @@ def main():
                 'unit': 'TFLOP/s', 'frac': round(ach / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
                 'launches_per_step': per[dom]['n'], 'avg_launch_ms': round(per[dom]['ms'] / per[dom]['n'], 4),
                 'algorithmic_gflop_per_launch': round(per[dom]['flop'] / per[dom]['n'] / 1e9, 3),
-                'flops_basis': 'multiplies the launches execute: implicit-GEMM convs 2*M*Cout*K; the Winograd F(2x2,3x3) '
-                               'GEMMs 2*16*tiles*Cin*Cout (2.25x fewer than the direct 3x3 they replace)'
+                'flops_basis': ('multiplies the launches execute: implicit-GEMM convs 2*M*Cout*K; the Winograd '
+                                'F(%dx%d,3x3) GEMMs 2*%d*tiles*Cin*Cout (%.2fx fewer than the direct 3x3 they replace)'
+                                % (E.WINOGRAD, E.WINOGRAD, (E.WINOGRAD + 2) ** 2,
+                                   9.0 * E.WINOGRAD ** 2 / (E.WINOGRAD + 2) ** 2))
                                if E.WINOGRAD else 'implicit-GEMM convs 2*M*Cout*K'}
     try:        # HBM bytes per launch of the dominant kernel from the committed PMC pass (profiles/rNN_traffic.json)
         import glob
@@ -213,7 +215,8 @@ def main():
                                   'elided' if args.no_fpn else 'executed (as written)'),
                    'global_batch': args.batch * world, 'parallelism': 'dp%d' % world,
                    'weights': 'seeded random init (no network for COCO weights)',
-                   'conv3x3': 'Winograd F(2x2,3x3) for stride-1 3x3 with >=256 channels, implicit GEMM elsewhere'
+                   'conv3x3': ('Winograd F(%dx%d,3x3) for stride-1 3x3 convs with >=%d channels, implicit GEMM elsewhere'
+                               % (E.WINOGRAD, E.WINOGRAD, 128 if E.WINOGRAD == 4 else 256))
                               if E.WINOGRAD else 'implicit GEMM'},
         'roofline': roofline,
         'step_conv_tflops': round(gflop_img * args.batch / (ms_per_step / 1e3) / 1e3, 2),

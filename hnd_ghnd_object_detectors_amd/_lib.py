@@ -52,10 +52,10 @@ _SIGNATURES = {
                                                                                     c_float_p, c_float_p, vp]),
     'hnd_transform_image_u8': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp] + [C.c_int] * 5 +
                                [C.c_float, C.c_float, c_float_p, c_float_p, vp]),
-    'hnd_wino_tiles_pad': (C.c_int64, [C.c_int, C.c_int, C.c_int]),
-    'hnd_wino_weights': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp]),
-    'hnd_wino_input': (C.c_int, [vp, vp] + [C.c_int] * 4 + [vp, vp, C.c_int, vp]),
-    'hnd_wino_output': (C.c_int, [vp, vp] + [C.c_int] * 5 + [vp, vp, vp, vp, C.c_int, vp]),
+    'hnd_wino_tiles_pad': (C.c_int64, [C.c_int] * 4),
+    'hnd_wino_weights': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    'hnd_wino_input': (C.c_int, [vp, vp] + [C.c_int] * 4 + [vp, vp, C.c_int, C.c_int, vp]),
+    'hnd_wino_output': (C.c_int, [vp, vp] + [C.c_int] * 5 + [vp, vp, vp, vp, C.c_int, C.c_int, vp]),
     'hnd_maxpool3x3s2_fwd': (C.c_int, [vp, vp, vp] + [C.c_int] * 6 + [vp]),
     'hnd_maxpool3x3s2_bwd_relu_scale': (C.c_int, [vp] * 5 + [C.c_int] * 6 + [vp]),
     'hnd_bn_finalize': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int64, vp, vp, vp, vp, vp,

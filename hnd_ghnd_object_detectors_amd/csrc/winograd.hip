@@ -1,4 +1,4 @@
-// Winograd F(2x2, 3x3) for the stride-1, pad-1 3x3 convolutions (frozen ResNet conv2, FPN output convs, and their
+// Winograd F(2x2, 3x3) and F(4x4, 3x3) for the stride-1, pad-1 3x3 convolutions (frozen ResNet conv2, FPN output convs, and their
 // data gradients): Y = A^T [ (G g G^T) .* (B^T d B) ] A per 2x2 output tile, i.e. 16 multiplies per input/output
 // channel pair instead of 36.  The 16 element-wise products over channels are 16 independent GEMMs
 //     M_f [tiles x cout] = V_f [tiles x cin] * U_f^T [cin x cout]
@@ -65,6 +65,8 @@ struct WinoGeom {
   int th, tw;              // tiles per image
   int tiles_pad;           // rows per component in V / M (multiple of 128)
 };
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // V[f][t][c] = (B^T d B)[f] of the 4x4 input patch of tile t (rows 2ty-1.., cols 2tx-1..), zero outside the image.
 // Optional prologue on in-bounds elements: a = x*scale[c] + shift[c], relu.
@@ -182,45 +184,236 @@ __global__ void wino_output_kernel(const float* __restrict__ m, float* __restric
   }
 }
 
+
+// ================================================================================== F(4x4, 3x3)
+// Interpolation points {0, +-1, +-2, inf}: 36 products per 4x4 output tile = 4x fewer multiplies than direct, and
+// the transformed tensors inflate by 36/16 = 2.25x (F(2x2,3x3): 4x).  Two channels per thread keep the 6x6 patch
+// in 72 VGPRs.
+__global__ void wino4_weights_kernel(const float* __restrict__ w, float* __restrict__ u, int cout, int cin, int dgrad,
+                                     int rows, int rows_pad, int kdim) {
+  const long long total = (long long)rows_pad * kdim;
+  const int kreal = dgrad ? cout : cin;
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    const int r = (int)(e / kdim), k = (int)(e - (long long)r * kdim);
+    const bool ok = r < rows && k < kreal;
+    float g[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        float v = 0.f;
+        if (ok) v = dgrad ? w[(((size_t)k * cin + r) * 3 + (2 - i)) * 3 + (2 - j)]
+                          : w[(((size_t)r * cin + k) * 3 + i) * 3 + j];
+        g[i][j] = v;
+      }
+    // G = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]
+    float t[6][3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const float a = g[0][j], b = g[1][j], c = g[2][j];
+      t[0][j] = a * (1.f / 4.f);
+      t[1][j] = -(a + b + c) * (1.f / 6.f);
+      t[2][j] = (-a + b - c) * (1.f / 6.f);
+      t[3][j] = a * (1.f / 24.f) + b * (1.f / 12.f) + c * (1.f / 6.f);
+      t[4][j] = a * (1.f / 24.f) - b * (1.f / 12.f) + c * (1.f / 6.f);
+      t[5][j] = c;
+    }
+    const size_t fs = (size_t)rows_pad * kdim;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const float a = t[i][0], b = t[i][1], c = t[i][2];
+      float* dst = u + ((size_t)(i * 6) * rows_pad + r) * kdim + k;
+      dst[0] = a * (1.f / 4.f);
+      dst[fs] = -(a + b + c) * (1.f / 6.f);
+      dst[2 * fs] = (-a + b - c) * (1.f / 6.f);
+      dst[3 * fs] = a * (1.f / 24.f) + b * (1.f / 12.f) + c * (1.f / 6.f);
+      dst[4 * fs] = a * (1.f / 24.f) - b * (1.f / 12.f) + c * (1.f / 6.f);
+      dst[5 * fs] = c;
+    }
+  }
+}
+
+// B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1] applied to 6 values
+#define HND_WINO4_BT(d0, d1, d2, d3, d4, d5, o0, o1, o2, o3, o4, o5) \
+  do {                                                               \
+    const f32x2 t0_ = 4.f * d0 - 5.f * d2 + d4;                      \
+    const f32x2 t1_ = -4.f * (d1 + d2) + d3 + d4;                    \
+    const f32x2 t2_ = 4.f * (d1 - d2) - d3 + d4;                     \
+    const f32x2 t3_ = -2.f * d1 - d2 + 2.f * d3 + d4;                \
+    const f32x2 t4_ = 2.f * d1 - d2 - 2.f * d3 + d4;                 \
+    const f32x2 t5_ = 4.f * d1 - 5.f * d3 + d5;                      \
+    o0 = t0_; o1 = t1_; o2 = t2_; o3 = t3_; o4 = t4_; o5 = t5_;      \
+  } while (0)
+
+__global__ void wino4_input_kernel(const float* __restrict__ x, float* __restrict__ v, const WinoGeom g,
+                                   const float* __restrict__ pro_scale, const float* __restrict__ pro_shift,
+                                   int pro_relu) {
+  const int c2n = g.c >> 1;
+  const long long tiles = (long long)g.n * g.th * g.tw;
+  const long long total = tiles * c2n;
+  const size_t fs = (size_t)g.tiles_pad * g.c;
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    const int c2 = (int)(e % c2n);
+    long long t = e / c2n;
+    const int tx = (int)(t % g.tw);
+    long long q = t / g.tw;
+    const int ty = (int)(q % g.th), b = (int)(q / g.th);
+    f32x2 ps = {1.f, 1.f}, pb = {0.f, 0.f};
+    if (pro_scale) {
+      ps = *(const f32x2*)(pro_scale + c2 * 2);
+      pb = *(const f32x2*)(pro_shift + c2 * 2);
+    }
+    const float floor_ = pro_relu ? 0.f : -INFINITY;
+    f32x2 d[6][6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int iy = 4 * ty - 1 + i;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const int ix = 4 * tx - 1 + j;
+        const bool ok = (unsigned)iy < (unsigned)g.h && (unsigned)ix < (unsigned)g.w;
+        const size_t off = ok ? (((size_t)b * g.h + iy) * g.w + ix) * g.c + c2 * 2 : 0;
+        f32x2 a = *(const f32x2*)(x + off);
+        if (pro_scale) {
+          a = a * ps + pb;
+          a.x = fmaxf(a.x, floor_); a.y = fmaxf(a.y, floor_);
+        }
+        const f32x2 z = {0.f, 0.f};
+        d[i][j] = ok ? a : z;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 6; ++j)            // B^T d (down the columns, in place)
+      HND_WINO4_BT(d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j], d[0][j], d[1][j], d[2][j], d[3][j], d[4][j],
+                   d[5][j]);
+    float* dst = v + (size_t)t * g.c + c2 * 2;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {          // (.) B (along the rows), straight to memory
+      f32x2 o0, o1, o2, o3, o4, o5;
+      HND_WINO4_BT(d[i][0], d[i][1], d[i][2], d[i][3], d[i][4], d[i][5], o0, o1, o2, o3, o4, o5);
+      *(f32x2*)(dst + (size_t)(i * 6 + 0) * fs) = o0;
+      *(f32x2*)(dst + (size_t)(i * 6 + 1) * fs) = o1;
+      *(f32x2*)(dst + (size_t)(i * 6 + 2) * fs) = o2;
+      *(f32x2*)(dst + (size_t)(i * 6 + 3) * fs) = o3;
+      *(f32x2*)(dst + (size_t)(i * 6 + 4) * fs) = o4;
+      *(f32x2*)(dst + (size_t)(i * 6 + 5) * fs) = o5;
+    }
+  }
+}
+
+// A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1] applied to 6 values
+#define HND_WINO4_AT(m0, m1, m2, m3, m4, m5, o0, o1, o2, o3) \
+  do {                                                       \
+    const f32x2 p12 = m1 + m2, q12 = m1 - m2, p34 = m3 + m4, q34 = m3 - m4; \
+    o0 = m0 + p12 + p34;                                     \
+    o1 = q12 + 2.f * q34;                                    \
+    o2 = p12 + 4.f * p34;                                    \
+    o3 = q12 + 8.f * q34 + m5;                               \
+  } while (0)
+
+__global__ void wino4_output_kernel(const float* __restrict__ m, float* __restrict__ y, const WinoGeom g, int cout,
+                                    const WinoEpilogue ep) {
+  const int c2n = cout >> 1;
+  const long long tiles = (long long)g.n * g.th * g.tw;
+  const long long total = tiles * c2n;
+  const size_t fs = (size_t)g.tiles_pad * cout;
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    const int c2 = (int)(e % c2n);
+    long long t = e / c2n;
+    const int tx = (int)(t % g.tw);
+    long long q = t / g.tw;
+    const int ty = (int)(q % g.th), b = (int)(q / g.th);
+    const float* src = m + (size_t)t * cout + c2 * 2;
+    f32x2 s[4][6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {          // A^T m (down the columns)
+      const f32x2 m0 = *(const f32x2*)(src + (size_t)(0 * 6 + j) * fs), m1 = *(const f32x2*)(src + (size_t)(1 * 6 + j) * fs),
+                  m2 = *(const f32x2*)(src + (size_t)(2 * 6 + j) * fs), m3 = *(const f32x2*)(src + (size_t)(3 * 6 + j) * fs),
+                  m4 = *(const f32x2*)(src + (size_t)(4 * 6 + j) * fs), m5 = *(const f32x2*)(src + (size_t)(5 * 6 + j) * fs);
+      HND_WINO4_AT(m0, m1, m2, m3, m4, m5, s[0][j], s[1][j], s[2][j], s[3][j]);
+    }
+    f32x2 es = {1.f, 1.f}, eb = {0.f, 0.f};
+    if (ep.epi_scale) es = *(const f32x2*)(ep.epi_scale + c2 * 2);
+    if (ep.epi_shift) eb = *(const f32x2*)(ep.epi_shift + c2 * 2);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int oy = 4 * ty + a;
+      f32x2 o[4];
+      HND_WINO4_AT(s[a][0], s[a][1], s[a][2], s[a][3], s[a][4], s[a][5], o[0], o[1], o[2], o[3]);
+#pragma unroll
+      for (int bb = 0; bb < 4; ++bb) {
+        const int ox = 4 * tx + bb;
+        if (oy >= g.h || ox >= g.w) continue;
+        f32x2 v = o[bb] * es + eb;
+        const size_t off = (((size_t)b * g.h + oy) * g.w + ox) * g.c + c2 * 2;
+        if (ep.res1) v += *(const f32x2*)(ep.res1 + off);
+        if (ep.mask) {
+          const f32x2 k = *(const f32x2*)(ep.mask + off);
+          v.x = k.x > 0.f ? v.x : 0.f; v.y = k.y > 0.f ? v.y : 0.f;
+        }
+        if (ep.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); }
+        *(f32x2*)(y + off) = v;
+      }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
 
-int64_t hnd_wino_tiles_pad(int n, int h, int w) {
-  const long long t = (long long)n * ((h + 1) / 2) * ((w + 1) / 2);
+int64_t hnd_wino_tiles_pad(int n, int h, int w, int tile) {
+  if (tile != 2 && tile != 4) return -1;
+  const long long t = (long long)n * ((h + tile - 1) / tile) * ((w + tile - 1) / tile);
   return (t + 127) / 128 * 128;
 }
 
-int hnd_wino_weights(const float* weight, float* u, int cout, int cin, int dgrad, void* stream) {
-  HND_REQUIRE(weight && u && cout > 0 && cin > 0, "hnd_wino_weights: bad arguments");
+int hnd_wino_weights(const float* weight, float* u, int cout, int cin, int dgrad, int tile, void* stream) {
+  HND_REQUIRE(weight && u && cout > 0 && cin > 0 && (tile == 2 || tile == 4), "hnd_wino_weights: bad arguments");
   const int rows = dgrad ? cin : cout, kreal = dgrad ? cout : cin;
   HND_REQUIRE(kreal % 32 == 0, "hnd_wino_weights: GEMM depth %d must be a multiple of 32", kreal);
   const int rows_pad = (rows + 63) / 64 * 64;
-  hipLaunchKernelGGL(wino_weights_kernel, dim3(grid_for((long long)rows_pad * kreal)), dim3(256), 0,
-                     hnd::as_stream(stream), weight, u, cout, cin, dgrad, rows, rows_pad, kreal);
+  if (tile == 2)
+    hipLaunchKernelGGL(wino_weights_kernel, dim3(grid_for((long long)rows_pad * kreal)), dim3(256), 0,
+                       hnd::as_stream(stream), weight, u, cout, cin, dgrad, rows, rows_pad, kreal);
+  else
+    hipLaunchKernelGGL(wino4_weights_kernel, dim3(grid_for((long long)rows_pad * kreal)), dim3(256), 0,
+                       hnd::as_stream(stream), weight, u, cout, cin, dgrad, rows, rows_pad, kreal);
   return hnd::check_launch("hnd_wino_weights");
 }
 
 int hnd_wino_input(const float* x, float* v, int n, int h, int w, int c, const float* pro_scale,
-                   const float* pro_shift, int pro_relu, void* stream) {
-  HND_REQUIRE(x && v && n > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0, "hnd_wino_input: bad arguments");
+                   const float* pro_shift, int pro_relu, int tile, void* stream) {
+  HND_REQUIRE(x && v && n > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0 && (tile == 2 || tile == 4),
+              "hnd_wino_input: bad arguments");
   HND_REQUIRE(pro_scale == nullptr || pro_shift != nullptr, "hnd_wino_input: pro_shift is required with pro_scale");
-  WinoGeom g{n, h, w, c, (h + 1) / 2, (w + 1) / 2, (int)hnd_wino_tiles_pad(n, h, w)};
+  WinoGeom g{n, h, w, c, (h + tile - 1) / tile, (w + tile - 1) / tile, (int)hnd_wino_tiles_pad(n, h, w, tile)};
   const long long tiles = (long long)n * g.th * g.tw;
-  hipLaunchKernelGGL(wino_input_kernel, dim3(grid_for(tiles * (c / 4))), dim3(256), 0, hnd::as_stream(stream), x, v, g,
-                     pro_scale, pro_shift, pro_relu);
+  if (tile == 2)
+    hipLaunchKernelGGL(wino_input_kernel, dim3(grid_for(tiles * (c / 4))), dim3(256), 0, hnd::as_stream(stream), x, v,
+                       g, pro_scale, pro_shift, pro_relu);
+  else
+    hipLaunchKernelGGL(wino4_input_kernel, dim3(grid_for(tiles * (c / 2))), dim3(256), 0, hnd::as_stream(stream), x, v,
+                       g, pro_scale, pro_shift, pro_relu);
   return hnd::check_launch("hnd_wino_input");
 }
 
 int hnd_wino_output(const float* m, float* y, int n, int h, int w, int cout, int ldc, const float* epi_scale,
-                    const float* epi_shift, const float* res1, const float* mask, int relu, void* stream) {
-  HND_REQUIRE(m && y && n > 0 && h > 0 && w > 0 && cout > 0 && cout % 4 == 0 && ldc >= cout && ldc % 4 == 0,
-              "hnd_wino_output: bad arguments");
-  WinoGeom g{n, h, w, ldc, (h + 1) / 2, (w + 1) / 2, (int)hnd_wino_tiles_pad(n, h, w)};
+                    const float* epi_shift, const float* res1, const float* mask, int relu, int tile, void* stream) {
+  HND_REQUIRE(m && y && n > 0 && h > 0 && w > 0 && cout > 0 && cout % 4 == 0 && ldc >= cout && ldc % 4 == 0 &&
+                  (tile == 2 || tile == 4), "hnd_wino_output: bad arguments");
+  WinoGeom g{n, h, w, ldc, (h + tile - 1) / tile, (w + tile - 1) / tile, (int)hnd_wino_tiles_pad(n, h, w, tile)};
   WinoEpilogue ep{epi_scale, epi_shift, res1, mask, relu};
   const long long tiles = (long long)n * g.th * g.tw;
-  hipLaunchKernelGGL(wino_output_kernel, dim3(grid_for(tiles * (cout / 4))), dim3(256), 0, hnd::as_stream(stream), m, y,
-                     g, cout, ep);
+  if (tile == 2)
+    hipLaunchKernelGGL(wino_output_kernel, dim3(grid_for(tiles * (cout / 4))), dim3(256), 0, hnd::as_stream(stream), m,
+                       y, g, cout, ep);
+  else
+    hipLaunchKernelGGL(wino4_output_kernel, dim3(grid_for(tiles * (cout / 2))), dim3(256), 0, hnd::as_stream(stream), m,
+                       y, g, cout, ep);
   return hnd::check_launch("hnd_wino_output");
 }
 

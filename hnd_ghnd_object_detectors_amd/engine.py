@@ -22,7 +22,7 @@ import torch
 from . import ops
 
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1
-WINOGRAD = os.environ.get('HND_WINOGRAD', '1') != '0'
+WINOGRAD = int(os.environ.get('HND_WINOGRAD', '4'))      # output tile of the Winograd 3x3 path: 4, 2, or 0 = off
 PROFILE = {'enabled': False, 'records': []}     # bench.py: per-launch HIP events on the launch stream
 # DistillationBox sets 'stream' while it runs teacher + student: their feature pyramids (whose outputs the
 # distillation criterion never reads) are then issued on that stream and overlap the backward pass
@@ -128,13 +128,13 @@ class WeightCache(object):
 class WinoCache(object):
     """Winograd-domain weights (forward and transposed) of one frozen 3x3 conv, transformed once per version."""
 
-    def __init__(self, weight):
-        self.weight, self.packs, self.ver = weight, {}, None
+    def __init__(self, weight, tile):
+        self.weight, self.tile, self.packs, self.ver = weight, tile, {}, None
 
     def get(self, dgrad=False):
         ww = self.packs.get(dgrad)
         if ww is None:
-            ww = self.packs[dgrad] = ops.WinoWeights(self.weight.detach(), dgrad)
+            ww = self.packs[dgrad] = ops.WinoWeights(self.weight.detach(), dgrad, self.tile)
             self.ver = (self.weight._version, self.weight.data_ptr())
         return ww
 
@@ -148,9 +148,13 @@ class WinoCache(object):
 
 
 def use_winograd(cin, cout, stride):
-    """F(2x2,3x3) pays when the 16 GEMMs are deep enough to run at MFMA rate and the 4x inflated transformed tensors
-    stay cheap next to them: measured x1.26-1.95 for 256/512 channels, x1.04 for 128 (tools/bench_wino.py)."""
-    return WINOGRAD and stride == 1 and min(cin, cout) >= 256 and cin % 32 == 0 and cout % 4 == 0
+    """Winograd output tile (0 = direct) for a 3x3 conv.  It pays when the (tile+2)^2 GEMMs are deep enough to run
+    at MFMA rate and the inflated transformed tensors stay cheap next to them (tools/bench_wino.py, batch 16):
+    F(4x4,3x3) x2.2-2.8 over the direct kernel for 256/512 channels and x1.7 for 128; F(2x2,3x3) x1.3-2.0 for
+    256/512 and x1.0 for 128."""
+    if WINOGRAD not in (2, 4) or stride != 1 or cin % 32 != 0 or cout % 4 != 0:
+        return 0
+    return WINOGRAD if min(cin, cout) >= (128 if WINOGRAD == 4 else 256) else 0
 
 
 # =========================================================================================== transform
@@ -295,7 +299,8 @@ class FrozenLayerEngine(object):
             b.f1, b.f2, b.f3 = FrozenAffine(m.bn1), FrozenAffine(m.bn2), FrozenAffine(m.bn3)
             b.wd = WeightCache(m.downsample[0].weight) if b.has_ds else None
             b.fd = FrozenAffine(m.downsample[1]) if b.has_ds else None
-            b.wino = WinoCache(m.conv2.weight) if use_winograd(b.planes, b.planes, b.stride) else None
+            tile = use_winograd(b.planes, b.planes, b.stride)
+            b.wino = WinoCache(m.conv2.weight, tile) if tile else None
             self.blocks.append(b)
         self.bufs = None
         self.plan_key = None
@@ -373,7 +378,7 @@ class FrozenLayerEngine(object):
 
     def _wino_scratch(self, n, h, w, cin, cout):
         """V / M scratch of the Winograd launches of this engine (they run one after another on one stream)."""
-        nv, nm = ops.WinoConv.scratch_elems(n, h, w, cin, cout)
+        nv, nm = ops.WinoConv.scratch_elems(n, h, w, cin, cout, WINOGRAD)
         self._wino_need = (max(nv, getattr(self, '_wino_need', (0, 0))[0]), max(nm, getattr(self, '_wino_need', (0, 0))[1]))
         return self.bufs.get('wino_v', (self._wino_need[0],)), self.bufs.get('wino_m', (self._wino_need[1],))
 
@@ -675,8 +680,8 @@ class FpnEngine(object):
     def __init__(self, inner_blocks, layer_blocks):
         self.inner = [(m, WeightCache(m.weight)) for m in inner_blocks]
         self.layer = [(m, WeightCache(m.weight)) for m in layer_blocks]
-        self.wino = [WinoCache(m.weight) if use_winograd(m.weight.shape[1], m.weight.shape[0], 1) else None
-                     for m in layer_blocks]
+        self.wino = [WinoCache(m.weight, use_winograd(m.weight.shape[1], m.weight.shape[0], 1))
+                     if use_winograd(m.weight.shape[1], m.weight.shape[0], 1) else None for m in layer_blocks]
         self.bufs = None
         self.plan_key = None
         self.flops_fwd = 0
@@ -702,7 +707,8 @@ class FpnEngine(object):
             flops = 0
             # Winograd scratch sized for the finest level up front (the loop runs coarse -> fine)
             n0, h0, w0, _ = feats[0].shape
-            need = ops.WinoConv.scratch_elems(n0, h0, w0, 256, 256) if any(w is not None for w in self.wino) else (0, 0)
+            need = (ops.WinoConv.scratch_elems(n0, h0, w0, 256, 256, WINOGRAD)
+                    if any(w is not None for w in self.wino) else (0, 0))
             for i in range(nlev - 1, -1, -1):
                 f = feats[i]
                 n, h, w, c = f.shape
@@ -714,7 +720,7 @@ class FpnEngine(object):
                 ml, wl = self.layer[i]
                 self.results[i] = self.bufs.get('p%d' % i, (n, h, w, ml.weight.shape[0]))
                 if self.wino[i] is not None:            # 3x3 256->256 output conv: Winograd F(2x2,3x3)
-                    nv, nm = ops.WinoConv.scratch_elems(n, h, w, 256, ml.weight.shape[0])
+                    nv, nm = ops.WinoConv.scratch_elems(n, h, w, 256, ml.weight.shape[0], WINOGRAD)
                     need = (max(nv, need[0]), max(nm, need[1]))
                     v, mm = self.bufs.get('wino_v', (need[0],)), self.bufs.get('wino_m', (need[1],))
                     self.fwd += ops.WinoConv(inner[i], self.wino[i].get(False), self.results[i], v, mm,

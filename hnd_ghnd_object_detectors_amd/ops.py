@@ -394,32 +394,33 @@ def roundtrip_f16(x):
 
 
 # ------------------------------------------------------------------------------ Winograd F(2x2, 3x3)
-def wino_tiles_pad(n, h, w):
-    return int(_L.hnd_wino_tiles_pad(n, h, w))
+def wino_tiles_pad(n, h, w, tile=2):
+    return int(_L.hnd_wino_tiles_pad(n, h, w, tile))
 
 
 class WinoWeights(object):
-    """U = G g G^T of one 3x3 conv weight in packed GEMM-operand layout [16][rows_pad][depth]; dgrad: transposed conv."""
+    """U = G g G^T of one 3x3 conv weight in packed GEMM-operand layout [(tile+2)^2][rows_pad][depth]; dgrad:
+    transposed conv.  tile = 2 (F(2x2,3x3)) or 4 (F(4x4,3x3))."""
 
-    def __init__(self, weight, dgrad=False):
+    def __init__(self, weight, dgrad=False, tile=2):
         cout, cin, kh, kw = weight.shape
-        assert kh == 3 and kw == 3 and weight.is_contiguous()
-        self.src, self.dgrad = weight, dgrad
+        assert kh == 3 and kw == 3 and weight.is_contiguous() and tile in (2, 4)
+        self.src, self.dgrad, self.tile, self.ncomp = weight, dgrad, tile, (tile + 2) ** 2
         self.rows, self.depth = (cin, cout) if dgrad else (cout, cin)
         assert self.depth % 32 == 0, 'Winograd path needs a GEMM depth that is a multiple of 32'
         self.rows_pad = round_up(self.rows, 64)
-        self.buf = torch.empty(16 * self.rows_pad * self.depth, dtype=torch.float32, device=weight.device)
+        self.buf = torch.empty(self.ncomp * self.rows_pad * self.depth, dtype=torch.float32, device=weight.device)
         self.repack()
 
     def repack(self):
         cout, cin = self.src.shape[0], self.src.shape[1]
-        check(_L.hnd_wino_weights(ptr(self.src), ptr(self.buf), cout, cin, int(self.dgrad), stream_ptr()),
+        check(_L.hnd_wino_weights(ptr(self.src), ptr(self.buf), cout, cin, int(self.dgrad), self.tile, stream_ptr()),
               'hnd_wino_weights')
 
 
 class WinoConv(object):
-    """One stride-1 pad-1 3x3 convolution (or its data gradient) as input transform -> 16 GEMMs in one igemm launch
-    -> output transform.  x [N,H,W,C] -> y [N,H,W,ldc]; v / m are caller-provided scratch (see scratch_elems)."""
+    """One stride-1 pad-1 3x3 convolution (or its data gradient) as input transform -> (tile+2)^2 GEMMs in one igemm
+    launch -> output transform.  x [N,H,W,C] -> y [N,H,W,ldc]; v / m are caller-provided scratch (see scratch_elems)."""
 
     def __init__(self, x, ww, y, v, m, pro_scale=None, pro_shift=None, pro_relu=False, epi_scale=None, epi_shift=None,
                  res1=None, mask=None, relu=False):
@@ -427,10 +428,12 @@ class WinoConv(object):
         assert tuple(y.shape[:3]) == (n, h, w) and c == ww.depth
         self.x, self.y, self.ww = x, y, ww
         self.geom = (n, h, w, c)
-        self.tiles_pad = wino_tiles_pad(n, h, w)
+        tile, nc = ww.tile, ww.ncomp
+        self.tile = tile
+        self.tiles_pad = wino_tiles_pad(n, h, w, tile)
         self.cout = round_up(ww.rows, 4)
         assert self.cout <= y.shape[3]
-        need_v, need_m = 16 * self.tiles_pad * c, 16 * self.tiles_pad * self.cout
+        need_v, need_m = nc * self.tiles_pad * c, nc * self.tiles_pad * self.cout
         assert v.numel() >= need_v and m.numel() >= need_m
         if pro_scale is not None and pro_shift is None:
             pro_shift = _zeros(c, x.device)
@@ -438,34 +441,34 @@ class WinoConv(object):
         self.epi = (epi_scale, epi_shift, res1, mask, int(relu))
         for t in (res1, mask):
             assert t is None or tuple(t.shape) == tuple(y.shape)
-        self.v = v[:need_v].view(1, 1, 16 * self.tiles_pad, c)
-        self.m = m[:need_m].view(1, 1, 16 * self.tiles_pad, self.cout)
+        self.v = v[:need_v].view(1, 1, nc * self.tiles_pad, c)
+        self.m = m[:need_m].view(1, 1, nc * self.tiles_pad, self.cout)
         pw = PackedWeight.__new__(PackedWeight)
         pw.buf, pw.kdim, pw.rows, pw.chan_pad, pw.chan_real = ww.buf, ww.depth, ww.rows, c, c
-        self.gemm = conv_desc(self.v, pw, self.m, kh=1, kw=1, oh=1, ow=16 * self.tiles_pad, sh=1, dh=1, bh=0, sw=1,
+        self.gemm = conv_desc(self.v, pw, self.m, kh=1, kw=1, oh=1, ow=nc * self.tiles_pad, sh=1, dh=1, bh=0, sw=1,
                               dw=1, bw=0, cout=self.cout)
         self.gemm.desc.w_group_rows = self.tiles_pad
         self.gemm.desc.w_group_stride = ww.rows_pad * ww.depth
-        tiles = n * ((h + 1) // 2) * ((w + 1) // 2)
-        self.gemm.flops = 2 * 16 * tiles * ww.rows * ww.depth          # multiplies actually executed
+        tiles = n * ((h + tile - 1) // tile) * ((w + tile - 1) // tile)
+        self.gemm.flops = 2 * nc * tiles * ww.rows * ww.depth          # multiplies actually executed
         self.flops = self.gemm.flops
         self.variant = self.gemm.variant
 
     @staticmethod
-    def scratch_elems(n, h, w, cin, cout):
-        tp = wino_tiles_pad(n, h, w)
-        return 16 * tp * cin, 16 * tp * round_up(cout, 4)
+    def scratch_elems(n, h, w, cin, cout, tile=2):
+        tp, nc = wino_tiles_pad(n, h, w, tile), (tile + 2) ** 2
+        return nc * tp * cin, nc * tp * round_up(cout, 4)
 
     def _run_input(self, stream=None):
         n, h, w, c = self.geom
         check(_L.hnd_wino_input(ptr(self.x), ptr(self.v), n, h, w, c, ptr(self.pro[0]), ptr(self.pro[1]), self.pro[2],
-                                stream if stream is not None else stream_ptr()), 'hnd_wino_input')
+                                self.tile, stream if stream is not None else stream_ptr()), 'hnd_wino_input')
 
     def _run_output(self, stream=None):
         n, h, w, c = self.geom
         es, eb, r1, mk, relu = self.epi
         check(_L.hnd_wino_output(ptr(self.m), ptr(self.y), n, h, w, self.cout, self.y.shape[3], ptr(es), ptr(eb),
-                                 ptr(r1), ptr(mk), relu, stream if stream is not None else stream_ptr()),
+                                 ptr(r1), ptr(mk), relu, self.tile, stream if stream is not None else stream_ptr()),
               'hnd_wino_output')
 
     def launches(self, tag):

@@ -157,23 +157,25 @@ int hnd_transform_image_u8(const uint8_t* src, int h, int w, int hwc, int flip, 
                            int out_w, int hp, int wp, float scale_h, float scale_w, const float mean[3],
                            const float std[3], void* stream);
 
-/* ---- Winograd F(2x2, 3x3) for stride-1 pad-1 3x3 convolutions (torchvision Bottleneck.conv2 and the FPN output
- * convs built at src/models/org/rcnn.py:391-414; forward and data gradient) -------------------------------------
- * y = out_transform( GEMM_f( in_transform(x), U_f ) ), f = 0..15, with the 16 GEMMs issued as ONE hnd_conv2d_igemm
- * launch (1x1 conv over 16*tiles_pad "pixels", w_group_rows = tiles_pad, w_group_stride = rows_pad*depth).
- * hnd_wino_tiles_pad: rows per component = n*ceil(h/2)*ceil(w/2) rounded up to 128.
- * hnd_wino_weights:   OIHW [cout][cin][3][3] -> u [16][round_up(rows,64)][depth] (forward: rows = cout, depth = cin;
+/* ---- Winograd F(tile x tile, 3x3), tile = 2 or 4, for stride-1 pad-1 3x3 convolutions (torchvision Bottleneck.conv2
+ * and the FPN output convs built at src/models/org/rcnn.py:391-414; forward and data gradient) ----------------------
+ * y = out_transform( GEMM_f( in_transform(x), U_f ) ), f = 0..(tile+2)^2-1, with all GEMMs issued as ONE
+ * hnd_conv2d_igemm launch (1x1 conv over ncomp*tiles_pad "pixels", w_group_rows = tiles_pad, w_group_stride =
+ * rows_pad*depth).  tile 2: 16 products per 2x2 outputs (2.25x fewer multiplies than direct, transformed tensors 4x);
+ * tile 4: 36 per 4x4 outputs (4x fewer, tensors 2.25x, points 0, +-1, +-2, inf: ~1e-5 relative fp32 error).
+ * hnd_wino_tiles_pad: rows per component = n*ceil(h/tile)*ceil(w/tile) rounded up to 128.
+ * hnd_wino_weights:   OIHW [cout][cin][3][3] -> u [ncomp][round_up(rows,64)][depth] (forward: rows = cout, depth = cin;
  *                     dgrad != 0: rows = cin, depth = cout, taps flipped -- the transposed convolution).
  * hnd_wino_input:     x [n][h][w][c] (+ optional per-channel prologue scale/shift/relu on in-bounds elements)
- *                     -> v [16][tiles_pad][c].
- * hnd_wino_output:    m [16][tiles_pad][cout] -> y [n][h][w][ldc], epilogue order as hnd_conv2d_igemm:
+ *                     -> v [ncomp][tiles_pad][c].
+ * hnd_wino_output:    m [ncomp][tiles_pad][cout] -> y [n][h][w][ldc], epilogue order as hnd_conv2d_igemm:
  *                     scale/shift, + res1, mask (ReLU backward), ReLU. */
-int64_t hnd_wino_tiles_pad(int n, int h, int w);
-int hnd_wino_weights(const float* weight, float* u, int cout, int cin, int dgrad, void* stream);
+int64_t hnd_wino_tiles_pad(int n, int h, int w, int tile);
+int hnd_wino_weights(const float* weight, float* u, int cout, int cin, int dgrad, int tile, void* stream);
 int hnd_wino_input(const float* x, float* v, int n, int h, int w, int c, const float* pro_scale,
-                   const float* pro_shift, int pro_relu, void* stream);
+                   const float* pro_shift, int pro_relu, int tile, void* stream);
 int hnd_wino_output(const float* m, float* y, int n, int h, int w, int cout, int ldc, const float* epi_scale,
-                    const float* epi_shift, const float* res1, const float* mask, int relu, void* stream);
+                    const float* epi_shift, const float* res1, const float* mask, int relu, int tile, void* stream);
 
 /* nn.MaxPool2d(3, 2, 1) (custom/resnet.py:30,99) NHWC; idx (uint8 tap 0..8) kept for backward. */
 int hnd_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* idx, int n, int h, int w, int c, int oh, int ow,

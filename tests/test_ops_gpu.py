@@ -509,9 +509,10 @@ def test_conv_bias_in_epilogue_feeds_bn_statistics(ops):
     assert relerr(tot[0], ref.sum(dim=(0, 2, 3))) < 1e-4 and relerr(tot[1], (ref * ref).sum(dim=(0, 2, 3))) < 1e-4
 
 
+@pytest.mark.parametrize('tile', [2, 4])
 @pytest.mark.parametrize('n,cin,h,w,cout', [(2, 64, 13, 17, 96), (1, 256, 50, 84, 256), (3, 32, 8, 8, 64),
                                             (2, 128, 25, 42, 128), (1, 64, 1, 5, 32)])
-def test_winograd_conv3x3_forward_matches_direct(ops, n, cin, h, w, cout):
+def test_winograd_conv3x3_forward_matches_direct(ops, n, cin, h, w, cout, tile):
     """F(2x2,3x3): input transform -> 16 GEMMs in one igemm launch -> output transform, odd sizes, full epilogue"""
     g = gen(40 + n + cin + h)
     x = torch.randn(n, cin, h, w, generator=g)
@@ -519,16 +520,18 @@ def test_winograd_conv3x3_forward_matches_direct(ops, n, cin, h, w, cout):
     sc, sh = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
     res = torch.randn(n, cout, h, w, generator=g)
     ref = F.relu(F.conv2d(x, wt, None, 1, 1) * sc[None, :, None, None] + sh[None, :, None, None] + res)
-    ww = ops.WinoWeights(wt.to(DEV).contiguous())
-    nv, nm = ops.WinoConv.scratch_elems(n, h, w, cin, cout)
+    ww = ops.WinoWeights(wt.to(DEV).contiguous(), tile=tile)
+    nv, nm = ops.WinoConv.scratch_elems(n, h, w, cin, cout, tile)
     v, m = torch.empty(nv, device=DEV), torch.empty(nm, device=DEV)
     y = torch.full((n, h, w, cout), float('nan'), device=DEV)
     ops.WinoConv(nhwc(x), ww, y, v, m, epi_scale=sc.to(DEV), epi_shift=sh.to(DEV), res1=nhwc(res), relu=True).run()
     ops.sync_check()
-    assert relerr(nchw(y), ref) < 1e-4, relerr(nchw(y), ref)
+    # F(4x4,3x3) multiplies by 4 / 5 / 8 and 1/24 in its transforms: ~1e-5 relative in fp32 (F(2x2): ~1e-6)
+    assert relerr(nchw(y), ref) < (1e-4 if tile == 2 else 2e-4), relerr(nchw(y), ref)
 
 
-def test_winograd_conv3x3_dgrad_with_prologue_and_mask(ops):
+@pytest.mark.parametrize('tile', [2, 4])
+def test_winograd_conv3x3_dgrad_with_prologue_and_mask(ops, tile):
     """data gradient of a 3x3 conv as the transposed Winograd conv: FrozenBN scale on load, ReLU mask on store"""
     g = gen(47)
     n, cin, h, w, cout = 2, 64, 14, 19, 128
@@ -541,13 +544,13 @@ def test_winograd_conv3x3_dgrad_with_prologue_and_mask(ops):
     mk = torch.randn(n, cin, h, w, generator=g)
     base = torch.randn(n, cin, h, w, generator=g)
     ref = torch.where(mk > 0, x.grad + base, torch.zeros_like(base))
-    ww = ops.WinoWeights(wt.to(DEV).contiguous(), dgrad=True)
-    nv, nm = ops.WinoConv.scratch_elems(n, h, w, cout, cin)
+    ww = ops.WinoWeights(wt.to(DEV).contiguous(), dgrad=True, tile=tile)
+    nv, nm = ops.WinoConv.scratch_elems(n, h, w, cout, cin, tile)
     v, m = torch.empty(nv, device=DEV), torch.empty(nm, device=DEV)
     dx = torch.full((n, h, w, cin), float('nan'), device=DEV)
     ops.WinoConv(nhwc(dy), ww, dx, v, m, pro_scale=sc.to(DEV), res1=nhwc(base), mask=nhwc(mk)).run()
     ops.sync_check()
-    assert relerr(nchw(dx), ref) < 1e-4
+    assert relerr(nchw(dx), ref) < (1e-4 if tile == 2 else 2e-4)
 
 
 def test_subsample_and_fill(ops):

@@ -33,16 +33,19 @@ def main():
         sh = torch.randn(cout, device=dev)
         y0, y1 = torch.empty(n, h, w, cout, device=dev), torch.empty(n, h, w, cout, device=dev)
         direct = ops.conv_forward(x, ops.pack_weights(wt), y0, 3, 1, 1, epi_shift=sh, relu=True)
-        ww = ops.WinoWeights(wt)
-        nv, nm = ops.WinoConv.scratch_elems(n, h, w, cin, cout)
-        v, m = torch.empty(nv, device=dev), torch.empty(nm, device=dev)
-        wino = ops.WinoConv(x, ww, y1, v, m, epi_shift=sh, relu=True)
-        td, tw = timed(direct.run), timed(wino.run)
-        tg = timed(wino.gemm.run)
-        err = float((y0 - y1).abs().max() / y0.abs().max())
-        print('%-28s direct %7.3f ms (%5.1f TF)  winograd %7.3f ms (gemm %6.3f ms %5.1f TF, %s)  x%.2f  maxrel %.1e'
-              % (name, td, direct.flops / td / 1e9, tw, tg, wino.gemm.flops / tg / 1e9, wino.variant, td / tw, err),
-              flush=True)
+        td = timed(direct.run)
+        line = '%-26s direct %7.3f ms (%5.1f TF)' % (name, td, direct.flops / td / 1e9)
+        for tile in (2, 4):
+            ww = ops.WinoWeights(wt, tile=tile)
+            nv, nm = ops.WinoConv.scratch_elems(n, h, w, cin, cout, tile)
+            v, m = torch.empty(nv, device=dev), torch.empty(nm, device=dev)
+            wino = ops.WinoConv(x, ww, y1, v, m, epi_shift=sh, relu=True)
+            tw, tg = timed(wino.run), timed(wino.gemm.run)
+            err = float((y0 - y1).abs().max() / y0.abs().max())
+            line += ' | F(%d,3) %7.3f ms (gemm %6.3f ms %5.1f TF %s) x%.2f err %.1e' % (
+                tile, tw, tg, wino.gemm.flops / tg / 1e9, wino.variant.split('_')[-1], td / tw, err)
+            del v, m
+        print(line, flush=True)
 
 
 if __name__ == '__main__':
