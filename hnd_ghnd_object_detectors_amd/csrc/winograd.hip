@@ -361,6 +361,200 @@ __global__ void wino4_output_kernel(const float* __restrict__ m, float* __restri
   }
 }
 
+
+// ================================================================================== F(4x4, 2x2)
+// The student head's 2x2 convolutions (src/models/mimic/resnet_layer.py:43-62) and their data gradients: points
+// {0, 1, -1, 2, inf}, 25 products per 4x4 output tile instead of 64 (2.56x fewer), transformed tensors 25/16 = 1.56x.
+//   A^T = [1 1 1 1 0; 0 1 -1 2 0; 0 1 1 4 0; 0 1 -1 8 1]
+//   G   = [1/2 0; -1/2 -1/2; -1/6 1/6; 1/6 1/3; 0 1]
+//   B^T = [2 -1 -2 1 0; 0 -2 -1 1 0; 0 2 -3 1 0; 0 -1 0 1 0; 0 2 -1 -2 1]
+// Correlation with padding q in {0, 1}: out[y][x] = sum_ij w[i][j] in[y+i-q][x+j-q], output (h+2q-1) x (w+2q-1).
+// The data gradient of such a conv is the same correlation with flipped, transposed weights and padding 1-q.
+__global__ void wino2_weights_kernel(const float* __restrict__ w, float* __restrict__ u, int cout, int cin, int dgrad,
+                                     int rows, int rows_pad, int kdim) {
+  const long long total = (long long)rows_pad * kdim;
+  const int kreal = dgrad ? cout : cin;
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    const int r = (int)(e / kdim), k = (int)(e - (long long)r * kdim);
+    const bool ok = r < rows && k < kreal;
+    float g[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        float v = 0.f;
+        if (ok) v = dgrad ? w[(((size_t)k * cin + r) * 2 + (1 - i)) * 2 + (1 - j)]
+                          : w[(((size_t)r * cin + k) * 2 + i) * 2 + j];
+        g[i][j] = v;
+      }
+    float t[5][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const float a = g[0][j], b = g[1][j];
+      t[0][j] = 0.5f * a;
+      t[1][j] = -0.5f * (a + b);
+      t[2][j] = (b - a) * (1.f / 6.f);
+      t[3][j] = a * (1.f / 6.f) + b * (1.f / 3.f);
+      t[4][j] = b;
+    }
+    const size_t fs = (size_t)rows_pad * kdim;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const float a = t[i][0], b = t[i][1];
+      float* dst = u + ((size_t)(i * 5) * rows_pad + r) * kdim + k;
+      dst[0] = 0.5f * a;
+      dst[fs] = -0.5f * (a + b);
+      dst[2 * fs] = (b - a) * (1.f / 6.f);
+      dst[3 * fs] = a * (1.f / 6.f) + b * (1.f / 3.f);
+      dst[4 * fs] = b;
+    }
+  }
+}
+
+#define HND_WINO2_BT(d0, d1, d2, d3, d4, o0, o1, o2, o3, o4) \
+  do {                                                       \
+    const f32x2 t0_ = 2.f * (d0 - d2) - d1 + d3;             \
+    const f32x2 t1_ = -2.f * d1 - d2 + d3;                   \
+    const f32x2 t2_ = 2.f * d1 - 3.f * d2 + d3;              \
+    const f32x2 t3_ = d3 - d1;                               \
+    const f32x2 t4_ = 2.f * (d1 - d3) - d2 + d4;             \
+    o0 = t0_; o1 = t1_; o2 = t2_; o3 = t3_; o4 = t4_;        \
+  } while (0)
+
+struct Wino2Geom {
+  int n, h, w, c;          // input tensor
+  int oh, ow;              // output extent (h + 2q - 1)
+  int th, tw, tiles_pad, pad;
+};
+
+__global__ void wino2_input_kernel(const float* __restrict__ x, float* __restrict__ v, const Wino2Geom g,
+                                   const float* __restrict__ pro_scale, const float* __restrict__ pro_shift,
+                                   int pro_relu) {
+  const int c2n = g.c >> 1;
+  const long long tiles = (long long)g.n * g.th * g.tw;
+  const long long total = tiles * c2n;
+  const size_t fs = (size_t)g.tiles_pad * g.c;
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    const int c2 = (int)(e % c2n);
+    long long t = e / c2n;
+    const int tx = (int)(t % g.tw);
+    long long q = t / g.tw;
+    const int ty = (int)(q % g.th), b = (int)(q / g.th);
+    f32x2 ps = {1.f, 1.f}, pb = {0.f, 0.f};
+    if (pro_scale) {
+      ps = *(const f32x2*)(pro_scale + c2 * 2);
+      pb = *(const f32x2*)(pro_shift + c2 * 2);
+    }
+    const float floor_ = pro_relu ? 0.f : -INFINITY;
+    f32x2 d[5][5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int iy = 4 * ty - g.pad + i;
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        const int ix = 4 * tx - g.pad + j;
+        const bool ok = (unsigned)iy < (unsigned)g.h && (unsigned)ix < (unsigned)g.w;
+        const size_t off = ok ? (((size_t)b * g.h + iy) * g.w + ix) * g.c + c2 * 2 : 0;
+        f32x2 a = *(const f32x2*)(x + off);
+        if (pro_scale) {
+          a = a * ps + pb;
+          a.x = fmaxf(a.x, floor_); a.y = fmaxf(a.y, floor_);
+        }
+        const f32x2 z = {0.f, 0.f};
+        d[i][j] = ok ? a : z;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+      HND_WINO2_BT(d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[0][j], d[1][j], d[2][j], d[3][j], d[4][j]);
+    float* dst = v + (size_t)t * g.c + c2 * 2;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      f32x2 o0, o1, o2, o3, o4;
+      HND_WINO2_BT(d[i][0], d[i][1], d[i][2], d[i][3], d[i][4], o0, o1, o2, o3, o4);
+      *(f32x2*)(dst + (size_t)(i * 5 + 0) * fs) = o0;
+      *(f32x2*)(dst + (size_t)(i * 5 + 1) * fs) = o1;
+      *(f32x2*)(dst + (size_t)(i * 5 + 2) * fs) = o2;
+      *(f32x2*)(dst + (size_t)(i * 5 + 3) * fs) = o3;
+      *(f32x2*)(dst + (size_t)(i * 5 + 4) * fs) = o4;
+    }
+  }
+}
+
+#define HND_WINO2_AT(m0, m1, m2, m3, m4, o0, o1, o2, o3) \
+  do {                                                   \
+    const f32x2 p12 = m1 + m2, q12 = m1 - m2;            \
+    o0 = m0 + p12 + m3;                                  \
+    o1 = q12 + 2.f * m3;                                 \
+    o2 = p12 + 4.f * m3;                                 \
+    o3 = q12 + 8.f * m3 + m4;                            \
+  } while (0)
+
+// Output transform (+ scale/shift, ReLU) of the 2x2 Winograd conv.  With `stats`, every block also writes the partial
+// (sum v, sum v^2) per output channel of the values it stored -> stats[blockIdx][2][cout]: the train-mode BatchNorm
+// statistics hnd_bn_finalize consumes (ntiles = gridDim.x).  Requires 512 % cout == 0 so a thread keeps its channels.
+__global__ void wino2_output_kernel(const float* __restrict__ m, float* __restrict__ y, const Wino2Geom g, int cout,
+                                    int ldc, const float* __restrict__ epi_scale, const float* __restrict__ epi_shift,
+                                    int relu, float* __restrict__ stats) {
+  __shared__ float red[2][512];
+  const int c2n = cout >> 1;
+  const long long tiles = (long long)g.n * g.th * g.tw;
+  const long long total = tiles * c2n;
+  const size_t fs = (size_t)g.tiles_pad * cout;
+  f32x2 s1 = {0.f, 0.f}, s2 = {0.f, 0.f};
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    const int c2 = (int)(e % c2n);
+    long long t = e / c2n;
+    const int tx = (int)(t % g.tw);
+    long long q = t / g.tw;
+    const int ty = (int)(q % g.th), b = (int)(q / g.th);
+    const float* src = m + (size_t)t * cout + c2 * 2;
+    f32x2 s[4][5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const f32x2 m0 = *(const f32x2*)(src + (size_t)(0 * 5 + j) * fs), m1 = *(const f32x2*)(src + (size_t)(1 * 5 + j) * fs),
+                  m2 = *(const f32x2*)(src + (size_t)(2 * 5 + j) * fs), m3 = *(const f32x2*)(src + (size_t)(3 * 5 + j) * fs),
+                  m4 = *(const f32x2*)(src + (size_t)(4 * 5 + j) * fs);
+      HND_WINO2_AT(m0, m1, m2, m3, m4, s[0][j], s[1][j], s[2][j], s[3][j]);
+    }
+    f32x2 es = {1.f, 1.f}, eb = {0.f, 0.f};
+    if (epi_scale) es = *(const f32x2*)(epi_scale + c2 * 2);
+    if (epi_shift) eb = *(const f32x2*)(epi_shift + c2 * 2);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int oy = 4 * ty + a;
+      f32x2 o[4];
+      HND_WINO2_AT(s[a][0], s[a][1], s[a][2], s[a][3], s[a][4], o[0], o[1], o[2], o[3]);
+#pragma unroll
+      for (int bb = 0; bb < 4; ++bb) {
+        const int ox = 4 * tx + bb;
+        if (oy >= g.oh || ox >= g.ow) continue;
+        f32x2 v = o[bb] * es + eb;
+        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); }
+        *(f32x2*)(y + (((size_t)b * g.oh + oy) * g.ow + ox) * ldc + c2 * 2) = v;
+        s1 += v;
+        s2 += v * v;
+      }
+    }
+  }
+  if (stats) {
+    // threads tid and tid + k*c2n hold the same channel pair: fold them in a fixed order
+    red[0][threadIdx.x * 2] = s1.x; red[0][threadIdx.x * 2 + 1] = s1.y;
+    red[1][threadIdx.x * 2] = s2.x; red[1][threadIdx.x * 2 + 1] = s2.y;
+    __syncthreads();
+    if ((int)threadIdx.x < cout) {
+      float a1 = 0.f, a2 = 0.f;
+      for (int k = threadIdx.x; k < 512; k += cout) { a1 += red[0][k]; a2 += red[1][k]; }
+      float* st = stats + (size_t)blockIdx.x * 2 * cout;
+      st[threadIdx.x] = a1;
+      st[cout + threadIdx.x] = a2;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -415,6 +609,53 @@ int hnd_wino_output(const float* m, float* y, int n, int h, int w, int cout, int
     hipLaunchKernelGGL(wino4_output_kernel, dim3(grid_for(tiles * (cout / 2))), dim3(256), 0, hnd::as_stream(stream), m,
                        y, g, cout, ep);
   return hnd::check_launch("hnd_wino_output");
+}
+
+/* ---- F(4x4, 2x2): the 2x2 convolutions of the student head ---- */
+int64_t hnd_wino2_tiles_pad(int n, int oh, int ow) {
+  const long long t = (long long)n * ((oh + 3) / 4) * ((ow + 3) / 4);
+  return (t + 127) / 128 * 128;
+}
+
+int hnd_wino2_stats_blocks(int n, int oh, int ow, int cout) {
+  const long long tiles = (long long)n * ((oh + 3) / 4) * ((ow + 3) / 4);
+  long long b = (tiles * (cout / 2) + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+}
+
+int hnd_wino2_weights(const float* weight, float* u, int cout, int cin, int dgrad, void* stream) {
+  HND_REQUIRE(weight && u && cout > 0 && cin > 0, "hnd_wino2_weights: bad arguments");
+  const int rows = dgrad ? cin : cout, kreal = dgrad ? cout : cin;
+  HND_REQUIRE(kreal % 32 == 0, "hnd_wino2_weights: GEMM depth %d must be a multiple of 32", kreal);
+  const int rows_pad = (rows + 63) / 64 * 64;
+  hipLaunchKernelGGL(wino2_weights_kernel, dim3(grid_for((long long)rows_pad * kreal)), dim3(256), 0,
+                     hnd::as_stream(stream), weight, u, cout, cin, dgrad, rows, rows_pad, kreal);
+  return hnd::check_launch("hnd_wino2_weights");
+}
+
+int hnd_wino2_input(const float* x, float* v, int n, int h, int w, int c, int pad, const float* pro_scale,
+                    const float* pro_shift, int pro_relu, void* stream) {
+  HND_REQUIRE(x && v && n > 0 && h > 0 && w > 0 && c > 0 && c % 2 == 0 && (pad == 0 || pad == 1) &&
+                  h + 2 * pad - 1 > 0 && w + 2 * pad - 1 > 0, "hnd_wino2_input: bad arguments");
+  HND_REQUIRE(pro_scale == nullptr || pro_shift != nullptr, "hnd_wino2_input: pro_shift is required with pro_scale");
+  const int oh = h + 2 * pad - 1, ow = w + 2 * pad - 1;
+  Wino2Geom g{n, h, w, c, oh, ow, (oh + 3) / 4, (ow + 3) / 4, (int)hnd_wino2_tiles_pad(n, oh, ow), pad};
+  const long long tiles = (long long)n * g.th * g.tw;
+  hipLaunchKernelGGL(wino2_input_kernel, dim3(grid_for(tiles * (c / 2))), dim3(256), 0, hnd::as_stream(stream), x, v, g,
+                     pro_scale, pro_shift, pro_relu);
+  return hnd::check_launch("hnd_wino2_input");
+}
+
+int hnd_wino2_output(const float* m, float* y, int n, int oh, int ow, int cout, int ldc, const float* epi_scale,
+                     const float* epi_shift, int relu, float* stats, void* stream) {
+  HND_REQUIRE(m && y && n > 0 && oh > 0 && ow > 0 && cout > 0 && cout % 2 == 0 && ldc >= cout && ldc % 2 == 0,
+              "hnd_wino2_output: bad arguments");
+  HND_REQUIRE(stats == nullptr || 512 % cout == 0, "hnd_wino2_output: stats need 512 %% cout == 0 (cout=%d)", cout);
+  Wino2Geom g{n, 0, 0, 0, oh, ow, (oh + 3) / 4, (ow + 3) / 4, (int)hnd_wino2_tiles_pad(n, oh, ow), 0};
+  const int blocks = hnd_wino2_stats_blocks(n, oh, ow, cout);
+  hipLaunchKernelGGL(wino2_output_kernel, dim3(blocks), dim3(256), 0, hnd::as_stream(stream), m, y, g, cout, ldc,
+                     epi_scale, epi_shift, relu, stats);
+  return hnd::check_launch("hnd_wino2_output");
 }
 
 }  // extern "C"

@@ -147,6 +147,27 @@ class WinoCache(object):
             self.ver = ver
 
 
+class Wino2Cache(object):
+    """F(4x4,2x2) weights (forward / transposed) of one head conv; trainable, so re-transformed every step."""
+
+    def __init__(self, weight):
+        self.weight, self.packs, self.ver = weight, {}, None
+
+    def get(self, dgrad=False):
+        ww = self.packs.get(dgrad)
+        if ww is None:
+            ww = self.packs[dgrad] = ops.Wino2Weights(self.weight.detach(), dgrad)
+        return ww
+
+    def refresh(self, force=False):
+        ver = (self.weight._version, self.weight.data_ptr())
+        if force or ver != self.ver:
+            for ww in self.packs.values():
+                ww.src = self.weight.detach()
+                ww.repack()
+            self.ver = ver
+
+
 def use_winograd(cin, cout, stride):
     """Winograd output tile (0 = direct) for a 3x3 conv.  It pays when the (tile+2)^2 GEMMs are deep enough to run
     at MFMA rate and the inflated transformed tensors stay cheap next to them (tools/bench_wino.py, batch 16):
@@ -447,7 +468,7 @@ class FrozenLayerEngine(object):
 
 # =========================================================================================== student head
 class _HeadConv(object):
-    __slots__ = ('conv', 'bn', 'pad', 'relu', 'cin', 'cout', 'cs_in', 'cs_out', 'wc')
+    __slots__ = ('conv', 'bn', 'pad', 'relu', 'cin', 'cout', 'cs_in', 'cs_out', 'wc', 'wino')
 
 
 class HeadEngine(object):
@@ -464,6 +485,10 @@ class HeadEngine(object):
             hc.cout, hc.cin = conv.weight.shape[0], conv.weight.shape[1]
             hc.cs_in, hc.cs_out = ops.chan_pad_of(hc.cin), ops.chan_pad_of(hc.cout)
             hc.wc = WeightCache(conv.weight)
+            # F(4x4,2x2) pays for the two deep decoder convs (128->256, 256->256: x1.2-1.45 forward and dgrad,
+            # tools/bench_wino2.py); with 64 channels on either side the 25 GEMMs are HBM-bound and lose
+            hc.wino = Wino2Cache(conv.weight) if (WINOGRAD and min(hc.cin, hc.cout) >= 128 and
+                                                  512 % hc.cout == 0) else None
             self.layers.append(hc)
         self.bufs = None
         self.plan_key = None
@@ -475,6 +500,11 @@ class HeadEngine(object):
         if self.bufs is None:
             self.bufs = Buffers(x.device)
         for hc in self.layers:
+            if hc.wino is not None:
+                hc.wino.get(False)
+                hc.wino.refresh(force=training)
+                hc.wc.refresh(force=training)        # transposed / wgrad-side packs, if any were made
+                continue
             hc.wc.get(False, hc.cs_in)
             hc.wc.refresh(force=training)
         ptrs = tuple(t.data_ptr() for hc in self.layers
@@ -491,7 +521,8 @@ class HeadEngine(object):
                 bn = hc.bn
                 ops.fbn_fold(bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
                              eps=BN_EPS, cs=hc.cs_out, out=(self.scale[i], self.shift[i]))
-            _run(self.convs[i], 'layer1.conv%d' % i)
+            for l, tag in self.convs[i]:
+                _run(l, tag)
             if codec is not None and i == self.encoder_len - 1:
                 # eval-time bottleneck transformer on z = encoder output (logical [N, bch, H, W]); the codec
                 # writes the dequantised tensor back into the same buffer, which the decoder plan reads
@@ -503,7 +534,7 @@ class HeadEngine(object):
             if training:
                 bn = hc.bn
                 m = self.count[i]
-                ops.bn_finalize(self.stats[i], ops.stats_tiles(m), hc.cout, hc.cs_out, m, bn.weight.detach(),
+                ops.bn_finalize(self.stats[i], self.ntiles[i], hc.cout, hc.cs_out, m, bn.weight.detach(),
                                 bn.bias.detach(), bn.running_mean, bn.running_var, bn.num_batches_tracked,
                                 BN_MOMENTUM, BN_EPS, self.scale[i], self.shift[i], self.mean[i], self.rstd[i])
         ops.affine_relu(self.y[-1], self.scale[-1], self.shift[-1], self.out, self.layers[-1].relu)
@@ -515,19 +546,27 @@ class HeadEngine(object):
         b = self.bufs
         self.x = x
         self.y, self.stats, self.scale, self.shift, self.mean, self.rstd = [], [], [], [], [], []
-        self.convs, self.count = [], []
+        self.convs, self.count, self.ntiles = [], [], []
         cur, cur_scale, cur_shift, cur_relu = x, None, None, False
         flops = 0
         for i, hc in enumerate(self.layers):
             oh, ow = ops.conv_out_size(h, 2, 1, hc.pad), ops.conv_out_size(w, 2, 1, hc.pad)
             y = b.get('y%d' % i, (n, oh, ow, hc.cs_out))
             m = n * oh * ow
-            st = b.get('stats%d' % i, (ops.stats_tiles(m), 2, hc.cs_out)) if training else None
+            nt = ops.Wino2Conv.stats_blocks(n, oh, ow, hc.cs_out) if hc.wino is not None else ops.stats_tiles(m)
+            st = b.get('stats%d' % i, (nt, 2, hc.cs_out)) if training else None
             sc, sh = b.get('scale%d' % i, (hc.cs_out,)), b.get('shift%d' % i, (hc.cs_out,))
             mu, rs = b.get('mean%d' % i, (hc.cs_out,)), b.get('rstd%d' % i, (hc.cs_out,))
-            self.convs.append(ops.conv_forward(cur, hc.wc.get(False, hc.cs_in), y, 2, 1, hc.pad,
-                                               pro_scale=cur_scale, pro_shift=cur_shift, pro_relu=cur_relu,
-                                               stats=st))
+            if hc.wino is not None:
+                v, mm = self._wino_scratch(n, oh, ow, hc.cs_in, hc.cs_out)
+                self.convs.append(ops.Wino2Conv(cur, hc.wino.get(False), y, v, mm, hc.pad, pro_scale=cur_scale,
+                                                pro_shift=cur_shift, pro_relu=cur_relu,
+                                                stats=st).launches('layer1.conv%d' % i))
+            else:
+                self.convs.append([(ops.conv_forward(cur, hc.wc.get(False, hc.cs_in), y, 2, 1, hc.pad,
+                                                     pro_scale=cur_scale, pro_shift=cur_shift, pro_relu=cur_relu,
+                                                     stats=st), 'layer1.conv%d' % i)])
+            self.ntiles.append(nt)
             flops += 2 * m * hc.cout * 4 * hc.cin
             self.y.append(y)
             self.stats.append(st)
@@ -540,6 +579,12 @@ class HeadEngine(object):
             h, w = oh, ow
         self.out = b.get('out', (n, h, w, self.layers[-1].cs_out))
         self.flops_fwd = flops
+
+    def _wino_scratch(self, n, oh, ow, cin, cout):
+        nv, nm = ops.Wino2Conv.scratch_elems(n, oh, ow, cin, cout)
+        cur = getattr(self, '_wino_need', (0, 0))
+        self._wino_need = (max(nv, cur[0]), max(nm, cur[1]))
+        return self.bufs.get('wino_v', (self._wino_need[0],)), self.bufs.get('wino_m', (self._wino_need[1],))
 
     def bottleneck(self):
         """(raw conv output, scale, shift, relu) of the encoder's last conv = the bottleneck tensor z."""
@@ -556,6 +601,10 @@ class HeadEngine(object):
         if not hasattr(self, 'parts'):
             self.parts = {}
         for hc in self.layers[lo:hi]:
+            if hc.wino is not None:
+                hc.wino.get(False)
+                hc.wino.refresh()
+                continue
             hc.wc.get(False, hc.cs_in)
             hc.wc.refresh()
         b = self.bufs
@@ -577,8 +626,14 @@ class HeadEngine(object):
                 hc = self.layers[i]
                 oh, ow = ops.conv_out_size(h, 2, 1, hc.pad), ops.conv_out_size(w, 2, 1, hc.pad)
                 y = b.get('%s.y%d' % (part, i), (n, oh, ow, hc.cs_out))
-                plan['convs'].append(ops.conv_forward(cur, hc.wc.get(False, hc.cs_in), y, 2, 1, hc.pad,
-                                                      pro_scale=pro[0], pro_shift=pro[1], pro_relu=pro[2]))
+                tag = 'layer1.%s.conv%d' % (part, i)
+                if hc.wino is not None:          # same arithmetic as the unsplit model
+                    v, mm = self._wino_scratch(n, oh, ow, hc.cs_in, hc.cs_out)
+                    plan['convs'] += ops.Wino2Conv(cur, hc.wino.get(False), y, v, mm, hc.pad, pro_scale=pro[0],
+                                                   pro_shift=pro[1], pro_relu=pro[2]).launches(tag)
+                else:
+                    plan['convs'].append((ops.conv_forward(cur, hc.wc.get(False, hc.cs_in), y, 2, 1, hc.pad,
+                                                           pro_scale=pro[0], pro_shift=pro[1], pro_relu=pro[2]), tag))
                 plan['y'].append(y)
                 cur, pro, h, w = y, plan['fold'][i] + (hc.relu,), oh, ow
             plan['out'] = b.get('%s.out' % part, cur.shape) if part == 'decoder' else cur
@@ -587,8 +642,8 @@ class HeadEngine(object):
             bn = self.layers[i].bn
             ops.fbn_fold(bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, eps=BN_EPS,
                          cs=self.layers[i].cs_out, out=(sc, sh))
-        for i, l in enumerate(plan['convs']):
-            _run(l, 'layer1.%s.conv%d' % (part, lo + i))
+        for l, tag in plan['convs']:
+            _run(l, tag)
         if part == 'decoder':
             last = len(self.layers) - 1
             ops.affine_relu(plan['y'][-1], plan['fold'][last][0], plan['fold'][last][1], plan['out'],
@@ -617,8 +672,8 @@ class HeadEngine(object):
             ops.bn_bwd_apply(g, self.y[i], self.scale[i], self.shift[i], st['k123'], hc.relu, g)   # in place -> dy
             if st['wgrad'] is not None:
                 _run(st['wgrad'], 'layer1.conv%d.wgrad' % i)
-            for l in st['dgrad']:
-                _run(l, 'layer1.conv%d.dgrad' % i)
+            for l, tag in st['dgrad']:
+                _run(l, tag)
         return self.g_in if need_input_grad else None
 
     def _build_backward(self, grad_dst, need_input_grad):
@@ -659,10 +714,16 @@ class HeadEngine(object):
                 flops += 2 * npix * hc.cout * 4 * hc.cin
             st['dgrad'] = []
             tgt = gbuf[i - 1] if i > 0 else self.g_in
-            if tgt is not None:
+            if tgt is not None and hc.wino is not None:
+                nd, hd, wd, _ = tgt.shape
+                v, mm = self._wino_scratch(nd, hd, wd, hc.cs_out, hc.cs_in)
+                st['dgrad'] = ops.Wino2Conv(gbuf[i], hc.wino.get(True), tgt, v, mm,
+                                            1 - hc.pad).launches('layer1.conv%d.dgrad' % i)
+                flops += 2 * npix * hc.cout * 4 * hc.cin
+            elif tgt is not None:
                 pk = hc.wc.get(True, hc.cs_out)
                 ls, _ = _dgrad_with_pack(gbuf[i], hc, tgt, pk)
-                st['dgrad'] = ls
+                st['dgrad'] = [(l, 'layer1.conv%d.dgrad' % i) for l in ls]
                 flops += 2 * npix * hc.cout * 4 * hc.cin
             self.bsteps[i] = st
         self.flops_bwd = flops

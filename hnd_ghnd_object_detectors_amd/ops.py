@@ -482,6 +482,90 @@ class WinoConv(object):
         self._run_output(stream)
 
 
+class Wino2Weights(object):
+    """F(4x4,2x2) weights of one 2x2 conv in packed GEMM-operand layout [25][rows_pad][depth]; dgrad: transposed conv."""
+
+    def __init__(self, weight, dgrad=False):
+        cout, cin, kh, kw = weight.shape
+        assert kh == 2 and kw == 2 and weight.is_contiguous()
+        self.src, self.dgrad, self.ncomp = weight, dgrad, 25
+        self.rows, self.depth = (cin, cout) if dgrad else (cout, cin)
+        assert self.depth % 32 == 0, 'Winograd path needs a GEMM depth that is a multiple of 32'
+        self.rows_pad = round_up(self.rows, 64)
+        self.buf = torch.empty(25 * self.rows_pad * self.depth, dtype=torch.float32, device=weight.device)
+        self.repack()
+
+    def repack(self):
+        cout, cin = self.src.shape[0], self.src.shape[1]
+        check(_L.hnd_wino2_weights(self.src.data_ptr(), ptr(self.buf), cout, cin, int(self.dgrad), stream_ptr()),
+              'hnd_wino2_weights')
+
+
+class Wino2Conv(object):
+    """One 2x2 correlation with padding `pad` in {0, 1} (a head conv, or -- with Wino2Weights(dgrad=True) and padding
+    1 - pad_of_the_conv -- its data gradient): x [N,H,W,C] -> y [N,H+2pad-1,W+2pad-1,ldc].  Optional BN(+ReLU)
+    prologue on load; optional per-block BN statistics of the stored output (stats: [stats_blocks][2][cout])."""
+
+    def __init__(self, x, ww, y, v, m, pad, pro_scale=None, pro_shift=None, pro_relu=False, epi_scale=None,
+                 epi_shift=None, relu=False, stats=None):
+        n, h, w, c = _nhwc(x)
+        oh, ow = h + 2 * pad - 1, w + 2 * pad - 1
+        assert tuple(y.shape[:3]) == (n, oh, ow) and c == ww.depth and pad in (0, 1)
+        self.x, self.y, self.ww, self.pad = x, y, ww, pad
+        self.geom = (n, h, w, c, oh, ow)
+        self.tiles_pad = int(_L.hnd_wino2_tiles_pad(n, oh, ow))
+        self.cout = round_up(ww.rows, 2)
+        assert self.cout <= y.shape[3]
+        need_v, need_m = 25 * self.tiles_pad * c, 25 * self.tiles_pad * self.cout
+        assert v.numel() >= need_v and m.numel() >= need_m
+        if pro_scale is not None and pro_shift is None:
+            pro_shift = _zeros(c, x.device)
+        self.pro = (pro_scale, pro_shift, int(pro_relu))
+        self.epi = (epi_scale, epi_shift, int(relu))
+        self.stats = stats
+        if stats is not None:
+            assert stats.numel() >= self.stats_blocks(n, oh, ow, self.cout) * 2 * self.cout
+        self.v = v[:need_v].view(1, 1, 25 * self.tiles_pad, c)
+        self.m = m[:need_m].view(1, 1, 25 * self.tiles_pad, self.cout)
+        pw = PackedWeight.__new__(PackedWeight)
+        pw.buf, pw.kdim, pw.rows, pw.chan_pad, pw.chan_real = ww.buf, ww.depth, ww.rows, c, c
+        self.gemm = conv_desc(self.v, pw, self.m, kh=1, kw=1, oh=1, ow=25 * self.tiles_pad, sh=1, dh=1, bh=0, sw=1,
+                              dw=1, bw=0, cout=self.cout)
+        self.gemm.desc.w_group_rows = self.tiles_pad
+        self.gemm.desc.w_group_stride = ww.rows_pad * ww.depth
+        tiles = n * ((oh + 3) // 4) * ((ow + 3) // 4)
+        self.gemm.flops = 2 * 25 * tiles * ww.rows * ww.depth
+        self.flops, self.variant = self.gemm.flops, self.gemm.variant
+
+    @staticmethod
+    def scratch_elems(n, oh, ow, cin, cout):
+        tp = int(_L.hnd_wino2_tiles_pad(n, oh, ow))
+        return 25 * tp * cin, 25 * tp * round_up(cout, 2)
+
+    @staticmethod
+    def stats_blocks(n, oh, ow, cout):
+        return int(_L.hnd_wino2_stats_blocks(n, oh, ow, cout))
+
+    def _run_input(self, stream=None):
+        n, h, w, c, oh, ow = self.geom
+        check(_L.hnd_wino2_input(ptr(self.x), ptr(self.v), n, h, w, c, self.pad, ptr(self.pro[0]), ptr(self.pro[1]),
+                                 self.pro[2], stream if stream is not None else stream_ptr()), 'hnd_wino2_input')
+
+    def _run_output(self, stream=None):
+        n, h, w, c, oh, ow = self.geom
+        check(_L.hnd_wino2_output(ptr(self.m), ptr(self.y), n, oh, ow, self.cout, self.y.shape[3], ptr(self.epi[0]),
+                                  ptr(self.epi[1]), self.epi[2], ptr(self.stats),
+                                  stream if stream is not None else stream_ptr()), 'hnd_wino2_output')
+
+    def launches(self, tag):
+        return [(_Step(self._run_input), tag + '.wino_in'), (self.gemm, tag), (_Step(self._run_output), tag + '.wino_out')]
+
+    def run(self, stream=None):
+        self._run_input(stream)
+        self.gemm.run(stream)
+        self._run_output(stream)
+
+
 class _Step(object):
     """a plan entry without MFMA work"""
     __slots__ = ('fn', 'flops')

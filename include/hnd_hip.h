@@ -177,6 +177,20 @@ int hnd_wino_input(const float* x, float* v, int n, int h, int w, int c, const f
 int hnd_wino_output(const float* m, float* y, int n, int h, int w, int cout, int ldc, const float* epi_scale,
                     const float* epi_shift, const float* res1, const float* mask, int relu, int tile, void* stream);
 
+/* ---- Winograd F(4x4, 2x2) for the student head's 2x2 convolutions (src/models/mimic/resnet_layer.py:43-62), forward
+ * (padding 1 in the encoder, 0 in the decoder) and data gradient (the same correlation with flipped, transposed
+ * weights and padding 1 - pad): 25 GEMMs in one grouped hnd_conv2d_igemm launch, 2.56x fewer multiplies than direct.
+ * Geometry is given by the OUTPUT extent oh x ow = (h + 2*pad - 1) x (w + 2*pad - 1).
+ * hnd_wino2_output with `stats` also emits the per-block partial (sum, sum of squares) per channel of what it stored:
+ * stats[hnd_wino2_stats_blocks(...)][2][cout], the layout hnd_bn_finalize reads (ntiles = number of blocks). */
+int64_t hnd_wino2_tiles_pad(int n, int oh, int ow);
+int hnd_wino2_stats_blocks(int n, int oh, int ow, int cout);
+int hnd_wino2_weights(const float* weight, float* u, int cout, int cin, int dgrad, void* stream);
+int hnd_wino2_input(const float* x, float* v, int n, int h, int w, int c, int pad, const float* pro_scale,
+                    const float* pro_shift, int pro_relu, void* stream);
+int hnd_wino2_output(const float* m, float* y, int n, int oh, int ow, int cout, int ldc, const float* epi_scale,
+                     const float* epi_shift, int relu, float* stats, void* stream);
+
 /* nn.MaxPool2d(3, 2, 1) (custom/resnet.py:30,99) NHWC; idx (uint8 tap 0..8) kept for backward. */
 int hnd_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* idx, int n, int h, int w, int c, int oh, int ow,
                          void* stream);

@@ -553,6 +553,47 @@ def test_winograd_conv3x3_dgrad_with_prologue_and_mask(ops, tile):
     assert relerr(nchw(dx), ref) < (1e-4 if tile == 2 else 2e-4)
 
 
+@pytest.mark.parametrize('n,cin,h,w,cout,pad', [(2, 64, 13, 17, 64, 1), (2, 256, 21, 30, 256, 0), (1, 128, 9, 9, 256, 0),
+                                                (3, 64, 8, 11, 256, 1), (2, 256, 12, 16, 64, 1)])
+def test_winograd_conv2x2_forward_prologue_and_bn_stats(ops, n, cin, h, w, cout, pad):
+    """F(4x4,2x2) head conv: BN+ReLU on load, raw output + per-channel (sum, sum^2) partials for the next BN"""
+    g = gen(60 + cin + h)
+    x = torch.randn(n, cin, h, w, generator=g)
+    ps, pb = torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g) * 0.3
+    wt = torch.randn(cout, cin, 2, 2, generator=g) / math.sqrt(cin * 4)
+    ref = F.conv2d(F.relu(x * ps[None, :, None, None] + pb[None, :, None, None]), wt, None, 1, pad)
+    oh, ow = ref.shape[2], ref.shape[3]
+    ww = ops.Wino2Weights(wt.to(DEV).contiguous())
+    nv, nm = ops.Wino2Conv.scratch_elems(n, oh, ow, cin, cout)
+    v, m = torch.empty(nv, device=DEV), torch.empty(nm, device=DEV)
+    y = torch.full((n, oh, ow, cout), float('nan'), device=DEV)
+    nb = ops.Wino2Conv.stats_blocks(n, oh, ow, cout)
+    st = torch.full((nb, 2, cout), float('nan'), device=DEV)
+    ops.Wino2Conv(nhwc(x), ww, y, v, m, pad, pro_scale=ps.to(DEV), pro_shift=pb.to(DEV), pro_relu=True, stats=st).run()
+    ops.sync_check()
+    assert relerr(nchw(y), ref) < 2e-4, relerr(nchw(y), ref)
+    tot = st.sum(dim=0).cpu()
+    assert relerr(tot[0], ref.sum(dim=(0, 2, 3))) < 2e-4 and relerr(tot[1], (ref * ref).sum(dim=(0, 2, 3))) < 2e-4
+
+
+@pytest.mark.parametrize('pad', [0, 1])
+def test_winograd_conv2x2_dgrad(ops, pad):
+    g = gen(71 + pad)
+    n, cin, h, w, cout = 2, 128, 14, 19, 256
+    x = torch.randn(n, cin, h, w, generator=g, requires_grad=True)
+    wt = torch.randn(cout, cin, 2, 2, generator=g) / math.sqrt(cin * 4)
+    out = F.conv2d(x, wt, None, 1, pad)
+    dy = torch.randn(out.shape, generator=g)
+    out.backward(dy)
+    ww = ops.Wino2Weights(wt.to(DEV).contiguous(), dgrad=True)
+    nv, nm = ops.Wino2Conv.scratch_elems(n, h, w, cout, cin)
+    v, m = torch.empty(nv, device=DEV), torch.empty(nm, device=DEV)
+    dx = torch.full((n, h, w, cin), float('nan'), device=DEV)
+    ops.Wino2Conv(nhwc(dy), ww, dx, v, m, 1 - pad).run()
+    ops.sync_check()
+    assert relerr(nchw(dx), x.grad) < 2e-4
+
+
 def test_subsample_and_fill(ops):
     x = torch.randn(2, 256, 7, 9, generator=gen(14))
     y = torch.empty(2, 4, 5, 256, device=DEV)

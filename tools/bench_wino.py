@@ -10,7 +10,8 @@ from hnd_ghnd_object_detectors_amd import ops  # noqa: E402
 
 SHAPES = {'fpn.layer0 256@200x336': (256, 200, 336, 256), 'fpn.layer1 256@100x168': (256, 100, 168, 256),
           'layer3.conv2 256@50x84': (256, 50, 84, 256), 'layer4.conv2 512@25x42': (512, 25, 42, 512),
-          'layer2.conv2 128@100x168': (128, 100, 168, 128), 'fpn.layer2 256@50x84': (256, 50, 84, 256)}
+          'layer2.conv2 128@100x168': (128, 100, 168, 128), 'fpn.layer2 256@50x84': (256, 50, 84, 256),
+          'layer1.conv2 64@200x336': (64, 200, 336, 64), 'fpn.layer3 256@25x42': (256, 25, 42, 256)}
 
 
 def timed(fn, iters=10):
