@@ -30,6 +30,10 @@ def short(name):
                      ('wgrad_kernelILi128', 'wgrad_m128'), ('wgrad_kernelILi64', 'wgrad_m64')):
         if key in name:
             return lab
+    for key in ('wino4_input', 'wino4_output', 'wino4_weights', 'wino2_input', 'wino2_output', 'wino2_weights',
+                'wino_input', 'wino_output', 'wino_weights'):
+        if key + '_kernel' in name:
+            return key
     name = name.replace('void ', '').replace('(anonymous namespace)::', '').replace('_ZN12_GLOBAL__N_1', '')
     return name.split('(')[0][:48]
 
