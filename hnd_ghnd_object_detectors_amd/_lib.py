@@ -28,7 +28,8 @@ class WgradDesc(C.Structure):
     """struct hnd_wgrad_desc"""
     _fields_ = [(n, vp) for n in ('x', 'dy', 'dw', 'slabs', 'pro_scale', 'pro_shift')] + \
                [(n, C.c_int32) for n in ('n', 'h', 'w_', 'cin', 'cin_real', 'oh', 'ow', 'cout', 'ldy',
-                                         'kh', 'kw', 'stride', 'pad', 'pro_relu', 'splitk')]
+                                         'kh', 'kw', 'stride', 'pad', 'pro_relu', 'splitk', 'groups')] + \
+               [(n, C.c_int64) for n in ('x_group_stride', 'dy_group_stride', 'dw_group_stride')]
 
 
 class MsePair(C.Structure):
@@ -61,6 +62,8 @@ _SIGNATURES = {
     'hnd_wino2_weights': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     'hnd_wino2_input': (C.c_int, [vp, vp] + [C.c_int] * 5 + [vp, vp, C.c_int, vp]),
     'hnd_wino2_output': (C.c_int, [vp, vp] + [C.c_int] * 5 + [vp, vp, C.c_int, vp, vp]),
+    'hnd_wino2_dy': (C.c_int, [vp, vp] + [C.c_int] * 5 + [vp]),
+    'hnd_wino2_wgrad_output': (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),
     'hnd_maxpool3x3s2_fwd': (C.c_int, [vp, vp, vp] + [C.c_int] * 6 + [vp]),
     'hnd_maxpool3x3s2_bwd_relu_scale': (C.c_int, [vp] * 5 + [C.c_int] * 6 + [vp]),
     'hnd_bn_finalize': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int64, vp, vp, vp, vp, vp,

@@ -40,6 +40,10 @@ __global__ void __launch_bounds__(256, (BKW == 16 ? 4 : 2)) wgrad_kernel(const W
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 1, wn = wave >> 1;
 
+  // batched launch: blockIdx.y selects one of `groups` independent problems (operands / slabs a fixed stride apart)
+  const int grp = blockIdx.y;
+  const float* __restrict__ xg = d.x + (size_t)grp * (size_t)d.x_group_stride;
+  const float* __restrict__ dyg = d.dy + (size_t)grp * (size_t)d.dy_group_stride;
   int bid = blockIdx.x;
   const int tiles = a.rtiles * a.ctiles;
   const int split = bid / tiles;
@@ -82,7 +86,7 @@ __global__ void __launch_bounds__(256, (BKW == 16 ? 4 : 2)) wgrad_kernel(const W
     for (int i = 0; i < A_N; ++i) {
       const int m = mbase + a_r + i * A_RPI;
       const bool ok = m < a.M && a_cok;
-      const float* p = d.dy + (size_t)(ok ? m : 0) * d.ldy + (ok ? r0 + a_c4 : 0);
+      const float* p = dyg + (size_t)(ok ? m : 0) * d.ldy + (ok ? r0 + a_c4 : 0);
       f32x4 v;
       if (a_vec) {                       // thread-constant: the whole float4 lies inside [0, cout)
         v = *(const f32x4*)p;
@@ -109,7 +113,7 @@ __global__ void __launch_bounds__(256, (BKW == 16 ? 4 : 2)) wgrad_kernel(const W
       const int ih = oh_ * d.stride - d.pad + ti, iw = ow_ * d.stride - d.pad + tj;
       const bool ok = m < a.M && b_cok && (unsigned)ih < (unsigned)d.h && (unsigned)iw < (unsigned)d.w_;
       const size_t off = ok ? ((size_t)((int)n_ * d.h + ih) * d.w_ + iw) * d.cin + ci : 0;
-      rb[i] = *(const f32x4*)(d.x + off);
+      rb[i] = *(const f32x4*)(xg + off);
       bok |= (ok ? 1u : 0u) << i;
     }
   };
@@ -174,7 +178,7 @@ __global__ void __launch_bounds__(256, (BKW == 16 ? 4 : 2)) wgrad_kernel(const W
     }
   }
   // partial tile -> slab[split][co][col]; D[i=co][j=col]: lane -> col, regs -> co
-  float* slab = d.slabs + (size_t)split * a.co_pad * a.ncols_pad;
+  float* slab = d.slabs + ((size_t)grp * d.splitk + split) * a.co_pad * a.ncols_pad;
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -189,7 +193,10 @@ __global__ void __launch_bounds__(256, (BKW == 16 ? 4 : 2)) wgrad_kernel(const W
 
 // sum the slabs in split order and write dW in torch OIHW layout
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int splitk, int co_pad,
-                                    int ncols_pad, int cout, int cin, int cin_real, int kh, int kw) {
+                                    int ncols_pad, int cout, int cin, int cin_real, int kh, int kw,
+                                    long long dw_group_stride) {
+  slabs += (size_t)blockIdx.y * splitk * co_pad * ncols_pad;
+  dw += (size_t)blockIdx.y * (size_t)dw_group_stride;
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // over cout * kh*kw * cin_real in (co, tap, ci) order
   const int per_co = kh * kw * cin_real;
   if (idx >= cout * per_co) return;
@@ -224,7 +231,7 @@ int plan(const hnd_wgrad_desc& d, WgradArgs& a, int BKW) {
   const int total_steps = (a.M + BKW - 1) / BKW;
   int splitk = d.splitk;
   if (splitk <= 0) {
-    const int tiles = a.rtiles * a.ctiles;
+    const int tiles = a.rtiles * a.ctiles * (d.groups > 1 ? d.groups : 1);
     splitk = (1024 + tiles - 1) / tiles;          // ~4 blocks per CU
     const int max_by_work = (total_steps + 15) / 16;   // at least 16 k-steps per split
     if (splitk > max_by_work) splitk = max_by_work;
@@ -244,7 +251,7 @@ extern "C" size_t hnd_conv2d_wgrad_workspace(const hnd_wgrad_desc* desc) {
   hnd_wgrad_desc d = *desc;
   if (d.cin <= 0 || d.cout <= 0 || d.kh <= 0 || d.kw <= 0 || d.oh <= 0 || d.ow <= 0 || d.n <= 0) return 0;
   plan(d, a, wgrad_bk());
-  return (size_t)a.d.splitk * a.co_pad * a.ncols_pad * sizeof(float);
+  return (size_t)(d.groups > 1 ? d.groups : 1) * a.d.splitk * a.co_pad * a.ncols_pad * sizeof(float);
 }
 
 extern "C" int hnd_conv2d_wgrad(const hnd_wgrad_desc* desc, void* stream) {
@@ -263,18 +270,22 @@ extern "C" int hnd_conv2d_wgrad(const hnd_wgrad_desc* desc, void* stream) {
   const int bk = wgrad_bk();
   const int bmw = plan(d, a, bk);
   hipStream_t s = hnd::as_stream(stream);
-  const int grid = a.rtiles * a.ctiles * a.d.splitk;
+  const int groups = d.groups > 1 ? d.groups : 1;
+  HND_REQUIRE(groups == 1 || (d.x_group_stride > 0 && d.dy_group_stride > 0 && d.dw_group_stride > 0),
+              "hnd_conv2d_wgrad: group strides must be positive when groups > 1");
+  const dim3 grid(a.rtiles * a.ctiles * a.d.splitk, groups);
   if (bk == 16) {
-    if (bmw == 128) hipLaunchKernelGGL((wgrad_kernel<128, 16>), dim3(grid), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((wgrad_kernel<64, 16>), dim3(grid), dim3(256), 0, s, a);
+    if (bmw == 128) hipLaunchKernelGGL((wgrad_kernel<128, 16>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((wgrad_kernel<64, 16>), grid, dim3(256), 0, s, a);
   } else {
-    if (bmw == 128) hipLaunchKernelGGL((wgrad_kernel<128, 32>), dim3(grid), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((wgrad_kernel<64, 32>), dim3(grid), dim3(256), 0, s, a);
+    if (bmw == 128) hipLaunchKernelGGL((wgrad_kernel<128, 32>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((wgrad_kernel<64, 32>), grid, dim3(256), 0, s, a);
   }
   int rc = hnd::check_launch("hnd_conv2d_wgrad");
   if (rc) return rc;
   const int total = d.cout * d.kh * d.kw * d.cin_real;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, s, d.slabs, d.dw, a.d.splitk,
-                     a.co_pad, a.ncols_pad, d.cout, d.cin, d.cin_real, d.kh, d.kw);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256, groups), dim3(256), 0, s, d.slabs, d.dw,
+                     a.d.splitk, a.co_pad, a.ncols_pad, d.cout, d.cin, d.cin_real, d.kh, d.kw,
+                     (long long)d.dw_group_stride);
   return hnd::check_launch("hnd_conv2d_wgrad(reduce)");
 }

@@ -555,6 +555,90 @@ __global__ void wino2_output_kernel(const float* __restrict__ m, float* __restri
   }
 }
 
+
+// ---------------------------------------------------------------------------------- F(2x2 taps, 4x4 tile): weight gradient
+// dW[i][j] = sum over tiles of sum_ab dy_t[a][b] d_t[a+i][b+j] is the minimal-filtering problem F(2x2, 4x4) with the
+// dy tile in the role of the filter.  Same points {0, 1, -1, 2, inf} => the data transform B^T d B is the V the
+// forward pass already produced; this kernel makes Z = G' dy_t G'^T,
+//   G' = [1/2 0 0 0; -1/2 -1/2 -1/2 -1/2; -1/6 1/6 -1/6 1/6; 1/6 1/3 2/3 4/3; 0 0 0 1],
+// 25 grouped GEMMs reduce S_f[co][ci] = sum_t Z_f[t][co] V_f[t][ci] over the tiles, and
+// dW = A'^T S A', A'^T = [1 1 1 1 0; 0 1 -1 2 1], is a per-(co, ci) epilogue.
+#define HND_WINO2_GP(g0, g1, g2, g3, o0, o1, o2, o3, o4)                                   \
+  do {                                                                                     \
+    const f32x2 e_ = g0 + g2, f_ = g1 + g3;                                                \
+    o0 = 0.5f * g0;                                                                        \
+    o1 = -0.5f * (e_ + f_);                                                                \
+    o2 = (f_ - e_) * (1.f / 6.f);                                                          \
+    o3 = g0 * (1.f / 6.f) + g1 * (1.f / 3.f) + g2 * (2.f / 3.f) + g3 * (4.f / 3.f);        \
+    o4 = g3;                                                                               \
+  } while (0)
+
+__global__ void wino2_dy_kernel(const float* __restrict__ dy, float* __restrict__ z, const Wino2Geom g, int cout,
+                                int ldy) {
+  const int c2n = cout >> 1;
+  const long long tiles = (long long)g.n * g.th * g.tw;
+  const long long total = tiles * c2n;
+  const size_t fs = (size_t)g.tiles_pad * cout;
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    const int c2 = (int)(e % c2n);
+    long long t = e / c2n;
+    const int tx = (int)(t % g.tw);
+    long long q = t / g.tw;
+    const int ty = (int)(q % g.th), b = (int)(q / g.th);
+    f32x2 d[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int oy = 4 * ty + a;
+#pragma unroll
+      for (int bb = 0; bb < 4; ++bb) {
+        const int ox = 4 * tx + bb;
+        const bool ok = oy < g.oh && ox < g.ow;
+        const size_t off = ok ? (((size_t)b * g.oh + oy) * g.ow + ox) * ldy + c2 * 2 : 0;
+        const f32x2 v = *(const f32x2*)(dy + off);
+        const f32x2 zz = {0.f, 0.f};
+        d[a][bb] = ok ? v : zz;
+      }
+    }
+    f32x2 r[5][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) HND_WINO2_GP(d[0][j], d[1][j], d[2][j], d[3][j], r[0][j], r[1][j], r[2][j], r[3][j], r[4][j]);
+    float* dst = z + (size_t)t * cout + c2 * 2;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      f32x2 o0, o1, o2, o3, o4;
+      HND_WINO2_GP(r[i][0], r[i][1], r[i][2], r[i][3], o0, o1, o2, o3, o4);
+      *(f32x2*)(dst + (size_t)(i * 5 + 0) * fs) = o0;
+      *(f32x2*)(dst + (size_t)(i * 5 + 1) * fs) = o1;
+      *(f32x2*)(dst + (size_t)(i * 5 + 2) * fs) = o2;
+      *(f32x2*)(dst + (size_t)(i * 5 + 3) * fs) = o3;
+      *(f32x2*)(dst + (size_t)(i * 5 + 4) * fs) = o4;
+    }
+  }
+}
+
+// dW[co][ci][i][j] = (A'^T S A')[i][j],  S_f[co][ci] at s[f*cout*cin + co*cin + ci]
+__global__ void wino2_wgrad_out_kernel(const float* __restrict__ s, float* __restrict__ dw, int cout, int cin) {
+  const long long total = (long long)cout * cin;
+  const size_t fs = (size_t)total;
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    float t[2][5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const float m0 = s[(0 * 5 + j) * fs + e], m1 = s[(1 * 5 + j) * fs + e], m2 = s[(2 * 5 + j) * fs + e],
+                  m3 = s[(3 * 5 + j) * fs + e], m4 = s[(4 * 5 + j) * fs + e];
+      t[0][j] = m0 + m1 + m2 + m3;
+      t[1][j] = m1 - m2 + 2.f * m3 + m4;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      dw[e * 4 + i * 2 + 0] = t[i][0] + t[i][1] + t[i][2] + t[i][3];
+      dw[e * 4 + i * 2 + 1] = t[i][1] - t[i][2] + 2.f * t[i][3] + t[i][4];
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -656,6 +740,26 @@ int hnd_wino2_output(const float* m, float* y, int n, int oh, int ow, int cout, 
   hipLaunchKernelGGL(wino2_output_kernel, dim3(blocks), dim3(256), 0, hnd::as_stream(stream), m, y, g, cout, ldc,
                      epi_scale, epi_shift, relu, stats);
   return hnd::check_launch("hnd_wino2_output");
+}
+
+/* Winograd-domain weight gradient of a 2x2 head conv: z = G' dy G'^T per 4x4 tile of dy [n][oh][ow][ldy] ->
+ * z [25][tiles_pad][cout]; after the 25 grouped GEMMs s[f][cout][cin] = sum_t z_f[t][co] v_f[t][ci]
+ * (hnd_conv2d_wgrad, groups = 25), hnd_wino2_wgrad_output writes dW [cout][cin][2][2]. */
+int hnd_wino2_dy(const float* dy, float* z, int n, int oh, int ow, int cout, int ldy, void* stream) {
+  HND_REQUIRE(dy && z && n > 0 && oh > 0 && ow > 0 && cout > 0 && cout % 2 == 0 && ldy >= cout && ldy % 2 == 0,
+              "hnd_wino2_dy: bad arguments");
+  Wino2Geom g{n, 0, 0, 0, oh, ow, (oh + 3) / 4, (ow + 3) / 4, (int)hnd_wino2_tiles_pad(n, oh, ow), 0};
+  const long long tiles = (long long)n * g.th * g.tw;
+  hipLaunchKernelGGL(wino2_dy_kernel, dim3(grid_for(tiles * (cout / 2))), dim3(256), 0, hnd::as_stream(stream), dy, z,
+                     g, cout, ldy);
+  return hnd::check_launch("hnd_wino2_dy");
+}
+
+int hnd_wino2_wgrad_output(const float* s, float* dw, int cout, int cin, void* stream) {
+  HND_REQUIRE(s && dw && cout > 0 && cin > 0, "hnd_wino2_wgrad_output: bad arguments");
+  hipLaunchKernelGGL(wino2_wgrad_out_kernel, dim3(grid_for((long long)cout * cin)), dim3(256), 0,
+                     hnd::as_stream(stream), s, dw, cout, cin);
+  return hnd::check_launch("hnd_wino2_wgrad_output");
 }
 
 }  // extern "C"

@@ -546,7 +546,7 @@ class HeadEngine(object):
         b = self.bufs
         self.x = x
         self.y, self.stats, self.scale, self.shift, self.mean, self.rstd = [], [], [], [], [], []
-        self.convs, self.count, self.ntiles = [], [], []
+        self.convs, self.count, self.ntiles, self.wino_fwd = [], [], [], {}
         cur, cur_scale, cur_shift, cur_relu = x, None, None, False
         flops = 0
         for i, hc in enumerate(self.layers):
@@ -559,9 +559,12 @@ class HeadEngine(object):
             mu, rs = b.get('mean%d' % i, (hc.cs_out,)), b.get('rstd%d' % i, (hc.cs_out,))
             if hc.wino is not None:
                 v, mm = self._wino_scratch(n, oh, ow, hc.cs_in, hc.cs_out)
-                self.convs.append(ops.Wino2Conv(cur, hc.wino.get(False), y, v, mm, hc.pad, pro_scale=cur_scale,
-                                                pro_shift=cur_shift, pro_relu=cur_relu,
-                                                stats=st).launches('layer1.conv%d' % i))
+                if training:        # the transformed input is kept: the weight gradient reuses it
+                    v = b.get('wino_keep_v%d' % i, (ops.Wino2Conv.scratch_elems(n, oh, ow, hc.cs_in, hc.cs_out)[0],))
+                wl = ops.Wino2Conv(cur, hc.wino.get(False), y, v, mm, hc.pad, pro_scale=cur_scale,
+                                   pro_shift=cur_shift, pro_relu=cur_relu, stats=st)
+                self.wino_fwd[i] = wl
+                self.convs.append(wl.launches('layer1.conv%d' % i))
             else:
                 self.convs.append([(ops.conv_forward(cur, hc.wc.get(False, hc.cs_in), y, 2, 1, hc.pad,
                                                      pro_scale=cur_scale, pro_shift=cur_shift, pro_relu=cur_relu,
@@ -585,6 +588,17 @@ class HeadEngine(object):
         cur = getattr(self, '_wino_need', (0, 0))
         self._wino_need = (max(nv, cur[0]), max(nm, cur[1]))
         return self.bufs.get('wino_v', (self._wino_need[0],)), self.bufs.get('wino_m', (self._wino_need[1],))
+
+    def _wino_slab_elems(self, fw, hc):
+        """split-K workspace of the grouped Winograd wgrad launch (sized for the largest layer that uses it)"""
+        n, h, w, c, oh, ow = fw.geom
+        d = ops.WgradDesc()
+        tiles = n * ((oh + 3) // 4) * ((ow + 3) // 4)
+        d.n, d.h, d.w_, d.cin, d.cin_real, d.oh, d.ow, d.cout, d.ldy = 1, 1, tiles, c, hc.cin, 1, tiles, hc.cout, hc.cout
+        d.kh, d.kw, d.stride, d.pad, d.groups = 1, 1, 1, 0, 25
+        need = (ops.wgrad_workspace_of(d) + 3) // 4
+        self._wino_slab_need = max(need, getattr(self, '_wino_slab_need', 0))
+        return self._wino_slab_need
 
     def bottleneck(self):
         """(raw conv output, scale, shift, relu) of the encoder's last conv = the bottleneck tensor z."""
@@ -670,8 +684,8 @@ class HeadEngine(object):
             ops.bn_bwd_finalize(st['part'], st['ntiles'], hc.cout, hc.cs_out, self.count[i], hc.bn.weight.detach(),
                                 self.mean[i], self.rstd[i], st['dgamma'], st['dbeta'], st['k123'])
             ops.bn_bwd_apply(g, self.y[i], self.scale[i], self.shift[i], st['k123'], hc.relu, g)   # in place -> dy
-            if st['wgrad'] is not None:
-                _run(st['wgrad'], 'layer1.conv%d.wgrad' % i)
+            for l, tag in st['wgrad']:
+                _run(l, tag)
             for l, tag in st['dgrad']:
                 _run(l, tag)
         return self.g_in if need_input_grad else None
@@ -707,10 +721,19 @@ class HeadEngine(object):
             src = self.x if i == 0 else self.y[i - 1]
             pro = (None, None, False) if i == 0 else (self.scale[i - 1], self.shift[i - 1], self.layers[i - 1].relu)
             dw = grad_dst.get(hc.conv.weight, None)
-            st['wgrad'] = None
-            if dw is not None:
-                st['wgrad'] = ops.conv_wgrad(src, gbuf[i], dw, 2, 1, hc.pad, pro_scale=pro[0], pro_shift=pro[1],
-                                             pro_relu=pro[2], slabs=slabs)
+            st['wgrad'] = []
+            if dw is not None and i in self.wino_fwd and hc.cs_out == hc.cout and hc.cs_in == hc.cin:
+                # Winograd-domain weight gradient: forward V x transformed dy, 25 grouped split-K reductions
+                fw = self.wino_fwd[i]
+                _, zbuf = self._wino_scratch(fw.geom[0], fw.geom[4], fw.geom[5], hc.cs_in, hc.cs_out)
+                sbuf = b.get('wino_s%d' % i, (25 * hc.cout * hc.cin,))
+                st['wgrad'] = ops.Wino2Wgrad(fw, gbuf[i], dw, zbuf, sbuf,
+                                             b.get('wino_slabs', (self._wino_slab_elems(fw, hc),))
+                                             ).launches('layer1.conv%d.wgrad' % i)
+                flops += 2 * npix * hc.cout * 4 * hc.cin
+            elif dw is not None:
+                st['wgrad'] = [(ops.conv_wgrad(src, gbuf[i], dw, 2, 1, hc.pad, pro_scale=pro[0], pro_shift=pro[1],
+                                               pro_relu=pro[2], slabs=slabs), 'layer1.conv%d.wgrad' % i)]
                 flops += 2 * npix * hc.cout * 4 * hc.cin
             st['dgrad'] = []
             tgt = gbuf[i - 1] if i > 0 else self.g_in

@@ -254,6 +254,11 @@ def conv_wgrad(x, dy, dw, k, stride=1, pad=0, pro_scale=None, pro_shift=None, pr
     return WgradLaunch(d, (x, dy, dw, slabs, pro_scale, pro_shift), 2 * n * oh * ow * cout * k * k * cin_real)
 
 
+def wgrad_workspace_of(desc):
+    """bytes of split-K workspace hnd_conv2d_wgrad needs for a filled-in WgradDesc"""
+    return int(_L.hnd_conv2d_wgrad_workspace(C.byref(desc)))
+
+
 def wgrad_workspace_bytes(n, h, w, cin, oh, ow, cout, k, stride, pad):
     d = WgradDesc()
     d.n, d.h, d.w_, d.cin, d.cin_real, d.oh, d.ow, d.cout, d.ldy = n, h, w, cin, cin, oh, ow, cout, chan_pad_of(cout)
@@ -564,6 +569,55 @@ class Wino2Conv(object):
         self._run_input(stream)
         self.gemm.run(stream)
         self._run_output(stream)
+
+
+class Wino2Wgrad(object):
+    """dW of a 2x2 head conv in the Winograd domain (F(2x2 taps, 4x4 tile)): reuses the forward pass's transformed
+    input `fwd.v`, transforms dy (z), reduces the 25 component products over the tiles in ONE grouped split-K
+    wgrad launch and inverse-transforms into dw [cout, cin, 2, 2]."""
+
+    def __init__(self, fwd, dy, dw, z, s, slabs=None):
+        assert isinstance(fwd, Wino2Conv) and not fwd.ww.dgrad
+        n, h, w, c, oh, ow = fwd.geom
+        cout, cin = dw.shape[0], dw.shape[1]
+        assert tuple(dw.shape) == (cout, cin, 2, 2) and dw.is_contiguous() and cin == c and cout % 2 == 0
+        assert tuple(dy.shape[:3]) == (n, oh, ow) and dy.shape[3] >= cout
+        tp = fwd.tiles_pad
+        tiles = n * ((oh + 3) // 4) * ((ow + 3) // 4)
+        assert z.numel() >= 25 * tp * cout and s.numel() >= 25 * cout * cin
+        self.fwd, self.dy, self.dw, self.z, self.s = fwd, dy, dw, z, s
+        self.geom = (n, oh, ow, cout, dy.shape[3], cin)
+        d = WgradDesc()
+        d.x, d.dy, d.dw = ptr(fwd.v), ptr(z), ptr(s)
+        d.n, d.h, d.w_, d.cin, d.cin_real = 1, 1, tiles, c, cin
+        d.oh, d.ow, d.cout, d.ldy = 1, tiles, cout, cout
+        d.kh, d.kw, d.stride, d.pad, d.splitk = 1, 1, 1, 0, 0
+        d.groups = 25
+        d.x_group_stride, d.dy_group_stride, d.dw_group_stride = tp * c, tp * cout, cout * cin
+        need = _L.hnd_conv2d_wgrad_workspace(C.byref(d))
+        if slabs is None or slabs.numel() * 4 < need:
+            slabs = torch.empty((need + 3) // 4, dtype=torch.float32, device=dy.device)
+        d.slabs = ptr(slabs)
+        self.gemm = WgradLaunch(d, (fwd.v, z, s, slabs), 2 * 25 * tiles * cout * cin)
+        self.flops, self.variant = self.gemm.flops, self.gemm.variant
+
+    def _run_dy(self, stream=None):
+        n, oh, ow, cout, ldy, cin = self.geom
+        check(_L.hnd_wino2_dy(ptr(self.dy), ptr(self.z), n, oh, ow, cout, ldy,
+                              stream if stream is not None else stream_ptr()), 'hnd_wino2_dy')
+
+    def _run_out(self, stream=None):
+        n, oh, ow, cout, ldy, cin = self.geom
+        check(_L.hnd_wino2_wgrad_output(ptr(self.s), ptr(self.dw), cout, cin,
+                                        stream if stream is not None else stream_ptr()), 'hnd_wino2_wgrad_output')
+
+    def launches(self, tag):
+        return [(_Step(self._run_dy), tag + '.wino_dy'), (self.gemm, tag), (_Step(self._run_out), tag + '.wino_out')]
+
+    def run(self, stream=None):
+        self._run_dy(stream)
+        self.gemm.run(stream)
+        self._run_out(stream)
 
 
 class _Step(object):

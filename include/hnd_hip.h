@@ -120,6 +120,11 @@ typedef struct hnd_wgrad_desc {
   int32_t kh, kw, stride, pad;
   int32_t pro_relu;
   int32_t splitk;          /* 0 = choose */
+  /* batched launch (0 or 1 = single): `groups` independent problems of this geometry whose operands lie
+   * x_group_stride / dy_group_stride / dw_group_stride floats apart (the 25 component GEMMs of the Winograd-domain
+   * weight gradient); the workspace holds `groups` consecutive slab sets. */
+  int32_t groups;
+  int64_t x_group_stride, dy_group_stride, dw_group_stride;
 } hnd_wgrad_desc;
 
 size_t hnd_conv2d_wgrad_workspace(const hnd_wgrad_desc* desc);
@@ -190,6 +195,12 @@ int hnd_wino2_input(const float* x, float* v, int n, int h, int w, int c, int pa
                     const float* pro_shift, int pro_relu, void* stream);
 int hnd_wino2_output(const float* m, float* y, int n, int oh, int ow, int cout, int ldc, const float* epi_scale,
                      const float* epi_shift, int relu, float* stats, void* stream);
+/* Weight gradient of the same convs in the Winograd domain, F(2x2 taps, 4x4 tile) over the same points: the data
+ * transform is the v [25][tiles_pad][cin] hnd_wino2_input made in the forward pass (keep it); hnd_wino2_dy makes
+ * z [25][tiles_pad][cout] from dy [n][oh][ow][ldy]; 25 grouped reductions over the tiles (hnd_conv2d_wgrad with
+ * kh = kw = 1, groups = 25, x = v, dy = z) give s [25][cout][cin]; hnd_wino2_wgrad_output -> dW [cout][cin][2][2]. */
+int hnd_wino2_dy(const float* dy, float* z, int n, int oh, int ow, int cout, int ldy, void* stream);
+int hnd_wino2_wgrad_output(const float* s, float* dw, int cout, int cin, void* stream);
 
 /* nn.MaxPool2d(3, 2, 1) (custom/resnet.py:30,99) NHWC; idx (uint8 tap 0..8) kept for backward. */
 int hnd_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* idx, int n, int h, int w, int c, int oh, int ow,

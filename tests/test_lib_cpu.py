@@ -28,7 +28,7 @@ def test_ctypes_structs_match_header_layout():
     from hnd_ghnd_object_detectors_amd import _lib
     import ctypes
     assert ctypes.sizeof(_lib.ConvDesc) == 11 * 8 + 30 * 4
-    assert ctypes.sizeof(_lib.WgradDesc) == 6 * 8 + 15 * 4 + 4     # padded to 8
+    assert ctypes.sizeof(_lib.WgradDesc) == 6 * 8 + 16 * 4 + 3 * 8
     assert ctypes.sizeof(_lib.MsePair) == 3 * 8 + 8 + 4 + 4
 
 

@@ -594,6 +594,35 @@ def test_winograd_conv2x2_dgrad(ops, pad):
     assert relerr(nchw(dx), x.grad) < 2e-4
 
 
+@pytest.mark.parametrize('n,cin,h,w,cout,pad', [(2, 128, 14, 19, 256, 0), (3, 256, 9, 12, 256, 0), (2, 64, 10, 10, 128, 1)])
+def test_winograd_conv2x2_wgrad_reuses_forward_transform(ops, n, cin, h, w, cout, pad):
+    """dW in the Winograd domain: forward V (with the BN+ReLU prologue baked in) x transformed dy, 25 grouped
+    split-K reductions, inverse transform -- against autograd"""
+    g = gen(80 + cin + h)
+    x = torch.randn(n, cin, h, w, generator=g)
+    ps, pb = torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g) * 0.3
+    wt = (torch.randn(cout, cin, 2, 2, generator=g) / math.sqrt(cin * 4)).requires_grad_(True)
+    out = F.conv2d(F.relu(x * ps[None, :, None, None] + pb[None, :, None, None]), wt, None, 1, pad)
+    dy = torch.randn(out.shape, generator=g)
+    out.backward(dy)
+    oh, ow = out.shape[2], out.shape[3]
+    ww = ops.Wino2Weights(wt.detach().to(DEV).contiguous())
+    nv, nm = ops.Wino2Conv.scratch_elems(n, oh, ow, cin, cout)
+    v, m = torch.empty(nv, device=DEV), torch.full((nm,), float('nan'), device=DEV)
+    y = torch.empty(n, oh, ow, cout, device=DEV)
+    fwd = ops.Wino2Conv(nhwc(x), ww, y, v, m, pad, pro_scale=ps.to(DEV), pro_shift=pb.to(DEV), pro_relu=True)
+    fwd.run()
+    dw = torch.full((cout, cin, 2, 2), float('nan'), device=DEV)
+    s = torch.empty(25 * cout * cin, device=DEV)
+    outs = []
+    for _ in range(2):
+        ops.Wino2Wgrad(fwd, nhwc(dy), dw, m, s).run()       # z may alias the forward's M scratch
+        ops.sync_check()
+        outs.append(dw.cpu().clone())
+    assert relerr(outs[0], wt.grad) < 2e-4, relerr(outs[0], wt.grad)
+    assert torch.equal(outs[0], outs[1])                     # fixed-order reductions: bit-reproducible
+
+
 def test_subsample_and_fill(ops):
     x = torch.randn(2, 256, 7, 9, generator=gen(14))
     y = torch.empty(2, 4, 5, 256, device=DEV)

@@ -47,6 +47,14 @@ def main():
                 tdir / tw)
             if not dgrad:
                 line += ' err %.1e' % float((y0 - y1).abs().max() / y0.abs().max())
+                # weight gradient: direct split-K wgrad vs the Winograd-domain one that reuses this V
+                dw0, dw1 = torch.empty_like(wt), torch.empty_like(wt)
+                wdir = ops.conv_wgrad(x, y0, dw0, 2, 1, pad)
+                sbuf = torch.empty(25 * cout * cin, device=dev)
+                wwin = ops.Wino2Wgrad(wino, y0, dw1, m, sbuf)
+                t0, t1 = timed(wdir.run), timed(wwin.run)
+                line += ' | wgrad direct %6.3f wino %6.3f ms x%.2f err %.1e' % (
+                    t0, t1, t0 / t1, float((dw0 - dw1).abs().max() / dw0.abs().max()))
             del v, m
         print(line, flush=True)
 
