@@ -28,6 +28,9 @@ SHAPES = {
     'S10_3x3_256-256@200': (256, 200, 336, 256, 3, 1, 1, False),
     'S11_2x2_256-256@201': (256, 201, 337, 256, 2, 1, 0, False),
     'S12_3x3s2_128-128@200': (128, 200, 336, 128, 3, 2, 1, False),
+    'S13_1x1_256-256@200': (256, 200, 336, 256, 1, 1, 0, False),      # the shape class of the Winograd GEMMs
+    'S14_1x1_512-512@100': (512, 100, 168, 512, 1, 1, 0, False),
+    'S15_1x1_128-128@200': (128, 200, 336, 128, 1, 1, 0, False),
 }
 
 
