@@ -791,7 +791,8 @@ class FpnEngine(object):
             flops = 0
             # Winograd scratch sized for the finest level up front (the loop runs coarse -> fine)
             n0, h0, w0, _ = feats[0].shape
-            need = (ops.WinoConv.scratch_elems(n0, h0, w0, 256, 256, WINOGRAD)
+            oc = self.layer[0][0].weight.shape[0]
+            need = (ops.WinoConv.scratch_elems(n0, h0, w0, oc, oc, WINOGRAD)
                     if any(w is not None for w in self.wino) else (0, 0))
             for i in range(nlev - 1, -1, -1):
                 f = feats[i]
@@ -804,7 +805,7 @@ class FpnEngine(object):
                 ml, wl = self.layer[i]
                 self.results[i] = self.bufs.get('p%d' % i, (n, h, w, ml.weight.shape[0]))
                 if self.wino[i] is not None:            # 3x3 256->256 output conv: Winograd F(2x2,3x3)
-                    nv, nm = ops.WinoConv.scratch_elems(n, h, w, 256, ml.weight.shape[0], WINOGRAD)
+                    nv, nm = ops.WinoConv.scratch_elems(n, h, w, ml.weight.shape[1], ml.weight.shape[0], WINOGRAD)
                     need = (max(nv, need[0]), max(nm, need[1]))
                     v, mm = self.bufs.get('wino_v', (need[0],)), self.bufs.get('wino_m', (need[1],))
                     self.fwd += ops.WinoConv(inner[i], self.wino[i].get(False), self.results[i], v, mm,
