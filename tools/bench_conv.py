@@ -31,6 +31,11 @@ SHAPES = {
     'S13_1x1_256-256@200': (256, 200, 336, 256, 1, 1, 0, False),      # the shape class of the Winograd GEMMs
     'S14_1x1_512-512@100': (512, 100, 168, 512, 1, 1, 0, False),
     'S15_1x1_128-128@200': (128, 200, 336, 128, 1, 1, 0, False),
+    'S16_1x1_128-256@200': (128, 200, 336, 256, 1, 1, 0, False),
+    'S17_1x1_512-256@100': (512, 100, 168, 256, 1, 1, 0, False),
+    'S18_1x1_256-256@50': (256, 50, 84, 256, 1, 1, 0, False),
+    'S19_1x1_256-256@100': (256, 100, 168, 256, 1, 1, 0, False),
+    'S20_1x1_64-256@200': (64, 200, 336, 256, 1, 1, 0, False),
 }
 
 
