@@ -10,12 +10,16 @@ One "step" = what mimic_runner.distill_model does per batch (reference src/mimic
 DistillationBox forward (teacher + student incl. the FPN both run, as written), zero_grad, backward,
 gradient all-reduce (N > 1), Adam step, loss.item().  Inputs are resident in HBM before the timed region.
 Prints ONE JSON line (rank 0) with the contract fields plus `roofline` (dominant kernel, measured with HIP
-events on the launch stream during the last timed step) and `cpu_baseline` (the CPU oracle on this host).
+events on the launch stream during one extra, untimed, single-stream step after the timed loop) and `cpu_baseline`
+(the CPU oracle on this host).  The first step's loss is checked against the CPU oracle's value for the same seeded
+weights and batch (tests/golden/bench_first_loss.json, written by tests/golden/make_bench_loss.py) -- outside the
+timed region; a mismatch aborts the run.
 """
 import argparse
 import contextlib
 import json
 import os
+import re
 import sys
 import time
 
@@ -43,13 +47,27 @@ def parse():
     ap.add_argument('--no_cpu_baseline', action='store_true')
     ap.add_argument('--no_fpn', action='store_true', help='elide the loss-dead FPN (reported separately, never default)')
     ap.add_argument('--cpu_batch', type=int, default=2)
-    ap.add_argument('--cpu_steps', type=int, default=1)
+    ap.add_argument('--cpu_steps', type=int, default=3, help='timed oracle steps after 1 warm-up (SURVEY.md 8d)')
     ap.add_argument('--cpu_threads', type=int, default=32)
     ap.add_argument('--dist_backend', default='nccl', help="'nccl' (= RCCL); 'gloo' only to exercise the multi-rank "
                     "code path on a single-GPU box together with --share_device")
     ap.add_argument('--share_device', action='store_true', help='testing: every rank uses cuda:0')
     ap.add_argument('--detail', default=None, help='write the per-launch table of the profiled step to this file')
     return ap.parse_args()
+
+
+def physical_cores():
+    """distinct (socket, core) pairs of this host (hyper-threads share one)"""
+    try:
+        seen, phys = set(), None
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('physical id'):
+                phys = line.split(':')[1].strip()
+            elif line.startswith('core id'):
+                seen.add((phys, line.split(':')[1].strip()))
+        return len(seen) or None
+    except OSError:
+        return None
 
 
 def cpu_baseline(teacher, student, args, terms):
@@ -70,9 +88,23 @@ def cpu_baseline(teacher, student, args, terms):
         orc.step(images)
     dt = time.time() - t0
     return {'value': round(args.cpu_batch * args.cpu_steps / dt, 4), 'unit': 'img/s', 'cores': cores, 'kind': 'port',
+            'host_logical_cpus': os.cpu_count(), 'host_physical_cores': physical_cores(),
             'sample': '%d warm-up + %d timed %s steps of batch %d at 3x%dx%d, torch %s CPU oracle (oracle/hnd_oracle.py), '
                       '%d threads' % (1, args.cpu_steps, args.method.upper(), args.cpu_batch, args.height, args.width,
                                       torch.__version__, cores)}
+
+
+def first_loss_reference(args, rank):
+    """the CPU oracle's loss for this run's first step (same seeded weights and batch), or None if the
+    configuration is not one of the pinned ones"""
+    if (args.height, args.width) != (800, 1333):
+        return None
+    try:
+        cases = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'bench_first_loss.json')))['cases']
+    except (OSError, ValueError, KeyError):
+        return None
+    case = cases.get('%s/batch%d/rank%d' % (args.model, args.batch, rank))
+    return None if case is None else case[args.method]
 
 
 def main():
@@ -110,8 +142,6 @@ def main():
     student_w = DistributedStudent(student) if world > 1 else student
     box = DistillationBox(teacher, student_w, config['train']['criterion'])
     optimizer = func_util.get_optimizer(student, 'Adam', config['train']['optimizer']['params'])
-    if world > 1:
-        student_w.attach_optimizer(optimizer)
     warm = main_util.warmup_lr_scheduler(optimizer, 1000, 1.0 / 1000.0)     # epoch-0 warm-up, mimic_runner.py:43-46
 
     g = torch.Generator().manual_seed(1234 + rank)              # per-rank seeded synthetic shard
@@ -120,55 +150,92 @@ def main():
     targets = [{'boxes': torch.tensor([[0.125 * w, 0.125 * h, 0.5 * w, 0.5 * h]], device=dev),
                 'labels': torch.tensor([1], device=dev)} for _ in range(args.batch)]
 
-    def step():
+    def step(sync=True):
         loss = box(images, [dict(t) for t in targets])
         optimizer.zero_grad()
-        loss.backward()
-        if world > 1:
-            student_w.reduce_gradients()
-        optimizer.step()
+        loss.backward()                                         # N > 1: fires the flat gradient all-reduce (RCCL)
+        optimizer.step()                                        # waits for it stream-side, applies the 1/world mean
         warm.step()
-        return loss.item()                                      # MetricLogger.update -> one host sync per step
+        return loss.item() if sync else loss                    # MetricLogger.update -> one host sync per step
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    # ---- parity gate, outside the timed region: this run's very first step against the CPU oracle's loss
+    first = step()
+    ref_first = first_loss_reference(args, rank)
+    loss_check = None
+    if ref_first is not None:
+        rel = abs(first - ref_first) / abs(ref_first)
+        loss_check = {'first_step_loss': first, 'oracle': ref_first, 'rel_err': rel, 'tol': 1e-3,
+                      'source': 'tests/golden/bench_first_loss.json'}
+        if not rel < 1e-3:
+            raise SystemExit('bench.py: first-step loss %r differs from the CPU oracle\'s %r (rel %.2e > 1e-3): '
+                             'the HIP path is wrong at the benchmarked configuration' % (first, ref_first, rel))
+    last = first
+    for _ in range(args.warmup - 1):
         last = step()
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        if i == args.steps - 1:
-            E.PROFILE['enabled'], E.PROFILE['records'] = True, []
         last = step()
-    E.PROFILE['enabled'] = False
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # ---- untimed extras (every rank runs them: the steps contain the all-reduce)
+    # host enqueue cost: wall time to ISSUE a step with no host sync in it (what one Python process per GPU pays)
+    nh = 3
+    fence()
+    h0 = time.perf_counter()
+    for _ in range(nh):
+        step(sync=False)
+    host_enqueue_ms = (time.perf_counter() - h0) / nh * 1e3
+    fence()
+    # per-launch HIP events: one extra single-stream step (kernels timed running alone)
+    E.PROFILE['enabled'], E.PROFILE['records'] = True, []
+    step()
+    E.PROFILE['enabled'] = False
+    fence()
     if rank != 0:
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
         return
 
-    # ---- roofline of the dominant kernel from the per-launch HIP events of the last timed step
-    per = {}
+    # ---- roofline of the dominant kernel from the per-launch HIP events of the profiled step
+    per, groups = {}, {}
+    re_3x3 = re.compile(r'^(layer\d\.\d+\.conv2|fpn\.layer\d)(\.dgrad)?(\.wino_(in|out))?$')
+    re_head = re.compile(r'^(layer1\.conv\d)(\.dgrad|\.wgrad)?(\.wino_(in|out|dy))?$')
     for tag, launch, e0, e1 in E.PROFILE['records']:
-        d = per.setdefault(launch.variant, {'ms': 0.0, 'flop': 0.0, 'n': 0})
-        d['ms'] += e0.elapsed_time(e1)
-        d['flop'] += launch.flops
-        d['n'] += 1
+        ms = e0.elapsed_time(e1)
+        if launch.flops:
+            d = per.setdefault(launch.variant, {'ms': 0.0, 'flop': 0.0, 'n': 0})
+            d['ms'] += ms
+            d['flop'] += launch.flops
+            d['n'] += 1
+        m3, mh = re_3x3.match(tag), re_head.match(tag)
+        if m3:
+            gkey = ('conv3x3', 'all')
+        elif mh:
+            gkey = ('head2x2', mh.group(1)[len('layer1.'):] + (mh.group(2) or '.fwd'))
+        else:
+            continue
+        g_ = groups.setdefault(gkey, {'ms': 0.0, 'alg': 0.0})
+        g_['ms'] += ms
+        g_['alg'] += launch.alg_flops
     kernels = {k: {'launches': v['n'], 'ms': round(v['ms'], 3), 'tflops': round(v['flop'] / v['ms'] / 1e9, 2)}
                for k, v in per.items() if v['ms'] > 0}
     dom = max(per, key=lambda k: per[k]['ms'])
     ach = per[dom]['flop'] / per[dom]['ms'] / 1e9
     roofline = {'bound': 'mfma', 'kernel': dom, 'achieved': round(ach, 2), 'peak': FP32_MFMA_PEAK_TFLOPS,
                 'unit': 'TFLOP/s', 'frac': round(ach / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
+                'traffic_measured_in_run': False,
                 'launches_per_step': per[dom]['n'], 'avg_launch_ms': round(per[dom]['ms'] / per[dom]['n'], 4),
                 'algorithmic_gflop_per_launch': round(per[dom]['flop'] / per[dom]['n'] / 1e9, 3),
                 'flops_basis': ('multiplies the launches execute: implicit-GEMM convs 2*M*Cout*K; the Winograd '
@@ -176,14 +243,34 @@ def main():
                                 % (E.WINOGRAD, E.WINOGRAD, (E.WINOGRAD + 2) ** 2,
                                    9.0 * E.WINOGRAD ** 2 / (E.WINOGRAD + 2) ** 2))
                                if E.WINOGRAD else 'implicit-GEMM convs 2*M*Cout*K'}
-    try:        # HBM bytes per launch of the dominant kernel from the committed PMC pass (profiles/rNN_traffic.json)
+    run_cfg = {'batch': args.batch, 'method': args.method, 'model': args.model, 'winograd': E.WINOGRAD,
+               'no_fpn': bool(args.no_fpn), 'height': args.height, 'width': args.width}
+    try:        # HBM bytes per launch of the dominant kernel from the newest committed PMC pass OF THIS CONFIGURATION
         import glob
-        tf = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_traffic.json')))[-1]
-        roofline['traffic'] = json.load(open(tf))['kernels'][dom]['traffic_bytes_per_launch']
-        roofline['traffic_source'] = os.path.basename(tf)
-    except Exception:
-        pass
+        for tf in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_traffic.json')), reverse=True):
+            prof = json.load(open(tf))
+            if prof.get('config') == run_cfg and dom in prof['kernels']:
+                roofline['traffic'] = prof['kernels'][dom]['traffic_bytes_per_launch']
+                roofline['traffic_source'] = os.path.basename(tf) + ' (separate rocprofv3 --pmc passes of this config)'
+                break
+        else:
+            roofline['traffic_source'] = 'no committed PMC profile matches this configuration'
+    except Exception as exc:        # a malformed profile file must not lose the measurement
+        roofline['traffic_source'] = 'unreadable profile: %s' % exc
+    # "3x3-conv roofline fraction" = algorithmic 2*MAC of the 3x3 convs (frozen conv2 fwd + dgrad, FPN
+    # output convs) / their summed kernel time INCLUDING the Winograd transforms / fp32 MFMA peak; and the 2x2 head
+    g3 = groups.get(('conv3x3', 'all'))
+    conv3x3 = None
+    if g3 and g3['ms'] > 0:
+        tf3 = g3['alg'] / g3['ms'] / 1e9
+        conv3x3 = {'algorithmic_gflop': round(g3['alg'] / 1e9, 1), 'ms': round(g3['ms'], 3),
+                   'tflops': round(tf3, 2), 'frac': round(tf3 / FP32_MFMA_PEAK_TFLOPS, 4)}
+    head2x2 = {k[1]: {'algorithmic_gflop': round(v['alg'] / 1e9, 2), 'ms': round(v['ms'], 3),
+                      'tflops': round(v['alg'] / v['ms'] / 1e9, 2),
+                      'frac': round(v['alg'] / v['ms'] / 1e9 / FP32_MFMA_PEAK_TFLOPS, 4)}
+               for k, v in sorted(groups.items()) if k[0] == 'head2x2' and v['ms'] > 0}
     conv_ms = sum(v['ms'] for v in per.values())
+    E.PROFILE['records'] = [r for r in E.PROFILE['records'] if r[1].flops]      # --detail lists the MFMA launches
     if args.detail:
         agg = {}
         for tag, launch, e0, e1 in E.PROFILE['records']:
@@ -219,6 +306,10 @@ def main():
                                % (E.WINOGRAD, E.WINOGRAD, 128 if E.WINOGRAD == 4 else 256))
                               if E.WINOGRAD else 'implicit GEMM'},
         'roofline': roofline,
+        'conv3x3_roofline': conv3x3,
+        'head2x2_roofline': head2x2,
+        'loss_check': loss_check,
+        'host_enqueue_ms_per_step': round(host_enqueue_ms, 3),
         'step_conv_tflops': round(gflop_img * args.batch / (ms_per_step / 1e3) / 1e3, 2),
         'conv_kernel_ms_per_step': round(conv_ms, 2),
         'kernels': kernels,

@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('HND_LIB_PATH') or os.path.join(_HERE, 'libhnd_hip.so')     # env: kernel experiments
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 c_float_p = C.POINTER(C.c_float)
 vp = C.c_void_p
@@ -91,6 +91,11 @@ _SIGNATURES = {
     'hnd_channel_sum_scratch_elems': (C.c_size_t, [C.c_int]),
     'hnd_channel_sum': (C.c_int, [vp, vp, C.c_int64, C.c_int, C.c_int, vp, vp]),
     'hnd_sgd_step_flat': (C.c_int, [vp, vp, vp, C.c_int64] + [C.c_float] * 4 + [C.c_int, C.c_int, C.c_float, vp]),
+    'hnd_comm_unique_id': (C.c_int, [vp, C.c_size_t]),
+    'hnd_comm_init': (C.c_int, [C.c_int, C.c_int, vp, C.c_size_t, C.POINTER(vp)]),
+    'hnd_allreduce_avg_flat': (C.c_int, [vp, vp, C.c_int64, vp]),
+    'hnd_comm_destroy': (C.c_int, [vp]),
+    'hnd_workspace_size': (C.c_size_t, [C.c_int, vp, C.c_int64]),
 }
 
 EXPORTED_SYMBOLS = tuple(sorted(_SIGNATURES))

@@ -37,6 +37,17 @@ int hnd_sync_check(void* stream) {
   return HND_ERR_ASYNC;
 }
 
+size_t hnd_workspace_size(int op, const void* desc, int64_t arg) {
+  switch (op) {
+    case HND_OP_CONV2D_WGRAD: return desc ? hnd_conv2d_wgrad_workspace((const hnd_wgrad_desc*)desc) : 0;
+    case HND_OP_MSE: return hnd_mse_scratch_elems() * sizeof(double);
+    case HND_OP_QUANTIZE_U8: return hnd_minmax_scratch_elems() * sizeof(float);
+    case HND_OP_CHANNEL_SUM: return hnd_channel_sum_scratch_elems((int)arg) * sizeof(float);
+    case HND_OP_COMM_UNIQUE_ID: return 128;
+    default: return 0;
+  }
+}
+
 const char* hnd_device_arch(void) {
   static thread_local char arch[256] = "";
   int dev = 0;

@@ -474,6 +474,10 @@ __global__ void minmax_kernel(const float* __restrict__ x, long long npix, int c
   }
 }
 
+// The codec is byte work: it must reproduce myutils.tensor_util.quantize_tensor bit for bit on identical fp32 input
+// (tests/test_ops_gpu.py, torch.equal on the bytes).  Every operation below is therefore a single correctly rounded
+// IEEE fp32 operation in the reference's order -- explicit __fdiv_rn / __fadd_rn / __fsub_rn so that neither
+// -ffp-contract=fast nor a reciprocal rewrite of the loop-invariant divisor can change a rounding.
 __global__ void qparams_kernel(const float* __restrict__ part, int nblocks, float qmax, float* __restrict__ qp) {
   float lo = INFINITY, hi = -INFINITY;
   for (int i = threadIdx.x; i < nblocks; i += 64) {
@@ -486,10 +490,10 @@ __global__ void qparams_kernel(const float* __restrict__ part, int nblocks, floa
     hi = fmaxf(hi, __shfl_xor(hi, o));
   }
   if (threadIdx.x == 0) {
-    const float scale = (hi - lo) / (qmax - 0.f);
-    float zp = 0.f - lo / scale;
+    const float scale = __fdiv_rn(__fsub_rn(hi, lo), qmax);        // (max - min) / (qmax - qmin), qmin = 0
+    float zp = __fsub_rn(0.f, __fdiv_rn(lo, scale));               // qmin - min / scale
     zp = zp < 0.f ? 0.f : (zp > qmax ? qmax : zp);
-    qp[0] = lo; qp[1] = hi; qp[2] = scale; qp[3] = truncf(zp);
+    qp[0] = lo; qp[1] = hi; qp[2] = scale; qp[3] = truncf(zp);     // int(zero_point)
   }
 }
 
@@ -501,9 +505,9 @@ __global__ void quantize_kernel(const float* __restrict__ x, long long npix, int
        e += (long long)gridDim.x * blockDim.x) {
     float v = 0.f;
     if ((int)(e % cs) < c) {
-      v = zp + x[e] / scale;
-      v = v < 0.f ? 0.f : (v > qmax ? qmax : v);
-      v = rintf(v);
+      v = __fadd_rn(zp, __fdiv_rn(x[e], scale));                   // zero_point + x / scale
+      v = v < 0.f ? 0.f : (v > qmax ? qmax : v);                   // clamp_(qmin, qmax)
+      v = rintf(v);                                                // round_(): half to even
     }
     q[e] = (uint8_t)v;
   }
@@ -515,7 +519,7 @@ __global__ void dequantize_kernel(const uint8_t* __restrict__ q, const float* __
   const long long total = npix * cs;
   for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
        e += (long long)gridDim.x * blockDim.x)
-    x[e] = ((int)(e % cs) < c) ? scale * ((float)q[e] - zp) : 0.f;
+    x[e] = ((int)(e % cs) < c) ? __fmul_rn(scale, __fsub_rn((float)q[e], zp)) : 0.f;      // scale * (q - zero_point)
 }
 
 __global__ void roundtrip_f16_kernel(float* x, long long n) {

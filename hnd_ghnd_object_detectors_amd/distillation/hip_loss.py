@@ -74,6 +74,9 @@ class _DistillLossFn(torch.autograd.Function):
             ops.scale_by_device_scalar(buf, go)
         body.hnd_backward(st['top'], st['loss_grads'], grad_dst)
         del views
+        hook = getattr(body, '_post_backward', None)
+        if hook is not None:        # parallel.DistributedStudent: the stem's wgrad (last kernel) is enqueued -> exchange
+            hook(arena, flat)
         # fresh views (refcount 1) so AccumulateGrad adopts them without a copy
         return (None, None) + tuple(arena.views(flat))
 

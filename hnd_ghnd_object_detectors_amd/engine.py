@@ -30,7 +30,7 @@ DEFER_FPN = {'stream': None}
 
 
 def _run(launch, tag=None):
-    if PROFILE['enabled'] and launch.flops:
+    if PROFILE['enabled'] and tag is not None:          # every tagged plan entry, incl. the flop-less Winograd transforms
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         launch.run()
@@ -42,6 +42,13 @@ def _run(launch, tag=None):
 
 def version_of(tensors):
     return tuple(t._version for t in tensors)
+
+
+def weight_version(w):
+    """staleness key of a packed / transformed copy of parameter `w`.  The fused optimizers update parameters through
+    raw pointers (optim.py -> hnd_adam_step_flat / hnd_sgd_step_flat), which never bumps ``_version``; they advance
+    ``ops.PARAM_EPOCH`` instead, so a train-then-eval sequence in one process repacks trainable weights."""
+    return (w._version, w.data_ptr(), ops.PARAM_EPOCH[0] if w.requires_grad else -1)
 
 
 class Buffers(object):
@@ -117,7 +124,7 @@ class WeightCache(object):
 
     def refresh(self, force=False):
         """re-run the pack kernels if the parameter changed (or always, for trainable weights)."""
-        ver = (self.weight._version, self.weight.data_ptr())
+        ver = weight_version(self.weight)
         if force or ver != self.ver:
             for pk in self.packs.values():
                 pk.src = self.weight.detach()
@@ -135,11 +142,11 @@ class WinoCache(object):
         ww = self.packs.get(dgrad)
         if ww is None:
             ww = self.packs[dgrad] = ops.WinoWeights(self.weight.detach(), dgrad, self.tile)
-            self.ver = (self.weight._version, self.weight.data_ptr())
+            self.ver = weight_version(self.weight)
         return ww
 
     def refresh(self):
-        ver = (self.weight._version, self.weight.data_ptr())
+        ver = weight_version(self.weight)
         if ver != self.ver:
             for ww in self.packs.values():
                 ww.src = self.weight.detach()
@@ -160,7 +167,7 @@ class Wino2Cache(object):
         return ww
 
     def refresh(self, force=False):
-        ver = (self.weight._version, self.weight.data_ptr())
+        ver = weight_version(self.weight)
         if force or ver != self.ver:
             for ww in self.packs.values():
                 ww.src = self.weight.detach()

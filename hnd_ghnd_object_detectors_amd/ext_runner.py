@@ -77,10 +77,8 @@ def train_model(model, optimizer, data_loader, device, epoch, log_freq, wrapper=
             print('Loss is {}, stopping training'.format(logged))
             sys.exit(1)
         optimizer.zero_grad()
-        loss.backward()
-        if wrapper is not None:
-            wrapper.reduce_gradients()          # one flat all-reduce; the mean is folded into the SGD launch
-        optimizer.step()
+        loss.backward()             # DistributedStudent fires the flat gradient all-reduce from inside backward,
+        optimizer.step()            # the fused SGD launch waits for it and applies the 1/world mean
         if warmup is not None:
             warmup.step()
         meters.update(loss=logged, loss_ext_classifier=logged, lr=optimizer.param_groups[0]['lr'])

@@ -74,10 +74,8 @@ def distill_model(distillation_box, data_loader, optimizer, log_freq, device, ep
         targets = [{key: value.to(device, non_blocking=True) for key, value in t.items()} for t in targets]
         loss = distillation_box(images, targets)
         optimizer.zero_grad()
-        loss.backward()
-        if student_wrapper is not None:
-            student_wrapper.reduce_gradients()      # one flat all-reduce (RCCL); the mean is folded into Adam
-        optimizer.step()
+        loss.backward()             # DistributedStudent fires the flat gradient all-reduce from inside backward,
+        optimizer.step()            # the fused Adam launch waits for it and applies the 1/world mean
         if warmup is not None:
             warmup.step()
         meters.update(loss=loss, lr=optimizer.param_groups[0]['lr'])

@@ -32,11 +32,13 @@ class _FilterLogitsFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_output):
-        engine, arena = ctx.state
+        engine, arena, post_backward = ctx.state
         flat = arena.pick()
         grad_dst = {p: v for p, v in zip(arena.params, arena.views(flat))}
         engine.backward(grad_output.detach().float().contiguous(), grad_dst)
         del grad_dst
+        if post_backward is not None:       # parallel.DistributedStudent: fire the gradient exchange
+            post_backward(arena, flat)
         return (None, None) + tuple(arena.views(flat))       # fresh views: AccumulateGrad adopts them uncopied
 
 
@@ -70,7 +72,7 @@ class Ext4ResNet(BaseExtClassifier):
             raise RuntimeError('the neural filter trains all of its tensors together (ext_runner.py:196-197)')
         if self._arena is None or [id(p) for p in self._arena.params] != [id(p) for p in params]:
             self._arena = GradArena(params)
-        return _FilterLogitsFn.apply(out, (eng, self._arena), *params)
+        return _FilterLogitsFn.apply(out, (eng, self._arena, getattr(self, '_post_backward', None)), *params)
 
 
 def get_ext_classifier(backbone):

@@ -13,6 +13,9 @@ from . import _lib
 from ._lib import ConvDesc, WgradDesc, MsePair, check
 
 _L = _lib.load()
+# advanced by every fused optimizer step: packed-weight caches (engine.weight_version) key on it because the raw-pointer
+# parameter update does not touch torch's tensor version counter
+PARAM_EPOCH = [0]
 
 
 def stream_ptr():
@@ -88,10 +91,11 @@ def fbn_fold(weight, bias, mean, var, eps=0.0, cs=None, out=None):
 # --------------------------------------------------------------------------------------- conv launches
 class ConvLaunch(object):
     """One prebuilt hnd_conv2d_igemm launch (descriptor + keep-alive references)."""
-    __slots__ = ('desc', 'ref', 'keep', 'flops', 'variant')
+    __slots__ = ('desc', 'ref', 'keep', 'flops', 'alg_flops', 'variant')
 
     def __init__(self, desc, keep, flops=0):
         self.desc, self.keep, self.flops = desc, keep, flops
+        self.alg_flops = flops      # 2*MAC of the convolution this launch stands for (== flops unless Winograd)
         self.ref = C.byref(desc)
         # which kernel instantiation hnd_conv2d_igemm dispatches to (mirrors csrc/conv_igemm.hip)
         self.variant = 'igemm_c4_128x64' if desc.cin == 4 else \
@@ -221,10 +225,11 @@ def conv_dgrad(dy, w_param, dx, k, stride=1, pad=0, accumulate=False, **kw_):
 
 
 class WgradLaunch(object):
-    __slots__ = ('desc', 'ref', 'keep', 'flops', 'variant')
+    __slots__ = ('desc', 'ref', 'keep', 'flops', 'alg_flops', 'variant')
 
     def __init__(self, desc, keep, flops):
         self.desc, self.keep, self.flops = desc, keep, flops
+        self.alg_flops = flops
         self.ref = C.byref(desc)
         self.variant = 'wgrad_m128' if desc.cout >= 128 else 'wgrad_m64'
 
@@ -367,6 +372,7 @@ def adam_step_flat(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step
     check(_L.hnd_adam_step_flat(ptr(param), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), param.numel(), float(lr),
                                 float(beta1), float(beta2), float(eps), int(step), float(grad_scale), stream_ptr()),
           'hnd_adam_step_flat')
+    PARAM_EPOCH[0] += 1
 
 
 def subsample2(x, y):
@@ -456,6 +462,7 @@ class WinoConv(object):
         self.gemm.desc.w_group_stride = ww.rows_pad * ww.depth
         tiles = n * ((h + tile - 1) // tile) * ((w + tile - 1) // tile)
         self.gemm.flops = 2 * nc * tiles * ww.rows * ww.depth          # multiplies actually executed
+        self.gemm.alg_flops = 2 * n * h * w * ww.rows * 9 * ww.depth   # the direct 3x3 convolution it computes
         self.flops = self.gemm.flops
         self.variant = self.gemm.variant
 
@@ -540,6 +547,7 @@ class Wino2Conv(object):
         self.gemm.desc.w_group_stride = ww.rows_pad * ww.depth
         tiles = n * ((oh + 3) // 4) * ((ow + 3) // 4)
         self.gemm.flops = 2 * 25 * tiles * ww.rows * ww.depth
+        self.gemm.alg_flops = 2 * n * oh * ow * ww.rows * 4 * ww.depth  # the direct 2x2 convolution it computes
         self.flops, self.variant = self.gemm.flops, self.gemm.variant
 
     @staticmethod
@@ -599,6 +607,7 @@ class Wino2Wgrad(object):
             slabs = torch.empty((need + 3) // 4, dtype=torch.float32, device=dy.device)
         d.slabs = ptr(slabs)
         self.gemm = WgradLaunch(d, (fwd.v, z, s, slabs), 2 * 25 * tiles * cout * cin)
+        self.gemm.alg_flops = 2 * n * oh * ow * cout * 4 * cin
         self.flops, self.variant = self.gemm.flops, self.gemm.variant
 
     def _run_dy(self, stream=None):
@@ -622,10 +631,10 @@ class Wino2Wgrad(object):
 
 class _Step(object):
     """a plan entry without MFMA work"""
-    __slots__ = ('fn', 'flops')
+    __slots__ = ('fn', 'flops', 'alg_flops', 'variant')
 
     def __init__(self, fn):
-        self.fn, self.flops = fn, 0
+        self.fn, self.flops, self.alg_flops, self.variant = fn, 0, 0, 'transform'
 
     def run(self, stream=None):
         self.fn(stream)
@@ -686,6 +695,7 @@ def sgd_step_flat(param, grad, buf, lr, momentum, dampening, weight_decay, neste
     check(_L.hnd_sgd_step_flat(ptr(param), ptr(grad), ptr(buf), param.numel(), float(lr), float(momentum),
                                float(dampening), float(weight_decay), int(bool(nesterov)), int(bool(first_step)),
                                float(grad_scale), stream_ptr()), 'hnd_sgd_step_flat')
+    PARAM_EPOCH[0] += 1
 
 
 def interp_out_size(size, scale):

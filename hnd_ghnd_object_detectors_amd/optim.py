@@ -9,7 +9,7 @@ and their gradients sit in flat arenas (the normal case), else one launch per te
 """
 import torch
 
-from . import ops
+from . import ops, parallel
 
 
 class FusedAdam(torch.optim.Adam):
@@ -17,13 +17,20 @@ class FusedAdam(torch.optim.Adam):
         if weight_decay != 0 or amsgrad:
             raise NotImplementedError('FusedAdam: weight_decay / amsgrad are not used by the hnd/ghnd configs')
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False)
-        self.grad_scale = 1.0          # set to 1/world_size by parallel.DistributedStudent (sum all-reduce)
+        self.grad_scale = 1.0          # extra factor on the gradients (tests); the DP mean comes from parallel
         self._flat = None
 
     # ---------------------------------------------------------------- flat arenas
     def _flatten(self, group, plist):
         """move the trainable tensors (and their Adam moments) into contiguous arenas; parameters keep their
-        identity (only .data is re-pointed), so optimizers / DDP / state_dict are unaffected."""
+        identity (only .data is re-pointed), so optimizers / DDP / state_dict are unaffected.  Tensors whose step
+        counts differ (a hand-edited checkpoint) cannot share one launch: nothing is touched then and the
+        per-tensor path is used from now on (decided once, not per step)."""
+        ids = [id(p) for p in plist]
+        steps = set(int(self.state[p]['step']) if 'exp_avg' in self.state[p] else 0 for p in plist)
+        if len(steps) != 1:
+            print('FusedAdam: per-tensor step counts differ (%s); using one launch per tensor' % sorted(steps))
+            return {'ids': ids, 'per_tensor': True}
         offsets, total = [], 0
         for p in plist:
             offsets.append(total)
@@ -31,7 +38,6 @@ class FusedAdam(torch.optim.Adam):
         dev = plist[0].device
         flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
         flat_m, flat_v = torch.zeros_like(flat_p), torch.zeros_like(flat_p)
-        steps = set()
         for o, p in zip(offsets, plist):
             n = p.numel()
             flat_p[o:o + n].copy_(p.data.reshape(-1))
@@ -40,17 +46,11 @@ class FusedAdam(torch.optim.Adam):
             if 'exp_avg' in st:                       # resumed from a checkpoint
                 flat_m[o:o + n].copy_(st['exp_avg'].reshape(-1))
                 flat_v[o:o + n].copy_(st['exp_avg_sq'].reshape(-1))
-                steps.add(int(st['step']))
-            else:
-                steps.add(0)
             st['exp_avg'] = flat_m[o:o + n].view(p.shape)
             st['exp_avg_sq'] = flat_v[o:o + n].view(p.shape)
             if 'step' not in st:
                 st['step'] = torch.tensor(0.0)
-        if len(steps) != 1:
-            return None
-        return {'ids': [id(p) for p in plist], 'offsets': offsets, 'total': total, 'p': flat_p, 'm': flat_m,
-                'v': flat_v}
+        return {'ids': ids, 'offsets': offsets, 'total': total, 'p': flat_p, 'm': flat_m, 'v': flat_v}
 
     def _grads_are_flat(self, flat, plist):
         base = plist[0].grad.data_ptr()
@@ -76,12 +76,15 @@ class FusedAdam(torch.optim.Adam):
             if flat is None or flat['ids'] != [id(p) for p in plist]:
                 flat = self._flatten(group, plist)
                 self._flat = flat
-            flat_g = self._grads_are_flat(flat, plist) if flat is not None else None
+            flat_g = self._grads_are_flat(flat, plist) if not flat.get('per_tensor') else None
+            # gradient all-reduces fired from inside backward (parallel.DistributedStudent): wait stream-side, and
+            # fold the 1/world mean of a sum all-reduce into this launch
+            grad_scale = self.grad_scale * parallel.finish_pending(flat_g)
             if flat_g is not None and all(p.data_ptr() == flat['p'].data_ptr() + o * 4
                                           for o, p in zip(flat['offsets'], plist)):
                 step = int(self.state[plist[0]]['step']) + 1
                 ops.adam_step_flat(flat['p'], flat_g, flat['m'], flat['v'], group['lr'], beta1, beta2, group['eps'],
-                                   step, self.grad_scale)
+                                   step, grad_scale)
                 for p in plist:
                     self.state[p]['step'] = torch.tensor(float(step))
             else:
@@ -94,7 +97,7 @@ class FusedAdam(torch.optim.Adam):
                     step = int(st['step']) + 1
                     g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                     ops.adam_step_flat(p.data, g, st['exp_avg'], st['exp_avg_sq'], group['lr'], beta1, beta2,
-                                       group['eps'], step, self.grad_scale)
+                                       group['eps'], step, grad_scale)
                     st['step'] = torch.tensor(float(step))
         return None
 
@@ -110,6 +113,11 @@ class FusedSGD(torch.optim.SGD):
         self._flat = None
 
     def _flatten(self, plist):
+        ids = [id(p) for p in plist]
+        started = set(self.state[p].get('momentum_buffer') is not None for p in plist)
+        if len(started) != 1:           # nothing touched; per-tensor path from now on (decided once)
+            print('FusedSGD: some tensors have a momentum buffer and some do not; using one launch per tensor')
+            return {'ids': ids, 'per_tensor': True}
         offsets, total = [], 0
         for p in plist:
             offsets.append(total)
@@ -117,21 +125,16 @@ class FusedSGD(torch.optim.SGD):
         dev = plist[0].device
         flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
         flat_b = torch.zeros_like(flat_p)
-        started = set()
         for o, p in zip(offsets, plist):
             n = p.numel()
             flat_p[o:o + n].copy_(p.data.reshape(-1))
             p.data = flat_p[o:o + n].view(p.shape)
             st = self.state[p]
             buf = st.get('momentum_buffer')
-            started.add(buf is not None)
             if buf is not None:                       # resumed from a checkpoint
                 flat_b[o:o + n].copy_(buf.reshape(-1))
             st['momentum_buffer'] = flat_b[o:o + n].view(p.shape) if buf is not None else None
-        if len(started) != 1:
-            return None
-        return {'ids': [id(p) for p in plist], 'offsets': offsets, 'total': total, 'p': flat_p, 'b': flat_b,
-                'started': started.pop()}
+        return {'ids': ids, 'offsets': offsets, 'total': total, 'p': flat_p, 'b': flat_b, 'started': started.pop()}
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -146,11 +149,12 @@ class FusedSGD(torch.optim.SGD):
             if flat is None or flat['ids'] != [id(p) for p in plist]:
                 flat = self._flatten(plist)
                 self._flat = flat
-            flat_g = FusedAdam._grads_are_flat(self, flat, plist) if flat is not None else None
+            flat_g = FusedAdam._grads_are_flat(self, flat, plist) if not flat.get('per_tensor') else None
+            grad_scale = self.grad_scale * parallel.finish_pending(flat_g)
             if flat_g is not None and all(p.data_ptr() == flat['p'].data_ptr() + o * 4
                                           for o, p in zip(flat['offsets'], plist)):
                 ops.sgd_step_flat(flat['p'], flat_g, flat['b'], *hyper, first_step=not flat['started'],
-                                  grad_scale=self.grad_scale)
+                                  grad_scale=grad_scale)
                 if not flat['started'] and group['momentum'] != 0:
                     for o, p in zip(flat['offsets'], plist):
                         self.state[p]['momentum_buffer'] = flat['b'][o:o + p.numel()].view(p.shape)
@@ -163,5 +167,5 @@ class FusedSGD(torch.optim.SGD):
                         st['momentum_buffer'] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                     ops.sgd_step_flat(p.data, g, st.get('momentum_buffer'), *hyper, first_step=first,
-                                      grad_scale=self.grad_scale)
+                                      grad_scale=grad_scale)
         return None

@@ -1,16 +1,81 @@
 """Data parallelism for the distillation step: one process per GPU, RCCL over xGMI.
 
-The reference wraps the student in torch DistributedDataParallel (src/mimic_runner.py:141-143): per step one
-gradient-averaging all-reduce of the 25 trainable tensors (586 566 floats) plus a broadcast of every buffer.
-Here the gradients already live in ONE flat arena, so the exchange is a single in-place ``all_reduce`` of that
-arena (torch.distributed backend 'nccl' == RCCL on ROCm); the 1/world factor is folded into the fused Adam
-launch.  BatchNorm statistics stay local to each rank exactly like the reference (no SyncBN); running stats
-are broadcast from rank 0 only when asked (``sync_buffers``: before evaluation / checkpointing) instead of at
-every forward -- training-mode outputs do not depend on them.
+The reference wraps the student in torch DistributedDataParallel (src/mimic_runner.py:141-143): its training loop
+stays ``zero_grad(); loss.backward(); optimizer.step()`` (:52-54) because DDP's hooks average the gradients of the
+25 trainable tensors (586 566 floats) across ranks INSIDE backward, and it broadcasts every buffer at each forward.
+
+``DistributedStudent`` keeps that contract.  The hand-written backward plan writes all gradients into ONE flat
+arena; when its last kernel (the stem's weight gradient) has been enqueued it calls the hook registered here, which
+fires a single in-place all-reduce of that arena on the communication stream; the fused optimizers wait for it
+(stream-side, no host block) right before their launch and fold the 1/world mean into it.  No
+``reduce_gradients()`` call is needed in the loop (it survives as a no-op-compatible explicit form).
+
+Exchange back ends:
+  * default: ``torch.distributed`` (backend 'nccl' == RCCL on ROCm) ``all_reduce(async_op=True)``; 'gloo' is what
+    the CPU / shared-GPU tests use;
+  * ``HND_NATIVE_COMM=1`` (backend 'nccl' only): the C ABI's own communicator -- ``hnd_comm_init`` /
+    ``hnd_allreduce_avg_flat`` of include/hnd_hip.h (ncclAvg on a dedicated HIP stream), the id shipped over the
+    existing process group.
+
+BatchNorm statistics stay local to each rank exactly like the reference (no SyncBN).  Deviation, documented:
+buffers are broadcast from rank 0 at construction and on ``sync_buffers()`` (before evaluation / checkpointing)
+instead of at every forward -- training-mode outputs do not depend on the running statistics.
 """
+import ctypes as C
+import os
+
 import torch
 import torch.distributed as dist
 from torch import nn
+
+# reductions in flight: (flat tensor, waiter, scale) -- consumed by finish_pending() from the fused optimizers
+_PENDING = []
+
+
+def finish_pending(flat_grad=None):
+    """Called by FusedAdam / FusedSGD right before their launch: make the current stream wait for every gradient
+    all-reduce in flight and return the factor the summed gradients still have to be multiplied by (1/world for a
+    sum all-reduce, 1.0 when nothing was pending or the exchange already averaged)."""
+    scale = 1.0
+    while _PENDING:
+        flat, waiter, s = _PENDING.pop()
+        waiter()
+        if flat_grad is None or flat.data_ptr() == flat_grad.data_ptr():
+            scale = s
+    return scale
+
+
+class _NativeComm(object):
+    """the C ABI's RCCL communicator (include/hnd_hip.h: hnd_comm_*), id distributed over torch.distributed"""
+
+    def __init__(self, rank, world, device):
+        from . import _lib
+        self.lib = _lib.load()
+        self.check = _lib.check
+        nbytes = int(self.lib.hnd_workspace_size(5, None, 0))           # HND_OP_COMM_UNIQUE_ID
+        buf = C.create_string_buffer(nbytes)
+        if rank == 0:
+            self.check(self.lib.hnd_comm_unique_id(buf, nbytes), 'hnd_comm_unique_id')
+        box = [bytes(buf.raw)]
+        dist.broadcast_object_list(box, src=0)
+        self.handle = C.c_void_p()
+        with torch.cuda.device(device):
+            self.check(self.lib.hnd_comm_init(rank, world, box[0], nbytes, C.byref(self.handle)), 'hnd_comm_init')
+        self.stream = torch.cuda.Stream(device=device)
+
+    def all_reduce_avg(self, flat):
+        """enqueue on the communication stream, ordered after everything already on the current stream"""
+        self.stream.wait_stream(torch.cuda.current_stream())
+        self.check(self.lib.hnd_allreduce_avg_flat(self.handle, flat.data_ptr(), flat.numel(),
+                                                   self.stream.cuda_stream), 'hnd_allreduce_avg_flat')
+        done = torch.cuda.Event()
+        done.record(self.stream)
+        return lambda: torch.cuda.current_stream().wait_event(done)
+
+    def close(self):
+        if self.handle:
+            self.lib.hnd_comm_destroy(self.handle)
+            self.handle = C.c_void_p()
 
 
 class DistributedStudent(nn.Module):
@@ -21,15 +86,26 @@ class DistributedStudent(nn.Module):
         self.module = module
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.optimizer = optimizer
+        self.native = None
+        self.reductions = 0            # all-reduces fired so far (tests / logging)
         if self.world > 1:
             for p in module.parameters():          # same start on every rank (DDP broadcasts at construction)
                 dist.broadcast(p.data, 0)
             self.sync_buffers()
+            if os.environ.get('HND_NATIVE_COMM', '0') != '0':
+                if dist.get_backend() != 'nccl':
+                    raise RuntimeError('HND_NATIVE_COMM=1 needs the nccl (= RCCL) process group: one GPU per rank')
+                dev = next(module.parameters()).device
+                self.native = _NativeComm(dist.get_rank(), self.world, dev)
+            body = module.backbone.body
+            body._post_backward = self._on_backward_done
+            ext = body.get_ext_classifier() if hasattr(body, 'get_ext_classifier') else None
+            if ext is not None:                    # neural-filter training: its 14 tensors have their own arena
+                ext._post_backward = self._on_backward_done
 
     def attach_optimizer(self, optimizer):
+        """kept for callers of the round-1 API; the fused optimizers pick the mean factor up by themselves"""
         self.optimizer = optimizer
-        if hasattr(optimizer, 'grad_scale'):
-            optimizer.grad_scale = 1.0 / self.world
 
     def sync_buffers(self):
         if self.world > 1:
@@ -39,26 +115,36 @@ class DistributedStudent(nn.Module):
     def forward(self, *args, **kwargs):
         return self.module(*args, **kwargs)
 
-    def reduce_gradients(self):
-        """call between loss.backward() and optimizer.step(): sums the flat gradient arena across ranks."""
+    # ------------------------------------------------------------------ the exchange
+    def _on_backward_done(self, arena, flat):
+        """hook of the hand-written backward (distillation/hip_loss.py, models/ext/classifier.py): every gradient of
+        this step has been ENQUEUED into `flat`; fire the exchange behind it."""
         if self.world == 1:
             return
-        body = self.module.backbone.body
-        arenas = [getattr(body, '_grad_arena', None)]
-        ext = body.get_ext_classifier() if hasattr(body, 'get_ext_classifier') else None
-        if ext is not None:                        # neural-filter training: its 14 tensors have their own arena
-            arenas = [getattr(ext, '_arena', None)]
-        arenas = [a for a in arenas if a is not None]
-        if arenas:
-            for arena in arenas:
-                dist.all_reduce(arena.flat[arena.cur])
-        else:
-            for p in self.module.parameters():
-                if p.grad is not None:
-                    dist.all_reduce(p.grad)
-        if self.optimizer is None or not hasattr(self.optimizer, 'grad_scale'):
-            raise RuntimeError('attach_optimizer(FusedAdam / FusedSGD) first: the 1/world factor is applied in the '
-                               'optimizer launch')
+        lo, hi = flat.data_ptr(), flat.data_ptr() + flat.numel() * 4
+        for p in arena.params:
+            if p.grad is not None and not (lo <= p.grad.data_ptr() < hi):
+                # a live .grad in the OTHER arena means autograd will accumulate this step's gradient into it after
+                # this hook: the arena being reduced would not be what the optimizer consumes
+                raise RuntimeError('DistributedStudent: a parameter still holds a gradient from an earlier backward; '
+                                   'call optimizer.zero_grad() (set_to_none) before loss.backward() as '
+                                   'mimic_runner.distill_model does -- gradient accumulation is not supported')
+        self.reductions += 1
+        if self.native is not None:
+            _PENDING.append((flat, self.native.all_reduce_avg(flat), 1.0))
+            return
+        work = dist.all_reduce(flat, async_op=True)              # sum; 1/world is folded into the optimizer launch
+        _PENDING.append((flat, work.wait, 1.0 / self.world))
+
+    def reduce_gradients(self):
+        """explicit form of round 1's loop (between loss.backward() and optimizer.step()).  The exchange now fires
+        from inside backward, so this only covers models whose gradients did not come from a flat arena."""
+        if self.world == 1 or _PENDING or self.reductions:
+            return
+        for p in self.module.parameters():
+            if p.grad is not None:
+                dist.all_reduce(p.grad)
+                p.grad.mul_(1.0 / self.world)
 
 
 def all_reduce_flat_(flat, world):

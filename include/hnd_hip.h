@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define HND_ABI_VERSION 2
+#define HND_ABI_VERSION 3
 
 typedef enum hnd_status {
   HND_OK = 0,
@@ -306,6 +306,33 @@ int hnd_channel_sum(const float* x, float* out, int64_t npix, int c, int cs, flo
 int hnd_sgd_step_flat(float* param, const float* grad, float* momentum_buf, int64_t numel, float lr, float momentum,
                       float dampening, float weight_decay, int nesterov, int first_step, float grad_scale,
                       void* stream);
+
+/* ---- data-parallel gradient exchange: replaces torch DistributedDataParallel's gradient
+ * averaging for the student (src/mimic_runner.py:141-143; process group of src/utils/main_util.py:43-62).
+ * One process per GPU; RCCL over xGMI, resolved at run time (the RCCL PyTorch-ROCm already loaded is reused).
+ *   rank 0:  hnd_comm_unique_id(id, 128) -> ship the 128 bytes to every rank (the host does this over its
+ *            torch.distributed store / any side channel) -> every rank: hnd_comm_init(rank, world, id, 128, &comm)
+ *            with its GPU current.  The communicator is the ONLY persistent object the library owns.
+ *   per step: hnd_allreduce_avg_flat(comm, flat_grad, n, stream): in-place average of the flat fp32 gradient arena
+ *            (586 566 floats for the b3ch student) enqueued on `stream`; the caller orders it after the last
+ *            weight-gradient kernel and before hnd_adam_step_flat with stream events. */
+int hnd_comm_unique_id(void* id_out, size_t bytes);
+int hnd_comm_init(int rank, int world, const void* unique_id, size_t bytes, void** comm_out);
+int hnd_allreduce_avg_flat(void* comm, float* flat, int64_t n, void* stream);
+int hnd_comm_destroy(void* comm);
+
+/* ---- generic workspace query: bytes of caller-provided scratch an op needs.  `desc` is the op's
+ * descriptor where it has one (hnd_wgrad_desc for HND_OP_CONV2D_WGRAD), `arg` an op-specific integer (channels for
+ * HND_OP_CHANNEL_SUM), both ignored otherwise.  The op-specific helpers above return the same numbers. */
+typedef enum hnd_op {
+  HND_OP_CONV2D_IGEMM = 0,   /* no workspace                                   */
+  HND_OP_CONV2D_WGRAD = 1,   /* split-K slabs, desc = const hnd_wgrad_desc*    */
+  HND_OP_MSE = 2,            /* double[hnd_mse_scratch_elems()]                */
+  HND_OP_QUANTIZE_U8 = 3,    /* float[hnd_minmax_scratch_elems()]              */
+  HND_OP_CHANNEL_SUM = 4,    /* float[hnd_channel_sum_scratch_elems(arg)]      */
+  HND_OP_COMM_UNIQUE_ID = 5  /* bytes of the id buffer of hnd_comm_unique_id   */
+} hnd_op;
+size_t hnd_workspace_size(int op, const void* desc, int64_t arg);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,54 @@
+#!/usr/bin/env python
+"""Pin bench.py's first-step loss: the CPU oracle (oracle/hnd_oracle.py, itself pinned to the reference by
+make_golden.py) evaluates the distillation loss of bench.py's EXACT first step -- same seeded weights
+(synthetic.build_distillation_pair(seed=0)), same seeded batch (torch.rand, seed 1234 + rank), batch 16 at
+3x800x1333 -- forward only (no autograd graph, so batch 16 fits the build container), FPN skipped (dead w.r.t. the
+loss).  bench.py asserts its warm-up step 0 against these numbers outside the timed region.
+
+usage:  python tests/golden/make_bench_loss.py        -> tests/golden/bench_first_loss.json
+"""
+import contextlib
+import json
+import os
+import sys
+import time
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from oracle import hnd_oracle as O  # noqa: E402
+
+
+def main():
+    from hnd_ghnd_object_detectors_amd.configs import make_config
+    from hnd_ghnd_object_detectors_amd.synthetic import build_distillation_pair
+    torch.set_num_threads(8)
+    out = {'script': 'tests/golden/make_bench_loss.py', 'torch': torch.__version__, 'cases': {}}
+    for model, batch, ranks in (('faster_rcnn', 16, (0, 1)), ('faster_rcnn', 4, (0,)), ('mask_rcnn', 8, (0,)),
+                                ('keypoint_rcnn', 8, (0,))):
+        config = make_config(model, 'ghnd', 3, batch_size=batch, pretrained=False, ckpt_root='/nonexistent')
+        with contextlib.redirect_stdout(sys.stderr):
+            teacher, student = build_distillation_pair(config, torch.device('cpu'), seed=0)
+        t_sd = {k: v.detach().clone() for k, v in teacher.state_dict().items()}
+        s_sd = {k: v.detach().clone() for k, v in student.state_dict().items()}
+        if model == 'keypoint_rcnn':
+            continue        # bench draws fixed_sizes from python's RNG per step; pinned by the golden fixtures instead
+        orc = O.DistillOracle(t_sd, s_sd, terms=O.GHND_TERMS, min_size=(800,), max_size=1333, with_fpn=False)
+        for rank in ranks:
+            g = torch.Generator().manual_seed(1234 + rank)
+            images = [torch.rand(3, 800, 1333, generator=g) for _ in range(batch)]
+            t0 = time.time()
+            with torch.no_grad():
+                loss, per_term, *_ = orc.forward(images, update_buffers=False)
+            key = '%s/batch%d/rank%d' % (model, batch, rank)
+            out['cases'][key] = {'ghnd': float(loss), 'hnd': float(per_term['layer1']),
+                                 'terms': {k: float(v) for k, v in per_term.items()}}
+            print(key, out['cases'][key], '%.0f s' % (time.time() - t0), flush=True)
+    with open(os.path.join(HERE, 'bench_first_loss.json'), 'w') as fp:
+        json.dump(out, fp, indent=1, sort_keys=True)
+
+
+if __name__ == '__main__':
+    main()

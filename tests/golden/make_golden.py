@@ -54,6 +54,23 @@ CASES = OrderedDict((
                                  sizes=[(64, 96)], min_size=64, max_size=128, steps=1, seed=15, bch=6)),
     ('full_ghnd_faster', dict(yaml='ghnd/faster_rcnn-backbone_resnet50-b3ch.yaml', model='faster_rcnn',
                               sizes=[(800, 1333)], min_size=800, max_size=1333, steps=1, seed=16, full=True)),
+    # full-size pins of every BASELINE.json config (round 2).  b4 is the reference's own train batch_size
+    # (config/ghnd/faster_rcnn-backbone_resnet50-b3ch.yaml:65); batch 16 does not fit this container's RAM through
+    # the reference's autograd graph, so the GPU tests reach batch 16 from these by replication (BN batch statistics,
+    # features and Adam updates are invariant under replicating the batch; loss and gradients scale by the factor).
+    ('full_ghnd_faster_b4', dict(yaml='ghnd/faster_rcnn-backbone_resnet50-b3ch.yaml', model='faster_rcnn',
+                                 sizes=[(800, 1333)] * 4, min_size=800, max_size=1333, steps=1, seed=17, full=True)),
+    ('full_hnd_faster_b2', dict(yaml='hnd/faster_rcnn-backbone_resnet50-b3ch.yaml', model='faster_rcnn',
+                                sizes=[(800, 1333)] * 2, min_size=800, max_size=1333, steps=1, seed=18, full=True)),
+    ('full_ghnd_mask_b2', dict(yaml='ghnd/mask_rcnn-backbone_resnet50-b3ch.yaml', model='mask_rcnn',
+                               sizes=[(800, 1333), (800, 1200)], min_size=800, max_size=1333, steps=1, seed=19,
+                               full=True)),
+    ('full_ghnd_keypoint_b2', dict(yaml='ghnd/keypoint_rcnn-backbone_resnet50-b3ch.yaml', model='keypoint_rcnn',
+                                   sizes=[(800, 1333), (1333, 800)], min_size=[640, 672, 704, 736, 768, 800],
+                                   max_size=1333, steps=1, seed=20, num_classes=2, full=True)),
+    # BASELINE.json configs[3] quotes Mask R-CNN at batch 8 per GPU
+    ('full_ghnd_mask_b8', dict(yaml='ghnd/mask_rcnn-backbone_resnet50-b3ch.yaml', model='mask_rcnn',
+                               sizes=[(800, 1333)] * 8, min_size=800, max_size=1333, steps=1, seed=22, full=True)),
 ))
 
 
@@ -206,7 +223,9 @@ def run_case(name, case):
     assert worst < 1e-5 and worst_grad < (2e-4 if case.get('full') else 1e-5), 'oracle restatement diverges from the reference'
     path = os.path.join(HERE, name + '.npz')
     np.savez_compressed(path, **out)
-    print('   wrote %s (%.1f KB)' % (path, os.path.getsize(path) / 1024.0))
+    import resource
+    print('   wrote %s (%.1f KB); peak RSS %.1f GB' % (path, os.path.getsize(path) / 1024.0,
+                                                    resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1048576.0))
 
 
 def run_eval_codec_case(name='tiny_eval_quantized'):
@@ -231,8 +250,25 @@ def run_eval_codec_case(name='tiny_eval_quantized'):
     worst = 0.0
     for tag, use in (('plain', False), ('quantized', True)):
         student.backbone.body.layer1.use_bottleneck_transformer = use
+        captured = []
+        hook = student.backbone.body.layer1.encoder.register_forward_hook(lambda m, i, o: captured.append(o.detach()))
         with torch.no_grad():
             feats = student([im.clone() for im in images])
+        hook.remove()
+        if use:
+            # what crosses the link: the reference's own Quantizer (structure/transformer.py:131-140) on the reference's
+            # own bottleneck tensor z.  Byte work -> the GPU test demands these exact bytes for this exact z.
+            from structure.transformer import Dequantizer, Quantizer      # reference classes
+            from oracle.myutils_r import quantize_tensor as oracle_quantize
+            z_ref = captured[0]
+            qz, _ = Quantizer(8)(z_ref.clone(), None)
+            out['quantized/z'] = z_ref.numpy()
+            out['quantized/bytes'] = qz.tensor.numpy()
+            out['quantized/scale'] = np.float32(float(qz.scale))
+            out['quantized/zero_point'] = np.float32(float(qz.zero_point))
+            out['quantized/dequantized'] = Dequantizer(8)(qz, None)[0].numpy()
+            o_q = oracle_quantize(z_ref.clone(), 8)
+            assert torch.equal(o_q.tensor, qz.tensor) and float(o_q.scale) == float(qz.scale)
         x, _ = O.transform_images(images, (64,), 128)
         o_h, o_f = O.backbone_forward(x, O.cast_state(s_sd, torch.float32), student=True, training=False,
                                       codec_bits=8 if use else None)

@@ -130,6 +130,38 @@ def test_distill_steps_match_reference_golden(name):
                                                                           worst['grad']))
 
 
+def test_eval_after_a_training_step_uses_the_updated_weights():
+    """FusedAdam updates parameters through raw pointers (no torch version bump); the packed / Winograd
+    weight caches must still notice, so a train-then-eval sequence in one process (ext_runner's per-epoch validation,
+    split / eval after distillation) runs the UPDATED conv weights.  lr is raised so a stale pack would be far off."""
+    z, meta = G.load('tiny_ghnd_faster')
+    cfg, t_sd, s_sd, teacher, student, box, opt, warm = _setup(meta)
+    images, targets = G.case_inputs(meta)
+    ims, tgs = _to_dev(images, targets)
+    student.eval()
+    with torch.no_grad():
+        before = student(ims)[0].clone()                    # builds the eval-mode plans and packs
+    student.train()
+    for group in opt.param_groups:
+        group['lr'] = 5e-2
+    for _ in range(2):
+        loss = box(ims, [dict(t) for t in tgs])
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    student.eval()
+    with torch.no_grad():
+        feats = student(ims)
+    sd = OrderedDict((k, v.detach().cpu().clone()) for k, v in student.state_dict().items())
+    x, _ = O.transform_images(images, (meta['min_size'],), meta['max_size'])
+    _, o_f = O.backbone_forward(x, O.cast_state(sd, torch.float32), student=True, training=False)
+    assert float((feats[0] - before).abs().max()) > 1e-3         # the step really moved the output
+    for k, v in feats.items():
+        ref = o_f[k]
+        err = float((v.cpu().double() - ref.double()).norm() / ref.double().norm())
+        assert err < FEAT_TOL, (k, err)
+
+
 def test_transform_and_fpn_match_golden():
     z, meta = G.load('tiny_ghnd_faster')
     cfg, t_sd, s_sd, teacher, student, box, opt, warm = _setup(meta)
@@ -294,6 +326,21 @@ def test_eval_with_quantized_bottleneck_matches_reference_golden():
     assert torch.equal(a, b)
 
 
+def test_quantizer_reproduces_reference_bytes_on_reference_bottleneck():
+    """Byte work is bit-exact: the package's Quantizer / Dequantizer (reference src/structure/transformer.py:131-153)
+    fed the REFERENCE's own bottleneck tensor z (fixture ``quantized/z``) must emit exactly the bytes, scale,
+    zero_point and dequantised floats the reference's Quantizer emitted for it."""
+    from hnd_ghnd_object_detectors_amd.structure.transformer import Dequantizer, Quantizer
+    z = G.load_raw('tiny_eval_quantized')
+    z_ref = torch.from_numpy(z['quantized/z']).to(DEV)                   # [N, 3, h, w] fp32
+    qz, _ = Quantizer(8)(z_ref, None)
+    assert qz.tensor.dtype == torch.uint8 and tuple(qz.tensor.shape) == tuple(z_ref.shape)
+    assert torch.equal(qz.tensor.cpu(), torch.from_numpy(z['quantized/bytes']))
+    assert float(qz.scale) == float(z['quantized/scale']) and float(qz.zero_point) == float(z['quantized/zero_point'])
+    deq, _ = Dequantizer(8)(qz, None)
+    assert torch.equal(deq.cpu(), torch.from_numpy(z['quantized/dequantized']))
+
+
 @pytest.mark.parametrize('quantization,tag,tol', [(None, 'plain', FEAT_TOL), (8, 'quantized', 2e-2)])
 def test_head_tail_split_matches_reference_golden(quantization, tag, tol):
     """split_rcnn_model: RcnnHead (transform + stem + encoder [+ uint8 quantiser]) -> z -> RcnnTail ([dequantiser]
@@ -339,27 +386,127 @@ def test_head_tail_split_matches_reference_golden(quantization, tag, tol):
         tail(zq, tensors_shape, image_sizes, original_sizes)
 
 
-def test_full_size_step_matches_reference_checksums():
-    """800x1333 (padded 800x1344), batch 1: size-independent fingerprints of every hooked map, loss, gradients."""
-    z, meta = G.load('full_ghnd_faster')
+FULL = ['full_ghnd_faster', 'full_ghnd_faster_b4', 'full_hnd_faster_b2', 'full_ghnd_mask_b2', 'full_ghnd_keypoint_b2',
+        'full_ghnd_mask_b8']
+
+
+def _full_step(z, meta, repeat=1):
+    """one distillation step of a full-size fixture's inputs (the batch replicated `repeat` times) on the HIP path"""
     cfg, t_sd, s_sd, teacher, student, box, opt, warm = _setup(meta)
     images, targets = G.case_inputs(meta)
-    ims, tgs = _to_dev(images, targets)
+    ims, tgs = _to_dev(images * repeat, [dict(t) for t in targets * repeat])
+    if meta['model'] == 'keypoint_rcnn':
+        random.seed(100)                  # tool.py:45-48 draws one size per image from python's RNG
     loss = box(ims, tgs)
+    return cfg, teacher, student, box, opt, warm, ims, tgs, loss
+
+
+@pytest.mark.parametrize('name', FULL)
+def test_full_size_step_matches_reference_checksums(name):
+    """3x800x1333 inputs (padded 800x1344; Keypoint: sizes drawn per image as tool.py:45-48, padded 1248x1120) at the
+    reference's own batch sizes: fingerprints (sum, sum of squares, 64 strided samples) of every hooked map, the
+    loss and its terms, all 23 non-degenerate gradients and the parameters after the Adam step, against what the
+    REFERENCE produced for the same seeded inputs (tests/golden/make_golden.py)."""
+    if not os.path.exists(os.path.join(G.GOLDEN_DIR, name + '.npz')):
+        pytest.skip('fixture %s not generated (needs > 48 GB of host RAM in the build container)' % name)
+    z, meta = G.load(name)
+    cfg, teacher, student, box, opt, warm, ims, tgs, loss = _full_step(z, meta)
+    if meta['model'] == 'keypoint_rcnn':
+        want = [int(v) for v in z['step0/fixed_sizes']]
+        random.seed(100)
+        assert [random.choice(teacher.transform.min_size) for _ in ims] == want
+    hp, wp = (int(v) for v in z['batched_shape'][2:])
+    assert tuple(_hooked(teacher, 'backbone.body.layer1').shape) == (len(ims), 256, hp // 4, wp // 4)
     ref = float(z['step0/loss'])
     assert abs(loss.item() - ref) / ref < LOSS_TOL
-    for k in MU.terms_of(cfg):
+    per_term = loss.per_term.cpu()
+    for i, k in enumerate(MU.terms_of(cfg)):
+        rt = float(z['step0/term/%s' % k])
+        assert abs(float(per_term[i]) - rt) / rt < LOSS_TOL, k
         path = 'backbone.body.' + k
         G.compare(z, 'step0/teacher/' + k, _hooked(teacher, path).contiguous(), FEAT_TOL)
         G.compare(z, 'step0/student/' + k, _hooked(student, path).contiguous(), FEAT_TOL)
     opt.zero_grad()
     loss.backward()
+    assert abs(opt.param_groups[0]['lr'] - float(z['step0/lr'])) < 1e-12
     for n, p in student.named_parameters():
         if p.requires_grad and not n.endswith(G.ZERO_GRAD_SUFFIXES):
             G.compare(z, 'step0/grad/' + n, p.grad, 5e-3)
-    # idempotence: the same batch through the same weights reproduces the loss bit for bit (deterministic kernels)
-    loss2 = box(ims, tgs)
-    assert loss2.item() == loss.item()
+    opt.step()
+    sd = student.state_dict()
+    for n in O.trainable_keys(sd):
+        if not n.endswith(G.ZERO_GRAD_SUFFIXES):
+            G.compare(z, 'after/param/' + n, sd[n], 2e-3, atol=1e-6)
+    for n in z.files:
+        if n.startswith('after/buffer/'):
+            key = n[len('after/buffer/'):]
+            refb, got = torch.from_numpy(z[n]).double(), sd[key].cpu().double()
+            assert float((got - refb).abs().max()) <= 1e-4 * (1 + float(refb.abs().max())), key
+
+
+def test_batch16_is_the_reference_batch4_replicated():
+    """The benchmarked configuration (batch 16 at 3x800x1333) pinned to the reference without a 90 GB CPU run: the
+    reference's own batch of 4 (config/ghnd/...b3ch.yaml:65, fixture full_ghnd_faster_b4) replicated 4x.  Train-mode
+    BatchNorm statistics are invariant under replicating the batch, so every hooked map of images 0..3 must match
+    the reference's batch-4 fingerprints, images 4k..4k+3 must equal images 0..3 BIT FOR BIT (same arithmetic per
+    pixel whatever the position in the batch), the loss is 4x the reference's and every gradient 4x the reference's
+    (sum reduction); Adam's update is invariant under a gradient scale, so the parameters after the step match too."""
+    z, meta = G.load('full_ghnd_faster_b4')
+    cfg, teacher, student, box, opt, warm, ims, tgs, loss = _full_step(z, meta, repeat=4)
+    assert len(ims) == 16
+    ref = 4.0 * float(z['step0/loss'])
+    assert abs(loss.item() - ref) / ref < LOSS_TOL
+    per_term = loss.per_term.cpu()
+    for i, k in enumerate(MU.terms_of(cfg)):
+        assert abs(float(per_term[i]) - 4.0 * float(z['step0/term/%s' % k])) / (4.0 * float(z['step0/term/%s' % k])) < LOSS_TOL
+        for who, model in (('teacher', teacher), ('student', student)):
+            out = _hooked(model, 'backbone.body.' + k)
+            assert out.shape[0] == 16
+            G.compare(z, 'step0/%s/%s' % (who, k), out[:4].contiguous(), FEAT_TOL)
+            for r in range(1, 4):
+                assert torch.equal(out[4 * r:4 * r + 4], out[:4]), (who, k, r)
+    opt.zero_grad()
+    loss.backward()
+    for n, p in student.named_parameters():
+        if p.requires_grad and not n.endswith(G.ZERO_GRAD_SUFFIXES):
+            G.compare(z, 'step0/grad/' + n, p.grad * 0.25, 5e-3)
+    opt.step()
+    sd = student.state_dict()
+    for n in O.trainable_keys(sd):
+        if not n.endswith(G.ZERO_GRAD_SUFFIXES):
+            G.compare(z, 'after/param/' + n, sd[n], 2e-3, atol=1e-6)
+
+
+def test_batch16_teacher_maps_equal_batch1_maps_bitwise_and_steps_are_reproducible():
+    """Two batch-16 properties that need no CPU run.  (i) the frozen teacher has no cross-image coupling: the hooked
+    maps of image i inside a batch of 16 distinct images equal the maps of the same image alone, bit for bit --
+    whatever block tile / Winograd grouping / XCD remap the 16x larger grid picks.  (ii) two identical batch-16
+    steps from the same state give bit-identical loss, per-term losses and gradients (fixed-order reductions)."""
+    from hnd_ghnd_object_detectors_amd.myutils.pytorch import module_util
+    z, meta = G.load('full_ghnd_faster_b4')
+    cfg, t_sd, s_sd, teacher, student, box, opt, warm = _setup(meta)
+    g = torch.Generator().manual_seed(77)
+    images = [torch.rand(3, 800, 1333, generator=g) for _ in range(16)]
+    targets = [{'boxes': torch.tensor([[100.0, 100.0, 400.0, 300.0]]), 'labels': torch.tensor([1])} for _ in images]
+    ims, tgs = _to_dev(images, targets)
+    runs = []
+    for _ in range(2):
+        loss = box(ims, [dict(t) for t in tgs])
+        opt.zero_grad()
+        loss.backward()
+        runs.append((loss.item(), loss.per_term.cpu().clone(),
+                     OrderedDict((n, p.grad.clone()) for n, p in student.named_parameters() if p.requires_grad)))
+    assert runs[0][0] == runs[1][0] and torch.equal(runs[0][1], runs[1][1])
+    for n in runs[0][2]:
+        assert torch.equal(runs[0][2][n], runs[1][2][n]), n
+    paths = ['backbone.body.layer%d' % i for i in range(1, 5)]
+    maps16 = [module_util.get_module(teacher, p).__dict__['distillation_box']['output'].clone() for p in paths]
+    for i in (0, 7, 15):
+        with torch.no_grad():
+            teacher([ims[i]])
+        for p, m16 in zip(paths, maps16):
+            one = module_util.get_module(teacher, p).__dict__['distillation_box']['output']
+            assert torch.equal(one[0], m16[i]), (p, i)
 
 
 def test_checkpoint_resume_continues_the_same_trajectory(tmp_path):
@@ -571,6 +718,68 @@ def test_mimic_runner_two_ranks_share_one_gpu(tmp_path):
     ck = torch.load(ckpt, weights_only=False)
     assert len(ck['model']) == 293 and len(ck['optimizer']['state']) == 25
     assert all(torch.isfinite(v).all() for v in ck['model'].values() if v.is_floating_point())
+
+
+def test_two_ranks_take_the_oracle_step_on_the_mean_gradient(tmp_path):
+    """DDP arithmetic (reference src/mimic_runner.py:141-143 + :52-54): 2 ranks, each its own seeded batch and LOCAL
+    BatchNorm statistics, reference loop verbatim (no explicit reduce call).  After every step BOTH ranks must hold
+    bit-identical parameters, and those must equal the oracle's Adam step on the MEAN of the two ranks' oracle
+    gradients (each rank's gradient computed by the CPU oracle on that rank's batch from the same weights)."""
+    import subprocess
+    import socket
+    import sys
+    from tests.ddp_worker import rank_batch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    steps = 2
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+           '127.0.0.1', '--master-port', str(port), os.path.join(root, 'tests', 'ddp_worker.py'), str(tmp_path),
+           str(steps)]
+    res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    r0 = torch.load(str(tmp_path / 'rank0.pt'), weights_only=False)
+    r1 = torch.load(str(tmp_path / 'rank1.pt'), weights_only=False)
+    assert r0['reductions'] == r1['reductions'] == steps           # one flat all-reduce per backward, fired by the hook
+    _, meta = G.load('tiny_ghnd_faster')
+    cfg = MU.config_for(meta)
+    terms = MU.terms_of(cfg)
+    t_sd, s_sd = MU.oracle_states(meta['seed'])
+    kw = dict(terms=terms, min_size=(meta['min_size'],), max_size=meta['max_size'])
+    ranks = [O.DistillOracle(t_sd, s_sd, **kw) for _ in range(2)]             # per-rank gradient + local BN buffers
+    keys = ranks[0].keys
+    mean_p = [ranks[0].s[k].detach().clone().requires_grad_(True) for k in keys]
+    adam = torch.optim.Adam(mean_p, lr=1e-3)
+    sched = torch.optim.lr_scheduler.LambdaLR(adam, lambda x: 1 if x >= 4 else 1e-3 * (1 - x / 4.0) + x / 4.0)
+    batches = [rank_batch(meta, r)[0] for r in range(2)]
+    worst = 0.0
+    for step in range(steps):
+        grads = []
+        for r, orc in enumerate(ranks):
+            with torch.no_grad():
+                for k, p in zip(keys, mean_p):
+                    orc.s[k].copy_(p)
+            loss, *_ = orc.forward(batches[r])
+            gs = torch.autograd.grad(loss, [orc.s[k] for k in keys])
+            grads.append(gs)
+            got = (r0, r1)[r]['history'][step]['loss']
+            assert abs(got - float(loss)) / abs(float(loss)) < LOSS_TOL, (step, r, got, float(loss))
+        adam.zero_grad()
+        for p, g0, g1 in zip(mean_p, grads[0], grads[1]):
+            p.grad = (g0 + g1) * 0.5
+        adam.step()
+        sched.step()
+        for k, p in zip(keys, mean_p):
+            a, b = r0['history'][step]['params'][k], r1['history'][step]['params'][k]
+            assert torch.equal(a, b), (step, k)                     # both ranks: the same update, bit for bit
+            if k.endswith(G.ZERO_GRAD_SUFFIXES):
+                continue
+            err = float((a.double() - p.detach().double()).norm() / (p.detach().double().norm() + 1e-6 * p.numel() ** 0.5))
+            worst = max(worst, err)
+            assert err < 2e-3, (step, k, err)
+    print('\n[ddp] worst relative parameter error vs the oracle mean-gradient step: %.2e' % worst)
 
 
 def test_mimic_runner_on_coco_format_folder(tmp_path, capsys):
