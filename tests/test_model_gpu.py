@@ -3,6 +3,7 @@
  (2) the CPU oracle on fresh seeded inputs.
 Bar (north_star): feature maps and losses within 1e-3 relative fp32; gradients within 2e-3 rel-L2
 (SURVEY.md hard parts: the two zero-gradient BN biases are excluded)."""
+import os
 import random
 from collections import OrderedDict
 
@@ -28,15 +29,21 @@ def _sync_oracle(orc, student):
                 v.copy_(sd[k].detach().cpu().to(v.dtype))
 
 
+WORST_GRAD_RATIO = {'ratio': 0.0, 'name': None}      # achieved max of e_hip / e_ref over a test session (printed)
+
+
 def _grad_check(name, hip, ref32, ref64, tol=None):
     """The HIP gradient must be as close to the exact (fp64) gradient as the reference's own fp32 path:
-    within GRAD_TOL, or within 4x the fp32 reference's error where ReLU / max-pool decision flips make the
+    within GRAD_TOL, or within 2x the fp32 reference's error where ReLU / max-pool decision flips make the
     problem itself ill-conditioned at tiny spatial sizes (SURVEY.md 'Gradients are ill-conditioned'; a flip is a
-    discrete event, so two fp32 paths land at different multiples of the same noise scale)."""
+    discrete event, so two fp32 paths land at different multiples of the same noise scale).  The achieved worst
+    ratio e_hip / e_ref among gradients beyond GRAD_TOL is recorded and printed by the calling tests."""
     ref64 = ref64.double()
     e_hip = float((hip.cpu().double() - ref64).norm() / ref64.norm())
     e_ref = float((ref32.double() - ref64).norm() / ref64.norm())
-    assert e_hip <= max(tol or GRAD_TOL, 4.0 * e_ref), '%s: HIP %.2e vs fp64, reference fp32 %.2e' % (name, e_hip, e_ref)
+    if e_hip > (tol or GRAD_TOL) and e_ref > 0 and e_hip / e_ref > WORST_GRAD_RATIO['ratio']:
+        WORST_GRAD_RATIO.update(ratio=e_hip / e_ref, name=name)
+    assert e_hip <= max(tol or GRAD_TOL, 2.0 * e_ref), '%s: HIP %.2e vs fp64, reference fp32 %.2e' % (name, e_hip, e_ref)
     return e_hip
 
 
@@ -126,8 +133,9 @@ def test_distill_steps_match_reference_golden(name):
             got = sd[key].cpu().double()
             assert float((got - ref).abs().max()) <= 1e-4 * (1 + float(ref.abs().max())), key
     assert worst['loss'] < LOSS_TOL, worst
-    print('\n[%s] worst rel err: features %.2e  loss %.2e  grads %.2e' % (name, worst['feat'], worst['loss'],
-                                                                          worst['grad']))
+    print('\n[%s] worst rel err: features %.2e  loss %.2e  grads %.2e; worst e_hip/e_ref beyond %.0e so far: %.2f (%s)'
+          % (name, worst['feat'], worst['loss'], worst['grad'], GRAD_TOL, WORST_GRAD_RATIO['ratio'],
+             WORST_GRAD_RATIO['name']))
 
 
 def test_eval_after_a_training_step_uses_the_updated_weights():
