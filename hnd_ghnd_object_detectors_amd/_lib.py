@@ -96,6 +96,14 @@ _SIGNATURES = {
     'hnd_allreduce_avg_flat': (C.c_int, [vp, vp, C.c_int64, vp]),
     'hnd_comm_destroy': (C.c_int, [vp]),
     'hnd_workspace_size': (C.c_size_t, [C.c_int, vp, C.c_int64]),
+    'hnd_rpn_decode': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_float_p, C.c_float, C.c_float,
+                                 C.c_int64, C.c_int64, C.c_float, vp, vp, vp]),
+    'hnd_clip_boxes': (C.c_int, [vp, C.c_int64, C.c_float, C.c_float, vp]),
+    'hnd_nms_workspace': (C.c_size_t, [C.c_int64]),
+    'hnd_nms': (C.c_int, [vp, vp, C.c_int64, C.c_float, vp, vp, vp]),
+    'hnd_roi_align': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int64, C.c_float, C.c_int, C.c_int,
+                                C.c_int, vp, vp]),
+    'hnd_box_decode_clip': (C.c_int, [vp, C.c_int, vp, vp, C.c_int64, C.c_int] + [C.c_float] * 5 + [vp, vp]),
 }
 
 EXPORTED_SYMBOLS = tuple(sorted(_SIGNATURES))

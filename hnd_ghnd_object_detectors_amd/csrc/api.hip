@@ -44,6 +44,7 @@ size_t hnd_workspace_size(int op, const void* desc, int64_t arg) {
     case HND_OP_QUANTIZE_U8: return hnd_minmax_scratch_elems() * sizeof(float);
     case HND_OP_CHANNEL_SUM: return hnd_channel_sum_scratch_elems((int)arg) * sizeof(float);
     case HND_OP_COMM_UNIQUE_ID: return 128;
+    case HND_OP_NMS: return hnd_nms_workspace(arg);
     default: return 0;
   }
 }

@@ -292,65 +292,16 @@ class ImageList(object):
 
 
 # ------------------------------------------------------------------------------------------ detector heads
+# RPN / RoI box branch (eval mode, the validation path of SURVEY.md 8f row f4) live in detection.py; the mask /
+# keypoint predictors below are parameter holders with torchvision 0.4.2 names and shapes so reference checkpoints load.
+from .detection import (AnchorGenerator, RPNHead, RegionProposalNetwork, MultiScaleRoIAlign, TwoMLPHead,  # noqa: E402,F401
+                        FastRCNNPredictor, RoIHeads)
+
+
 class _NotOnPath(nn.Module):
-    """RPN / RoI heads: parameter holders with torchvision 0.4.2 names and shapes so reference checkpoints load.
-    They never execute on the distillation step (src/models/org/rcnn.py:109-110 returns before them)."""
-
     def forward(self, *args, **kwargs):
-        raise NotImplementedError('%s: detector heads are outside the distillation hot path of this build '
-                                  '(SURVEY.md section 8f, row f4)' % type(self).__name__)
-
-
-class AnchorGenerator(_NotOnPath):
-    def __init__(self, sizes=(128, 256, 512), aspect_ratios=(0.5, 1.0, 2.0)):
-        super().__init__()
-        if not isinstance(sizes[0], (list, tuple)):
-            sizes = tuple((s,) for s in sizes)
-        if not isinstance(aspect_ratios[0], (list, tuple)):
-            aspect_ratios = (aspect_ratios,) * len(sizes)
-        self.sizes, self.aspect_ratios = sizes, aspect_ratios
-
-    def num_anchors_per_location(self):
-        return [len(s) * len(a) for s, a in zip(self.sizes, self.aspect_ratios)]
-
-
-class RPNHead(_NotOnPath):
-    def __init__(self, in_channels, num_anchors):
-        super().__init__()
-        self.conv = Conv2d(in_channels, in_channels, kernel_size=3, stride=1, padding=1)
-        self.cls_logits = Conv2d(in_channels, num_anchors, kernel_size=1, stride=1)
-        self.bbox_pred = Conv2d(in_channels, num_anchors * 4, kernel_size=1, stride=1)
-        for m in self.children():
-            nn.init.normal_(m.weight, std=0.01)
-            nn.init.constant_(m.bias, 0)
-
-
-class RegionProposalNetwork(_NotOnPath):
-    def __init__(self, anchor_generator, head, *args, **kwargs):
-        super().__init__()
-        self.anchor_generator, self.head = anchor_generator, head
-
-
-class MultiScaleRoIAlign(_NotOnPath):
-    def __init__(self, featmap_names, output_size, sampling_ratio):
-        super().__init__()
-        if isinstance(output_size, int):
-            output_size = (output_size, output_size)
-        self.featmap_names, self.output_size, self.sampling_ratio = featmap_names, tuple(output_size), sampling_ratio
-
-
-class TwoMLPHead(_NotOnPath):
-    def __init__(self, in_channels, representation_size):
-        super().__init__()
-        self.fc6 = Linear(in_channels, representation_size)
-        self.fc7 = Linear(representation_size, representation_size)
-
-
-class FastRCNNPredictor(_NotOnPath):
-    def __init__(self, in_channels, num_classes):
-        super().__init__()
-        self.cls_score = Linear(in_channels, num_classes)
-        self.bbox_pred = Linear(in_channels, num_classes * 4)
+        raise NotImplementedError('%s: the mask / keypoint branches of the detector are not built (checkpoint '
+                                  'selection reads the bbox mAP only, src/mimic_runner.py:97)' % type(self).__name__)
 
 
 class MaskRCNNHeads(nn.Sequential):
@@ -385,11 +336,3 @@ class KeypointRCNNPredictor(_NotOnPath):
         super().__init__()
         self.kps_score_lowres = ConvTranspose2d(in_channels, num_keypoints, 4, stride=2, padding=1)
         self.up_scale, self.out_channels = 2, num_keypoints
-
-
-class RoIHeads(_NotOnPath):
-    def __init__(self, box_roi_pool, box_head, box_predictor, *args, **kwargs):
-        super().__init__()
-        self.box_roi_pool, self.box_head, self.box_predictor = box_roi_pool, box_head, box_predictor
-        self.mask_roi_pool = self.mask_head = self.mask_predictor = None
-        self.keypoint_roi_pool = self.keypoint_head = self.keypoint_predictor = None

@@ -5,10 +5,12 @@
 Kept from the reference: the command-line flags (:17-29), the YAML schema, ``--json`` overrides, the checkpoint
 dictionary, and the per-batch order of operations of ``distill_model`` (:48-58): device upload, DistillationBox,
 ``zero_grad`` / ``backward`` / ``step``, the epoch-0 linear warm-up, one logged ``loss.item()`` per iteration.
-Different, and outside the hot path: without ``--synthetic_batches N`` (seeded synthetic COCO-shaped batches, used
-by the tests and benchmarks) batches come from the COCO-format folders of the yaml through utils/coco_util.py
-(no pycocotools), decoded images travel as uint8 to the device; checkpoints are kept on the lowest mean
-training loss instead of validation mAP (:94-100 needs RPN / RoI heads / NMS, out of this build's scope).
+Also kept: the per-epoch validation (:92-100, COCO bbox mAP through the eval-mode detector on the HIP path) that
+selects the checkpoint, and the final test-split evaluation (:109-121, :148-150).  Different, and outside the hot
+path: without ``--synthetic_batches N`` (seeded synthetic COCO-shaped batches, used by the tests and benchmarks)
+batches come from the COCO-format folders of the yaml through utils/coco_util.py (no pycocotools), decoded images
+travel as uint8 to the device; with synthetic batches there is no validation set and the lowest mean training loss
+selects the checkpoint (stored under its own key ``best_loss``).
 One process per GPU (torchrun / torch.distributed.run); RANK / LOCAL_RANK / WORLD_SIZE come from the environment
 exactly as in the reference's ``init_distributed_mode``.
 """
@@ -82,7 +84,13 @@ def distill_model(distillation_box, data_loader, optimizer, log_freq, device, ep
     return meters.loss.global_avg
 
 
-def distill(teacher_model, student_model, train_loader, device, distributed, distill_backbone_only, config, args):
+def distill(teacher_model, student_model, train_loader, val_loader, device, distributed, distill_backbone_only,
+            config, args):
+    """reference :62-106.  After every epoch the student is validated (COCO bbox mAP through the eval-mode detector:
+    RPN -> RoI box head -> NMS, utils/main_util.evaluate) and the checkpoint is kept on the best mAP
+    (``best_value``), exactly as the reference does.  Without a validation loader (``--synthetic_batches``: no
+    dataset) the lowest mean distillation loss decides instead and is stored under its own key ``best_loss``, so a
+    loss is never compared with a reference-produced mAP on resume."""
     train_config = config['train']
     box = DistillationBox(teacher_model, student_model, train_config['criterion'])
     optimizer = func_util.get_optimizer(student_model, train_config['optimizer']['type'],
@@ -91,12 +99,13 @@ def distill(teacher_model, student_model, train_loader, device, distributed, dis
                                            train_config['scheduler']['params'])
     wrapper = student_model if isinstance(student_model, DistributedStudent) else None
     student = student_model if wrapper is None else wrapper.module
-    if wrapper is not None:
-        wrapper.attach_optimizer(optimizer)
     ckpt_file_path = config['student_model']['ckpt']
-    best = None
+    best_val_map, best_loss = 0.0, None
     if file_util.check_if_exists(ckpt_file_path):       # resume optimizer + scheduler (weights came via get_model)
-        best, _, _ = load_ckpt(ckpt_file_path, optimizer=optimizer, lr_scheduler=lr_scheduler)
+        best_val_map, _, _ = load_ckpt(ckpt_file_path, optimizer=optimizer, lr_scheduler=lr_scheduler)
+        best_val_map = float(best_val_map or 0.0)
+        best_loss = torch.load(ckpt_file_path, map_location='cpu', weights_only=False).get('best_loss')
+    use_bottleneck_transformer = args.transform_bottleneck
     started = time.time()
     for epoch in range(args.num_epochs or train_config['num_epochs']):
         if hasattr(train_loader, 'set_epoch'):
@@ -106,15 +115,39 @@ def distill(teacher_model, student_model, train_loader, device, distributed, dis
         teacher_model.distill_backbone_only = student.distill_backbone_only = distill_backbone_only
         student.backbone.body.layer1.use_bottleneck_transformer = False      # reference :90
         mean_loss = distill_model(box, train_loader, optimizer, train_config['log_freq'], device, epoch, wrapper)
-        improved = not isinstance(best, float) or mean_loss < best
-        if improved and misc_util.is_main_process():
-            print('Updating ckpt (mean distillation loss: {} -> {:.4f})'.format(best, mean_loss))
-            best = float(mean_loss)
-            save_ckpt(student, optimizer, lr_scheduler, best, config, args, ckpt_file_path)
+        if val_loader is not None:                                            # reference :92-100
+            student.distill_backbone_only = False
+            student.backbone.body.layer1.use_bottleneck_transformer = use_bottleneck_transformer
+            if wrapper is not None:
+                wrapper.sync_buffers()          # rank 0's BatchNorm running statistics everywhere (see parallel.py)
+            coco_evaluator = main_util.evaluate(student, val_loader, device=device)
+            val_map = float(coco_evaluator.coco_eval['bbox'].stats[0])
+            if val_map > best_val_map and misc_util.is_main_process():
+                print('Updating ckpt (Best BBox mAP: {:.4f} -> {:.4f})'.format(best_val_map, val_map))
+                best_val_map = val_map
+                save_ckpt(student, optimizer, lr_scheduler, best_val_map, config, args, ckpt_file_path)
+        elif (best_loss is None or mean_loss < best_loss) and misc_util.is_main_process():
+            print('Updating ckpt (no validation set; mean distillation loss: {} -> {:.4f})'.format(best_loss, mean_loss))
+            best_loss = float(mean_loss)
+            save_ckpt(student, optimizer, lr_scheduler, best_val_map, config, args, ckpt_file_path,
+                      extra={'best_loss': best_loss})
         lr_scheduler.step()
     if distributed:
         dist.barrier()
     print('Training time {}'.format(datetime.timedelta(seconds=int(time.time() - started))))
+
+
+def evaluate(teacher_model, student_model, test_loader, device, student_only, use_bottleneck_transformer):
+    """reference :109-121: COCO evaluation of the teacher (unless skipped) and the student on the test split"""
+    teacher = teacher_model.module if isinstance(teacher_model, DistributedStudent) else teacher_model
+    student = student_model.module if isinstance(student_model, DistributedStudent) else student_model
+    teacher.distill_backbone_only = student.distill_backbone_only = False
+    student.backbone.body.layer1.use_bottleneck_transformer = use_bottleneck_transformer
+    if not student_only:
+        print('[Teacher model]')
+        main_util.evaluate(teacher, test_loader, device=device)
+    print('\n[Student model]')
+    return main_util.evaluate(student, test_loader, device=device)
 
 
 def main(args):
@@ -132,6 +165,7 @@ def main(args):
     freeze_modules(student_model, student_config)
     print('Updatable parameters: {}'.format(module_util.get_updatable_param_names(student_model)))
     batch_size = config['train']['batch_size']
+    val_loader = test_loader = None
     if args.synthetic_batches > 0:
         height, width = (int(v) for v in args.image_size.split('x'))
         train_sampler = None
@@ -139,16 +173,20 @@ def main(args):
                                                           student_config['name'], rank=misc_util.get_rank(),
                                                           decoded=args.decoded_input)
     else:       # COCO-format folders named by the yaml (reference :128-129); uint8 images unless -host_float_input
-        train_sampler, train_loader, _, _ = data_util.get_coco_data_loaders(
+        train_sampler, train_loader, val_loader, test_loader = data_util.get_coco_data_loaders(
             config['dataset'], batch_size, distributed, decoded=not args.host_float_input)
         if train_sampler is not None and hasattr(train_sampler, 'set_epoch'):
             train_loader.set_epoch = train_sampler.set_epoch        # distill() advances the shard per epoch
     if distributed:
         student_model = DistributedStudent(student_model)
     if args.distill:
-        distill(teacher_model, student_model, train_loader, device, distributed,
+        distill(teacher_model, student_model, train_loader, val_loader, device, distributed,
                 student_config['distill_backbone_only'], config, args)
-    print('COCO evaluation is outside this build; distilled checkpoint: {}'.format(student_config['ckpt']))
+        load_ckpt(student_config['ckpt'], model=student_model.module if distributed else student_model)
+    if test_loader is not None:                                     # reference :148-150
+        evaluate(teacher_model, student_model, test_loader, device, args.skip_teacher_eval, args.transform_bottleneck)
+    else:
+        print('no dataset (--synthetic_batches): COCO evaluation skipped; checkpoint: {}'.format(student_config['ckpt']))
 
 
 if __name__ == '__main__':

@@ -20,9 +20,11 @@ def unwrap(model):
     return model
 
 
-def save_ckpt(model, optimizer, lr_scheduler, best_value, config, args, output_file_path):
+def save_ckpt(model, optimizer, lr_scheduler, best_value, config, args, output_file_path, extra=None):
     payload = dict(zip(CKPT_KEYS, (unwrap(model).state_dict(), optimizer.state_dict(), best_value,
                                    lr_scheduler.state_dict(), config, args)))
+    if extra:           # this build's additions ride under their own keys (never overloading `best_value`)
+        payload.update(extra)
     file_util.make_parent_dirs(output_file_path)
     misc_util.save_on_master(payload, output_file_path)
 

@@ -74,7 +74,13 @@ class CustomRCNNTransform(nn.Module):
         return hipnn.ImageList(tensors, image_sizes), targets
 
     def postprocess(self, result, image_shapes, original_image_sizes):
-        raise NotImplementedError('detection post-processing is outside the distillation hot path')
+        """GeneralizedRCNNTransform.postprocess (box branch): detections back to the original image frame"""
+        if self.training:
+            return result
+        from ...detection import resize_boxes as resize_back
+        for i, (pred, im_s, o_im_s) in enumerate(zip(result, image_shapes, original_image_sizes)):
+            result[i]['boxes'] = resize_back(pred['boxes'], im_s, o_im_s)
+        return result
 
 
 class CustomRCNN(nn.Module):
@@ -97,6 +103,7 @@ class CustomRCNN(nn.Module):
     def forward(self, images, targets=None, fixed_sizes=None):
         if self.training and targets is None:
             raise ValueError('In training mode, targets should be passed')
+        original_image_sizes = [tuple(img.shape[-2:]) for img in images]
         images, targets = self.transform(images, targets, fixed_sizes)
         features = self.backbone(images.tensors)
         if self.distill_backbone_only:
@@ -110,8 +117,14 @@ class CustomRCNN(nn.Module):
                 return [{'boxes': torch.empty(0, 4), 'labels': torch.empty(0, dtype=torch.int64),
                          'scores': torch.empty(0), 'masks': torch.zeros(100, ch, height, width),
                          'keypoints': torch.empty(0, 17, 3), 'keypoints_scores': torch.empty(0, 17)}]
-        raise NotImplementedError('RPN / RoI heads (full detection forward) are outside the distillation hot path of '
-                                  'this build; set distill_backbone_only=True (SURVEY.md section 8f, row f4)')
+        if self.training:
+            raise NotImplementedError('detection losses (RPN / RoI heads in training mode) are never computed by the '
+                                      'hnd/ghnd configs: they train with distill_backbone_only and org_loss_factor 0')
+        if isinstance(features, torch.Tensor):
+            features = OrderedDict([(0, features)])
+        proposals, _ = self.rpn(images, features, targets)                      # reference :124-127
+        detections, _ = self.roi_heads(features, proposals, images.image_sizes, targets)
+        return self.transform.postprocess(detections, images.image_sizes, original_image_sizes)
 
 
 class FasterRCNN(CustomRCNN):
@@ -136,14 +149,20 @@ class FasterRCNN(CustomRCNN):
                                                          ((0.5, 1.0, 2.0),) * 5)
         if rpn_head is None:
             rpn_head = hipnn.RPNHead(out_channels, rpn_anchor_generator.num_anchors_per_location()[0])
-        rpn = hipnn.RegionProposalNetwork(rpn_anchor_generator, rpn_head)
+        rpn = hipnn.RegionProposalNetwork(rpn_anchor_generator, rpn_head, rpn_fg_iou_thresh, rpn_bg_iou_thresh,
+                                          rpn_batch_size_per_image, rpn_positive_fraction,
+                                          dict(training=rpn_pre_nms_top_n_train, testing=rpn_pre_nms_top_n_test),
+                                          dict(training=rpn_post_nms_top_n_train, testing=rpn_post_nms_top_n_test),
+                                          rpn_nms_thresh)
         if box_roi_pool is None:
             box_roi_pool = hipnn.MultiScaleRoIAlign(featmap_names=[0, 1, 2, 3], output_size=7, sampling_ratio=2)
         if box_head is None:
             box_head = hipnn.TwoMLPHead(out_channels * box_roi_pool.output_size[0] ** 2, 1024)
         if box_predictor is None:
             box_predictor = hipnn.FastRCNNPredictor(1024, num_classes)
-        roi_heads = hipnn.RoIHeads(box_roi_pool, box_head, box_predictor)
+        roi_heads = hipnn.RoIHeads(box_roi_pool, box_head, box_predictor, box_fg_iou_thresh, box_bg_iou_thresh,
+                                   box_batch_size_per_image, box_positive_fraction, bbox_reg_weights, box_score_thresh,
+                                   box_nms_thresh, box_detections_per_img)
         transform = CustomRCNNTransform(min_size, max_size, image_mean or [0.485, 0.456, 0.406],
                                         image_std or [0.229, 0.224, 0.225])
         super().__init__(backbone, rpn, roi_heads, transform)

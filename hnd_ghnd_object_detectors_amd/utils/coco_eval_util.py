@@ -1,0 +1,282 @@
+"""COCO bbox evaluation for the validation path (role of the reference's src/utils/coco_eval_util.py:15-150).
+
+The reference drives pycocotools' ``COCOeval`` (third-party, pinned 2.0.1 in Pipfile.lock, absent from this image:
+PARITY UNPINNED for its arithmetic) and selects the checkpoint on ``coco_eval['bbox'].stats[0]``
+(src/mimic_runner.py:94-100).  ``BBoxEval`` restates COCOeval's published algorithm for ``iouType='bbox'`` in numpy
+(host-side bookkeeping over at most 100 detections per image; not a device workload):
+
+  * IoU of detection vs ground truth in xywh; against a crowd box the union is the detection's own area;
+  * per image / category / area range: ground truths sorted non-ignored first, detections by descending score
+    (stable), greedy matching per IoU threshold 0.50:0.05:0.95 with the "prefer a non-ignored match" rule,
+    unmatched detections outside the area range ignored;
+  * accumulate: per category / area / maxDets, detections of all images merged by score (stable), cumulative
+    TP / FP -> precision made monotone from the right, sampled at the 101 recall thresholds;
+  * summarize: the twelve standard statistics; ``stats[0]`` = AP @[.50:.95 | all | 100].
+
+Only 'bbox' is built: the mask / keypoint branches of the detector are not (checkpoint selection needs bbox only).
+"""
+import copy
+from collections import defaultdict
+
+import numpy as np
+import torch
+
+from . import misc_util
+
+
+class CocoGT(object):
+    """ground truth in COCO terms: images, categories, annotations (bbox xywh, area, iscrowd, id)"""
+
+    def __init__(self):
+        self.images, self.categories, self.anns = {}, set(), defaultdict(list)
+        self._next_id = 1
+
+    def add(self, image_id, bbox_xywh, category_id, area=None, iscrowd=0, height=None, width=None):
+        self.images[image_id] = {'id': image_id, 'height': height, 'width': width}
+        self.categories.add(int(category_id))
+        x, y, w, h = (float(v) for v in bbox_xywh)
+        self.anns[image_id].append({'id': self._next_id, 'image_id': image_id, 'category_id': int(category_id),
+                                    'bbox': [x, y, w, h], 'area': float(w * h if area is None else area),
+                                    'iscrowd': int(iscrowd)})
+        self._next_id += 1
+
+
+def get_coco_api_from_dataset(dataset):
+    """convert_to_coco_api of the reference (:150-200): walk the dataset's targets (boxes xyxy, labels, area,
+    iscrowd, image_id) into a ground-truth index; a dataset exposing ``.coco`` annotations directly is read as is."""
+    for _ in range(10):
+        if isinstance(dataset, torch.utils.data.Subset):
+            dataset = dataset.dataset
+    gt = CocoGT()
+    if hasattr(dataset, 'coco') and hasattr(dataset.coco, 'annotations'):
+        for img_id in dataset.ids:
+            info = dataset.coco.imgs[img_id]
+            gt.images[img_id] = {'id': img_id, 'height': info.get('height'), 'width': info.get('width')}
+            for a in dataset.coco.annotations(img_id):
+                gt.add(img_id, a['bbox'], a['category_id'], a.get('area'), a.get('iscrowd', 0), info.get('height'),
+                       info.get('width'))
+        return gt
+    for idx in range(len(dataset)):
+        img, targets = dataset[idx]
+        image_id = int(targets['image_id'])
+        boxes = targets['boxes'].clone().float().cpu()
+        boxes[:, 2:] -= boxes[:, :2]
+        areas = targets['area'].tolist() if 'area' in targets else [None] * len(boxes)
+        crowd = targets['iscrowd'].tolist() if 'iscrowd' in targets else [0] * len(boxes)
+        gt.images[image_id] = {'id': image_id, 'height': int(img.shape[-2]), 'width': int(img.shape[-1])}
+        for b, l, a, c in zip(boxes.tolist(), targets['labels'].tolist(), areas, crowd):
+            gt.add(image_id, b, l, a, c, int(img.shape[-2]), int(img.shape[-1]))
+    return gt
+
+
+def get_iou_types(model):
+    """the reference adds 'segm' / 'keypoints' for Mask / Keypoint R-CNN (:225-233); only the box branch is built"""
+    return ['bbox']
+
+
+def bbox_iou(dt, gt, iscrowd):
+    """pycocotools maskApi bbIou: dt [D, 4], gt [G, 4] in xywh -> [D, G]; crowd gt: union = area(dt)"""
+    dt, gt = np.asarray(dt, dtype=np.float64).reshape(-1, 4), np.asarray(gt, dtype=np.float64).reshape(-1, 4)
+    out = np.zeros((len(dt), len(gt)))
+    if len(dt) == 0 or len(gt) == 0:
+        return out
+    da, ga = dt[:, 2] * dt[:, 3], gt[:, 2] * gt[:, 3]
+    w = np.minimum(dt[:, None, 0] + dt[:, None, 2], gt[None, :, 0] + gt[None, :, 2]) - \
+        np.maximum(dt[:, None, 0], gt[None, :, 0])
+    h = np.minimum(dt[:, None, 1] + dt[:, None, 3], gt[None, :, 1] + gt[None, :, 3]) - \
+        np.maximum(dt[:, None, 1], gt[None, :, 1])
+    inter = np.where((w <= 0) | (h <= 0), 0.0, w * h)
+    union = np.where(np.asarray(iscrowd, dtype=bool)[None, :], da[:, None], da[:, None] + ga[None, :] - inter)
+    return inter / union
+
+
+class BBoxEval(object):
+    """COCOeval(cocoGt, cocoDt, 'bbox'): evaluate() -> accumulate() -> summarize(); ``stats`` as pycocotools"""
+
+    def __init__(self, gt):
+        self.gt = gt
+        self.iou_thrs = np.linspace(.5, 0.95, int(np.round((0.95 - .5) / .05)) + 1, endpoint=True)
+        self.rec_thrs = np.linspace(.0, 1.00, int(np.round((1.00 - .0) / .01)) + 1, endpoint=True)
+        self.max_dets = [1, 10, 100]
+        self.area_rng = [[0 ** 2, 1e5 ** 2], [0 ** 2, 32 ** 2], [32 ** 2, 96 ** 2], [96 ** 2, 1e5 ** 2]]
+        self.area_lbl = ['all', 'small', 'medium', 'large']
+        self.dts = defaultdict(list)          # (image_id, category_id) -> detections
+        self.img_ids = []
+        self.eval = None
+        self.stats = np.zeros(12)
+
+    def add_detections(self, results):
+        """results: list of {'image_id', 'category_id', 'bbox' (xywh), 'score'} (loadRes)"""
+        for i, r in enumerate(results):
+            d = dict(r)
+            d['area'] = d['bbox'][2] * d['bbox'][3]
+            d['id'] = i + 1
+            self.dts[(d['image_id'], d['category_id'])].append(d)
+
+    def _evaluate_img(self, img_id, cat_id, a_rng, max_det):
+        gt = [dict(g) for g in self.gt.anns.get(img_id, []) if g['category_id'] == cat_id]
+        dt = self.dts.get((img_id, cat_id), [])
+        if len(gt) == 0 and len(dt) == 0:
+            return None
+        for g in gt:
+            g['_ignore'] = 1 if (g['iscrowd'] or g['area'] < a_rng[0] or g['area'] > a_rng[1]) else 0
+        gtind = np.argsort([g['_ignore'] for g in gt], kind='mergesort')
+        gt = [gt[i] for i in gtind]
+        dtind = np.argsort([-d['score'] for d in dt], kind='mergesort')
+        dt = [dt[i] for i in dtind[0:max_det]]
+        iscrowd = [int(g['iscrowd']) for g in gt]
+        # computeIoU uses the detections sorted by score, truncated to maxDets[-1]
+        dt_all = [self.dts.get((img_id, cat_id), [])[i] for i in dtind[0:self.max_dets[-1]]]
+        ious = bbox_iou([d['bbox'] for d in dt_all], [g['bbox'] for g in gt], iscrowd)
+        T, G, D = len(self.iou_thrs), len(gt), len(dt)
+        gtm, dtm = np.zeros((T, G)), np.zeros((T, D))
+        gt_ig = np.array([g['_ignore'] for g in gt])
+        dt_ig = np.zeros((T, D))
+        if len(ious) != 0:
+            for tind, t in enumerate(self.iou_thrs):
+                for dind in range(D):
+                    iou = min([t, 1 - 1e-10])
+                    m = -1
+                    for gind in range(G):
+                        if gtm[tind, gind] > 0 and not iscrowd[gind]:
+                            continue
+                        if m > -1 and gt_ig[m] == 0 and gt_ig[gind] == 1:
+                            break
+                        if ious[dind, gind] < iou:
+                            continue
+                        iou = ious[dind, gind]
+                        m = gind
+                    if m == -1:
+                        continue
+                    dt_ig[tind, dind] = gt_ig[m]
+                    dtm[tind, dind] = gt[m]['id']
+                    gtm[tind, m] = dt[dind]['id']
+        a = np.array([d['area'] < a_rng[0] or d['area'] > a_rng[1] for d in dt]).reshape((1, len(dt)))
+        dt_ig = np.logical_or(dt_ig, np.logical_and(dtm == 0, np.repeat(a, T, 0)))
+        return {'dtMatches': dtm, 'dtScores': [d['score'] for d in dt], 'gtIgnore': gt_ig, 'dtIgnore': dt_ig}
+
+    def evaluate(self, img_ids=None):
+        self.img_ids = sorted(set(img_ids if img_ids is not None else self.gt.images.keys()))
+        self.cat_ids = sorted(self.gt.categories)
+        max_det = self.max_dets[-1]
+        self.eval_imgs = [self._evaluate_img(i, c, a, max_det) for c in self.cat_ids for a in self.area_rng
+                          for i in self.img_ids]
+
+    def accumulate(self):
+        T, R, K, A, M = len(self.iou_thrs), len(self.rec_thrs), len(self.cat_ids), len(self.area_rng), len(self.max_dets)
+        precision, recall = -np.ones((T, R, K, A, M)), -np.ones((T, K, A, M))
+        I0 = len(self.img_ids)
+        for k in range(K):
+            for a in range(A):
+                for m, max_det in enumerate(self.max_dets):
+                    E = [self.eval_imgs[k * A * I0 + a * I0 + i] for i in range(I0)]
+                    E = [e for e in E if e is not None]
+                    if len(E) == 0:
+                        continue
+                    dt_scores = np.concatenate([e['dtScores'][0:max_det] for e in E])
+                    inds = np.argsort(-dt_scores, kind='mergesort')
+                    dtm = np.concatenate([e['dtMatches'][:, 0:max_det] for e in E], axis=1)[:, inds]
+                    dt_ig = np.concatenate([e['dtIgnore'][:, 0:max_det] for e in E], axis=1)[:, inds]
+                    gt_ig = np.concatenate([e['gtIgnore'] for e in E])
+                    npig = np.count_nonzero(gt_ig == 0)
+                    if npig == 0:
+                        continue
+                    tps = np.logical_and(dtm, np.logical_not(dt_ig))
+                    fps = np.logical_and(np.logical_not(dtm), np.logical_not(dt_ig))
+                    tp_sum, fp_sum = np.cumsum(tps, axis=1).astype(float), np.cumsum(fps, axis=1).astype(float)
+                    for t, (tp, fp) in enumerate(zip(tp_sum, fp_sum)):
+                        nd = len(tp)
+                        rc = tp / npig
+                        pr = tp / (fp + tp + np.spacing(1))
+                        q = np.zeros((R,))
+                        recall[t, k, a, m] = rc[-1] if nd else 0
+                        pr = pr.tolist()
+                        for i in range(nd - 1, 0, -1):
+                            if pr[i] > pr[i - 1]:
+                                pr[i - 1] = pr[i]
+                        idx = np.searchsorted(rc, self.rec_thrs, side='left')
+                        for ri, pi in enumerate(idx):
+                            if pi < nd:
+                                q[ri] = pr[pi]
+                        precision[t, :, k, a, m] = q
+        self.eval = {'precision': precision, 'recall': recall}
+
+    def _summarize(self, ap=1, iou_thr=None, area='all', max_dets=100):
+        a, m = self.area_lbl.index(area), self.max_dets.index(max_dets)
+        s = self.eval['precision'] if ap == 1 else self.eval['recall']
+        if iou_thr is not None:
+            s = s[np.where(np.isclose(iou_thr, self.iou_thrs))[0]]
+        s = s[:, :, :, a, m] if ap == 1 else s[:, :, a, m]
+        mean_s = -1 if len(s[s > -1]) == 0 else float(np.mean(s[s > -1]))
+        title, typ = ('Average Precision', '(AP)') if ap == 1 else ('Average Recall', '(AR)')
+        iou_str = '{:0.2f}:{:0.2f}'.format(self.iou_thrs[0], self.iou_thrs[-1]) if iou_thr is None \
+            else '{:0.2f}'.format(iou_thr)
+        print(' {:<18} {} @[ IoU={:<9} | area={:>6s} | maxDets={:>3d} ] = {:0.3f}'.format(title, typ, iou_str, area,
+                                                                                          max_dets, mean_s))
+        return mean_s
+
+    def summarize(self):
+        S = self._summarize
+        self.stats = np.array([S(1), S(1, .5), S(1, .75), S(1, area='small'), S(1, area='medium'), S(1, area='large'),
+                               S(0, max_dets=1), S(0, max_dets=10), S(0), S(0, area='small'), S(0, area='medium'),
+                               S(0, area='large')])
+        return self.stats
+
+
+class CocoEvaluator(object):
+    """same surface as the reference's class: update(res) per batch, synchronize_between_processes(), accumulate(),
+    summarize(); ``coco_eval['bbox'].stats[0]`` is the validation mAP mimic_runner compares."""
+
+    def __init__(self, coco_gt, iou_types):
+        assert isinstance(iou_types, (list, tuple))
+        unsupported = [t for t in iou_types if t != 'bbox']
+        if unsupported:
+            raise NotImplementedError('iou types %s: only the box branch of the detector is built' % unsupported)
+        self.coco_gt = copy.deepcopy(coco_gt)
+        self.iou_types = list(iou_types)
+        self.coco_eval = {t: BBoxEval(self.coco_gt) for t in self.iou_types}
+        self.img_ids, self.results = [], []
+
+    def update(self, predictions):
+        self.img_ids.extend(sorted(set(predictions.keys())))
+        self.results.extend(self.prepare_for_coco_detection(predictions))
+
+    @staticmethod
+    def prepare_for_coco_detection(predictions):
+        out = []
+        for image_id, pred in predictions.items():
+            if len(pred) == 0 or len(pred['boxes']) == 0:
+                continue
+            boxes = pred['boxes'].detach().cpu().clone().float()
+            boxes[:, 2:] -= boxes[:, :2]                                   # xyxy -> xywh (convert_to_xywh)
+            for b, s, l in zip(boxes.tolist(), pred['scores'].tolist(), pred['labels'].tolist()):
+                out.append({'image_id': image_id, 'category_id': l, 'bbox': b, 'score': s})
+        return out
+
+    def synchronize_between_processes(self):
+        gathered = misc_util.all_gather((self.img_ids, self.results))
+        img_ids, results = [], []
+        for ids, res in gathered:
+            img_ids.extend(ids)
+            results.extend(res)
+        # keep one copy per image (DistributedSampler may pad a shard with repeats)
+        seen, uniq = set(), []
+        for r in results:
+            key = (r['image_id'], r['category_id'], tuple(r['bbox']), r['score'])
+            if key not in seen:
+                seen.add(key)
+                uniq.append(r)
+        self.img_ids, self.results = sorted(set(img_ids)), uniq
+        for ev in self.coco_eval.values():
+            ev.dts = defaultdict(list)
+            ev.add_detections(self.results)
+            ev.evaluate(self.img_ids)
+
+    def accumulate(self):
+        for ev in self.coco_eval.values():
+            ev.accumulate()
+
+    def summarize(self):
+        for iou_type, ev in self.coco_eval.items():
+            print('IoU metric: {}'.format(iou_type))
+            ev.summarize()

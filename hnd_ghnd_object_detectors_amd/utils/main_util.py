@@ -1,4 +1,4 @@
-"""Runner utilities (mirror of the reference's src/utils/main_util.py:14-72; COCO `evaluate` is out of scope)."""
+"""Runner utilities (mirror of the reference's src/utils/main_util.py:14-113, incl. the COCO bbox `evaluate` of the validation path)."""
 import builtins as __builtin__
 import json
 import os
@@ -74,6 +74,33 @@ def warmup_lr_scheduler(optimizer, warmup_iters, warmup_factor):
     return torch.optim.lr_scheduler.LambdaLR(optimizer, lambda x: warmup_factor_at(x, warmup_iters, warmup_factor))
 
 
+@torch.no_grad()
 def evaluate(model, data_loader, device):
-    raise NotImplementedError('COCO mAP evaluation (RPN / RoIAlign / NMS + pycocotools) is outside the distillation '
-                              'hot path of this build (SURVEY.md section 8f, row f4)')
+    """COCO bbox evaluation of `model` over `data_loader` (reference :75-113): eval-mode detector forward
+    (RPN -> RoI box head -> NMS on the HIP path), predictions keyed by image_id into CocoEvaluator, gathered over
+    ranks, accumulated and summarised.  Returns the evaluator (``coco_eval['bbox'].stats[0]`` = mAP)."""
+    import time
+    from . import misc_util
+    from .coco_eval_util import CocoEvaluator, get_coco_api_from_dataset, get_iou_types
+    cpu_device = torch.device('cpu')
+    model.eval()
+    metric_logger = misc_util.MetricLogger(delimiter='  ')
+    coco = get_coco_api_from_dataset(data_loader.dataset)
+    coco_evaluator = CocoEvaluator(coco, get_iou_types(model))
+    for image, targets in metric_logger.log_every(data_loader, 100, 'Test:'):
+        image = [img.to(device) for img in image]
+        torch.cuda.synchronize()
+        model_time = time.time()
+        outputs = model(image)
+        outputs = [{k: v.to(cpu_device) for k, v in t.items()} for t in outputs]
+        model_time = time.time() - model_time
+        res = {int(target['image_id']): output for target, output in zip(targets, outputs)}
+        evaluator_time = time.time()
+        coco_evaluator.update(res)
+        evaluator_time = time.time() - evaluator_time
+        metric_logger.update(model_time=model_time, evaluator_time=evaluator_time)
+    print('Averaged stats:', metric_logger)
+    coco_evaluator.synchronize_between_processes()
+    coco_evaluator.accumulate()
+    coco_evaluator.summarize()
+    return coco_evaluator

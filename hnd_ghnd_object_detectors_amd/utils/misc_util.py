@@ -143,3 +143,13 @@ def reduce_dict(input_dict, average=True):
         if average:
             packed /= world
     return dict(zip(keys, packed))
+
+
+def all_gather(data):
+    """every rank's picklable `data` as a list (reference misc_util.all_gather, :72-110: pickle + padded tensors;
+    here torch.distributed's object collective does the same job)"""
+    if get_world_size() == 1:
+        return [data]
+    out = [None] * get_world_size()
+    torch.distributed.all_gather_object(out, data)
+    return out

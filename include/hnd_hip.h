@@ -321,6 +321,40 @@ int hnd_comm_init(int rank, int world, const void* unique_id, size_t bytes, void
 int hnd_allreduce_avg_flat(void* comm, float* flat, int64_t n, void* stream);
 int hnd_comm_destroy(void* comm);
 
+/* ---- validation path: box branch of the eval-mode detector, reached from
+ * src/utils/main_util.py:75-113 (evaluate) -> src/models/org/rcnn.py:124-127 (rpn -> roi_heads -> postprocess); the
+ * arithmetic is torchvision 0.4.2's (models/detection/{rpn,roi_heads,_utils}.py, ops/{boxes,poolers}.py and the native
+ * CPU operators csrc/cpu/{nms_cpu,ROIAlign_cpu}.cpp).  Convolutions / Linear layers of the heads run on
+ * hnd_conv2d_igemm (fc6 = a 7x7 "valid" conv over the pooled 7x7 map).  Kept sets are index work: on identical
+ * inputs hnd_nms returns exactly the CPU operator's set (every IoU term is one correctly rounded fp32 operation).
+ *
+ * hnd_rpn_decode: head = RPN head output of one pyramid level [n][h][w][ldc], channel a = objectness logit of anchor
+ *   a, channel A + 4a + c = box delta c of anchor a.  Writes objectness[n][anchors_per_image] and
+ *   proposals[n][anchors_per_image][4] at level_offset in (y, x, a) order (concat_box_prediction_layers), where the
+ *   anchor is base_anchors[a] (HOST pointer, A x 4 floats: AnchorGenerator.generate_anchors) + (x*stride_w, y*stride_h)
+ *   and the box is BoxCoder(1,1,1,1).decode_single with dw, dh clamped to xform_clip = log(1000/16). */
+int hnd_rpn_decode(const float* head, int n, int h, int w, int ldc, int num_anchors, const float* base_anchors,
+                   float stride_h, float stride_w, int64_t level_offset, int64_t anchors_per_image, float xform_clip,
+                   float* objectness, float* proposals, void* stream);
+/* clip_boxes_to_image: x to [0, width], y to [0, height], in place; boxes [n][4] */
+int hnd_clip_boxes(float* boxes, int64_t n, float height, float width, void* stream);
+/* torchvision.ops.nms.  boxes [n][4]; order [n] = indices in descending-score order (the host sorts);
+ * keep [n] (bytes) = 1 for boxes that survive greedy suppression at IoU > iou_threshold, indexed like boxes;
+ * workspace: hnd_nms_workspace(n) bytes.  n <= 65536. */
+size_t hnd_nms_workspace(int64_t n);
+int hnd_nms(const float* boxes, const int64_t* order, int64_t n, float iou_threshold, void* workspace,
+            uint8_t* keep, void* stream);
+/* torchvision.ops.roi_align (non-aligned form) on an NHWC feature map feat [n][h][w][c], c % 4 == 0.
+ * rois [K][5] = (batch index, x1, y1, x2, y2); idx [k] selects the rows this launch pools (one pyramid level of
+ * MultiScaleRoIAlign); out [K][pooled_h][pooled_w][c], row idx[i] written. */
+int hnd_roi_align(const float* feat, int n, int h, int w, int c, const float* rois, const int64_t* idx, int64_t k,
+                  float spatial_scale, int pooled_h, int pooled_w, int sampling_ratio, float* out, void* stream);
+/* RoIHeads.postprocess_detections, first half: BoxCoder(wx, wy, ww, wh).decode of every class's deltas
+ * deltas [nroi][ld] (class c at columns 4c..4c+3) against rois [nroi][5], then clip to that roi's image
+ * (image_hw [images][2] = height, width as floats); out [nroi][ncls][4]. */
+int hnd_box_decode_clip(const float* deltas, int ld, const float* rois, const float* image_hw, int64_t nroi, int ncls,
+                        float wx, float wy, float ww, float wh, float xform_clip, float* out, void* stream);
+
 /* ---- generic workspace query: bytes of caller-provided scratch an op needs.  `desc` is the op's
  * descriptor where it has one (hnd_wgrad_desc for HND_OP_CONV2D_WGRAD), `arg` an op-specific integer (channels for
  * HND_OP_CHANNEL_SUM), both ignored otherwise.  The op-specific helpers above return the same numbers. */
@@ -330,7 +364,8 @@ typedef enum hnd_op {
   HND_OP_MSE = 2,            /* double[hnd_mse_scratch_elems()]                */
   HND_OP_QUANTIZE_U8 = 3,    /* float[hnd_minmax_scratch_elems()]              */
   HND_OP_CHANNEL_SUM = 4,    /* float[hnd_channel_sum_scratch_elems(arg)]      */
-  HND_OP_COMM_UNIQUE_ID = 5  /* bytes of the id buffer of hnd_comm_unique_id   */
+  HND_OP_COMM_UNIQUE_ID = 5, /* bytes of the id buffer of hnd_comm_unique_id   */
+  HND_OP_NMS = 6             /* hnd_nms_workspace(arg = number of boxes)       */
 } hnd_op;
 size_t hnd_workspace_size(int op, const void* desc, int64_t arg);
 

@@ -161,6 +161,21 @@ def init_student_state(teacher_sd, seed, bch=3, dtype=torch.float32):
     return out
 
 
+# seeded random heads give near-uniform scores (everything ties); these factors spread RPN objectness / box deltas /
+# class logits enough that the eval-mode detector of the validation path (row f4) keeps ~800 proposals and fills its
+# 100 detections per image on the tiny fixtures -- NMS, top-k and the score threshold all bite
+DETECT_HEAD_SCALES = {'rpn.head.conv.weight': 6.0, 'rpn.head.cls_logits.weight': 30.0, 'rpn.head.bbox_pred.weight': 1.5,
+                      'roi_heads.box_head.fc6.weight': 2.0, 'roi_heads.box_head.fc7.weight': 2.0,
+                      'roi_heads.box_predictor.cls_score.weight': 20.0, 'roi_heads.box_predictor.bbox_pred.weight': 1.5}
+
+
+def scale_detector_heads(sd):
+    out = OrderedDict(sd)
+    for k, f in DETECT_HEAD_SCALES.items():
+        out[k] = sd[k] * f
+    return out
+
+
 def trainable_keys(student_sd):
     """conv1.weight + every *parameter* of layer1: the reference's 25 updatable tensors
     (mimic_runner.py:32-35 with yaml frozen_modules)."""

@@ -1,1 +1,1 @@
-"""import-only stub (BoxCoder etc. are outside the hot path)."""
+from oracle.tv042_det import BoxCoder  # noqa

@@ -7,9 +7,9 @@ behaviour is restated here in plain torch.  Call sites in the reference:
 
 Only the pieces that EXECUTE on the distillation step are behaviourally faithful
 (ResNet Bottleneck, FrozenBatchNorm2d without eps, IntermediateLayerGetter, FPN,
-GeneralizedRCNNTransform.normalize/batch_images, ImageList).  RPN / RoI heads are
-parameter holders with the 0.4.2 parameter names and shapes (they are never run
-when ``distill_backbone_only`` is set, ``src/models/org/rcnn.py:109-110``).
+GeneralizedRCNNTransform.normalize/batch_images, ImageList).  The eval-mode RPN / RoI box
+branch of the validation path (SURVEY.md 8f row f4) is restated in oracle/tv042_det.py;
+mask / keypoint predictors are parameter holders with the 0.4.2 names and shapes.
 """
 import math
 from collections import OrderedDict
@@ -320,73 +320,17 @@ class GeneralizedRCNNTransform(nn.Module):
         return result
 
 
-# --------------------------------------------------------------------------- param holders
-class AnchorGenerator(nn.Module):
-    def __init__(self, sizes=(128, 256, 512), aspect_ratios=(0.5, 1.0, 2.0)):
-        super().__init__()
-        if not isinstance(sizes[0], (list, tuple)):
-            sizes = tuple((s,) for s in sizes)
-        if not isinstance(aspect_ratios[0], (list, tuple)):
-            aspect_ratios = (aspect_ratios,) * len(sizes)
-        self.sizes, self.aspect_ratios = sizes, aspect_ratios
-
-    def num_anchors_per_location(self):
-        return [len(s) * len(a) for s, a in zip(self.sizes, self.aspect_ratios)]
-
-
-class RPNHead(nn.Module):
-    def __init__(self, in_channels, num_anchors):
-        super().__init__()
-        self.conv = nn.Conv2d(in_channels, in_channels, kernel_size=3, stride=1, padding=1)
-        self.cls_logits = nn.Conv2d(in_channels, num_anchors, kernel_size=1, stride=1)
-        self.bbox_pred = nn.Conv2d(in_channels, num_anchors * 4, kernel_size=1, stride=1)
-        for m in self.children():
-            nn.init.normal_(m.weight, std=0.01)
-            nn.init.constant_(m.bias, 0)
+# --------------------------------------------------------------------------- detection heads
+# RPN / RoI box branch (eval mode): behaviourally faithful restatements live in oracle/tv042_det.py (row f4);
+# the mask / keypoint predictors below stay parameter holders.
+from oracle.tv042_det import (AnchorGenerator, RPNHead, RegionProposalNetwork, concat_box_prediction_layers,  # noqa: E402,F401
+                              MultiScaleRoIAlign, TwoMLPHead, FastRCNNPredictor, RoIHeads, BoxCoder)
 
 
 def _not_on_path(name):
     def forward(self, *a, **k):
-        raise NotImplementedError('%s is outside the distillation hot path (oracle holder only)' % name)
+        raise NotImplementedError('%s is outside the restated paths (oracle holder only)' % name)
     return forward
-
-
-class RegionProposalNetwork(nn.Module):
-    def __init__(self, anchor_generator, head, fg_iou_thresh, bg_iou_thresh, batch_size_per_image,
-                 positive_fraction, pre_nms_top_n, post_nms_top_n, nms_thresh):
-        super().__init__()
-        self.anchor_generator, self.head = anchor_generator, head
-        self._pre_nms_top_n, self._post_nms_top_n, self.nms_thresh = pre_nms_top_n, post_nms_top_n, nms_thresh
-    forward = _not_on_path('RegionProposalNetwork')
-
-
-def concat_box_prediction_layers(*a, **k):
-    raise NotImplementedError('concat_box_prediction_layers: outside the hot path')
-
-
-class MultiScaleRoIAlign(nn.Module):
-    def __init__(self, featmap_names, output_size, sampling_ratio):
-        super().__init__()
-        if isinstance(output_size, int):
-            output_size = (output_size, output_size)
-        self.featmap_names, self.sampling_ratio, self.output_size = featmap_names, sampling_ratio, tuple(output_size)
-    forward = _not_on_path('MultiScaleRoIAlign')
-
-
-class TwoMLPHead(nn.Module):
-    def __init__(self, in_channels, representation_size):
-        super().__init__()
-        self.fc6 = nn.Linear(in_channels, representation_size)
-        self.fc7 = nn.Linear(representation_size, representation_size)
-    forward = _not_on_path('TwoMLPHead')
-
-
-class FastRCNNPredictor(nn.Module):
-    def __init__(self, in_channels, num_classes):
-        super().__init__()
-        self.cls_score = nn.Linear(in_channels, num_classes)
-        self.bbox_pred = nn.Linear(in_channels, num_classes * 4)
-    forward = _not_on_path('FastRCNNPredictor')
 
 
 class MaskRCNNHeads(nn.Sequential):
@@ -425,19 +369,6 @@ class KeypointRCNNPredictor(nn.Module):
         self.up_scale = 2
         self.out_channels = num_keypoints
     forward = _not_on_path('KeypointRCNNPredictor')
-
-
-class RoIHeads(nn.Module):
-    def __init__(self, box_roi_pool, box_head, box_predictor, fg_iou_thresh, bg_iou_thresh,
-                 batch_size_per_image, positive_fraction, bbox_reg_weights, score_thresh, nms_thresh,
-                 detections_per_img, mask_roi_pool=None, mask_head=None, mask_predictor=None,
-                 keypoint_roi_pool=None, keypoint_head=None, keypoint_predictor=None):
-        super().__init__()
-        self.box_roi_pool, self.box_head, self.box_predictor = box_roi_pool, box_head, box_predictor
-        self.mask_roi_pool, self.mask_head, self.mask_predictor = mask_roi_pool, mask_head, mask_predictor
-        self.keypoint_roi_pool, self.keypoint_head = keypoint_roi_pool, keypoint_head
-        self.keypoint_predictor = keypoint_predictor
-    forward = _not_on_path('RoIHeads')
 
 
 class _DetectionBase(nn.Module):

@@ -283,6 +283,46 @@ def run_eval_codec_case(name='tiny_eval_quantized'):
     print('   wrote %s (%.1f KB)' % (path, os.path.getsize(path) / 1024.0))
 
 
+def run_detect_case(name='tiny_detect_faster'):
+    """Validation path: the reference's CustomRCNN.forward in eval mode with
+    distill_backbone_only off (src/models/org/rcnn.py:124-127: rpn -> roi_heads -> transform.postprocess), teacher and
+    student, over the restated torchvision 0.4.2 detection pieces (oracle/tv042_det.py)."""
+    print('== %s' % name)
+    case = dict(yaml='ghnd/faster_rcnn-backbone_resnet50-b3ch.yaml', model='faster_rcnn', sizes=[(120, 180), (112, 200)],
+                min_size=128, max_size=256, steps=0, seed=31)
+    t_sd = O.scale_detector_heads(O.init_teacher_state(case['seed']))
+    s_sd = O.scale_detector_heads(O.init_student_state(t_sd, case['seed'] + 1000))
+    config, teacher, student = build_reference_models(case)
+    teacher.load_state_dict(t_sd, strict=True)
+    student.load_state_dict(s_sd, strict=True)
+    images, _ = make_inputs(case)
+    out = OrderedDict()
+    out['meta'] = np.array(json.dumps(case))
+    for tag, model in (('teacher', teacher), ('student', student)):
+        model.eval()
+        model.distill_backbone_only = False
+        with torch.no_grad():
+            dets = model([im.clone() for im in images])
+        rpn, roi = model.rpn.last, model.roi_heads.last
+        out[tag + '/rpn/objectness'] = rpn['objectness'].numpy()
+        out[tag + '/rpn/proposals'] = rpn['proposals'].numpy()
+        full = 10 ** 9 if tag == 'student' else 70000      # student (fewer proposals): stored whole for bit-exact checks
+        put(out, tag + '/roi/class_logits', roi['class_logits'], full_limit=full)
+        put(out, tag + '/roi/box_regression', roi['box_regression'], full_limit=full)
+        for i, (d, sc) in enumerate(zip(dets, rpn['scores'])):
+            out['%s/rpn/kept/%d' % (tag, i)] = np.int64(len(sc))
+            out['%s/rpn/kept_scores/%d' % (tag, i)] = sc.numpy()
+            out['%s/rpn/kept_boxes/%d' % (tag, i)] = model.rpn.last['boxes'][i].numpy()
+            for k, v in d.items():
+                out['%s/det/%d/%s' % (tag, i, k)] = v.numpy()
+        print('   %s: proposals kept %s, detections %s, top scores %s' % (
+            tag, [len(s) for s in rpn['scores']], [len(d['scores']) for d in dets],
+            [round(float(d['scores'].max()), 4) for d in dets]))
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **out)
+    print('   wrote %s (%.1f KB)' % (path, os.path.getsize(path) / 1024.0))
+
+
 def run_input_pipeline_case(name='tiny_input_pipeline'):
     """Decoded uint8 image -> reference ToTensor -> RandomHorizontalFlip (forced on / off) -> CustomRCNNTransform."""
     print('== %s' % name)
@@ -444,6 +484,8 @@ def main():
         run_case(name, case)
     if not args.only or args.only == 'tiny_eval_quantized':
         run_eval_codec_case()
+    if not args.only or args.only == 'tiny_detect_faster':
+        run_detect_case()
     if not args.only or args.only == 'tiny_input_pipeline':
         run_input_pipeline_case()
     if not args.only or args.only == 'tiny_ext_filter':

@@ -1,0 +1,100 @@
+"""CPU: the bbox COCO evaluator of the validation path (utils/coco_eval_util.py) on hand-computable cases.
+pycocotools (the reference's evaluator, src/utils/coco_eval_util.py) is not installable here, so these are the
+known-answer cases of its published algorithm: 10 IoU thresholds, 101 recall thresholds, precision envelope."""
+import numpy as np
+import pytest
+import torch
+
+from hnd_ghnd_object_detectors_amd.utils.coco_eval_util import BBoxEval, CocoEvaluator, CocoGT, bbox_iou
+
+
+def _gt(boxes):
+    """boxes: list of (image_id, [x, y, w, h], category, iscrowd)"""
+    gt = CocoGT()
+    for image_id, b, c, crowd in boxes:
+        gt.add(image_id, b, c, iscrowd=crowd, height=200, width=200)
+    return gt
+
+
+def _run(gt, dets, img_ids=None):
+    ev = BBoxEval(gt)
+    ev.add_detections([{'image_id': i, 'category_id': c, 'bbox': b, 'score': s} for i, b, c, s in dets])
+    ev.evaluate(img_ids)
+    ev.accumulate()
+    return ev.summarize()
+
+
+def test_iou_and_crowd_union():
+    iou = bbox_iou([[0, 0, 10, 10]], [[5, 0, 10, 10], [0, 0, 100, 100]], [0, 1])
+    assert abs(iou[0, 0] - 50.0 / 150.0) < 1e-12
+    assert abs(iou[0, 1] - 1.0) < 1e-12            # crowd: intersection / area(detection)
+
+
+def test_perfect_detections_score_one(capsys):
+    gt = _gt([(1, [10, 10, 50, 60], 1, 0), (1, [100, 20, 40, 40], 2, 0), (2, [5, 5, 120, 100], 1, 0)])
+    stats = _run(gt, [(1, [10, 10, 50, 60], 1, 0.9), (1, [100, 20, 40, 40], 2, 0.8), (2, [5, 5, 120, 100], 1, 0.7)])
+    assert all(abs(stats[i] - 1.0) < 1e-12 for i in (0, 1, 2, 8))
+    out = capsys.readouterr().out
+    assert 'Average Precision  (AP) @[ IoU=0.50:0.95 | area=   all | maxDets=100 ] = 1.000' in out
+
+
+def test_single_detection_at_iou_0_6():
+    # IoU = 60/100: counts as a match at thresholds 0.50, 0.55, 0.60 only -> AP = 3/10, AP50 = 1, AP75 = 0
+    gt = _gt([(1, [0, 0, 100, 100], 1, 0)])
+    stats = _run(gt, [(1, [0, 0, 60, 100], 1, 0.5)])
+    assert abs(stats[0] - 0.3) < 1e-12 and abs(stats[1] - 1.0) < 1e-12 and stats[2] == 0.0
+
+
+def test_one_true_positive_one_false_positive_two_ground_truths():
+    # recall reaches 0.5 at precision 1 -> 51 of the 101 recall thresholds (0.00 .. 0.50) score 1, the rest 0
+    gt = _gt([(1, [0, 0, 50, 50], 1, 0), (1, [100, 100, 50, 50], 1, 0)])
+    stats = _run(gt, [(1, [0, 0, 50, 50], 1, 0.9), (1, [60, 60, 20, 20], 1, 0.8)])
+    assert abs(stats[0] - 51.0 / 101.0) < 1e-12
+    # the false positive first: precision 0.5 at recall 0.5
+    stats = _run(gt, [(1, [0, 0, 50, 50], 1, 0.7), (1, [60, 60, 20, 20], 1, 0.8)])
+    assert abs(stats[0] - 0.5 * 51.0 / 101.0) < 1e-12
+
+
+def test_crowd_matches_are_ignored_not_false_positives():
+    gt = _gt([(1, [0, 0, 50, 50], 1, 0), (1, [100, 100, 80, 80], 1, 1)])
+    dets = [(1, [0, 0, 50, 50], 1, 0.9), (1, [110, 110, 20, 20], 1, 0.95), (1, [120, 120, 30, 30], 1, 0.85)]
+    stats = _run(gt, dets)                          # both detections inside the crowd region are ignored
+    assert abs(stats[0] - 1.0) < 1e-12
+
+
+def test_area_ranges_and_max_dets():
+    gt = _gt([(1, [0, 0, 20, 20], 1, 0), (1, [50, 50, 120, 120], 1, 0)])       # one small (400), one large (14400)
+    stats = _run(gt, [(1, [0, 0, 20, 20], 1, 0.6), (1, [50, 50, 120, 120], 1, 0.9)])
+    assert abs(stats[3] - 1.0) < 1e-12 and abs(stats[5] - 1.0) < 1e-12 and stats[4] == -1     # no medium objects
+    assert stats[6] == 0.5 and stats[7] == 1.0                                  # AR@1 sees only the top detection
+
+
+def test_evaluator_surface_and_image_without_predictions():
+    gt = _gt([(7, [10, 10, 40, 40], 3, 0), (8, [20, 20, 60, 30], 3, 0)])
+    ev = CocoEvaluator(gt, ['bbox'])
+    ev.update({7: {'boxes': torch.tensor([[10.0, 10.0, 50.0, 50.0]]), 'labels': torch.tensor([3]),
+                   'scores': torch.tensor([0.8])}})
+    ev.update({8: {'boxes': torch.zeros(0, 4), 'labels': torch.zeros(0, dtype=torch.int64), 'scores': torch.zeros(0)}})
+    ev.synchronize_between_processes()
+    ev.accumulate()
+    ev.summarize()
+    assert abs(ev.coco_eval['bbox'].stats[0] - 51.0 / 101.0) < 1e-12          # 1 of 2 ground truths found
+    with pytest.raises(NotImplementedError):
+        CocoEvaluator(gt, ['bbox', 'segm'])
+
+
+def test_ground_truth_from_a_dataset_of_targets():
+    from hnd_ghnd_object_detectors_amd.utils.coco_eval_util import get_coco_api_from_dataset
+
+    class DS(torch.utils.data.Dataset):
+        def __len__(self):
+            return 2
+
+        def __getitem__(self, i):
+            return torch.zeros(3, 50, 60), {'image_id': torch.tensor([i + 1]), 'labels': torch.tensor([1, 2]),
+                                            'boxes': torch.tensor([[1.0, 2.0, 11.0, 22.0], [5.0, 5.0, 9.0, 9.0]]),
+                                            'area': torch.tensor([200.0, 16.0]), 'iscrowd': torch.tensor([0, 1])}
+    gt = get_coco_api_from_dataset(torch.utils.data.Subset(DS(), [0, 1]))
+    assert sorted(gt.images) == [1, 2] and sorted(gt.categories) == [1, 2]
+    a = gt.anns[1][0]
+    assert a['bbox'] == [1.0, 2.0, 10.0, 20.0] and a['area'] == 200.0 and gt.anns[1][1]['iscrowd'] == 1

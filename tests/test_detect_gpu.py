@@ -1,0 +1,239 @@
+"""GPU: the validation path -- csrc/detect.hip operators against the CPU restatement of
+torchvision 0.4.2's operators (oracle/tv042_det.py), and the eval-mode detector against the fixture the REFERENCE's
+own src/models/org/rcnn.py forward produced (tests/golden/tiny_detect_faster.npz).
+
+Bars: kept sets / indices (NMS, top-k, thresholds) are index work -> bit-exact on identical inputs; box and feature
+arithmetic is fp32 -> 1e-3 relative (north_star), achieved figures are far tighter and asserted where stable."""
+from collections import OrderedDict
+
+import pytest
+import torch
+
+from oracle import hnd_oracle as O
+from oracle import tv042_det as TV
+from tests import golden_util as G
+from tests import model_util as MU
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device('cuda:0')
+
+
+def gen(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def random_boxes(n, g, size=200.0, clustered=True):
+    """boxes with heavy overlap (clusters around a few centres) so suppression chains are long"""
+    if clustered:
+        centres = torch.rand(max(n // 25, 1), 2, generator=g) * size
+        c = centres[torch.randint(0, centres.shape[0], (n,), generator=g)] + torch.randn(n, 2, generator=g) * 6
+    else:
+        c = torch.rand(n, 2, generator=g) * size
+    wh = torch.rand(n, 2, generator=g) * 40 + 2
+    return torch.cat([c - wh / 2, c + wh / 2], 1).contiguous()
+
+
+@pytest.mark.parametrize('n,thr,seed', [(1, 0.5, 0), (2, 0.5, 1), (63, 0.7, 2), (64, 0.5, 3), (65, 0.3, 4), (1000, 0.7, 5),
+                                        (4819, 0.7, 6), (3000, 0.5, 7)])
+def test_nms_kept_indices_are_bit_exact(n, thr, seed):
+    from hnd_ghnd_object_detectors_amd import detection as D
+    g = gen(100 + seed)
+    boxes = random_boxes(n, g)
+    scores = torch.rand(n, generator=g)
+    if n >= 64:                       # exact duplicates, zero-area and inverted boxes, tied scores
+        boxes[5] = boxes[4]
+        boxes[9, 2:] = boxes[9, :2]
+        boxes[11, 2] = boxes[11, 0] - 3.0
+        scores[20] = scores[21]
+    ref = TV.nms(boxes, scores, thr)
+    got = D.nms(boxes.to(DEV), scores.to(DEV), thr)
+    assert got.dtype == torch.int64 and torch.equal(got.cpu(), ref), (len(ref), len(got))
+    assert 0 < len(ref) <= n
+    # ascending-index result order of the 0.4.2 CPU operator
+    assert torch.equal(got.cpu(), got.cpu().sort()[0])
+
+
+def test_nms_empty_and_batched_offsets():
+    from hnd_ghnd_object_detectors_amd import detection as D
+    e = D.nms(torch.empty(0, 4, device=DEV), torch.empty(0, device=DEV), 0.5)
+    assert e.numel() == 0 and e.dtype == torch.int64
+    g = gen(9)
+    boxes, scores = random_boxes(2500, g), torch.rand(2500, generator=g)
+    idxs = torch.randint(0, 5, (2500,), generator=g)
+    ref = TV.batched_nms(boxes, scores, idxs, 0.7)
+    got = D.batched_nms(boxes.to(DEV), scores.to(DEV), idxs.to(DEV), 0.7)
+    assert torch.equal(got.cpu(), ref)
+    # groups never suppress each other: the union of per-group NMS
+    per = torch.cat([torch.nonzero(idxs == k).squeeze(1)[TV.nms(boxes[idxs == k], scores[idxs == k], 0.7)]
+                     for k in range(5)]).sort()[0]
+    assert torch.equal(ref, per)
+
+
+@pytest.mark.parametrize('sampling', [2, 0])
+def test_roi_align_matches_the_cpu_operator(sampling):
+    from hnd_ghnd_object_detectors_amd import _lib, ops
+    L = _lib.load()
+    g = gen(21 + sampling)
+    n, c, h, w = 2, 64, 25, 38
+    feat = torch.randn(n, c, h, w, generator=g)
+    k = 300
+    rois = torch.cat([torch.randint(0, n, (k, 1), generator=g).float(), random_boxes(k, g, 150.0, clustered=False)], 1)
+    rois[0, 1:] = torch.tensor([-30.0, -20.0, -5.0, -2.0])           # entirely outside (left / above)
+    rois[1, 1:] = torch.tensor([140.0, 90.0, 400.0, 300.0])          # runs far past the right / bottom edge
+    rois[2, 1:] = torch.tensor([50.0, 40.0, 50.2, 40.1])             # smaller than one feature cell
+    rois[3, 1:] = torch.tensor([0.0, 0.0, 151.9, 99.9])              # the whole map
+    scale = 0.25
+    ref = TV.roi_align(feat, rois, (7, 7), scale, sampling)          # [k, c, 7, 7]
+    f = feat.permute(0, 2, 3, 1).contiguous().to(DEV)
+    out = torch.full((k, 7, 7, c), float('nan'), device=DEV)
+    sel = torch.arange(0, k, 2, device=DEV)                          # one "level": every other roi
+    rd = rois.to(DEV).contiguous()
+    rc = L.hnd_roi_align(f.data_ptr(), n, h, w, c, rd.data_ptr(), sel.data_ptr(), sel.numel(), scale, 7, 7, sampling,
+                         out.data_ptr(), ops.stream_ptr())
+    assert rc == 0
+    ops.sync_check()
+    got = out.cpu().permute(0, 3, 1, 2)
+    assert torch.isnan(got[1::2]).all()                              # rows of other levels untouched
+    err = float((got[0::2] - ref[0::2]).abs().max())
+    assert err <= 1e-6 * float(ref.abs().max()), err
+    assert float(ref[0].abs().max()) == 0.0 and float(got[0].abs().max()) == 0.0
+
+
+def test_rpn_decode_matches_anchor_generator_and_box_coder():
+    from hnd_ghnd_object_detectors_amd import detection as D
+    from hnd_ghnd_object_detectors_amd.hipnn import ImageList
+    g = gen(31)
+    n, a = 2, 3
+    shapes = [(32, 48), (16, 24), (8, 12), (4, 6), (2, 3)]
+    img_hw = (128, 192)
+    ag = TV.AnchorGenerator(((32,), (64,), (128,), (256,), (512,)), ((0.5, 1.0, 2.0),) * 5)
+    obj = [torch.randn(n, a, h, w, generator=g) for h, w in shapes]
+    reg = [torch.randn(n, a * 4, h, w, generator=g) * 0.5 for h, w in shapes]
+    reg[0][0, 2, 0, 0] = 9.0                                          # dw beyond bbox_xform_clip
+    il = ImageList(torch.zeros(n, 3, *img_hw), [img_hw] * n)
+    anchors = ag(il, obj)
+    o_flat, r_flat = TV.concat_box_prediction_layers(obj, reg)
+    ref_prop = TV.BoxCoder((1.0, 1.0, 1.0, 1.0)).decode(r_flat, anchors).view(n, -1, 4)
+    ref_obj = o_flat.reshape(n, -1)
+    dag = D.AnchorGenerator(((32,), (64,), (128,), (256,), (512,)), ((0.5, 1.0, 2.0),) * 5)
+    for b0, b1 in zip(dag.cell_anchors(), ag.cell_anchors):
+        assert torch.equal(b0, b1)
+    total = ref_obj.shape[1]
+    objectness = torch.full((n, total), float('nan'), device=DEV)
+    proposals = torch.full((n, total, 4), float('nan'), device=DEV)
+    import ctypes as C
+    from hnd_ghnd_object_detectors_amd import _lib, ops
+    L = _lib.load()
+    off = 0
+    for (h, w), o, r, base in zip(shapes, obj, reg, dag.cell_anchors()):
+        head = torch.cat([o, r], 1).permute(0, 2, 3, 1).contiguous()           # [n, h, w, 15]
+        head = torch.nn.functional.pad(head, (0, 1)).to(DEV).contiguous()      # ldc 16
+        flat = (C.c_float * 12)(*[float(v) for v in base.reshape(-1)])
+        assert L.hnd_rpn_decode(head.data_ptr(), n, h, w, 16, a, flat, img_hw[0] / h, img_hw[1] / w, off, total,
+                                D.XFORM_CLIP, objectness.data_ptr(), proposals.data_ptr(), ops.stream_ptr()) == 0
+        off += h * w * a
+    ops.sync_check()
+    assert torch.equal(objectness.cpu(), ref_obj)                     # pure data movement: exact
+    p = proposals.cpu()
+    err = (p - ref_prop).abs().max() / ref_prop.abs().max()
+    assert float(err) < 2e-6, float(err)                              # expf vs torch.exp: last-ulp differences only
+    unclamped = reg[0][0, 2, 0, 0].exp() * (ref_prop[0, 0, 2] - ref_prop[0, 0, 0]) / 62.5
+    assert float(unclamped) > 10                                      # the clamp really acted on that box
+
+
+def test_box_decode_clip_matches_postprocess_arithmetic():
+    import ctypes as C
+    from hnd_ghnd_object_detectors_amd import _lib, ops
+    from hnd_ghnd_object_detectors_amd import detection as D
+    L = _lib.load()
+    g = gen(41)
+    k, ncls = 500, 91
+    props = [random_boxes(300, g, 180.0, False), random_boxes(200, g, 180.0, False)]
+    deltas = torch.randn(k, ncls * 4, generator=g)
+    shapes = [(120, 180), (112, 200)]
+    ref = TV.BoxCoder((10., 10., 5., 5.)).decode(deltas, props)
+    ref = torch.cat([TV.clip_boxes_to_image(b, s) for b, s in zip(ref.split([300, 200], 0), shapes)], 0)
+    rois = torch.cat([torch.cat([torch.full((len(b), 1), float(i)) for i, b in enumerate(props)], 0),
+                      torch.cat(props, 0)], 1).to(DEV).contiguous()
+    hw = torch.tensor([[float(a), float(b)] for a, b in shapes], device=DEV)
+    out = torch.empty(k, ncls, 4, device=DEV)
+    d = deltas.to(DEV)
+    assert L.hnd_box_decode_clip(d.data_ptr(), ncls * 4, rois.data_ptr(), hw.data_ptr(), k, ncls, 10., 10., 5., 5.,
+                                 D.XFORM_CLIP, out.data_ptr(), ops.stream_ptr()) == 0
+    ops.sync_check()
+    err = float((out.cpu() - ref).abs().max())
+    assert err < 2e-4, err            # coordinates up to 200: a last-ulp expf difference is ~2e-5
+
+
+# ------------------------------------------------------------------------------------------------ the detector
+def _detector(tag, meta):
+    cfg = MU.config_for(meta)
+    t_sd = O.scale_detector_heads(O.init_teacher_state(meta['seed']))
+    s_sd = O.scale_detector_heads(O.init_student_state(t_sd, meta['seed'] + 1000))
+    teacher, student = MU.build_pair(cfg, t_sd, s_sd, DEV)
+    model = teacher if tag == 'teacher' else student
+    model.eval()
+    model.distill_backbone_only = False
+    return model
+
+
+@pytest.mark.parametrize('tag', ['teacher', 'student'])
+def test_detector_stages_match_the_reference_fixture(tag):
+    """stage by stage against what the reference's own rcnn.py forward produced: (a) RPN head + anchors + decode;
+    (b) filter_proposals on the FIXTURE's objectness / proposals -> identical kept proposals (bit-exact index work);
+    (c) MultiScaleRoIAlign + box head on the fixture's proposals; (d) postprocess_detections on the fixture's logits
+    -> identical detections (student: logits stored whole); (e) the whole forward, end to end."""
+    from hnd_ghnd_object_detectors_amd.hipnn import to_nhwc
+    z, meta = G.load('tiny_detect_faster')
+    model = _detector(tag, meta)
+    images, _ = G.case_inputs(meta)
+    ims = [im.to(DEV) for im in images]
+    with torch.no_grad():
+        il, _ = model.transform(ims, None, None)
+        features = model.backbone(il.tensors)
+        feats = [to_nhwc(v) for v in features.values()]
+        # (a)
+        objectness, proposals, per_level = model.rpn.decode(il, feats)
+        ref_obj, ref_prop = torch.from_numpy(z[tag + '/rpn/objectness']), torch.from_numpy(z[tag + '/rpn/proposals'])
+        assert tuple(objectness.shape) == tuple(ref_obj.shape) and sum(per_level) == ref_obj.shape[1]
+        e_obj = float((objectness.cpu() - ref_obj).norm() / ref_obj.norm())
+        e_prop = float((proposals.cpu() - ref_prop).norm() / ref_prop.norm())
+        assert e_obj < 1e-3 and e_prop < 1e-3, (e_obj, e_prop)
+        # (b) identical inputs -> identical kept set, order and values
+        boxes, scores = model.rpn.filter_proposals(ref_prop.to(DEV), ref_obj.to(DEV), il.image_sizes, per_level)
+        ref_boxes = [torch.from_numpy(z['%s/rpn/kept_boxes/%d' % (tag, i)]) for i in range(len(ims))]
+        for i, (b, s) in enumerate(zip(boxes, scores)):
+            assert torch.equal(s.cpu(), torch.from_numpy(z['%s/rpn/kept_scores/%d' % (tag, i)])), i
+            assert torch.equal(b.cpu(), ref_boxes[i]), i
+        # (c)
+        pooled, rois = model.roi_heads.box_roi_pool(features, [b.to(DEV) for b in ref_boxes], il.image_sizes)
+        logits, deltas = model.roi_heads.box_branch(pooled)
+        G.compare(z, tag + '/roi/class_logits', logits, 1e-3)
+        G.compare(z, tag + '/roi/box_regression', deltas, 1e-3)
+        # (d)
+        if tag == 'student':
+            ref_logits = torch.from_numpy(z[tag + '/roi/class_logits']).to(DEV)
+            ref_deltas = torch.from_numpy(z[tag + '/roi/box_regression']).to(DEV)
+            b, s, l = model.roi_heads.postprocess_detections(ref_logits, ref_deltas, rois, [len(x) for x in ref_boxes],
+                                                             il.image_sizes)
+            for i in range(len(ims)):
+                dets = model.transform.postprocess([{'boxes': b[i]}], [il.image_sizes[i]], [tuple(images[i].shape[-2:])])
+                assert torch.equal(l[i].cpu(), torch.from_numpy(z['%s/det/%d/labels' % (tag, i)])), i
+                rs, rb = torch.from_numpy(z['%s/det/%d/scores' % (tag, i)]), torch.from_numpy(z['%s/det/%d/boxes' % (tag, i)])
+                assert float((s[i].cpu() - rs).abs().max()) < 1e-6
+                assert float((dets[0]['boxes'].cpu() - rb).abs().max()) < 1e-3
+        # (e) end to end: fp32 noise upstream may flip a near-tie, so match detections one to one with a tolerance
+        dets = model(ims)
+    assert isinstance(dets, list) and sorted(dets[0].keys()) == ['boxes', 'labels', 'scores']
+    for i, d in enumerate(dets):
+        rb = torch.from_numpy(z['%s/det/%d/boxes' % (tag, i)])
+        rl = torch.from_numpy(z['%s/det/%d/labels' % (tag, i)])
+        rs = torch.from_numpy(z['%s/det/%d/scores' % (tag, i)])
+        assert abs(len(d['scores']) - len(rs)) <= 2
+        db, dl, ds = d['boxes'].cpu(), d['labels'].cpu(), d['scores'].cpu()
+        hit = 0
+        for j in range(len(rs)):
+            m = (dl == rl[j]) & ((ds - rs[j]).abs() < 1e-3 * max(1.0, float(rs[j]))) & \
+                ((db - rb[j]).abs().max(1)[0] < 0.25)
+            hit += int(m.any())
+        assert hit >= 0.95 * len(rs), (tag, i, hit, len(rs))

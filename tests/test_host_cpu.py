@@ -48,8 +48,11 @@ def test_holders_refuse_eager_compute():
     _, student = MU.build_pair(cfg, t_sd, s_sd, torch.device('cpu'))
     with pytest.raises(RuntimeError, match='parameter holder'):
         student.backbone.body.conv1(torch.zeros(1, 3, 8, 8))
-    with pytest.raises(NotImplementedError):
-        student.rpn(None)
+    with pytest.raises(NotImplementedError):        # training-mode RPN (proposal losses) is never run by hnd/ghnd
+        student.rpn(None, None)
+    with pytest.raises(NotImplementedError):        # mask / keypoint branches stay parameter holders
+        from hnd_ghnd_object_detectors_amd import hipnn
+        hipnn.KeypointRCNNPredictor(512, 17)(None)
 
 
 def test_generated_yaml_equals_builder_and_reference_yaml_loads():

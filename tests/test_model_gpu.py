@@ -790,9 +790,22 @@ def test_two_ranks_take_the_oracle_step_on_the_mean_gradient(tmp_path):
     print('\n[ddp] worst relative parameter error vs the oracle mean-gradient step: %.2e' % worst)
 
 
-def test_mimic_runner_on_coco_format_folder(tmp_path, capsys):
+def test_mimic_runner_on_coco_format_folder(tmp_path, capsys, monkeypatch):
     """no --synthetic_batches: the runner reads the COCO-format folder named by the yaml (json index + PIL, no
-    pycocotools), batches by aspect ratio, ships uint8 images and runs the fused device transform."""
+    pycocotools), batches by aspect ratio, ships uint8 images and runs the fused device transform; after every epoch
+    it validates the student (eval-mode detector on the HIP path -> COCO bbox mAP) and keeps the checkpoint on the
+    best mAP (reference src/mimic_runner.py:92-100), then evaluates teacher and student on the test split (:148-150).
+    Random weights detect nothing, so the recorded mAP is nudged upward per call to exercise the selection rule."""
+    from hnd_ghnd_object_detectors_amd.utils import main_util as MUTIL
+    real_evaluate, calls = MUTIL.evaluate, []
+
+    def rising_evaluate(model, data_loader, device):
+        ev = real_evaluate(model, data_loader, device)          # the real detector + evaluator run
+        assert 0.0 <= ev.coco_eval['bbox'].stats[0] <= 1.0 or ev.coco_eval['bbox'].stats[0] == -1
+        calls.append(float(ev.coco_eval['bbox'].stats[0]))
+        ev.coco_eval['bbox'].stats[0] = 0.01 * len(calls)
+        return ev
+    monkeypatch.setattr(MUTIL, 'evaluate', rising_evaluate)
     import json
     import os
     from tests.coco_fixture import write_tiny_coco
@@ -813,7 +826,10 @@ def test_mimic_runner_on_coco_format_folder(tmp_path, capsys):
     random.seed(0)
     mimic_runner.main(mimic_runner.get_argparser().parse_args(argv))
     out = capsys.readouterr().out
-    assert 'Creating data loaders' in out and 'Epoch: [1]' in out and 'Updating ckpt' in out
+    assert 'Creating data loaders' in out and 'Epoch: [1]' in out
+    assert out.count('Updating ckpt (Best BBox mAP') == 2 and 'IoU metric: bbox' in out
+    assert 'Average Precision  (AP) @[ IoU=0.50:0.95 | area=   all | maxDets=100 ]' in out
+    assert '[Teacher model]' in out and '[Student model]' in out and len(calls) == 4      # 2 x val, teacher, student
     assert 'Count of instances per bin' in out
     ck = torch.load(ckpt, weights_only=False)
     assert all(torch.isfinite(v).all() for v in ck['model'].values() if v.is_floating_point())
