@@ -10,8 +10,13 @@
 //   hnd_box_decode_clip BoxCoder.decode(weights 10,10,5,5) + clip of RoIHeads.postprocess_detections, all classes
 // Index / byte results (kept sets) must equal the CPU operator's exactly on identical inputs, so every IoU / bilinear
 // expression below is written as single correctly-rounded IEEE operations in the reference's order
-// (__fmul_rn / __fadd_rn / __fsub_rn / __fdiv_rn: no FMA contraction, no reassociation).
+// (no FMA contraction, no reassociation).  NOTE: hipcc's __fmul_rn / __fadd_rn are plain `*` / `+` and WOULD be
+// fused into FMAs under the library-wide -ffp-contract=fast; contraction is therefore switched off for this whole
+// translation unit (pragma below + -ffp-contract=off for this file in the Makefile); the _rn spellings only document
+// the intended operation order.
 #include "common.h"
+
+#pragma clang fp contract(off)
 
 using hnd::f32x4;
 

@@ -476,9 +476,12 @@ __global__ void minmax_kernel(const float* __restrict__ x, long long npix, int c
 
 // The codec is byte work: it must reproduce myutils.tensor_util.quantize_tensor bit for bit on identical fp32 input
 // (tests/test_ops_gpu.py, torch.equal on the bytes).  Every operation below is therefore a single correctly rounded
-// IEEE fp32 operation in the reference's order -- explicit __fdiv_rn / __fadd_rn / __fsub_rn so that neither
-// -ffp-contract=fast nor a reciprocal rewrite of the loop-invariant divisor can change a rounding.
+// IEEE fp32 operation in the reference's order.  hipcc's __fdiv_rn / __fadd_rn / __fmul_rn are the plain operators,
+// so FMA contraction is switched off inside these three kernels (none of the expressions below has a multiply feeding
+// an add today; the pragma keeps it that way) and the division is the correctly rounded one (v_div_scale / fmas /
+// fixup sequence, checked in the ISA).
 __global__ void qparams_kernel(const float* __restrict__ part, int nblocks, float qmax, float* __restrict__ qp) {
+#pragma clang fp contract(off)
   float lo = INFINITY, hi = -INFINITY;
   for (int i = threadIdx.x; i < nblocks; i += 64) {
     lo = fminf(lo, part[i * 2]);
@@ -499,6 +502,7 @@ __global__ void qparams_kernel(const float* __restrict__ part, int nblocks, floa
 
 __global__ void quantize_kernel(const float* __restrict__ x, long long npix, int c, int cs,
                                 const float* __restrict__ qp, float qmax, uint8_t* __restrict__ q) {
+#pragma clang fp contract(off)
   const float scale = qp[2], zp = qp[3];
   const long long total = npix * cs;
   for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
@@ -515,6 +519,7 @@ __global__ void quantize_kernel(const float* __restrict__ x, long long npix, int
 
 __global__ void dequantize_kernel(const uint8_t* __restrict__ q, const float* __restrict__ qp, float* __restrict__ x,
                                   long long npix, int c, int cs) {
+#pragma clang fp contract(off)
   const float scale = qp[2], zp = qp[3];
   const long long total = npix * cs;
   for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;

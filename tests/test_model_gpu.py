@@ -579,7 +579,9 @@ def test_mimic_runner_cli_end_to_end(tmp_path, capsys):
     out = capsys.readouterr().out
     assert 'Updatable parameters' in out and 'Epoch: [1]' in out and 'Updating ckpt' in out
     ck = torch.load(ckpt, weights_only=False)
-    assert sorted(ck) == ['args', 'best_value', 'config', 'lr_scheduler', 'model', 'optimizer']
+    # the reference's six keys, plus this build's own key for the no-validation-set (synthetic) selection rule
+    assert sorted(ck) == ['args', 'best_loss', 'best_value', 'config', 'lr_scheduler', 'model', 'optimizer']
+    assert ck['best_value'] == 0.0 and ck['best_loss'] > 0
     assert ck['lr_scheduler']['last_epoch'] == 1 or ck['lr_scheduler']['last_epoch'] == 0
     assert len(ck['model']) == 293 and len(ck['optimizer']['state']) == 25
     # resume: the checkpoint is picked up (model via get_model, optimizer/scheduler via distill)
