@@ -35,6 +35,11 @@ __device__ __forceinline__ unsigned fdiv(unsigned x, const FastDiv f) {
   return (t + ((x - t) >> 1)) >> (f.shr - 1);
 }
 
+// Packed GEMM-operand row r (hnd_pack_weights, hnd_wino*_weights) holds output channel chan_of_row(r): inside every
+// group of 64 rows the four 16-row MFMA tiles are interleaved, so the four accumulator tiles a lane of the implicit-
+// GEMM kernel owns (rows 16*ni + lane%16 of its wave's 64) are four CONSECUTIVE output channels.
+__host__ __device__ inline int chan_of_row(int r) { return (r & ~63) | ((r & 15) << 2) | ((r >> 4) & 3); }
+
 inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }
 
 #define HND_REQUIRE(cond, ...)                \

@@ -2,14 +2,22 @@
 //
 //   C[m][co] = sum_k A[m][k] * W[co][k],   m = output pixel, k = (tap, ci)
 //
-// Block tile BM (pixels, 128 or 64) x BN (channels, 128 or 64) x 32 (k); 256 threads = 4 waves in a 2x2
-// grid, each wave owns BM/2 x BN/2 as (BM/64) x (BN/64) accumulators of v_mfma_f32_32x32x2_f32.  The host
-// picks the tile per launch: 128x128 where there are many tiles, smaller tiles where the grid would otherwise
-// fill the 256 CUs x 2 resident blocks unevenly (layer3/layer4: M = 67k / 17k pixels at batch 16).
-// Both operands are staged K-contiguous in LDS ([row][32+4 floats]; the 4-float pad makes the
-// ds_read_b128 fragment reads conflict-free) so a lane reads 4 consecutive k of its row with one
-// ds_read_b128 and feeds 4 MFMAs.  The reduction order inside a 8-wide k group is permuted
-// (lane half h takes k = 4h..4h+3) identically for A and B, which fp32 addition tolerates.
+// Block tile BM (pixels, 128 or 64) x BN (channels, 128 or 64) x BK (k, 16 or 32); 256 threads = 4 waves in a 2x2
+// grid, each wave owns BM/2 x BN/2 as (BM/32) x (BN/32) accumulator tiles of v_mfma_f32_16x16x4_f32.
+// WHY 16x16x4 AND NOT 32x32x2 (both exact fp32, both 64 flop/clk/SIMD): with three waves per SIMD issuing matrix
+// instructions -- what this kernel needs to hide its gather latency -- the 32x32x2 shape sustains only 63 % of the
+// matrix rate on MI355X while 16x16x4 holds 95 % (tools/probes/mfma_f32_probe.hip, profiles/r02_mfma_probe.txt: one
+// or two waves per SIMD reach 99 % with either shape, four waves 67 % / 79 %).  Round 1's 32x32x2 build sat at
+// exactly that ~65 %.
+// The host picks the tile per launch: 128x128 where there are many tiles, smaller tiles where the grid would otherwise
+// fill the 256 CUs unevenly (layer3/layer4: M = 67k / 17k pixels at batch 16).
+// Both operands are staged K-contiguous in LDS (unpadded [row][BK] rows, 16-byte chunks XOR-swizzled by f(row)) so a
+// lane reads 4 consecutive k of its row with one ds_read_b128 and feeds 4 MFMAs: lane group g = lane>>4 holds
+// k = 4g..4g+3 of a 16-wide k group, identically for A and B, i.e. MFMA s sums k = s, 4+s, 8+s, 12+s -- a fixed
+// permutation of the reduction order that fp32 addition tolerates (and that is the same for every tile variant, so
+// results do not depend on the tile picked).
+// The packed weight rows are channel-interleaved (hnd::chan_of_row): a lane's NI accumulator tiles are NI consecutive
+// output channels, which makes every epilogue access a 16-byte vector access.
 // Global -> register -> LDS staging is double buffered: tile t+1 is in flight while tile t is on
 // the matrix cores; one barrier per k-step.  The A gather applies the fused BatchNorm/ReLU
 // prologue in registers, and zero-fills out-of-range taps AFTER the prologue (padding is a zero
@@ -47,64 +55,77 @@ constexpr int blocks_per_cu() {
                   : ((BM == 64 && BN == 64) ? 4 : 2);
 }
 
-// Epilogue of one 32x32 accumulator tile.  FULL = the block's whole 128 x BN tile is in range (every tile of a
-// BN=128 launch but the last pixel tile): then there is no per-element control flow, hipcc issues the 8..24
-// residual / mask loads of a row group back to back (uniform branches only) and the stores stream behind counted
-// waits.  A divergent `if` per element would instead make every store wait vmcnt(0) for the previous one -- one
-// HBM round trip per element, which is what small-K 1x1 convs with a residual were bound by.
-template <bool FULL>
-__device__ __forceinline__ void epilogue_tile(const hnd_conv_desc& d, const f32x16& a, const int* rowoff,
-                                              const int* resoff, int rbase, int col, bool col_ok, float es, float eb,
-                                              float& s1, float& s2) {
+// Epilogue of one 16-row group of a wave: the lane holds rows 4*(lane>>4)+i (i = 0..3) and, thanks to the channel
+// interleave of the packed weights (hnd::chan_of_row), NI CONSECUTIVE output channels starting at col0 -- so residual /
+// mask loads and the stores are 16-byte (NI = 4) or 8-byte (NI = 2) vector accesses, 16 lanes covering 64 consecutive
+// channels of a pixel.  FULL = the block's whole BM x BN tile is in range and every pointer / ldc is vector-aligned:
+// then there is no per-element control flow, hipcc issues the loads of the 4 rows back to back (uniform branches only)
+// and the stores stream behind counted waits.  Otherwise a scalar, fully checked path runs (tile edges, ldc = 91 ...).
+template <int NI, bool FULL>
+__device__ __forceinline__ void epilogue_rows(const hnd_conv_desc& d, const f32x4 (&acc)[NI], const int* rowoff,
+                                              const int* resoff, int rbase, int col0, const float (&es)[NI],
+                                              const float (&eb)[NI], float (&s1)[NI], float (&s2)[NI]) {
+  typedef float vec __attribute__((ext_vector_type(NI)));
+  if (FULL) {
+    unsigned off[4];
+    vec r1v[4], r2v[4], mkv[4];
 #pragma unroll
-  for (int c = 0; c < 2; ++c) {
-    unsigned off[8];
-    float r1v[8], r2v[8], mkv[8];
-    unsigned okbits = 0;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int r = c * 8 + q;
-      const int po = rowoff[rbase + (r & 3) + 8 * (r >> 2)];
-      const bool ok = FULL || (po >= 0 && col_ok);
-      okbits |= (ok ? 1u : 0u) << q;
-      off[q] = ok ? (unsigned)po * (unsigned)d.ldc + (unsigned)col : 0u;      // 0 = a safe address to read
-      r1v[q] = 0.f; r2v[q] = 0.f; mkv[q] = 1.f;
+    for (int i = 0; i < 4; ++i) {
+      off[i] = (unsigned)rowoff[rbase + i] * (unsigned)d.ldc + (unsigned)col0;
+      r1v[i] = 0.f; r2v[i] = 0.f; mkv[i] = 1.f;
     }
     if (d.res1) {
       if (d.res1_mode == 1) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const int r = c * 8 + q;
-          const int pr = resoff[rbase + (r & 3) + 8 * (r >> 2)];
-          r1v[q] = d.res1[(size_t)(pr < 0 ? 0 : pr) * d.ldc + (((okbits >> q) & 1) ? col : 0)];
-        }
+        for (int i = 0; i < 4; ++i)
+          r1v[i] = *(const vec*)(d.res1 + (size_t)resoff[rbase + i] * d.ldc + col0);
       } else {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) r1v[q] = d.res1[off[q]];
+        for (int i = 0; i < 4; ++i) r1v[i] = *(const vec*)(d.res1 + off[i]);
       }
     }
     if (d.res2) {
 #pragma unroll
-      for (int q = 0; q < 8; ++q) r2v[q] = d.res2[off[q]];
+      for (int i = 0; i < 4; ++i) r2v[i] = *(const vec*)(d.res2 + off[i]);
     }
     if (d.mask) {
 #pragma unroll
-      for (int q = 0; q < 8; ++q) mkv[q] = d.mask[off[q]];
+      for (int i = 0; i < 4; ++i) mkv[i] = *(const vec*)(d.mask + off[i]);
     }
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      float v = a[c * 8 + q] * es + eb + r1v[q] + r2v[q];
-      v = mkv[q] > 0.f ? v : 0.f;
-      v = d.relu ? fmaxf(v, 0.f) : v;
-      if (FULL) {
-        d.y[off[q]] = v;
-      } else {
-        if ((okbits >> q) & 1) d.y[off[q]] = v; else v = 0.f;
+    for (int i = 0; i < 4; ++i) {
+      vec v;
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        float x = acc[ni][i] * es[ni] + eb[ni] + r1v[i][ni] + r2v[i][ni];
+        x = mkv[i][ni] > 0.f ? x : 0.f;
+        x = d.relu ? fmaxf(x, 0.f) : x;
+        v[ni] = x;
+        s1[ni] += x;
+        s2[ni] += x * x;
       }
-      s1 += v;
-      s2 += v * v;
+      *(vec*)(d.y + off[i]) = v;
     }
     asm volatile("" ::: "memory");
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int po = rowoff[rbase + i];
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const int col = col0 + ni;
+        if (po < 0 || col >= d.cout) continue;
+        const size_t o = (size_t)po * d.ldc + col;
+        float x = acc[ni][i] * es[ni] + eb[ni];
+        if (d.res1) x += d.res1_mode == 1 ? d.res1[(size_t)resoff[rbase + i] * d.ldc + col] : d.res1[o];
+        if (d.res2) x += d.res2[o];
+        if (d.mask) x = d.mask[o] > 0.f ? x : 0.f;
+        x = d.relu ? fmaxf(x, 0.f) : x;
+        d.y[o] = x;
+        s1[ni] += x;
+        s2[ni] += x * x;
+      }
+    }
   }
 }
 
@@ -112,16 +133,18 @@ template <int BM, int BN, int BK, bool CIN4, bool PRO>
 __global__ void __launch_bounds__(256, (blocks_per_cu<BM, BN, BK>()))
 igemm_kernel(const hnd_conv_desc d, const int ntiles) {
   // LDS rows are BK floats, unpadded, with the 16-byte chunks of a row XOR-swizzled by f(row) so that the
-  // ds_read_b128 fragment reads (16 rows per lane group) and the staging writes are both bank-conflict free:
-  // chunk c of row r lives at position c ^ f(r), f(r) = (r >> 2) & 3 for 64-byte rows, (r >> 1) & 7 for 128-byte.
+  // ds_read_b128 fragment reads (16 rows x 4 chunks per wave instruction) and the staging writes are both
+  // bank-conflict free: chunk c of row r lives at position c ^ f(r), f(r) = (r >> 2) & 3 for 64-byte rows,
+  // (r >> 1) & 7 for 128-byte rows.
   constexpr int LDK = BK;
   constexpr int CH = BK / 4;
   constexpr int TPR = BK / 4;            // threads per staged row (one float4 each)
   constexpr int RPP = 256 / TPR;         // rows staged per pass
   constexpr int RA = BM / RPP;           // A rows gathered per thread
   constexpr int RB = BN / RPP;           // B rows loaded per thread
-  constexpr int WTM = BM / 2;            // rows per wave
-  constexpr int MI = WTM / 32, NI = BN / 64;
+  constexpr int WTM = BM / 2, WTN = BN / 2;      // wave tile: 2 x 2 waves per block
+  constexpr int MI = WTM / 16, NI = WTN / 16;    // 16x16 accumulator tiles per wave
+  constexpr int KG = BK / 16;                    // 16-deep k groups per k-step (4 MFMAs of k = 4 each)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NST = 2;                     // LDS stages (double buffer)
   float* As = smem;                          // [NST][BM][BK]
@@ -142,10 +165,11 @@ igemm_kernel(const hnd_conv_desc d, const int ntiles) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 1, wn = wave >> 1;
   const int arow = tid / TPR, kq = tid % TPR;
+  const int l16 = lane & 15, g4 = lane >> 4;
   const int fa = (CH == 4 ? (arow >> 2) : (arow >> 1)) & (CH - 1);     // swizzle of this thread's staged rows
-  const int fl = (CH == 4 ? (lane >> 2) : (lane >> 1)) & (CH - 1);     // swizzle of this lane's fragment rows
+  const int fl = (CH == 4 ? (l16 >> 2) : (l16 >> 1)) & (CH - 1);       // swizzle of this lane's fragment rows
 
-  // per-thread gather rows (4 rows of the pixel tile, fixed for the whole k loop)
+  // per-thread gather rows (fixed for the whole k loop)
   int a_nb[RA], a_ih[RA], a_iw[RA];
   bool a_ok[RA];
 #pragma unroll
@@ -243,66 +267,67 @@ igemm_kernel(const hnd_conv_desc d, const int ntiles) {
     for (int i = 0; i < RB; ++i) store_b(buf, i);
   };
 
-  f32x16 acc[MI][NI];
+  f32x4 acc[MI][NI];
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // One k-step: MFMAs on LDS buffer `buf`; if ST the register tile is written to the other buffer piece by piece
-  // during the first half of the MFMA groups, if LD the following tile is gathered during the second half.
-  constexpr int KK = BK / 8, G = KK * 4, NP = RA + RB;
-  static_assert(NP <= G / 2, "staging pieces must fit in half of the MFMA groups");
+  // One k-step: MFMAs on LDS buffer `buf` in sub-groups of NI MFMAs (one A fragment element against the NI B
+  // fragments); if ST the register tile is written to the other buffer piece by piece during the first half of the
+  // sub-groups, if LD the following tile is gathered during the second half.  A lane's ds_read_b128 of a 16-row
+  // fragment (row l16, chunk lane>>4) holds k = 4*(lane>>4) + s for s = 0..3: element s feeds MFMA s of the k group.
+  constexpr int G = KG * MI * 4, NP = RA + RB;
+  static_assert(NP <= G / 2, "staging pieces must fit in half of the MFMA sub-groups");
   auto step = [&](int buf, auto st_tag, auto ld_tag) {
     constexpr bool ST = decltype(st_tag)::value, LD = decltype(ld_tag)::value;
-    const float* Ap = As + buf * BM * LDK + (wm * WTM + (lane & 31)) * LDK;
-    const float* Bp = Bs + buf * BN * LDK + (wn * (BN / 2) + (lane & 31)) * LDK;
-    const int hh = lane >> 5;
-    f32x4 a[MI], b[NI], an[MI], bn[NI];
+    const float* Ap = As + buf * BM * LDK + (wm * WTM + l16) * LDK;
+    const float* Bp = Bs + buf * BN * LDK + (wn * WTN + l16) * LDK;
+    f32x4 a, an, b[NI], bn[NI];
     {
-      const int o = ((0 * 2 + hh) ^ fl) * 4;
+      const int o = ((0 * 4 + g4) ^ fl) * 4;
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) a[mi] = *(const f32x4*)(Ap + mi * 32 * LDK + o);
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) b[ni] = *(const f32x4*)(Bp + ni * 32 * LDK + o);
+      for (int ni = 0; ni < NI; ++ni) b[ni] = *(const f32x4*)(Bp + ni * 16 * LDK + o);
+      a = *(const f32x4*)(Ap + o);
     }
+    an = a;
 #pragma unroll
-    for (int kk = 0; kk < KK; ++kk) {
+    for (int kg = 0; kg < KG; ++kg) {
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const int g = kk * 4 + s;
+      for (int mi = 0; mi < MI; ++mi) {
+        // the next A fragment (and, at the end of a k group, the next group's B fragments): four sub-groups ahead
+        if (mi + 1 < MI) {
+          an = *(const f32x4*)(Ap + (mi + 1) * 16 * LDK + ((kg * 4 + g4) ^ fl) * 4);
+        } else if (kg + 1 < KG) {
+          const int o = (((kg + 1) * 4 + g4) ^ fl) * 4;
+          an = *(const f32x4*)(Ap + o);
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
+          for (int ni = 0; ni < NI; ++ni) bn[ni] = *(const f32x4*)(Bp + ni * 16 * LDK + o);
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const int g = (kg * MI + mi) * 4 + s;
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][s], b[ni][s], acc[mi][ni], 0, 0, 0);
-        if (ST && g < NP) {
-          if (g < RA) store_a(buf ^ 1, g);
-          else store_b(buf ^ 1, g - RA);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[ni][s], acc[mi][ni], 0, 0, 0);
+          if (ST && g < NP) {
+            if (g < RA) store_a(buf ^ 1, g);
+            else store_b(buf ^ 1, g - RA);
+          }
+          if (LD && g >= G / 2) {
+            const int q = g - G / 2;
+            if (q == 0) load_begin();
+            if (q < RA) load_a(q);
+            else if (q < NP) load_b(q - RA);
+            if (q == NP - 1) load_end();
+          }
+          __builtin_amdgcn_sched_barrier(0);
         }
-        if (LD && g >= G / 2) {
-          const int q = g - G / 2;
-          if (q == 0) load_begin();
-          if (q < RA) load_a(q);
-          else if (q < NP) load_b(q - RA);
-          if (q == NP - 1) load_end();
+        a = an;
+        if (mi + 1 == MI && kg + 1 < KG) {
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) b[ni] = bn[ni];
         }
-        if (s == 1 && kk + 1 < KK) {      // next k-group's fragments: two MFMA groups ahead of their first use
-          const int o = (((kk + 1) * 2 + hh) ^ fl) * 4;
-#pragma unroll
-          for (int mi = 0; mi < MI; ++mi) an[mi] = *(const f32x4*)(Ap + mi * 32 * LDK + o);
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni) bn[ni] = *(const f32x4*)(Bp + ni * 32 * LDK + o);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      if (kk + 1 < KK) {
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) a[mi] = an[mi];
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) b[ni] = bn[ni];
       }
     }
   };
@@ -333,7 +358,7 @@ igemm_kernel(const hnd_conv_desc d, const int ntiles) {
   // (the k loop ended with a barrier: the staging buffers are free; As becomes the stats scratch, Bs the row tables)
   if (tid < BM) {
     const int m = m0 + tid;
-    int po = -1, pr = -1;
+    int po = -1, pr = 0;
     if (m < M) {
       const int ow_ = m % d.ow, t = m / d.ow, oh_ = t % d.oh, n_ = t / d.oh;
       const int yr = oh_ * d.y_sh + d.y_oh, yc = ow_ * d.y_sw + d.y_ow;
@@ -347,31 +372,39 @@ igemm_kernel(const hnd_conv_desc d, const int ntiles) {
 
   __syncthreads();
   float* red = As;   // [2 (wm)][2 (sum,sumsq)][BN], reused after the final barrier
-  const bool tile_full = (m0 + BM <= M) && (n0 + BN <= d.cout);
+  // the wave's NI tiles are rows rho0 + 16*ni + l16 of the packed weight matrix = channels col0 + ni (chan_of_row)
+  const int rho0 = n0 + wn * WTN;
+  const int col0 = (rho0 & ~63) + l16 * 4 + ((rho0 >> 4) & 3);
+  const uintptr_t align_bits = (uintptr_t)d.y | (uintptr_t)d.res1 | (uintptr_t)d.res2 | (uintptr_t)d.mask;
+  const bool tile_full = (m0 + BM <= M) && (n0 + BN <= d.cout) && (d.ldc % NI == 0) && (align_bits % (4 * NI) == 0);
+  float es[NI], eb[NI], s1[NI], s2[NI];
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
-    const int ct = wn * (BN / 2) + ni * 32 + (lane & 31);
-    const int col = n0 + ct;
-    const bool col_ok = col < d.cout;
-    const float es = (d.epi_scale && col_ok) ? d.epi_scale[col] : 1.f;
-    const float eb = (d.epi_shift && col_ok) ? d.epi_shift[col] : 0.f;
-    float s1 = 0.f, s2 = 0.f;
+    const bool col_ok = col0 + ni < d.cout;
+    es[ni] = (d.epi_scale && col_ok) ? d.epi_scale[col0 + ni] : 1.f;
+    eb[ni] = (d.epi_shift && col_ok) ? d.epi_shift[col0 + ni] : 0.f;
+    s1[ni] = 0.f;
+    s2[ni] = 0.f;
+  }
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-      const int rbase = wm * WTM + mi * 32 + 4 * (lane >> 5);
-      if (tile_full) epilogue_tile<true>(d, acc[mi][ni], rowoff, resoff, rbase, col, col_ok, es, eb, s1, s2);
-      else epilogue_tile<false>(d, acc[mi][ni], rowoff, resoff, rbase, col, col_ok, es, eb, s1, s2);
-    }
-    if (d.stats) {
-      s1 += __shfl_xor(s1, 32);
-      s2 += __shfl_xor(s2, 32);
-      if (lane < 32) {
-        red[(wm * 2 + 0) * BN + ct] = s1;
-        red[(wm * 2 + 1) * BN + ct] = s2;
-      }
-    }
+  for (int mi = 0; mi < MI; ++mi) {
+    const int rbase = wm * WTM + mi * 16 + 4 * g4;
+    if (tile_full) epilogue_rows<NI, true>(d, acc[mi], rowoff, resoff, rbase, col0, es, eb, s1, s2);
+    else epilogue_rows<NI, false>(d, acc[mi], rowoff, resoff, rbase, col0, es, eb, s1, s2);
   }
   if (d.stats) {
+    // per 128-row tile and channel: fold the four row groups of the wave (lane>>4), then the two row-waves
+    const int cl = col0 - n0;                  // channel index inside the block tile
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      float a1 = s1[ni], a2 = s2[ni];
+      a1 += __shfl_xor(a1, 16); a2 += __shfl_xor(a2, 16);
+      a1 += __shfl_xor(a1, 32); a2 += __shfl_xor(a2, 32);
+      if (g4 == 0) {
+        red[(wm * 2 + 0) * BN + cl + ni] = a1;
+        red[(wm * 2 + 1) * BN + cl + ni] = a2;
+      }
+    }
     __syncthreads();
     if (tid < BN && (n0 + tid) < d.cout) {
       float* st = d.stats + (size_t)mt * 2 * d.cout + n0 + tid;
@@ -381,16 +414,27 @@ igemm_kernel(const hnd_conv_desc d, const int ntiles) {
   }
 }
 
+// tuning knob: cap the resident blocks per CU below what registers / LDS allow by padding the dynamic LDS request
+// (160 KB per CU).  The matrix pipe serves two waves per SIMD at 99 % and three at 95 % (16x16x4), four at 79 %.
+int bpc_cap() {
+  static const int v = getenv("HND_IGEMM_BPC") ? atoi(getenv("HND_IGEMM_BPC")) : 0;
+  return v;
+}
+
 template <int BM, int BN, int BK, bool CIN4, bool PRO>
 int launch_pro(const hnd_conv_desc& d, hipStream_t stream) {
   static std::atomic<unsigned long long> attr_set{0};    // per device: the attribute lives on the device's function
   auto kern = igemm_kernel<BM, BN, BK, CIN4, PRO>;
+  size_t lds = lds_bytes<BM, BN, BK, PRO>();
+  if (bpc_cap() > 0) {
+    const size_t pad = (size_t)(160 * 1024) / (size_t)bpc_cap() - 1024;
+    if (pad > lds) lds = pad;
+  }
   int dev = 0;
   (void)hipGetDevice(&dev);
   const unsigned long long bit = 1ull << (dev & 63);
   if (!(attr_set.load(std::memory_order_relaxed) & bit)) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lds_bytes<BM, BN, BK, PRO>());
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       hnd::set_error("hipFuncSetAttribute(igemm<%d,%d>) failed: %s", BM, BN, hipGetErrorString(e));
       return HND_ERR_LAUNCH;
@@ -400,7 +444,6 @@ int launch_pro(const hnd_conv_desc& d, hipStream_t stream) {
   const long long M = (long long)d.n * d.oh * d.ow;
   const int mtiles = (int)((M + BM - 1) / BM);
   const int ntiles = (d.cout + BN - 1) / BN;
-  const size_t lds = lds_bytes<BM, BN, BK, PRO>();
   hipLaunchKernelGGL(kern, dim3(mtiles * ntiles), dim3(256), lds, stream, d, ntiles);
   return hnd::check_launch("hnd_conv2d_igemm");
 }

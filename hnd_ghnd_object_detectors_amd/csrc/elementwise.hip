@@ -38,7 +38,8 @@ __global__ void pack_weights_kernel(const float* __restrict__ src, float* __rest
   const long long total = (long long)rows_pad * kdim;
   for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
        e += (long long)gridDim.x * blockDim.x) {
-    const int r = (int)(e / kdim), k = (int)(e - (long long)r * kdim);
+    const int k = (int)(e % kdim);
+    const int r = hnd::chan_of_row((int)(e / kdim));        // packed row e / kdim holds this output channel
     const int tap = k / chan_pad, c = k - tap * chan_pad;
     float v = 0.f;
     const int rows = transposed ? cin : cout, chans = transposed ? cout : cin;

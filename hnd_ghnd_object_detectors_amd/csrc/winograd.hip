@@ -28,7 +28,8 @@ __global__ void wino_weights_kernel(const float* __restrict__ w, float* __restri
   const long long total = (long long)rows_pad * kdim;
   for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
        e += (long long)gridDim.x * blockDim.x) {
-    const int r = (int)(e / kdim), k = (int)(e - (long long)r * kdim);
+    const int pr = (int)(e / kdim), k = (int)(e - (long long)pr * kdim);      // packed row pr holds channel r
+    const int r = hnd::chan_of_row(pr);
     const int kreal = dgrad ? cout : cin;
     float g[3][3];
     const bool ok = r < rows && k < kreal;
@@ -53,7 +54,7 @@ __global__ void wino_weights_kernel(const float* __restrict__ w, float* __restri
     for (int i = 0; i < 4; ++i) {
       const float u0 = t[i][0], u1 = 0.5f * (t[i][0] + t[i][1] + t[i][2]), u2 = 0.5f * (t[i][0] - t[i][1] + t[i][2]),
                   u3 = t[i][2];
-      float* dst = u + ((size_t)(i * 4) * rows_pad + r) * kdim + k;
+      float* dst = u + ((size_t)(i * 4) * rows_pad + pr) * kdim + k;
       const size_t fs = (size_t)rows_pad * kdim;
       dst[0] = u0; dst[fs] = u1; dst[2 * fs] = u2; dst[3 * fs] = u3;
     }
@@ -195,7 +196,8 @@ __global__ void wino4_weights_kernel(const float* __restrict__ w, float* __restr
   const int kreal = dgrad ? cout : cin;
   for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
        e += (long long)gridDim.x * blockDim.x) {
-    const int r = (int)(e / kdim), k = (int)(e - (long long)r * kdim);
+    const int pr = (int)(e / kdim), k = (int)(e - (long long)pr * kdim);      // packed row pr holds channel r
+    const int r = hnd::chan_of_row(pr);
     const bool ok = r < rows && k < kreal;
     float g[3][3];
 #pragma unroll
@@ -223,7 +225,7 @@ __global__ void wino4_weights_kernel(const float* __restrict__ w, float* __restr
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
       const float a = t[i][0], b = t[i][1], c = t[i][2];
-      float* dst = u + ((size_t)(i * 6) * rows_pad + r) * kdim + k;
+      float* dst = u + ((size_t)(i * 6) * rows_pad + pr) * kdim + k;
       dst[0] = a * (1.f / 4.f);
       dst[fs] = -(a + b + c) * (1.f / 6.f);
       dst[2 * fs] = (-a + b - c) * (1.f / 6.f);
@@ -376,7 +378,8 @@ __global__ void wino2_weights_kernel(const float* __restrict__ w, float* __restr
   const int kreal = dgrad ? cout : cin;
   for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
        e += (long long)gridDim.x * blockDim.x) {
-    const int r = (int)(e / kdim), k = (int)(e - (long long)r * kdim);
+    const int pr = (int)(e / kdim), k = (int)(e - (long long)pr * kdim);      // packed row pr holds channel r
+    const int r = hnd::chan_of_row(pr);
     const bool ok = r < rows && k < kreal;
     float g[2][2];
 #pragma unroll
@@ -402,7 +405,7 @@ __global__ void wino2_weights_kernel(const float* __restrict__ w, float* __restr
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
       const float a = t[i][0], b = t[i][1];
-      float* dst = u + ((size_t)(i * 5) * rows_pad + r) * kdim + k;
+      float* dst = u + ((size_t)(i * 5) * rows_pad + pr) * kdim + k;
       dst[0] = 0.5f * a;
       dst[fs] = -0.5f * (a + b);
       dst[2 * fs] = (b - a) * (1.f / 6.f);

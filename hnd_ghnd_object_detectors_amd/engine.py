@@ -23,6 +23,7 @@ from . import ops
 
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1
 WINOGRAD = int(os.environ.get('HND_WINOGRAD', '4'))      # output tile of the Winograd 3x3 path: 4, 2, or 0 = off
+WINOGRAD_HEAD = os.environ.get('HND_WINOGRAD_HEAD', '1') != '0'     # F(4x4,2x2) for the two deep head convs
 PROFILE = {'enabled': False, 'records': []}     # bench.py: per-launch HIP events on the launch stream
 # DistillationBox sets 'stream' while it runs teacher + student: their feature pyramids (whose outputs the
 # distillation criterion never reads) are then issued on that stream and overlap the backward pass
@@ -175,12 +176,15 @@ class Wino2Cache(object):
             self.ver = ver
 
 
+WINOGRAD_FROZEN = os.environ.get('HND_WINOGRAD_FROZEN', '1') != '0'   # debugging knob: frozen / FPN 3x3 convs
+
+
 def use_winograd(cin, cout, stride):
     """Winograd output tile (0 = direct) for a 3x3 conv.  It pays when the (tile+2)^2 GEMMs are deep enough to run
     at MFMA rate and the inflated transformed tensors stay cheap next to them (tools/bench_wino.py, batch 16):
     F(4x4,3x3) x2.2-2.8 over the direct kernel for 256/512 channels and x1.7 for 128; F(2x2,3x3) x1.3-2.0 for
     256/512 and x1.0 for 128."""
-    if WINOGRAD not in (2, 4) or stride != 1 or cin % 32 != 0 or cout % 4 != 0:
+    if WINOGRAD not in (2, 4) or not WINOGRAD_FROZEN or stride != 1 or cin % 32 != 0 or cout % 4 != 0:
         return 0
     return WINOGRAD if min(cin, cout) >= (128 if WINOGRAD == 4 else 256) else 0
 
@@ -494,7 +498,7 @@ class HeadEngine(object):
             hc.wc = WeightCache(conv.weight)
             # F(4x4,2x2) pays for the two deep decoder convs (128->256, 256->256: x1.2-1.45 forward and dgrad,
             # tools/bench_wino2.py); with 64 channels on either side the 25 GEMMs are HBM-bound and lose
-            hc.wino = Wino2Cache(conv.weight) if (WINOGRAD and min(hc.cin, hc.cout) >= 128 and
+            hc.wino = Wino2Cache(conv.weight) if (WINOGRAD and WINOGRAD_HEAD and min(hc.cin, hc.cout) >= 128 and
                                                   512 % hc.cout == 0) else None
             self.layers.append(hc)
         self.bufs = None

@@ -54,7 +54,10 @@ def main():
         warm.step()
         history.append({'loss': loss.item(),
                         'params': {n: p.detach().cpu().clone() for n, p in student.named_parameters()
-                                   if p.requires_grad}})
+                                   if p.requires_grad},
+                        # after optimizer.step() the arena holds the all-reduced SUM of the ranks' gradients
+                        'grad_sum': {n: p.grad.detach().cpu().clone() for n, p in student.named_parameters()
+                                     if p.requires_grad}})
     torch.save({'history': history, 'reductions': wrapped.reductions}, os.path.join(out_dir, 'rank%d.pt' % rank))
     dist.barrier()
     dist.destroy_process_group()

@@ -123,9 +123,15 @@ def test_distill_steps_match_reference_golden(name):
         opt.step()
         warm.step()
     sd = student.state_dict()
+    # A single ReLU-mask flip (one activation of ~3e5 within rounding of zero landing on the other side than in the
+    # reference run) moves every upstream gradient by ~1e-3 -- inside the gradient bar above -- and Adam's normalised
+    # update then moves the small BatchNorm biases by several 1e-3 relative (tools/debug_bufs.py located exactly one
+    # differing mask element for this fixture between two builds whose buffers otherwise agree to 4e-6).  The updated
+    # parameters are therefore held to 2e-3 only when no flip happened (all gradients within 1e-4), else to 2e-2.
+    ptol = 2e-2 if (gtol or worst['grad'] > 1e-4) else 2e-3
     for n in O.trainable_keys(s_sd):
         if not n.endswith(G.ZERO_GRAD_SUFFIXES):
-            G.compare(z, 'after/param/' + n, sd[n], 2e-2 if gtol else 2e-3, atol=1e-6)
+            G.compare(z, 'after/param/' + n, sd[n], ptol, atol=1e-6)
     for n in z.files:
         if n.startswith('after/buffer/'):
             key = n[len('after/buffer/'):]
@@ -764,7 +770,21 @@ def test_two_ranks_take_the_oracle_step_on_the_mean_gradient(tmp_path):
     adam = torch.optim.Adam(mean_p, lr=1e-3)
     sched = torch.optim.lr_scheduler.LambdaLR(adam, lambda x: 1 if x >= 4 else 1e-3 * (1 - x / 4.0) + x / 4.0)
     batches = [rank_batch(meta, r)[0] for r in range(2)]
-    worst = 0.0
+    worst, worst_g = 0.0, 0.0
+    # the exchange itself, bit for bit: single-process HIP gradients of each rank's batch from the same initial
+    # weights (deterministic kernels) must SUM to exactly what both ranks hold after the all-reduce of step 0
+    from hnd_ghnd_object_detectors_amd.distillation.tool import DistillationBox
+    teacher, student = MU.build_pair(cfg, t_sd, s_sd, DEV)
+    box = DistillationBox(teacher, student, cfg['train']['criterion'])
+    local = []
+    for r in range(2):
+        ims, tgs = _to_dev(*rank_batch(meta, r))
+        for p in student.parameters():
+            p.grad = None
+        box(ims, tgs).backward()
+        local.append({n: p.grad.detach().cpu().clone() for n, p in student.named_parameters() if p.requires_grad})
+    for k in keys:
+        assert torch.equal(r0['history'][0]['grad_sum'][k], local[0][k] + local[1][k]), k
     for step in range(steps):
         grads = []
         for r, orc in enumerate(ranks):
@@ -777,8 +797,17 @@ def test_two_ranks_take_the_oracle_step_on_the_mean_gradient(tmp_path):
             got = (r0, r1)[r]['history'][step]['loss']
             assert abs(got - float(loss)) / abs(float(loss)) < LOSS_TOL, (step, r, got, float(loss))
         adam.zero_grad()
-        for p, g0, g1 in zip(mean_p, grads[0], grads[1]):
+        for k, p, g0, g1 in zip(keys, mean_p, grads[0], grads[1]):
             p.grad = (g0 + g1) * 0.5
+            if not k.endswith(G.ZERO_GRAD_SUFFIXES):      # the exchanged gradient: sum over ranks, identical on both
+                gs0, gs1 = r0['history'][step]['grad_sum'][k], r1['history'][step]['grad_sum'][k]
+                assert torch.equal(gs0, gs1), (step, k)
+                e = float((gs0.double() - (g0 + g1).double()).norm() / (g0 + g1).double().norm())
+                worst_g = max(worst_g, e)
+                assert e < 2e-2, (step, k, e)       # fp32 oracle vs fp32 HIP at 64 px: ReLU-mask flips on either side
+        # a ReLU-mask flip against the oracle run (see test_distill_steps_match_reference_golden) costs ~1e-3 on the
+        # gradients and several 1e-3 on the small BN biases after Adam: 2e-3 on parameters only when no flip happened
+        ptol = 2e-3 if worst_g < 1e-4 else 2e-2
         adam.step()
         sched.step()
         for k, p in zip(keys, mean_p):
@@ -788,8 +817,9 @@ def test_two_ranks_take_the_oracle_step_on_the_mean_gradient(tmp_path):
                 continue
             err = float((a.double() - p.detach().double()).norm() / (p.detach().double().norm() + 1e-6 * p.numel() ** 0.5))
             worst = max(worst, err)
-            assert err < 2e-3, (step, k, err)
-    print('\n[ddp] worst relative parameter error vs the oracle mean-gradient step: %.2e' % worst)
+            assert err < ptol, (step, k, err)
+    print('\n[ddp] worst relative error vs the oracle mean-gradient step: parameters %.2e, exchanged gradients %.2e'
+          % (worst, worst_g))
 
 
 def test_mimic_runner_on_coco_format_folder(tmp_path, capsys, monkeypatch):

@@ -242,15 +242,20 @@ def test_pack_weights_layouts(ops):
     pw = ops.pack_weights(wt.to(DEV).contiguous())
     buf = pw.buf.cpu().view(64, pw.kdim)
     assert pw.kdim == 64 and pw.chan_pad == 4
-    ref = torch.zeros(64, 64)
-    ref[:5, :36] = F.pad(wt.permute(0, 2, 3, 1), (0, 1)).reshape(5, 36)
+    # packed row r holds output channel (r & ~63) | ((r & 15) << 2) | ((r >> 4) & 3)  (hnd::chan_of_row: the four
+    # 16-row MFMA tiles of a 64-row group are interleaved so a lane's four accumulator tiles are consecutive channels)
+    chan = torch.tensor([(r & ~63) | ((r & 15) << 2) | ((r >> 4) & 3) for r in range(64)])
+    assert sorted(chan.tolist()) == list(range(64)) and chan[16] == 1 and chan[1] == 4
+    flat = torch.zeros(64, 64)
+    flat[:5, :36] = F.pad(wt.permute(0, 2, 3, 1), (0, 1)).reshape(5, 36)
+    ref = flat[chan]
     assert torch.equal(buf, ref)
     pt = ops.pack_weights(wt.to(DEV).contiguous(), transposed=True, chan_pad=8, taps=(1, 2, 1, 0, 2, 2))
     buf = pt.buf.cpu().view(64, pt.kdim)
-    ref = torch.zeros(64, pt.kdim)
+    flat = torch.zeros(64, pt.kdim)
     sub = wt[:, :, 1:2, 0::2]                                  # [o, i, 1, 2]
-    ref[:3, :16] = F.pad(sub.permute(1, 2, 3, 0), (0, 3)).reshape(3, 16)
-    assert torch.equal(buf, ref)
+    flat[:3, :16] = F.pad(sub.permute(1, 2, 3, 0), (0, 3)).reshape(3, 16)
+    assert torch.equal(buf, flat[chan])
 
 
 def test_fbn_fold(ops):
