@@ -482,6 +482,9 @@ int pick_tile(const hnd_conv_desc& d) {
   // the 512->512 @25x42 and 256->256 @50x84 3x3 convs, which the model then predicts within 3 %).
   struct Cand { int id, bm, bn, bpc; double eff, lone; };
   const int b16 = bk16_mask();
+  // (a re-fit of `eff` on the isolated-launch sweep of tools/bench_conv.py --tiles for the 16x16x4 kernel -- 1.00 /
+  // 0.945 / 0.977 / 0.913 -- picked differently and made the step 1.5 % slower: inside the step the launches run with
+  // the previous layer's output in L2 / MALL, so the round-1 constants, fitted in the step, stay)
   const Cand cands[4] = {{0, 128, 128, (b16 & 1) ? 3 : 2, (b16 & 1) ? 1.00 : 0.97, (b16 & 1) ? 0.45 : 0.57},
                          {1, 128, 64, (b16 & 2) ? 4 : 2, (b16 & 2) ? 0.90 : 0.88, (b16 & 2) ? 0.34 : 0.57},
                          {2, 64, 128, (b16 & 4) ? 4 : 2, (b16 & 4) ? 0.91 : 0.895, (b16 & 4) ? 0.34 : 0.57},
