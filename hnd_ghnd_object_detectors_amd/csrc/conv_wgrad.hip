@@ -4,10 +4,12 @@
 //
 // The reduction runs over pixels (1.1M..4.3M at batch 16), so both operands are staged exactly as
 // they lie in HBM -- [pixel][channel], channel contiguous -- and the MFMA fragments are read from
-// LDS with conflict-free ds_read_b32 (lane = channel).  fp32 MFMA issues one 32x32x2 every 64
-// cycles per SIMD, so one 4-byte LDS read per operand per MFMA is far below the LDS rate (a build that
-// transposes 4x4 blocks in registers to read fragments with ds_read_b128 measured 3 % slower and was dropped).
-// Block tile: BMW (64|128 output channels) x 128 (cols) x 32 (pixels); 4 waves 2x2.
+// LDS with ds_read_b32 (lane = channel).  v_mfma_f32_16x16x4_f32: lane l supplies channel l%16 of pixel l/16, so a
+// fragment read touches 4 pixel rows x 16 channels; the LDS row stride is padded to 16 mod 32 floats, which puts the
+// two pixel rows of each 32-lane read group on different bank halves (conflict-free).  16x16x4 rather than 32x32x2
+// because this kernel runs 3-4 waves per SIMD, where the 32x32x2 shape loses a third of the matrix rate
+// (tools/probes/mfma_f32_probe.hip).
+// Block tile: BMW (64|128 output channels) x 128 (cols) x 16 (pixels); 4 waves 2x2.
 // Each block reduces one contiguous pixel range (split-K); partial tiles go to slabs
 // [split][co_pad][ncols_pad] and a second kernel sums the slabs in fixed order and writes the
 // torch OIHW layout -> bitwise reproducible, no float atomics.
@@ -19,7 +21,6 @@
 namespace {
 
 using hnd::FastDiv;
-using hnd::f32x16;
 using hnd::f32x4;
 using hnd::fdiv;
 
@@ -31,11 +32,17 @@ struct WgradArgs {
   int ncols, ncols_pad, co_pad, rtiles, ctiles, steps_per_split, M;
 };
 
+constexpr int lds_stride(int n) { return n + 16; }        // == 16 (mod 32) floats for n = 64, 128
+
 template <int BMW, int BKW>
-__global__ void __launch_bounds__(256, (BKW == 16 ? 4 : 2)) wgrad_kernel(const WgradArgs a) {
-  __shared__ __attribute__((aligned(16))) float smem[2 * BKW * (BMW + BNW)];
-  float* As = smem;                       // [2][BKW][BMW]   dy tile
-  float* Bs = smem + 2 * BKW * BMW;       // [2][BKW][BNW]   gathered activation tile
+constexpr size_t wgrad_lds_bytes() { return (size_t)2 * BKW * (lds_stride(BMW) + lds_stride(BNW)) * sizeof(float); }
+
+template <int BMW, int BKW>
+__global__ void __launch_bounds__(256, (BKW == 16 ? 3 : 2)) wgrad_kernel(const WgradArgs a) {
+  constexpr int LDA = lds_stride(BMW), LDB = lds_stride(BNW);
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                       // [2][BKW][LDA]   dy tile
+  float* Bs = smem + 2 * BKW * LDA;       // [2][BKW][LDB]   gathered activation tile
   const hnd_wgrad_desc& d = a.d;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 1, wn = wave >> 1;
@@ -120,7 +127,7 @@ __global__ void __launch_bounds__(256, (BKW == 16 ? 4 : 2)) wgrad_kernel(const W
   auto lstore = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < A_N; ++i)
-      *(f32x4*)(As + (buf * BKW + a_r + i * A_RPI) * BMW + a_c4) = ra[i];
+      *(f32x4*)(As + (buf * BKW + a_r + i * A_RPI) * LDA + a_c4) = ra[i];
 #pragma unroll
     for (int i = 0; i < B_N; ++i) {
       f32x4 v = rb[i];
@@ -132,34 +139,34 @@ __global__ void __launch_bounds__(256, (BKW == 16 ? 4 : 2)) wgrad_kernel(const W
       }
       const bool ok = (bok >> i) & 1;
       v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
-      *(f32x4*)(Bs + (buf * BKW + b_r + i * 8) * BNW + b_c4) = v;
+      *(f32x4*)(Bs + (buf * BKW + b_r + i * 8) * LDB + b_c4) = v;
     }
   };
 
-  constexpr int MI = BMW / 64;   // 32-row MFMA tiles per wave along co
-  f32x16 acc[MI][2];
+  constexpr int MI = BMW / 32;   // 16-row MFMA tiles per wave along co (wave tile BMW/2 x 64)
+  constexpr int NI = 4;
+  f32x4 acc[MI][NI];
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  const int l16 = lane & 15, g4 = lane >> 4;
   auto compute = [&](int buf) {
-    const float* Ap = As + buf * BKW * BMW + (lane >> 5) * BMW + wm * (BMW / 2) + (lane & 31);
-    const float* Bp = Bs + buf * BKW * BNW + (lane >> 5) * BNW + wn * 64 + (lane & 31);
+    const float* Ap = As + buf * BKW * LDA + g4 * LDA + wm * (BMW / 2) + l16;
+    const float* Bp = Bs + buf * BKW * LDB + g4 * LDB + wn * 64 + l16;
 #pragma unroll
-    for (int kk = 0; kk < BKW / 2; ++kk) {
-      float av[MI], bv[2];
+    for (int kk = 0; kk < BKW / 4; ++kk) {
+      float av[MI], bv[NI];
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) av[mi] = Ap[kk * 2 * BMW + mi * 32];
+      for (int mi = 0; mi < MI; ++mi) av[mi] = Ap[kk * 4 * LDA + mi * 16];
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni) bv[ni] = Bp[kk * 2 * BNW + ni * 32];
+      for (int ni = 0; ni < NI; ++ni) bv[ni] = Bp[kk * 4 * LDB + ni * 16];
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi], bv[ni], acc[mi][ni], 0, 0, 0);
+        for (int ni = 0; ni < NI; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mi], bv[ni], acc[mi][ni], 0, 0, 0);
     }
   };
 
@@ -177,16 +184,16 @@ __global__ void __launch_bounds__(256, (BKW == 16 ? 4 : 2)) wgrad_kernel(const W
       cur ^= 1;
     }
   }
-  // partial tile -> slab[split][co][col]; D[i=co][j=col]: lane -> col, regs -> co
+  // partial tile -> slab[split][co][col]; D[i=co][j=col]: lane%16 -> col, lane/16 and regs -> co
   float* slab = d.slabs + ((size_t)grp * d.splitk + split) * a.co_pad * a.ncols_pad;
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
+    for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int co = r0 + wm * (BMW / 2) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const int cc = c0 + wn * 64 + ni * 32 + (lane & 31);
+      for (int r = 0; r < 4; ++r) {
+        const int co = r0 + wm * (BMW / 2) + mi * 16 + 4 * g4 + r;
+        const int cc = c0 + wn * 64 + ni * 16 + l16;
         slab[(size_t)co * a.ncols_pad + cc] = acc[mi][ni][r];
       }
 }
@@ -274,12 +281,22 @@ extern "C" int hnd_conv2d_wgrad(const hnd_wgrad_desc* desc, void* stream) {
   HND_REQUIRE(groups == 1 || (d.x_group_stride > 0 && d.dy_group_stride > 0 && d.dw_group_stride > 0),
               "hnd_conv2d_wgrad: group strides must be positive when groups > 1");
   const dim3 grid(a.rtiles * a.ctiles * a.d.splitk, groups);
+  // tuning knob HND_WGRAD_BPC: cap the resident blocks per CU by padding the dynamic LDS request.  Measured in the
+  // step (batch 16): 4 blocks/CU (the register / LDS limit, default) 5.95 ms, 3 -> 6.34 ms, 2 -> 5.97 ms for the
+  // cout >= 128 launches -- this kernel is not bound by matrix-pipe contention, so the uncapped occupancy stays
+  static const int bpc = getenv("HND_WGRAD_BPC") ? atoi(getenv("HND_WGRAD_BPC")) : 0;
+  const size_t floor_lds = bpc > 0 ? (size_t)(160 * 1024) / (size_t)bpc - 2048 : 0;
+  auto lds_of = [&](size_t need) { return need > floor_lds || floor_lds > 65536 ? need : floor_lds; };
   if (bk == 16) {
-    if (bmw == 128) hipLaunchKernelGGL((wgrad_kernel<128, 16>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((wgrad_kernel<64, 16>), grid, dim3(256), 0, s, a);
+    if (bmw == 128)
+      hipLaunchKernelGGL((wgrad_kernel<128, 16>), grid, dim3(256), lds_of(wgrad_lds_bytes<128, 16>()), s, a);
+    else
+      hipLaunchKernelGGL((wgrad_kernel<64, 16>), grid, dim3(256), lds_of(wgrad_lds_bytes<64, 16>()), s, a);
   } else {
-    if (bmw == 128) hipLaunchKernelGGL((wgrad_kernel<128, 32>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((wgrad_kernel<64, 32>), grid, dim3(256), 0, s, a);
+    if (bmw == 128)
+      hipLaunchKernelGGL((wgrad_kernel<128, 32>), grid, dim3(256), lds_of(wgrad_lds_bytes<128, 32>()), s, a);
+    else
+      hipLaunchKernelGGL((wgrad_kernel<64, 32>), grid, dim3(256), lds_of(wgrad_lds_bytes<64, 32>()), s, a);
   }
   int rc = hnd::check_launch("hnd_conv2d_wgrad");
   if (rc) return rc;
