@@ -85,6 +85,10 @@ if 'FETCH_SIZE' in traffic and 'WRITE_SIZE' in traffic:
             wv, wn = traffic['WRITE_SIZE'][k]
             tj['kernels'][k] = {'dispatches': fn, 'fetch_kib_raw': fv, 'write_kib': wv,
                                 'traffic_bytes_per_launch': int((2 * fv + wv) * 1024 / fn)}
+    try:        # the configuration these counters belong to (bench.py only quotes them for a matching run)
+        tj['config'] = json.loads(open(os.path.join(out, 'bench_trace.json')).read().strip().splitlines()[-1])['run_cfg']
+    except Exception:      # noqa
+        tj['config'] = None
     json.dump(tj, open(os.path.join(out, 'traffic.json'), 'w'), indent=1)
 
 fstats = glob.glob(os.path.join(out, 'filter', '*kernel_stats.csv'))
