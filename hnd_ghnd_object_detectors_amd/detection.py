@@ -419,6 +419,11 @@ class RoIHeads(nn.Module):
     def forward(self, features, proposals, image_shapes, targets=None):
         if self.training:
             raise NotImplementedError('RoIHeads training branch (detection losses): never run by the hnd/ghnd configs')
+        if sum(len(p) for p in proposals) == 0:         # nothing proposed (e.g. every box degenerate): empty detections
+            dev = proposals[0].device
+            empty = dict(boxes=torch.empty(0, 4, device=dev), labels=torch.empty(0, dtype=torch.int64, device=dev),
+                         scores=torch.empty(0, device=dev))
+            return [dict(empty) for _ in proposals], {}
         pooled, rois = self.box_roi_pool(features, proposals, image_shapes)
         class_logits, box_regression = self.box_branch(pooled)
         self.last = {'class_logits': class_logits, 'box_regression': box_regression, 'pooled': pooled}

@@ -2,9 +2,9 @@
 
 ``RcnnHead`` is what runs next to the camera: transform -> stem -> layer1 encoder [-> neural filter gate]
 [-> Quantizer]; its output ``z`` (3 channels at b3ch, uint8 when quantised) is what crosses the link.
-``RcnnTail`` continues on the server: [Dequantizer ->] layer1 decoder -> layer2..4 -> FPN.  The detector heads
-behind the pyramid (RPN / RoI heads / post-processing, reference :186-196) are outside this build (SURVEY.md
-8f-f4): ``RcnnTail.forward`` returns the pyramid when ``features_only`` is set and raises otherwise.
+``RcnnTail`` continues on the server: [Dequantizer ->] layer1 decoder -> layer2..4 -> FPN -> RPN -> RoI box head ->
+post-processing (reference :186-196; the eval-mode detector of detection.py); with ``features_only`` set it stops at
+the pyramid.
 Both halves run the same HIP engines as the unsplit model, in eval mode (inference deployment).
 """
 from collections import OrderedDict
@@ -12,7 +12,7 @@ from collections import OrderedDict
 from torch import nn
 
 from ... import engine as E
-from ...hipnn import attach, to_nhwc
+from ...hipnn import ImageList, attach, to_nhwc
 from ...structure.transformer import Compose, Dequantizer, Quantizer
 
 
@@ -72,8 +72,19 @@ class RcnnTail(nn.Module):
         features = self.sub_backbone.fpn(features)
         if self.features_only:
             return features
-        raise NotImplementedError('RPN / RoI heads behind the pyramid are outside this build (SURVEY.md 8f-f4); set '
-                                  'features_only=True to stop at the FPN features')
+        # reference :186-196: proposals -> detections -> back to the original image frame (the RPN only needs the
+        # padded batch SHAPE, which is why the reference ships `tensors_shape` across the link)
+        image_list = ImageList(_ShapeOnly(tensors_shape), image_sizes)
+        proposals, _ = self.rpn(image_list, features, targets)
+        detections, _ = self.roi_heads(features, proposals, image_sizes, targets)
+        return self.transform.postprocess(detections, image_sizes, original_image_sizes)
+
+
+class _ShapeOnly(object):
+    """stands in for the batched image tensor on the tail's side of the link: only its shape exists there"""
+
+    def __init__(self, shape):
+        self.shape = tuple(shape)
 
 
 def split_rcnn_model(model, quantization):

@@ -395,9 +395,18 @@ def test_head_tail_split_matches_reference_golden(quantization, tag, tol):
     for k, v in feats.items():
         G.compare(z, '%s/fpn/%s' % (tag, k), v.contiguous(), tol)
         assert torch.equal(v, whole[k]), k
-    with pytest.raises(NotImplementedError):
-        tail.features_only = False
-        tail(zq, tensors_shape, image_sizes, original_sizes)
+    # the whole split detector (reference split_rcnn.py:186-196): head -> link -> tail incl. RPN / RoI box head /
+    # NMS == the unsplit model's detections, bit for bit (same kernels on the same values)
+    tail.features_only = False
+    student.distill_backbone_only = False
+    with torch.no_grad():
+        dets_split = tail(zq, tensors_shape, image_sizes, original_sizes)
+        dets_whole = student(ims)
+    assert len(dets_split) == len(dets_whole) == len(ims)
+    for a, b in zip(dets_split, dets_whole):
+        assert sorted(a.keys()) == ['boxes', 'labels', 'scores']
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
 
 
 FULL = ['full_ghnd_faster', 'full_ghnd_faster_b4', 'full_hnd_faster_b2', 'full_ghnd_mask_b2', 'full_ghnd_keypoint_b2',

@@ -759,3 +759,30 @@ def test_bad_arguments_raise(ops):
     with pytest.raises(RuntimeError, match='cin=48'):
         pw = ops.pack_weights(w, chan_pad=48)
         ops.conv_forward(x, pw, torch.zeros(1, 4, 4, 64, device=DEV), 1).run()
+
+
+def test_native_rccl_communicator_world_of_one(ops):
+    """include/hnd_hip.h hnd_comm_*: the C ABI's own RCCL communicator (resolved at run time from the RCCL that
+    PyTorch-ROCm already loaded).  A 1-GPU box can only form a world of one, where the averaging all-reduce must be
+    the identity, bit for bit, and must run on the stream it is given."""
+    import ctypes as C
+    from hnd_ghnd_object_detectors_amd import _lib
+    L = _lib.load()
+    nbytes = int(L.hnd_workspace_size(5, None, 0))
+    assert nbytes == 128
+    uid = C.create_string_buffer(nbytes)
+    assert L.hnd_comm_unique_id(uid, nbytes) == 0, L.hnd_last_error_string()
+    assert any(b != 0 for b in uid.raw)
+    comm = C.c_void_p()
+    assert L.hnd_comm_init(0, 1, uid.raw, nbytes, C.byref(comm)) == 0, L.hnd_last_error_string()
+    g = gen(91)
+    flat = torch.randn(586566, generator=g).to(DEV)
+    before = flat.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    assert L.hnd_allreduce_avg_flat(comm, flat.data_ptr(), flat.numel(), side.cuda_stream) == 0, L.hnd_last_error_string()
+    side.synchronize()
+    assert torch.equal(flat, before)
+    assert L.hnd_allreduce_avg_flat(comm, None, 5, None) == -1                  # argument errors are reported
+    assert L.hnd_comm_init(3, 2, uid.raw, nbytes, C.byref(C.c_void_p())) == -1
+    assert L.hnd_comm_destroy(comm) == 0
