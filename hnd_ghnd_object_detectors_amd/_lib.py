@@ -124,6 +124,11 @@ def load():
         raise HndLibraryError(
             'libhnd_hip.so not found at %s: build it with `python -c "import __graft_entry__ as g; g.build()"` '
             '(or make -C hnd_ghnd_object_detectors_amd/csrc). There is no CPU fallback.' % LIB_PATH)
+    # PyTorch-ROCm ships its own HIP runtime (torch/lib/libamdhip64.so) and owns the device tensors this library works
+    # on: load it FIRST so libhnd_hip.so binds to that copy.  Loaded the other way round the process holds two HIP
+    # runtimes and this library's launches fail with "no ROCm-capable device is detected" (seen when build() and
+    # smoke() ran in one process).
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in _SIGNATURES.items():
         try:
