@@ -887,6 +887,53 @@ def test_mimic_runner_on_coco_format_folder(tmp_path, capsys, monkeypatch):
     assert len(a) == len(b) > 0 and all(abs(x - y) <= 1e-4 * abs(y) for x, y in zip(a, b)), (a, b)
 
 
+def test_hipgraph_replay_of_the_filter_training_step_is_bit_identical():
+    """graph.GraphedStep: the neural-filter training step (forward, hand-written backward, fused SGD, the torch
+    cross-entropy around them) captured into a hipGraph and replayed takes the SAME trajectory as eager launches, bit
+    for bit -- prebuilt descriptors on static buffers are exactly what a graph records."""
+    from hnd_ghnd_object_detectors_amd import ext_runner
+    from hnd_ghnd_object_detectors_amd.graph import GraphedStep
+    from hnd_ghnd_object_detectors_amd.myutils.pytorch import func_util
+    z, meta = G.load('tiny_ext_filter')
+    images, targets = G.ext_case_inputs(meta)
+    ims, tgs = _to_dev(images, targets)
+
+    def run(graphed):
+        s_sd, e_sd = MU.ext_states(meta['seed'])
+        cfg, model, ext = MU.build_ext_model(s_sd, e_sd, DEV, meta['min_size'], meta['max_size'])
+        model.train()
+        opt = func_util.get_optimizer(ext, 'SGD', {'lr': 1e-3, 'momentum': 0.9, 'weight_decay': 1e-4})
+        with torch.no_grad():
+            probe = [dict(t) for t in tgs]
+            model.transform(ims, probe, None)
+        labels = ext_runner.convert_target2ext_targets(probe, DEV)
+
+        def body():
+            logits = model(ims, [dict(t) for t in tgs])
+            loss = torch.nn.functional.cross_entropy(logits, labels)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            return loss.detach()
+        step = GraphedStep(body, key=lambda: opt.param_groups[0]['lr'], warmup=2) if graphed else body
+        losses = [float(step()) for _ in range(6)]
+        if graphed:
+            assert step.captures == 1
+            opt.param_groups[0]['lr'] = 5e-4                # a host-side hyper-parameter change re-captures
+            losses.append(float(step()))
+            assert step.captures == 2
+        else:
+            opt.param_groups[0]['lr'] = 5e-4
+            losses.append(float(step()))
+        params = OrderedDict((n, p.detach().clone()) for n, p in ext.named_parameters())
+        return losses, params
+    l0, p0 = run(False)
+    l1, p1 = run(True)
+    assert l0 == l1, (l0, l1)
+    for n in p0:
+        assert torch.equal(p0[n], p1[n]), n
+
+
 def test_ext_model_eval_with_quantised_bottleneck_equals_plain_student():
     """BASELINE config 5: Keypoint R-CNN b3ch + neural filter + int8 bottleneck.  In eval mode the filter model's
     pyramid (filter accepts) equals the filter-less student's with the same weights bit for bit, with and without

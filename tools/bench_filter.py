@@ -28,6 +28,7 @@ def main():
     ap.add_argument('--width', type=int, default=1333)
     ap.add_argument('--cpu_steps', type=int, default=2)
     ap.add_argument('--cpu_threads', type=int, default=32)
+    ap.add_argument('--graph', action='store_true', help='replay the step as a captured hipGraph (graph.GraphedStep)')
     args = ap.parse_args()
     from hnd_ghnd_object_detectors_amd import ext_runner
     from hnd_ghnd_object_detectors_amd.configs import make_ext_config
@@ -51,15 +52,31 @@ def main():
     images = [im.to(dev) for im in images]
     targets = [{k: v.to(dev) for k, v in t.items()} for t in targets]
 
-    def step():
+    # image-level labels (reference src/ext_runner.py:55-56) depend on the targets only: computed once, on the host,
+    # from what the model's transform leaves (so the captured step has no device -> host read in it)
+    with torch.no_grad():
+        probe = [dict(t) for t in targets]
+        model.transform(images, probe, None)
+    labels = ext_runner.convert_target2ext_targets(probe, dev)
+
+    def body():
         tg = [dict(t) for t in targets]
         logits = model(images, tg)
-        labels = ext_runner.convert_target2ext_targets(tg, dev)
         loss = torch.nn.functional.cross_entropy(logits, labels)
         opt.zero_grad()
         loss.backward()
         opt.step()
-        return float(loss.detach())
+        return loss.detach()
+
+    if args.graph:
+        from hnd_ghnd_object_detectors_amd.graph import GraphedStep
+        graphed = GraphedStep(body, key=lambda: tuple(g['lr'] for g in opt.param_groups), warmup=3)
+
+        def step():
+            return float(graphed())
+    else:
+        def step():
+            return float(body())
 
     for _ in range(args.warmup):
         step()
@@ -71,7 +88,8 @@ def main():
     dt = (time.perf_counter() - t0) / args.steps
     out = {'metric': 'neural-filter train-step images/sec at 3x%dx%d' % (args.height, args.width),
            'value': round(args.batch / dt, 2), 'unit': 'img/s', 'ms_per_step': round(dt * 1e3, 3),
-           'batch': args.batch, 'steps': args.steps, 'dtype': 'f32', 'last_loss': last}
+           'batch': args.batch, 'steps': args.steps, 'dtype': 'f32', 'last_loss': last,
+           'hipgraph': bool(args.graph)}
     if args.cpu_steps > 0:
         from oracle import hnd_oracle as O
         torch.set_num_threads(args.cpu_threads)
