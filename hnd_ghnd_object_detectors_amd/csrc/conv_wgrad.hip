@@ -198,23 +198,32 @@ __global__ void __launch_bounds__(256, (BKW == 16 ? 3 : 2)) wgrad_kernel(const W
       }
 }
 
-// sum the slabs in split order and write dW in torch OIHW layout
+// sum the slabs and write dW in torch OIHW layout.  Fixed order (bit-reproducible): wave q of the block sums the
+// slabs k = q, q+4, q+8, ... in increasing k, then the four partial sums are added in the order ((0+1)+2)+3.  Four
+// k-lanes per output keep 4x more loads in flight than one serial chain per output (up to 512 slabs deep).
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int splitk, int co_pad,
                                     int ncols_pad, int cout, int cin, int cin_real, int kh, int kw,
                                     long long dw_group_stride) {
+  __shared__ float red[4][64];
   slabs += (size_t)blockIdx.y * splitk * co_pad * ncols_pad;
   dw += (size_t)blockIdx.y * (size_t)dw_group_stride;
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // over cout * kh*kw * cin_real in (co, tap, ci) order
+  const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int idx = blockIdx.x * 64 + lane;   // over cout * kh*kw * cin_real in (co, tap, ci) order
   const int per_co = kh * kw * cin_real;
-  if (idx >= cout * per_co) return;
-  const int co = idx / per_co, rem = idx - co * per_co;
+  const bool ok = idx < cout * per_co;
+  const int co = ok ? idx / per_co : 0, rem = ok ? idx - co * per_co : 0;
   const int tap = rem / cin_real, ci = rem - tap * cin_real;
   const size_t off = (size_t)co * ncols_pad + tap * cin + ci;
   const size_t stride = (size_t)co_pad * ncols_pad;
   float s = 0.f;
-  for (int k = 0; k < splitk; ++k) s += slabs[off + k * stride];
-  const int i = tap / kw, j = tap - i * kw;
-  dw[(((size_t)co * cin_real + ci) * kh + i) * kw + j] = s;
+  if (ok)
+    for (int k = q; k < splitk; k += 4) s += slabs[off + k * stride];
+  red[q][lane] = s;
+  __syncthreads();
+  if (q == 0 && ok) {
+    const int i = tap / kw, j = tap - i * kw;
+    dw[(((size_t)co * cin_real + ci) * kh + i) * kw + j] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+  }
 }
 
 // k-step depth of the build in use: 16 (32 KB LDS, 4 resident blocks per CU) unless HND_WGRAD_BK=32
@@ -301,7 +310,7 @@ extern "C" int hnd_conv2d_wgrad(const hnd_wgrad_desc* desc, void* stream) {
   int rc = hnd::check_launch("hnd_conv2d_wgrad");
   if (rc) return rc;
   const int total = d.cout * d.kh * d.kw * d.cin_real;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256, groups), dim3(256), 0, s, d.slabs, d.dw,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 63) / 64, groups), dim3(256), 0, s, d.slabs, d.dw,
                      a.d.splitk, a.co_pad, a.ncols_pad, d.cout, d.cin, d.cin_real, d.kh, d.kw,
                      (long long)d.dw_group_stride);
   return hnd::check_launch("hnd_conv2d_wgrad(reduce)");

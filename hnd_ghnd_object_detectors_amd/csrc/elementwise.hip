@@ -202,26 +202,36 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const uint8_t* 
 }
 
 // ------------------------------------------------------------------------------------ BN forward
-// one wave per channel; lanes stride over the tile partials, fp64 accumulate
-__global__ void bn_finalize_kernel(const float* __restrict__ partials, int ntiles, int c, int cs, double count,
-                                   const float* gamma, const float* beta, float* running_mean, float* running_var,
-                                   long long* nbt, float momentum, float eps, float* scale, float* shift,
-                                   float* save_mean, float* save_rstd) {
-  const int lane = threadIdx.x & 63;
-  const int ch = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (ch >= cs) return;
+// One 1024-thread block per 16 channels.  A wave's load covers 4 tiles x 16 channels (four 64-byte runs instead of 64
+// scattered dwords), the 16 waves stride over the tiles 64 at a time; fp64 accumulation in a fixed order: per lane in
+// increasing tile order, then the 4 tile sub-lanes (xor 16, xor 32), then the 16 waves in wave order.
+__global__ void __launch_bounds__(1024) bn_finalize_kernel(const float* __restrict__ partials, int ntiles, int c, int cs,
+                                   double count, const float* gamma, const float* beta, float* running_mean,
+                                   float* running_var, long long* nbt, float momentum, float eps, float* scale,
+                                   float* shift, float* save_mean, float* save_rstd) {
+  __shared__ double red[2][16][16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int cl = lane & 15, ts = lane >> 4;
+  const int ch = blockIdx.x * 16 + cl;
+  double s1 = 0.0, s2 = 0.0;
+  if (ch < c) {
+    for (int t = wave * 4 + ts; t < ntiles; t += 64) {
+      s1 += (double)partials[((size_t)t * 2 + 0) * cs + ch];
+      s2 += (double)partials[((size_t)t * 2 + 1) * cs + ch];
+    }
+  }
+  s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+  s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+  if (ts == 0) { red[0][wave][cl] = s1; red[1][wave][cl] = s2; }
+  __syncthreads();
+  if (threadIdx.x >= 16 || ch >= cs) return;
   if (ch >= c) {
-    if (lane == 0) { scale[ch] = 0.f; shift[ch] = 0.f; save_mean[ch] = 0.f; save_rstd[ch] = 0.f; }
+    scale[ch] = 0.f; shift[ch] = 0.f; save_mean[ch] = 0.f; save_rstd[ch] = 0.f;
     return;
   }
-  double s1 = 0.0, s2 = 0.0;
-  for (int t = lane; t < ntiles; t += 64) {
-    s1 += (double)partials[((size_t)t * 2 + 0) * cs + ch];
-    s2 += (double)partials[((size_t)t * 2 + 1) * cs + ch];
-  }
-  s1 = wave_sum_d(s1);
-  s2 = wave_sum_d(s2);
-  if (lane == 0) {
+  s1 = 0.0; s2 = 0.0;
+  for (int w = 0; w < 16; ++w) { s1 += red[0][w][cl]; s2 += red[1][w][cl]; }
+  {
     const double mean = s1 / count;
     double var = s2 / count - mean * mean;   // biased, used for normalisation
     if (var < 0.0) var = 0.0;
@@ -628,7 +638,7 @@ int hnd_bn_finalize(const float* partials, int ntiles, int c, int cs, int64_t co
   HND_REQUIRE(partials && gamma && beta && scale && shift && save_mean && save_rstd, "hnd_bn_finalize: null pointer");
   HND_REQUIRE(ntiles > 0 && c > 0 && cs >= c && count > 0, "hnd_bn_finalize: bad sizes");
   HND_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "hnd_bn_finalize: running stats mismatch");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((cs + 3) / 4), dim3(256), 0, hnd::as_stream(stream), partials, ntiles, c,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((cs + 15) / 16), dim3(1024), 0, hnd::as_stream(stream), partials, ntiles, c,
                      cs, (double)count, gamma, beta, running_mean, running_var, (long long*)num_batches_tracked,
                      momentum, eps, scale, shift, save_mean, save_rstd);
   return hnd::check_launch("hnd_bn_finalize");
