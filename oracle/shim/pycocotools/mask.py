@@ -1,5 +1,4 @@
-def _absent(*a, **k):
-    raise NotImplementedError('pycocotools is not available (import-only stub)')
+"""pycocotools.mask: box IoU only (oracle/pycoco_r.py); RLE functions raise."""
+from oracle.pycoco_r import mask as _m
 
-
-encode = decode = frPyObjects = area = toBbox = iou = merge = _absent
+iou, encode, decode, area, toBbox, frPyObjects, merge = _m.iou, _m.encode, _m.decode, _m.area, _m.toBbox, _m.frPyObjects, _m.merge

@@ -335,6 +335,64 @@ def run_detect_case(name='tiny_detect_faster'):
     print('   wrote %s (%.1f KB)' % (path, os.path.getsize(path) / 1024.0))
 
 
+def coco_eval_case_inputs(seed=51):
+    """ground truth and predictions of the evaluator fixture (seeded; shared with tests/golden_util.py)"""
+    g = torch.Generator().manual_seed(seed)
+    dataset, preds = [], {}
+    for i in range(6):
+        h, w = 360 + 30 * i, 480 + 24 * i
+        n = [3, 1, 5, 2, 0, 4][i]
+        xy = torch.rand(n, 2, generator=g) * torch.tensor([w * 0.5, h * 0.5])
+        wh = torch.rand(n, 2, generator=g) ** 2 * torch.tensor([w * 0.45, h * 0.45]) + 6
+        boxes = torch.cat([xy, xy + wh], 1)
+        labels = torch.randint(1, 4, (n,), generator=g)
+        crowd = (torch.rand(n, generator=g) < 0.15).to(torch.int64)
+        tgt = {'image_id': torch.tensor([200 + i]), 'boxes': boxes, 'labels': labels,
+               'area': (wh[:, 0] * wh[:, 1]), 'iscrowd': crowd}
+        dataset.append((torch.zeros(3, h, w), tgt))
+        # predictions: jittered copies of the ground truth (some dropped), a duplicate, and false positives
+        keep = torch.rand(n, generator=g) < 0.8
+        jit = (torch.rand(n, 4, generator=g) - 0.5) * torch.cat([wh, wh], 1) * 0.22
+        pb = (boxes + jit)[keep]
+        pl = labels[keep].clone()
+        if len(pl) > 1:
+            pl[0] = 1 + (pl[0] % 3)                       # one detection with the wrong class
+        fp = torch.rand(3, 2, generator=g) * torch.tensor([w * 0.7, h * 0.7])
+        fpb = torch.cat([fp, fp + torch.rand(3, 2, generator=g) * 30 + 3], 1)
+        pb = torch.cat([pb, pb[:1], fpb], 0)
+        pl = torch.cat([pl, pl[:1], torch.randint(1, 4, (3,), generator=g)], 0)
+        ps = torch.rand(len(pb), generator=g)
+        preds[200 + i] = {'boxes': pb, 'labels': pl, 'scores': ps}
+    return dataset, preds
+
+
+def run_coco_eval_case(name='tiny_coco_eval'):
+    """The reference's own evaluator code -- utils/coco_util.convert_to_coco_api, utils/coco_eval_util.CocoEvaluator
+    with its copies of loadRes / evaluate / createIndex (src/utils/coco_eval_util.py:15-150,198-345) -- over the
+    restated pycocotools (oracle/pycoco_r.py): ground truth from a dataset of targets, predictions fed in two
+    update() calls, synchronize / accumulate / summarize -> the twelve COCO statistics."""
+    print('== %s' % name)
+    from utils import coco_eval_util as ref_eval          # reference
+    from utils import coco_util as ref_coco               # reference
+    dataset, preds = coco_eval_case_inputs()
+    coco = ref_coco.convert_to_coco_api([(img, {k: v.clone() for k, v in t.items()}) for img, t in dataset])
+    ev = ref_eval.CocoEvaluator(coco, ['bbox'])
+    ids = sorted(preds)
+    ev.update({i: preds[i] for i in ids[:4]})
+    ev.update({i: preds[i] for i in ids[4:]})
+    ev.synchronize_between_processes()
+    ev.accumulate()
+    ev.summarize()
+    stats = np.array(ev.coco_eval['bbox'].stats, dtype=np.float64)
+    out = OrderedDict(stats=stats, seed=np.int64(51),
+                      precision_checksum=np.float64(ev.coco_eval['bbox'].eval['precision'].clip(min=0).sum()))
+    print('   stats', np.round(stats, 4).tolist())
+    assert 0.05 < stats[0] < 0.95 and stats[1] > stats[0] >= 0      # a non-trivial case
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **out)
+    print('   wrote %s (%.1f KB)' % (path, os.path.getsize(path) / 1024.0))
+
+
 def run_input_pipeline_case(name='tiny_input_pipeline'):
     """Decoded uint8 image -> reference ToTensor -> RandomHorizontalFlip (forced on / off) -> CustomRCNNTransform."""
     print('== %s' % name)
@@ -498,6 +556,8 @@ def main():
         run_eval_codec_case()
     if not args.only or args.only == 'tiny_detect_faster':
         run_detect_case()
+    if not args.only or args.only == 'tiny_coco_eval':
+        run_coco_eval_case()
     if not args.only or args.only == 'tiny_input_pipeline':
         run_input_pipeline_case()
     if not args.only or args.only == 'tiny_ext_filter':

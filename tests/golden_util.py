@@ -91,3 +91,33 @@ def compare(z, name, t, rtol, what='', atol=0.0):
         err = max(e_samples, e_ss, e_s)
     assert err <= rtol, '%s %s: rel err %.3e > %.1e' % (what, name, err, rtol)
     return err
+
+
+def coco_eval_case_inputs(seed=51):
+    """Re-create the seeded inputs of make_golden.coco_eval_case_inputs (kept in sync by test_coco_eval_cpu)."""
+    g = torch.Generator().manual_seed(seed)
+    dataset, preds = [], {}
+    for i in range(6):
+        h, w = 360 + 30 * i, 480 + 24 * i
+        n = [3, 1, 5, 2, 0, 4][i]
+        xy = torch.rand(n, 2, generator=g) * torch.tensor([w * 0.5, h * 0.5])
+        wh = torch.rand(n, 2, generator=g) ** 2 * torch.tensor([w * 0.45, h * 0.45]) + 6
+        boxes = torch.cat([xy, xy + wh], 1)
+        labels = torch.randint(1, 4, (n,), generator=g)
+        crowd = (torch.rand(n, generator=g) < 0.15).to(torch.int64)
+        tgt = {'image_id': torch.tensor([200 + i]), 'boxes': boxes, 'labels': labels,
+               'area': (wh[:, 0] * wh[:, 1]), 'iscrowd': crowd}
+        dataset.append((torch.zeros(3, h, w), tgt))
+        keep = torch.rand(n, generator=g) < 0.8
+        jit = (torch.rand(n, 4, generator=g) - 0.5) * torch.cat([wh, wh], 1) * 0.22
+        pb = (boxes + jit)[keep]
+        pl = labels[keep].clone()
+        if len(pl) > 1:
+            pl[0] = 1 + (pl[0] % 3)
+        fp = torch.rand(3, 2, generator=g) * torch.tensor([w * 0.7, h * 0.7])
+        fpb = torch.cat([fp, fp + torch.rand(3, 2, generator=g) * 30 + 3], 1)
+        pb = torch.cat([pb, pb[:1], fpb], 0)
+        pl = torch.cat([pl, pl[:1], torch.randint(1, 4, (3,), generator=g)], 0)
+        ps = torch.rand(len(pb), generator=g)
+        preds[200 + i] = {'boxes': pb, 'labels': pl, 'scores': ps}
+    return dataset, preds

@@ -98,3 +98,62 @@ def test_ground_truth_from_a_dataset_of_targets():
     assert sorted(gt.images) == [1, 2] and sorted(gt.categories) == [1, 2]
     a = gt.anns[1][0]
     assert a['bbox'] == [1.0, 2.0, 10.0, 20.0] and a['area'] == 200.0 and gt.anns[1][1]['iscrowd'] == 1
+
+
+def test_evaluator_matches_the_reference_evaluator_fixture():
+    """tiny_coco_eval.npz = the twelve statistics the REFERENCE's CocoEvaluator (its own loadRes / evaluate /
+    createIndex copies, convert_to_coco_api) produced for seeded ground truth + predictions (crowd boxes, a wrong
+    class, a duplicate, false positives; all three area ranges populated), over the restated pycocotools of
+    oracle/pycoco_r.py.  The product evaluator must reproduce them."""
+    from tests import golden_util as G
+    from hnd_ghnd_object_detectors_amd.utils.coco_eval_util import get_coco_api_from_dataset
+    z = G.load_raw('tiny_coco_eval')
+    dataset, preds = G.coco_eval_case_inputs(int(z['seed']))
+
+    class DS(torch.utils.data.Dataset):
+        def __len__(self):
+            return len(dataset)
+
+        def __getitem__(self, i):
+            img, t = dataset[i]
+            return img, {k: v.clone() for k, v in t.items()}
+    gt = get_coco_api_from_dataset(DS())
+    ev = CocoEvaluator(gt, ['bbox'])
+    ids = sorted(preds)
+    ev.update({i: preds[i] for i in ids[:4]})
+    ev.update({i: preds[i] for i in ids[4:]})
+    ev.synchronize_between_processes()
+    ev.accumulate()
+    ev.summarize()
+    got, ref = ev.coco_eval['bbox'].stats, z['stats']
+    assert np.abs(got - ref).max() < 1e-12, (got, ref)
+    assert abs(float(np.clip(ev.coco_eval['bbox'].eval['precision'], 0, None).sum()) - float(z['precision_checksum'])) < 1e-9
+
+
+def test_restated_pycocotools_agrees_on_the_hand_cases():
+    """oracle/pycoco_r.COCOeval (what the reference evaluator ran over) and the product BBoxEval are two independent
+    restatements of pycocotools: they must agree on the known-answer cases above as well"""
+    from oracle.pycoco_r import COCO, COCOeval
+    gt_boxes = [(1, [0, 0, 50, 50], 1, 0), (1, [100, 100, 50, 50], 1, 0), (1, [20, 20, 90, 90], 2, 1)]
+    dets = [(1, [0, 0, 50, 50], 1, 0.9), (1, [60, 60, 20, 20], 1, 0.8), (1, [30, 30, 40, 40], 2, 0.7)]
+    mine = _run(_gt(gt_boxes), dets)
+    c = COCO()
+    c.dataset = {'images': [{'id': 1}], 'categories': [{'id': 1}, {'id': 2}],
+                 'annotations': [{'id': k + 1, 'image_id': i, 'bbox': b, 'category_id': cat, 'iscrowd': crowd,
+                                  'area': float(b[2] * b[3])} for k, (i, b, cat, crowd) in enumerate(gt_boxes)]}
+    c.createIndex()
+    d = COCO()
+    d.dataset = {'images': [{'id': 1}], 'categories': [{'id': 1}, {'id': 2}],
+                 'annotations': [{'id': k + 1, 'image_id': i, 'bbox': b, 'category_id': cat, 'score': s, 'iscrowd': 0,
+                                  'area': float(b[2] * b[3])} for k, (i, b, cat, s) in enumerate(dets)]}
+    d.createIndex()
+    e = COCOeval(c, d, 'bbox')
+    p = e.params
+    e._prepare()
+    e.ious = {(i, k): e.computeIoU(i, k) for i in p.imgIds for k in p.catIds}
+    e.evalImgs = [e.evaluateImg(i, k, a, p.maxDets[-1]) for k in p.catIds for a in p.areaRng for i in p.imgIds]
+    import copy
+    e._paramsEval = copy.deepcopy(p)
+    e.accumulate()
+    e.summarize()
+    assert np.abs(np.asarray(e.stats) - mine).max() < 1e-12
