@@ -335,6 +335,67 @@ def run_detect_case(name='tiny_detect_faster'):
     print('   wrote %s (%.1f KB)' % (path, os.path.getsize(path) / 1024.0))
 
 
+class _ListDataset(torch.utils.data.Dataset):
+    """(image, target) pairs in memory: what main_util.evaluate needs from a dataset (convert_to_coco_api walks it)"""
+
+    def __init__(self, items):
+        self.items = items
+
+    def __len__(self):
+        return len(self.items)
+
+    def __getitem__(self, i):
+        img, t = self.items[i]
+        return img.clone(), {k: v.clone() for k, v in t.items()}
+
+
+def run_validation_case(name='tiny_val_map'):
+    """The reference's whole validation path, unmodified: utils/main_util.evaluate (src/utils/main_util.py:75-113)
+    drives the eval-mode detector (rcnn.py:124-127) over a batch-1 loader and its CocoEvaluator.  Ground truth = the
+    first detections of the model itself (so the mAP is far from 0 with random weights and moves if detections do)."""
+    print('== %s' % name)
+    from utils import main_util as ref_main                # reference
+    from utils import misc_util as ref_misc                # reference
+    case = dict(yaml='ghnd/faster_rcnn-backbone_resnet50-b3ch.yaml', model='faster_rcnn',
+                sizes=[(120, 180), (112, 200), (128, 160), (100, 190)], min_size=128, max_size=256, steps=0, seed=31)
+    t_sd = O.scale_detector_heads(O.init_teacher_state(case['seed']))
+    config, teacher, _ = build_reference_models(case)
+    teacher.load_state_dict(t_sd, strict=True)
+    teacher.eval()
+    teacher.distill_backbone_only = False
+    images, _ = make_inputs(case)
+    with torch.no_grad():
+        dets = teacher([im.clone() for im in images])
+    items, out = [], OrderedDict()
+    out['meta'] = np.array(json.dumps(case))
+    for i, (im, d) in enumerate(zip(images, dets)):
+        order = torch.argsort(d['scores'], descending=True)[:12]
+        boxes, labels = d['boxes'][order].clone(), d['labels'][order].clone()
+        wh = boxes[:, 2:] - boxes[:, :2]
+        ok = (wh > 1).all(1)
+        boxes, labels = boxes[ok], labels[ok]
+        wh = wh[ok]
+        tgt = {'image_id': torch.tensor([500 + i]), 'boxes': boxes, 'labels': labels, 'area': wh[:, 0] * wh[:, 1],
+               'iscrowd': torch.zeros(len(boxes), dtype=torch.int64)}
+        items.append((im, tgt))
+        out['gt/%d/boxes' % i], out['gt/%d/labels' % i] = boxes.numpy(), labels.numpy()
+    loader = torch.utils.data.DataLoader(_ListDataset(items), batch_size=1, shuffle=False,
+                                         collate_fn=ref_misc.collate_fn)
+    real_sync = torch.cuda.synchronize
+    torch.cuda.synchronize = lambda *a, **k: None          # main_util.py:91 syncs CUDA unconditionally; no GPU here
+    try:
+        ev = ref_main.evaluate(teacher, loader, device=torch.device('cpu'))
+    finally:
+        torch.cuda.synchronize = real_sync
+    stats = np.array(ev.coco_eval['bbox'].stats, dtype=np.float64)
+    out['stats'] = stats
+    print('   stats', np.round(stats, 4).tolist())
+    assert 0.1 < stats[0] < 1.0
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **out)
+    print('   wrote %s (%.1f KB)' % (path, os.path.getsize(path) / 1024.0))
+
+
 def coco_eval_case_inputs(seed=51):
     """ground truth and predictions of the evaluator fixture (seeded; shared with tests/golden_util.py)"""
     g = torch.Generator().manual_seed(seed)
@@ -558,6 +619,8 @@ def main():
         run_detect_case()
     if not args.only or args.only == 'tiny_coco_eval':
         run_coco_eval_case()
+    if not args.only or args.only == 'tiny_val_map':
+        run_validation_case()
     if not args.only or args.only == 'tiny_input_pipeline':
         run_input_pipeline_case()
     if not args.only or args.only == 'tiny_ext_filter':

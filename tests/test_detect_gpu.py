@@ -239,3 +239,34 @@ def _match(rb, rl, rs, db, dl, ds, frac, score_tol, box_tol):
             ((db - rb[j]).abs().max(1)[0] < box_tol)
         hit += int(m.any())
     assert hit >= frac * len(rs), (hit, len(rs))
+
+
+def test_validation_map_matches_the_reference_validation_run():
+    """tiny_val_map.npz: the reference's own main_util.evaluate (src/utils/main_util.py:75-113) on its eval-mode
+    detector, batch-1 loader, CocoEvaluator -> the twelve statistics.  The HIP path's main_util.evaluate over the same
+    images / ground truth must land on the same validation mAP (what mimic_runner compares for the checkpoint,
+    :94-100): detections agree to fp32 noise, so the statistics agree to a few 1e-3."""
+    import numpy as np
+    from hnd_ghnd_object_detectors_amd.utils import main_util, misc_util
+    z, meta = G.load('tiny_val_map')
+    model = _detector('teacher', meta)
+    images, _ = G.case_inputs(meta)
+    items = []
+    for i, im in enumerate(images):
+        boxes, labels = torch.from_numpy(z['gt/%d/boxes' % i]), torch.from_numpy(z['gt/%d/labels' % i])
+        wh = boxes[:, 2:] - boxes[:, :2]
+        items.append((im, {'image_id': torch.tensor([500 + i]), 'boxes': boxes, 'labels': labels,
+                           'area': wh[:, 0] * wh[:, 1], 'iscrowd': torch.zeros(len(boxes), dtype=torch.int64)}))
+
+    class DS(torch.utils.data.Dataset):
+        def __len__(self):
+            return len(items)
+
+        def __getitem__(self, i):
+            img, t = items[i]
+            return img.clone(), {k: v.clone() for k, v in t.items()}
+    loader = torch.utils.data.DataLoader(DS(), batch_size=1, shuffle=False, collate_fn=misc_util.collate_fn)
+    ev = main_util.evaluate(model, loader, device=DEV)
+    got, ref = np.asarray(ev.coco_eval['bbox'].stats), z['stats']
+    assert got.shape == (12,) and np.abs(got - ref).max() < 5e-3, (got.tolist(), ref.tolist())
+    assert abs(got[0] - ref[0]) < 2e-3
