@@ -104,6 +104,10 @@ _SIGNATURES = {
     'hnd_roi_align': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int64, C.c_float, C.c_int, C.c_int,
                                 C.c_int, vp, vp]),
     'hnd_box_decode_clip': (C.c_int, [vp, C.c_int, vp, vp, C.c_int64, C.c_int] + [C.c_float] * 5 + [vp, vp]),
+    'hnd_mask_probs': (C.c_int, [vp, vp, C.c_int64, C.c_int, C.c_int, vp, vp]),
+    'hnd_paste_masks': (C.c_int, [vp, vp, C.c_int64, C.c_int, C.c_int, C.c_int, vp, vp]),
+    'hnd_upsample_bilinear_nhwc': (C.c_int, [vp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
+    'hnd_heatmaps_to_keypoints': (C.c_int, [vp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]),
 }
 
 EXPORTED_SYMBOLS = tuple(sorted(_SIGNATURES))

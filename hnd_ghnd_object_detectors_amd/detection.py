@@ -365,6 +365,7 @@ class RoIHeads(nn.Module):
         self.keypoint_roi_pool, self.keypoint_head = keypoint_roi_pool, keypoint_head
         self.keypoint_predictor = keypoint_predictor
         self._lin = None
+        self._wc = None
         self.last = None
 
     def box_branch(self, pooled):
@@ -423,12 +424,165 @@ class RoIHeads(nn.Module):
             dev = proposals[0].device
             empty = dict(boxes=torch.empty(0, 4, device=dev), labels=torch.empty(0, dtype=torch.int64, device=dev),
                          scores=torch.empty(0, device=dev))
+            if self.mask_roi_pool is not None:
+                m = 2 * self.mask_roi_pool.output_size[0]
+                empty['masks'] = torch.empty(0, 1, m, m, device=dev)
+            if self.keypoint_roi_pool is not None:
+                nkp = self.keypoint_predictor.out_channels
+                empty['keypoints'] = torch.empty(0, nkp, 3, device=dev)
+                empty['keypoints_scores'] = torch.empty(0, nkp, device=dev)
             return [dict(empty) for _ in proposals], {}
         pooled, rois = self.box_roi_pool(features, proposals, image_shapes)
         class_logits, box_regression = self.box_branch(pooled)
         self.last = {'class_logits': class_logits, 'box_regression': box_regression, 'pooled': pooled}
         boxes, scores, labels = self.postprocess_detections(class_logits, box_regression, rois,
                                                             [len(p) for p in proposals], image_shapes)
-        # the mask / keypoint branches of roi_heads.py are not built: checkpoint selection reads the bbox mAP only
-        # (src/mimic_runner.py:97); their predictors stay checkpoint-compatible parameter holders
-        return [dict(boxes=boxes[i], labels=labels[i], scores=scores[i]) for i in range(len(boxes))], {}
+        result = [dict(boxes=boxes[i], labels=labels[i], scores=scores[i]) for i in range(len(boxes))]
+        if self.mask_roi_pool is not None:                       # roi_heads.py has_mask, eval branch
+            probs = self.mask_branch(features, boxes, labels, image_shapes)
+            for r, p in zip(result, probs):
+                r['masks'] = p
+        if self.keypoint_roi_pool is not None:                   # roi_heads.py has_keypoint, eval branch
+            kps, kp_scores = self.keypoint_branch(features, boxes, image_shapes)
+            for r, kp, sc in zip(result, kps, kp_scores):
+                r['keypoints'] = kp
+                r['keypoints_scores'] = sc
+        return result, {}
+
+    # ------------------------------------------------------------------ mask / keypoint branches (eval)
+    def _cache(self, key, weight):
+        if self._wc is None:
+            self._wc = {}
+        wc = self._wc.get(key)
+        if wc is None or wc.weight is not weight:
+            wc = self._wc[key] = E.WeightCache(weight)
+        return wc
+
+    def _conv3x3_relu_chain(self, x, convs, tag):
+        """[Conv2d(3x3, pad 1) + bias + ReLU] * len(convs) on an NHWC buffer, one hnd_conv2d_igemm launch each"""
+        for i, conv in enumerate(convs):
+            assert conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) \
+                and conv.dilation == (1, 1), 'the branch convs of torchvision 0.4.2 are 3x3 / stride 1 / pad 1'
+            wc = self._cache((tag, i), conv.weight)
+            pk = wc.get()
+            wc.refresh()
+            k, h, w, _ = x.shape
+            y = torch.empty((k, h, w, conv.weight.shape[0]), dtype=torch.float32, device=x.device)
+            E._run(ops.conv_forward(x, pk, y, 3, 1, 1, epi_shift=conv.bias.detach(), relu=True), '%s.conv%d' % (tag, i))
+            x = y
+        return x
+
+    def _conv_transpose(self, x, convt, tag, relu):
+        """nn.ConvTranspose2d == the data gradient of the conv with the same weight tensor: one dense launch per
+        output parity (ops.conv_dgrad), bias (+ ReLU) in the epilogue"""
+        k, h, w, _ = x.shape
+        ks, st, pd = convt.kernel_size[0], convt.stride[0], convt.padding[0]
+        oh, ow = (h - 1) * st - 2 * pd + ks, (w - 1) * st - 2 * pd + ks
+        y = torch.empty((k, oh, ow, convt.weight.shape[1]), dtype=torch.float32, device=x.device)
+        wc = self._cache((tag, 'T'), convt.weight)
+        launches, _ = ops.conv_dgrad(x, wc, y, ks, st, pd, epi_shift=convt.bias.detach(), relu=relu)
+        wc.refresh()
+        for l in launches:
+            E._run(l, tag)
+        return y
+
+    def mask_logits(self, features, det_boxes, image_shapes):
+        """mask_roi_pool -> mask_head (4 x conv3x3 + ReLU) -> conv5_mask (2x2 stride-2 transposed conv + ReLU) ->
+        mask_fcn_logits (1x1): NHWC [K, 28, 28, num_classes]"""
+        pooled, _ = self.mask_roi_pool(features, det_boxes, image_shapes)
+        convs = [m for m in self.mask_head if hasattr(m, 'weight')]
+        x = self._conv3x3_relu_chain(pooled, convs, 'mask_head')
+        x = self._conv_transpose(x, self.mask_predictor.conv5_mask, 'mask.conv5', relu=True)
+        fin = self.mask_predictor.mask_fcn_logits
+        wc = self._cache(('mask.logits', 0), fin.weight)
+        pk = wc.get()
+        wc.refresh()
+        k, h, w, _ = x.shape
+        logits = torch.empty((k, h, w, fin.weight.shape[0]), dtype=torch.float32, device=x.device)
+        E._run(ops.conv_forward(x, pk, logits, 1, 1, 0, epi_shift=fin.bias.detach()), 'mask.logits')
+        return logits
+
+    def mask_branch(self, features, det_boxes, labels, image_shapes):
+        """maskrcnn_inference: per image [n_i, 1, M, M] probabilities of each detection's predicted class"""
+        per_image = [len(b) for b in det_boxes]
+        dev = det_boxes[0].device
+        if sum(per_image) == 0:
+            m = 2 * self.mask_roi_pool.output_size[0]
+            return [torch.empty((0, 1, m, m), dtype=torch.float32, device=dev) for _ in det_boxes]
+        logits = self.mask_logits(features, det_boxes, image_shapes)
+        k, m, _, ldc = logits.shape
+        lab = torch.cat(labels).to(torch.int64).contiguous()
+        probs = torch.empty((k, 1, m, m), dtype=torch.float32, device=dev)
+        _check(_L.hnd_mask_probs(logits.data_ptr(), lab.data_ptr(), k, m, ldc, probs.data_ptr(), ops.stream_ptr()),
+               'hnd_mask_probs')
+        if self.last is not None:
+            self.last['mask_logits'] = logits
+        return list(probs.split(per_image, 0))
+
+    def keypoint_logits(self, features, det_boxes, image_shapes):
+        """keypoint_roi_pool -> keypoint_head (8 x conv3x3 + ReLU) -> kps_score_lowres (4x4 stride-2 transposed conv)
+        -> bilinear x2: NHWC [K, 56, 56, num_keypoints]"""
+        pooled, _ = self.keypoint_roi_pool(features, det_boxes, image_shapes)
+        convs = [m for m in self.keypoint_head if hasattr(m, 'weight')]
+        x = self._conv3x3_relu_chain(pooled, convs, 'keypoint_head')
+        pred = self.keypoint_predictor
+        low = self._conv_transpose(x, pred.kps_score_lowres, 'keypoint.lowres', relu=False)
+        k, h, w, c = low.shape
+        f = int(pred.up_scale)
+        up = torch.empty((k, h * f, w * f, c), dtype=torch.float32, device=low.device)
+        _check(_L.hnd_upsample_bilinear_nhwc(low.data_ptr(), k, h, w, c, f, up.data_ptr(), ops.stream_ptr()),
+               'hnd_upsample_bilinear_nhwc')
+        return up
+
+    def keypoint_branch(self, features, det_boxes, image_shapes):
+        """keypointrcnn_inference: per image keypoints [n_i, num_keypoints, 3] = (x, y, 1) and their heatmap scores"""
+        per_image = [len(b) for b in det_boxes]
+        dev = det_boxes[0].device
+        nkp = self.keypoint_predictor.out_channels
+        if sum(per_image) == 0:
+            return ([torch.empty((0, nkp, 3), dtype=torch.float32, device=dev) for _ in det_boxes],
+                    [torch.empty((0, nkp), dtype=torch.float32, device=dev) for _ in det_boxes])
+        maps = self.keypoint_logits(features, det_boxes, image_shapes)
+        k, h, w, ldc = maps.shape
+        rois = torch.cat(det_boxes, 0).to(torch.float32).contiguous()
+        xy = torch.empty((k, nkp, 3), dtype=torch.float32, device=dev)
+        sc = torch.empty((k, nkp), dtype=torch.float32, device=dev)
+        _check(_L.hnd_heatmaps_to_keypoints(maps.data_ptr(), k, h, w, ldc, nkp, rois.data_ptr(), xy.data_ptr(),
+                                            sc.data_ptr(), ops.stream_ptr()), 'hnd_heatmaps_to_keypoints')
+        if self.last is not None:
+            self.last['keypoint_logits'] = maps
+        return list(xy.split(per_image, 0)), list(sc.split(per_image, 0))
+
+
+def paste_masks_in_image(masks, boxes, img_shape, padding=1):
+    """transform.py postprocess -> roi_heads.paste_masks_in_image: masks [n, 1, M, M] probabilities, boxes [n, 4] in
+    the original image's frame -> [n, 1, im_h, im_w].  expand_boxes / the int64 truncation are the reference's tensor
+    expressions (fp32 element-wise ops: identical on any IEEE device); padding, bilinear resize and paste are one
+    hnd_paste_masks launch."""
+    assert padding == 1
+    n, m = masks.shape[0], masks.shape[-1]
+    im_h, im_w = int(img_shape[0]), int(img_shape[1])
+    out = torch.empty((n, 1, im_h, im_w), dtype=torch.float32, device=masks.device)
+    if n == 0:
+        return out
+    scale = float(m + 2 * padding) / m
+    w_half = (boxes[:, 2] - boxes[:, 0]) * .5
+    h_half = (boxes[:, 3] - boxes[:, 1]) * .5
+    x_c = (boxes[:, 2] + boxes[:, 0]) * .5
+    y_c = (boxes[:, 3] + boxes[:, 1]) * .5
+    w_half = w_half * scale
+    h_half = h_half * scale
+    exp = torch.stack([x_c - w_half, y_c - h_half, x_c + w_half, y_c + h_half], 1).to(torch.int64).contiguous()
+    probs = masks.contiguous()
+    _check(_L.hnd_paste_masks(probs.data_ptr(), exp.data_ptr(), n, m, im_h, im_w, out.data_ptr(), ops.stream_ptr()),
+           'hnd_paste_masks')
+    return out
+
+
+def resize_keypoints(keypoints, original_size, new_size):
+    """transform.py resize_keypoints: x by new_w / orig_w, y by new_h / orig_h (python-float ratios)"""
+    ratio_h, ratio_w = (float(s) / float(o) for s, o in zip(new_size, original_size))
+    out = keypoints.clone()
+    out[..., 0] *= ratio_w
+    out[..., 1] *= ratio_h
+    return out

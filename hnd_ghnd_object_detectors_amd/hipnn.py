@@ -292,16 +292,18 @@ class ImageList(object):
 
 
 # ------------------------------------------------------------------------------------------ detector heads
-# RPN / RoI box branch (eval mode, the validation path of SURVEY.md 8f row f4) live in detection.py; the mask /
-# keypoint predictors below are parameter holders with torchvision 0.4.2 names and shapes so reference checkpoints load.
+# RPN / RoI heads (eval mode, the validation path of SURVEY.md 8f row f4) live in detection.py; the mask / keypoint
+# heads below are parameter holders with torchvision 0.4.2 names and shapes (reference checkpoints load): RoIHeads runs
+# their convolutions on hnd_conv2d_igemm straight from these parameters (detection.RoIHeads.mask_branch /
+# keypoint_branch), so none of them has a forward of its own.
 from .detection import (AnchorGenerator, RPNHead, RegionProposalNetwork, MultiScaleRoIAlign, TwoMLPHead,  # noqa: E402,F401
                         FastRCNNPredictor, RoIHeads)
 
 
 class _NotOnPath(nn.Module):
     def forward(self, *args, **kwargs):
-        raise NotImplementedError('%s: the mask / keypoint branches of the detector are not built (checkpoint '
-                                  'selection reads the bbox mAP only, src/mimic_runner.py:97)' % type(self).__name__)
+        raise NotImplementedError('%s is a parameter holder: detection.RoIHeads drives its layers on the HIP path'
+                                  % type(self).__name__)
 
 
 class MaskRCNNHeads(nn.Sequential):

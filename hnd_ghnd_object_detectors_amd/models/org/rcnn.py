@@ -74,12 +74,18 @@ class CustomRCNNTransform(nn.Module):
         return hipnn.ImageList(tensors, image_sizes), targets
 
     def postprocess(self, result, image_shapes, original_image_sizes):
-        """GeneralizedRCNNTransform.postprocess (box branch): detections back to the original image frame"""
+        """GeneralizedRCNNTransform.postprocess: detections back to the original image frame -- boxes rescaled, masks
+        pasted into full-size images (hnd_paste_masks), keypoints rescaled"""
         if self.training:
             return result
-        from ...detection import resize_boxes as resize_back
+        from ...detection import resize_boxes as resize_back, paste_masks_in_image, resize_keypoints
         for i, (pred, im_s, o_im_s) in enumerate(zip(result, image_shapes, original_image_sizes)):
-            result[i]['boxes'] = resize_back(pred['boxes'], im_s, o_im_s)
+            boxes = resize_back(pred['boxes'], im_s, o_im_s)
+            result[i]['boxes'] = boxes
+            if 'masks' in pred:
+                result[i]['masks'] = paste_masks_in_image(pred['masks'], boxes, o_im_s)
+            if 'keypoints' in pred:
+                result[i]['keypoints'] = resize_keypoints(pred['keypoints'], im_s, o_im_s)
         return result
 
 

@@ -355,6 +355,26 @@ int hnd_roi_align(const float* feat, int n, int h, int w, int c, const float* ro
 int hnd_box_decode_clip(const float* deltas, int ld, const float* rois, const float* image_hw, int64_t nroi, int ncls,
                         float wx, float wy, float ww, float wh, float xform_clip, float* out, void* stream);
 
+/* ---- mask / keypoint branches of the eval-mode detector (torchvision 0.4.2 roi_heads.py maskrcnn_inference /
+ * keypointrcnn_inference / heatmaps_to_keypoints, transform.py postprocess -> paste_masks_in_image), reached from
+ * src/models/org/rcnn.py:124-127 for Mask / Keypoint R-CNN; their convolutions run on hnd_conv2d_igemm (the transposed
+ * ones as the data-gradient form).  csrc/detect_heads.hip. */
+/* probs[k][m][m] = sigmoid(logits[k][m][m][labels[k]]); logits NHWC with channel stride ldc */
+int hnd_mask_probs(const float* logits, const int64_t* labels, int64_t k, int m, int ldc, float* probs, void* stream);
+/* paste_masks_in_image after the host expanded / truncated the boxes: probs [k][m][m]; boxes [k][4] int64 (x0, y0, x1,
+ * y1, already scaled by (m+2)/m about the centre and truncated); out [k][im_h][im_w] = the mask, zero-padded by one
+ * pixel, resized bilinearly (align_corners=False) to (y1-y0+1, x1-x0+1) and pasted at (y0, x0), zero elsewhere */
+int hnd_paste_masks(const float* probs, const int64_t* boxes, int64_t k, int m, int im_h, int im_w, float* out,
+                    void* stream);
+/* F.interpolate(scale_factor=factor, mode='bilinear', align_corners=False) on an NHWC tensor in [k][h][w][c] */
+int hnd_upsample_bilinear_nhwc(const float* in, int64_t k, int h, int w, int c, int factor, float* out, void* stream);
+/* heatmaps_to_keypoints: maps [k][h][w][ldc] (keypoint j = channel j), rois [k][4] (x1, y1, x2, y2); per RoI the
+ * heatmaps are resized bicubically (A=-0.75, align_corners=False) to (ceil(max(y2-y1,1)), ceil(max(x2-x1,1))), the
+ * first maximum is located, xy [k][num_keypoints][3] = (x, y, 1), scores [k][num_keypoints] = the maximum.
+ * h*w*4 bytes must fit 64 KiB of LDS (56x56 here). */
+int hnd_heatmaps_to_keypoints(const float* maps, int64_t k, int h, int w, int ldc, int num_keypoints, const float* rois,
+                              float* xy, float* scores, void* stream);
+
 /* ---- generic workspace query: bytes of caller-provided scratch an op needs.  `desc` is the op's
  * descriptor where it has one (hnd_wgrad_desc for HND_OP_CONV2D_WGRAD), `arg` an op-specific integer (channels for
  * HND_OP_CHANNEL_SUM), both ignored otherwise.  The op-specific helpers above return the same numbers. */

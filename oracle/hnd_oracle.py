@@ -166,13 +166,22 @@ def init_student_state(teacher_sd, seed, bch=3, dtype=torch.float32):
 # 100 detections per image on the tiny fixtures -- NMS, top-k and the score threshold all bite
 DETECT_HEAD_SCALES = {'rpn.head.conv.weight': 6.0, 'rpn.head.cls_logits.weight': 30.0, 'rpn.head.bbox_pred.weight': 1.5,
                       'roi_heads.box_head.fc6.weight': 2.0, 'roi_heads.box_head.fc7.weight': 2.0,
-                      'roi_heads.box_predictor.cls_score.weight': 20.0, 'roi_heads.box_predictor.bbox_pred.weight': 1.5}
+                      'roi_heads.box_predictor.cls_score.weight': 20.0, 'roi_heads.box_predictor.bbox_pred.weight': 1.5,
+                      # Mask / Keypoint R-CNN only: mask logits spread to ~+-3 (masks are not all-or-nothing at the 0.5
+                      # threshold), keypoint heatmaps peaked well above fp32 noise (stable argmax)
+                      'roi_heads.mask_head.mask_fcn1.weight': 2.5, 'roi_heads.mask_head.mask_fcn2.weight': 2.5,
+                      'roi_heads.mask_head.mask_fcn3.weight': 2.5, 'roi_heads.mask_head.mask_fcn4.weight': 2.5,
+                      'roi_heads.mask_predictor.conv5_mask.weight': 3.0,
+                      'roi_heads.mask_predictor.mask_fcn_logits.weight': 20.0,
+                      'roi_heads.keypoint_predictor.kps_score_lowres.weight': 12.0}
+DETECT_HEAD_SCALES.update({'roi_heads.keypoint_head.%d.weight' % (2 * i): 1.8 for i in range(8)})
 
 
 def scale_detector_heads(sd):
     out = OrderedDict(sd)
     for k, f in DETECT_HEAD_SCALES.items():
-        out[k] = sd[k] * f
+        if k in sd:
+            out[k] = sd[k] * f
     return out
 
 

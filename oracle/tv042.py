@@ -316,15 +316,20 @@ class GeneralizedRCNNTransform(nn.Module):
         if self.training:
             return result
         for i, (pred, im_s, o_im_s) in enumerate(zip(result, image_shapes, original_image_sizes)):
-            result[i]['boxes'] = resize_boxes(pred['boxes'], im_s, o_im_s)
+            boxes = resize_boxes(pred['boxes'], im_s, o_im_s)
+            result[i]['boxes'] = boxes
+            if 'masks' in pred:
+                result[i]['masks'] = paste_masks_in_image(pred['masks'], boxes, o_im_s)
+            if 'keypoints' in pred:
+                result[i]['keypoints'] = resize_keypoints(pred['keypoints'], im_s, o_im_s)
         return result
 
 
 # --------------------------------------------------------------------------- detection heads
-# RPN / RoI box branch (eval mode): behaviourally faithful restatements live in oracle/tv042_det.py (row f4);
-# the mask / keypoint predictors below stay parameter holders.
+# RPN / RoI heads (eval mode, box + mask + keypoint branches): restatements live in oracle/tv042_det.py (row f4)
 from oracle.tv042_det import (AnchorGenerator, RPNHead, RegionProposalNetwork, concat_box_prediction_layers,  # noqa: E402,F401
-                              MultiScaleRoIAlign, TwoMLPHead, FastRCNNPredictor, RoIHeads, BoxCoder)
+                              MultiScaleRoIAlign, TwoMLPHead, FastRCNNPredictor, RoIHeads, BoxCoder,
+                              paste_masks_in_image)
 
 
 def _not_on_path(name):
@@ -368,7 +373,10 @@ class KeypointRCNNPredictor(nn.Module):
         self.kps_score_lowres = MiscConvTranspose2d(in_channels, num_keypoints, 4, stride=2, padding=1)
         self.up_scale = 2
         self.out_channels = num_keypoints
-    forward = _not_on_path('KeypointRCNNPredictor')
+
+    def forward(self, x):
+        x = self.kps_score_lowres(x)
+        return F.interpolate(x, scale_factor=self.up_scale, mode='bilinear', align_corners=False)
 
 
 class _DetectionBase(nn.Module):

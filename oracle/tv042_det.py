@@ -8,7 +8,8 @@ checkpoint (``src/mimic_runner.py:94-100``).  torchvision 0.4.2 (``Pipfile:8``) 
 
     torchvision/models/detection/rpn.py         AnchorGenerator, RPNHead, RegionProposalNetwork (eval branch)
     torchvision/models/detection/_utils.py      BoxCoder.decode
-    torchvision/models/detection/roi_heads.py   RoIHeads.forward / postprocess_detections (box branch, eval)
+    torchvision/models/detection/roi_heads.py   RoIHeads.forward / postprocess_detections (eval), maskrcnn_inference,
+                                                paste_masks_in_image, keypointrcnn_inference, heatmaps_to_keypoints
     torchvision/ops/boxes.py                    nms, batched_nms, clip_boxes_to_image, remove_small_boxes, box_area
     torchvision/ops/poolers.py                  MultiScaleRoIAlign, LevelMapper
     torchvision/csrc/cpu/{nms_cpu,ROIAlign_cpu}.cpp   the two native CPU operators
@@ -20,6 +21,12 @@ details are restated from the 0.4.2 sources as published and flagged below:
   * anchor strides are the true quotients ``image_size / grid_size`` (floats; 800/13 for the 'pool' level).
   * ``postprocess_detections`` has no "remove empty boxes" step (added in 0.5).
   * ``roi_align`` is the non-"aligned" form (no half-pixel shift; roi width/height clamped to >= 1).
+  * ``paste_masks_in_image``: masks zero-padded by 1 px, boxes expanded by (M+2)/M about their centre and truncated
+    to int64, each mask resized to (int(y1-y0+1), int(x1-x0+1)) with bilinear ``interpolate(align_corners=False)`` and
+    pasted into the clipped window (the 0.4.x Python loop; the sampled-grid GPU paste came with 0.6).
+  * ``heatmaps_to_keypoints``: per RoI BICUBIC ``interpolate(align_corners=False)`` of the 56x56 heatmaps to
+    (ceil(h), ceil(w)), argmax per keypoint, ``(idx + 0.5) * size / ceil(size) + offset``; visibility column = 1;
+    ``y_int = (pos - x_int) / w`` is an exact integer quotient.
 What IS pinned: the reference's own ``rcnn.py`` forward runs UNMODIFIED over these classes when
 tests/golden/make_golden.py writes the ``tiny_detect_*`` fixtures, and the HIP path is tested against them.
 Training-mode branches (RPN / RoI losses, matchers, samplers) are not restated: every hnd/ghnd config trains with
@@ -435,6 +442,112 @@ class FastRCNNPredictor(nn.Module):
 
 
 # --------------------------------------------------------------------------------------------- roi_heads.py
+def maskrcnn_inference(x, labels):
+    """sigmoid of the mask logits, the channel of each detection's predicted class, split per image -> [n_i,1,M,M]"""
+    mask_prob = x.sigmoid()
+    num_masks = x.shape[0]
+    boxes_per_image = [len(l) for l in labels]
+    labels = torch.cat(labels)
+    index = torch.arange(num_masks, device=labels.device)
+    mask_prob = mask_prob[index, labels][:, None]
+    return mask_prob.split(boxes_per_image, dim=0)
+
+
+def expand_boxes(boxes, scale):
+    w_half = (boxes[:, 2] - boxes[:, 0]) * .5
+    h_half = (boxes[:, 3] - boxes[:, 1]) * .5
+    x_c = (boxes[:, 2] + boxes[:, 0]) * .5
+    y_c = (boxes[:, 3] + boxes[:, 1]) * .5
+    w_half *= scale
+    h_half *= scale
+    boxes_exp = torch.zeros_like(boxes)
+    boxes_exp[:, 0] = x_c - w_half
+    boxes_exp[:, 2] = x_c + w_half
+    boxes_exp[:, 1] = y_c - h_half
+    boxes_exp[:, 3] = y_c + h_half
+    return boxes_exp
+
+
+def expand_masks(mask, padding):
+    M = mask.shape[-1]
+    scale = float(M + 2 * padding) / M
+    padded_mask = F.pad(mask, (padding,) * 4)
+    return padded_mask, scale
+
+
+def paste_mask_in_image(mask, box, im_h, im_w):
+    TO_REMOVE = 1
+    w = int(box[2] - box[0] + TO_REMOVE)
+    h = int(box[3] - box[1] + TO_REMOVE)
+    w = max(w, 1)
+    h = max(h, 1)
+    mask = mask.expand((1, 1, -1, -1))                       # batch and channel dims
+    mask = F.interpolate(mask, size=(h, w), mode='bilinear', align_corners=False)
+    mask = mask[0][0]
+    im_mask = torch.zeros((im_h, im_w), dtype=mask.dtype, device=mask.device)
+    x_0 = max(box[0], 0)
+    x_1 = min(box[2] + 1, im_w)
+    y_0 = max(box[1], 0)
+    y_1 = min(box[3] + 1, im_h)
+    im_mask[y_0:y_1, x_0:x_1] = mask[(y_0 - box[1]):(y_1 - box[1]), (x_0 - box[0]):(x_1 - box[0])]
+    return im_mask
+
+
+def paste_masks_in_image(masks, boxes, img_shape, padding=1):
+    masks, scale = expand_masks(masks, padding=padding)
+    boxes = expand_boxes(boxes, scale).to(dtype=torch.int64).tolist()
+    im_h, im_w = img_shape
+    res = [paste_mask_in_image(m[0], b, im_h, im_w) for m, b in zip(masks, boxes)]
+    if len(res) > 0:
+        res = torch.stack(res, dim=0)[:, None]
+    else:
+        res = masks.new_empty((0, 1, im_h, im_w))
+    return res
+
+
+def heatmaps_to_keypoints(maps, rois):
+    """(#rois, #keypoints, 3) with columns (x, y, 1) and the heatmap value at the argmax, per RoI"""
+    offset_x = rois[:, 0]
+    offset_y = rois[:, 1]
+    widths = rois[:, 2] - rois[:, 0]
+    heights = rois[:, 3] - rois[:, 1]
+    widths = widths.clamp(min=1)
+    heights = heights.clamp(min=1)
+    widths_ceil = widths.ceil()
+    heights_ceil = heights.ceil()
+    num_keypoints = maps.shape[1]
+    xy_preds = torch.zeros((len(rois), 3, num_keypoints), dtype=torch.float32, device=maps.device)
+    end_scores = torch.zeros((len(rois), num_keypoints), dtype=torch.float32, device=maps.device)
+    for i in range(len(rois)):
+        roi_map_width = int(widths_ceil[i].item())
+        roi_map_height = int(heights_ceil[i].item())
+        width_correction = widths[i] / roi_map_width
+        height_correction = heights[i] / roi_map_height
+        roi_map = F.interpolate(maps[i][None], size=(roi_map_height, roi_map_width), mode='bicubic',
+                                align_corners=False)[0]
+        w = roi_map.shape[2]
+        pos = roi_map.reshape(num_keypoints, -1).argmax(dim=1)
+        x_int = pos % w
+        y_int = (pos - x_int) // w                           # exact: pos - x_int is a multiple of w
+        x = (x_int.float() + 0.5) * width_correction
+        y = (y_int.float() + 0.5) * height_correction
+        xy_preds[i, 0, :] = x + offset_x[i]
+        xy_preds[i, 1, :] = y + offset_y[i]
+        xy_preds[i, 2, :] = 1
+        end_scores[i, :] = roi_map[torch.arange(num_keypoints), y_int, x_int]
+    return xy_preds.permute(0, 2, 1), end_scores
+
+
+def keypointrcnn_inference(x, boxes):
+    kp_probs, kp_scores = [], []
+    boxes_per_image = [len(box) for box in boxes]
+    for xx, bb in zip(x.split(boxes_per_image, dim=0), boxes):
+        kp_prob, scores = heatmaps_to_keypoints(xx, bb)
+        kp_probs.append(kp_prob)
+        kp_scores.append(scores)
+    return kp_probs, kp_scores
+
+
 class RoIHeads(nn.Module):
     def __init__(self, box_roi_pool, box_head, box_predictor, fg_iou_thresh, bg_iou_thresh,
                  batch_size_per_image, positive_fraction, bbox_reg_weights, score_thresh, nms_thresh,
@@ -482,6 +595,24 @@ class RoIHeads(nn.Module):
         self.last_image_shapes = list(image_shapes)
         boxes, scores, labels = self.postprocess_detections(class_logits, box_regression, proposals, image_shapes)
         result = [dict(boxes=boxes[i], labels=labels[i], scores=scores[i]) for i in range(len(boxes))]
-        # Mask / keypoint branches (roi_heads.py eval): not restated -- checkpoint selection reads bbox mAP only
-        # (src/mimic_runner.py:97 `coco_eval['bbox'].stats[0]`); their predictors stay parameter holders.
+        self.last_det_boxes = [b.clone() for b in boxes]         # in the resized image's frame (before postprocess)
+        if self.mask_roi_pool is not None:                       # has_mask (eval branch)
+            mask_proposals = [p['boxes'] for p in result]
+            mask_features = self.mask_roi_pool(features, mask_proposals, image_shapes)
+            mask_features = self.mask_head(mask_features)
+            mask_logits = self.mask_predictor(mask_features)
+            self.last['mask_logits'] = mask_logits
+            masks_probs = maskrcnn_inference(mask_logits, [r['labels'] for r in result])
+            for mask_prob, r in zip(masks_probs, result):
+                r['masks'] = mask_prob
+        if self.keypoint_roi_pool is not None:                   # has_keypoint (eval branch)
+            keypoint_proposals = [p['boxes'] for p in result]
+            keypoint_features = self.keypoint_roi_pool(features, keypoint_proposals, image_shapes)
+            keypoint_features = self.keypoint_head(keypoint_features)
+            keypoint_logits = self.keypoint_predictor(keypoint_features)
+            self.last['keypoint_logits'] = keypoint_logits
+            keypoints_probs, kp_scores = keypointrcnn_inference(keypoint_logits, keypoint_proposals)
+            for keypoint_prob, kps, r in zip(keypoints_probs, kp_scores, result):
+                r['keypoints'] = keypoint_prob
+                r['keypoints_scores'] = kps
         return result, {}

@@ -21,6 +21,8 @@ import random
 import sys
 from collections import OrderedDict
 
+sys.dont_write_bytecode = True       # importing /root/reference must not leave __pycache__ files in it
+
 import numpy as np
 import torch
 
@@ -283,15 +285,32 @@ def run_eval_codec_case(name='tiny_eval_quantized'):
     print('   wrote %s (%.1f KB)' % (path, os.path.getsize(path) / 1024.0))
 
 
+DETECT_CASES = {
+    'tiny_detect_faster': dict(yaml='ghnd/faster_rcnn-backbone_resnet50-b3ch.yaml', model='faster_rcnn',
+                               sizes=[(120, 180), (112, 200)], min_size=128, max_size=256, steps=0, seed=31),
+    'tiny_detect_mask': dict(yaml='ghnd/mask_rcnn-backbone_resnet50-b3ch.yaml', model='mask_rcnn',
+                             sizes=[(120, 180), (112, 200)], min_size=128, max_size=256, steps=0, seed=33),
+    'tiny_detect_keypoint': dict(yaml='ghnd/keypoint_rcnn-backbone_resnet50-b3ch.yaml', model='keypoint_rcnn',
+                                 sizes=[(120, 180), (112, 200)], min_size=128, max_size=256, steps=0, seed=35),
+}
+
+
+def detect_states(case):
+    kw = {'num_classes': 2} if case['model'] == 'keypoint_rcnn' else {}
+    t_sd = O.scale_detector_heads(O.init_teacher_state(case['seed'], case['model'], **kw))
+    s_sd = O.init_student_state(t_sd, case['seed'] + 1000)         # inherits the teacher's (already scaled) heads
+    return t_sd, s_sd
+
+
 def run_detect_case(name='tiny_detect_faster'):
     """Validation path: the reference's CustomRCNN.forward in eval mode with
     distill_backbone_only off (src/models/org/rcnn.py:124-127: rpn -> roi_heads -> transform.postprocess), teacher and
-    student, over the restated torchvision 0.4.2 detection pieces (oracle/tv042_det.py)."""
+    student, over the restated torchvision 0.4.2 detection pieces (oracle/tv042_det.py).  Mask / Keypoint R-CNN: the
+    mask / keypoint branches of roi_heads and transform.postprocess run as well (teacher only: the student's heads
+    are the teacher's)."""
     print('== %s' % name)
-    case = dict(yaml='ghnd/faster_rcnn-backbone_resnet50-b3ch.yaml', model='faster_rcnn', sizes=[(120, 180), (112, 200)],
-                min_size=128, max_size=256, steps=0, seed=31)
-    t_sd = O.scale_detector_heads(O.init_teacher_state(case['seed']))
-    s_sd = O.init_student_state(t_sd, case['seed'] + 1000)         # inherits the teacher's (already scaled) heads
+    case = dict(DETECT_CASES[name])
+    t_sd, s_sd = detect_states(case)
     config, teacher, student = build_reference_models(case)
     teacher.load_state_dict(t_sd, strict=True)
     student.load_state_dict(s_sd, strict=True)
@@ -326,7 +345,25 @@ def run_detect_case(name='tiny_detect_faster'):
             out['%s/rpn/kept_scores/%d' % (tag, i)] = sc.numpy()
             out['%s/rpn/kept_boxes/%d' % (tag, i)] = model.rpn.last['boxes'][i].numpy()
             for k, v in d.items():
+                if k == 'masks':        # [n, 1, H, W] probabilities pasted into the image: bits at the evaluator's 0.5
+                    out['%s/det/%d/masks_bits' % (tag, i)] = np.packbits((v > 0.5).numpy().reshape(len(v), -1), axis=1)
+                    out['%s/det/%d/masks_sum' % (tag, i)] = v.double().flatten(1).sum(1).numpy()
+                    out['%s/det/%d/masks_hw' % (tag, i)] = np.array(v.shape[-2:])
+                    continue
                 out['%s/det/%d/%s' % (tag, i, k)] = v.numpy()
+        if tag == 'teacher' and 'mask_logits' in roi:
+            # the branch's own sub-problems: probabilities of the predicted classes before pasting (input of
+            # paste_masks_in_image together with det/*/boxes), and the logits' fingerprint
+            labels = torch.cat([d['labels'] for d in dets])
+            ml = roi['mask_logits']
+            out['teacher/roi/mask_probs'] = ml.sigmoid()[torch.arange(len(ml)), labels].numpy()
+            put(out, 'teacher/roi/mask_logits', ml)
+            out['teacher/roi/det_boxes'] = torch.cat([p for p in model.roi_heads.last_det_boxes]).numpy()
+        if tag == 'teacher' and 'keypoint_logits' in roi:
+            kl = roi['keypoint_logits']
+            put(out, 'teacher/roi/keypoint_logits', kl)
+            out['teacher/roi/keypoint_logits_head'] = kl[:12].numpy()        # whole heatmaps of the first 12 RoIs
+            out['teacher/roi/det_boxes'] = torch.cat([p for p in model.roi_heads.last_det_boxes]).numpy()
         print('   %s: proposals kept %s, detections %s, top scores %s' % (
             tag, [len(s) for s in rpn['scores']], [len(d['scores']) for d in dets],
             [round(float(d['scores'].max()), 4) for d in dets]))
@@ -615,8 +652,9 @@ def main():
         run_case(name, case)
     if not args.only or args.only == 'tiny_eval_quantized':
         run_eval_codec_case()
-    if not args.only or args.only == 'tiny_detect_faster':
-        run_detect_case()
+    for name in DETECT_CASES:
+        if not args.only or args.only == name:
+            run_detect_case(name)
     if not args.only or args.only == 'tiny_coco_eval':
         run_coco_eval_case()
     if not args.only or args.only == 'tiny_val_map':

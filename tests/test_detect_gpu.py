@@ -168,7 +168,8 @@ def test_box_decode_clip_matches_postprocess_arithmetic():
 # ------------------------------------------------------------------------------------------------ the detector
 def _detector(tag, meta):
     cfg = MU.config_for(meta)
-    t_sd = O.scale_detector_heads(O.init_teacher_state(meta['seed']))
+    kw = {'num_classes': 2} if meta['model'] == 'keypoint_rcnn' else {}
+    t_sd = O.scale_detector_heads(O.init_teacher_state(meta['seed'], meta['model'], **kw))
     s_sd = O.init_student_state(t_sd, meta['seed'] + 1000)         # inherits the teacher's (already scaled) heads
     teacher, student = MU.build_pair(cfg, t_sd, s_sd, DEV)
     model = teacher if tag == 'teacher' else student
@@ -270,3 +271,184 @@ def test_validation_map_matches_the_reference_validation_run():
     got, ref = np.asarray(ev.coco_eval['bbox'].stats), z['stats']
     assert got.shape == (12,) and np.abs(got - ref).max() < 5e-3, (got.tolist(), ref.tolist())
     assert abs(got[0] - ref[0]) < 2e-3
+
+
+# ------------------------------------------------------------------------------- mask / keypoint branch operators
+def test_paste_masks_matches_the_python_loop_of_the_reference():
+    """hnd_paste_masks vs roi_heads.paste_masks_in_image (oracle restatement: F.pad + per-box bilinear F.interpolate +
+    window assignment): boxes inside, across every border, one pixel wide, and larger than the image"""
+    from hnd_ghnd_object_detectors_amd import detection as D
+    g = gen(61)
+    im_h, im_w, m = 97, 131, 28
+    boxes = torch.tensor([[10.3, 12.9, 60.2, 80.7], [-15.5, -8.2, 30.0, 40.0], [100.0, 70.0, 150.5, 120.25],
+                          [50.0, 50.0, 50.4, 50.3], [-20.0, -30.0, 160.0, 130.0], [5.5, 90.0, 125.0, 96.9],
+                          [0.0, 0.0, 131.0, 97.0], [64.2, 3.3, 66.9, 93.3]])
+    masks = torch.rand(len(boxes), 1, m, m, generator=g)
+    ref = TV.paste_masks_in_image(masks, boxes, (im_h, im_w))
+    got = D.paste_masks_in_image(masks.to(DEV), boxes.to(DEV), (im_h, im_w)).cpu()
+    assert got.shape == ref.shape == (len(boxes), 1, im_h, im_w)
+    assert torch.equal(got == 0, ref == 0)                    # the pasted window itself is index work
+    err = float((got - ref).abs().max())
+    assert err < 2e-6, err
+    flips = int(((got > 0.5) != (ref > 0.5)).sum())           # the evaluator's threshold (coco_eval_util.py:101)
+    assert flips <= 2, flips
+    empty = D.paste_masks_in_image(torch.empty(0, 1, m, m, device=DEV), torch.empty(0, 4, device=DEV), (im_h, im_w))
+    assert tuple(empty.shape) == (0, 1, im_h, im_w)
+
+
+def test_heatmaps_to_keypoints_matches_the_reference_loop():
+    """hnd_heatmaps_to_keypoints vs roi_heads.heatmaps_to_keypoints (per-RoI bicubic F.interpolate + argmax): the
+    located maxima are index work -> equal except where two resized values tie to the last bit"""
+    from hnd_ghnd_object_detectors_amd._lib import load
+    from hnd_ghnd_object_detectors_amd import ops
+    L = load()
+    g = gen(62)
+    k, nkp, hm = 9, 17, 56
+    maps = torch.randn(k, nkp, hm, hm, generator=g)
+    # smooth peaks on top of the noise for half of the maps (what trained heatmaps look like)
+    yy, xx = torch.meshgrid(torch.arange(hm).float(), torch.arange(hm).float(), indexing='ij')
+    for r in range(0, k, 2):
+        for j in range(nkp):
+            cy, cx = torch.rand(2, generator=g) * hm
+            maps[r, j] += 6 * torch.exp(-((yy - cy) ** 2 + (xx - cx) ** 2) / 30.0)
+    rois = torch.tensor([[3.2, 4.1, 80.7, 120.3], [10.0, 10.0, 10.4, 10.2], [0.0, 0.0, 200.0, 56.0],
+                         [50.5, 20.25, 106.5, 76.25], [7.0, 9.0, 300.9, 411.3], [1.0, 2.0, 29.0, 30.0],
+                         [100.0, 100.0, 101.5, 190.0], [20.0, 30.0, 76.0, 86.0], [0.5, 0.5, 640.0, 480.5]])
+    ref_xy, ref_sc = TV.heatmaps_to_keypoints(maps, rois)
+    nhwc = maps.permute(0, 2, 3, 1).contiguous().to(DEV)
+    xy = torch.empty(k, nkp, 3, device=DEV)
+    sc = torch.empty(k, nkp, device=DEV)
+    rc = L.hnd_heatmaps_to_keypoints(nhwc.data_ptr(), k, hm, hm, nkp, nkp, rois.to(DEV).data_ptr(), xy.data_ptr(),
+                                     sc.data_ptr(), ops.stream_ptr())
+    assert rc == 0
+    torch.cuda.synchronize()
+    same = (xy.cpu() == ref_xy).all(2)
+    assert float(same.float().mean()) >= 0.98, float(same.float().mean())
+    assert float((sc.cpu() - ref_sc).abs().max()) < 1e-4 * float(ref_sc.abs().max())
+    assert torch.all(xy[..., 2] == 1)
+
+
+def test_upsample_bilinear_matches_interpolate():
+    from hnd_ghnd_object_detectors_amd._lib import load
+    from hnd_ghnd_object_detectors_amd import ops
+    L = load()
+    x = torch.randn(5, 17, 28, 28, generator=gen(63))
+    ref = torch.nn.functional.interpolate(x, scale_factor=2, mode='bilinear', align_corners=False)
+    nhwc = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    out = torch.empty(5, 56, 56, 17, device=DEV)
+    assert L.hnd_upsample_bilinear_nhwc(nhwc.data_ptr(), 5, 28, 28, 17, 2, out.data_ptr(), ops.stream_ptr()) == 0
+    err = float((out.permute(0, 3, 1, 2).cpu() - ref).abs().max())
+    assert err < 1e-6, err
+
+
+def _fixture_detections(z, n_images):
+    det_boxes = torch.from_numpy(z['teacher/roi/det_boxes'])
+    per = [len(z['teacher/det/%d/labels' % i]) for i in range(n_images)]
+    labels = [torch.from_numpy(z['teacher/det/%d/labels' % i]) for i in range(n_images)]
+    return list(det_boxes.split(per, 0)), labels
+
+
+def test_mask_branch_matches_the_reference_fixture():
+    """tiny_detect_mask.npz: the reference's Mask R-CNN forward in eval mode (rcnn.py:124-127 -> roi_heads mask branch
+    -> transform.postprocess).  (a) mask head on the FIXTURE's detections -> logits / class probabilities;
+    (b) paste of the fixture's probabilities at the fixture's boxes -> the thresholded bits; (c) end to end."""
+    import numpy as np
+    from hnd_ghnd_object_detectors_amd import detection as D
+    z, meta = G.load('tiny_detect_mask')
+    model = _detector('teacher', meta)
+    images, _ = G.case_inputs(meta)
+    ims = [im.to(DEV) for im in images]
+    det_boxes, labels = _fixture_detections(z, len(ims))
+    with torch.no_grad():
+        il, _ = model.transform(ims, None, None)
+        features = model.backbone(il.tensors)
+        model.roi_heads.last = {}
+        probs = model.roi_heads.mask_branch(features, [b.to(DEV) for b in det_boxes], [l.to(DEV) for l in labels],
+                                            il.image_sizes)
+        logits = model.roi_heads.last['mask_logits'].permute(0, 3, 1, 2)
+        G.compare(z, 'teacher/roi/mask_logits', logits, 1e-3)
+        ref_probs = torch.from_numpy(z['teacher/roi/mask_probs'])
+        got = torch.cat(probs, 0)[:, 0].cpu()
+        e = float((got - ref_probs).norm() / ref_probs.norm())
+        assert e < 1e-4, e
+        # (b)
+        for i, im in enumerate(images):
+            n = len(labels[i])
+            off = sum(len(l) for l in labels[:i])
+            boxes = torch.from_numpy(z['teacher/det/%d/boxes' % i])
+            hw = tuple(int(v) for v in z['teacher/det/%d/masks_hw' % i])
+            assert hw == tuple(im.shape[-2:])
+            pasted = D.paste_masks_in_image(ref_probs[off:off + n, None].to(DEV), boxes.to(DEV), hw)
+            bits = np.packbits((pasted > 0.5).cpu().numpy().reshape(n, -1), axis=1)
+            ref_bits = z['teacher/det/%d/masks_bits' % i]
+            wrong = int(np.unpackbits(bits ^ ref_bits).sum())
+            assert wrong <= 4, wrong                                      # of n * H * W pixels
+            sums = pasted.double().flatten(1).sum(1).cpu().numpy()
+            assert np.allclose(sums, z['teacher/det/%d/masks_sum' % i], rtol=1e-5, atol=1e-3)
+        # (c)
+        dets = model(ims)
+    for i, d in enumerate(dets):
+        assert sorted(d.keys()) == ['boxes', 'labels', 'masks', 'scores']
+        assert tuple(d['masks'].shape) == (len(d['scores']), 1) + tuple(images[i].shape[-2:])
+        rb, rl = torch.from_numpy(z['teacher/det/%d/boxes' % i]), torch.from_numpy(z['teacher/det/%d/labels' % i])
+        ref_bits = np.unpackbits(z['teacher/det/%d/masks_bits' % i], axis=1)
+        got_bits = (d['masks'] > 0.5).cpu().numpy().reshape(len(d['scores']), -1)
+        hit = 0
+        for j in range(len(rl)):                  # detections may be reordered by an fp32 near-tie: match by box
+            m = ((d['labels'].cpu() == rl[j]) & ((d['boxes'].cpu() - rb[j]).abs().max(1)[0] < 0.05)).nonzero()
+            if len(m):
+                a, b = got_bits[int(m[0])], ref_bits[j][:got_bits.shape[1]]
+                hit += int((a != b).sum() <= max(2, 0.002 * a.size))
+        assert hit >= 0.9 * len(rl), (hit, len(rl))
+
+
+def test_keypoint_branch_matches_the_reference_fixture():
+    """tiny_detect_keypoint.npz: the reference's Keypoint R-CNN forward in eval mode.  (a) keypoint head on the
+    FIXTURE's detections -> heatmaps; (b) heatmaps_to_keypoints on the fixture's own heatmaps; (c) end to end."""
+    from hnd_ghnd_object_detectors_amd._lib import load
+    from hnd_ghnd_object_detectors_amd import ops
+    z, meta = G.load('tiny_detect_keypoint')
+    model = _detector('teacher', meta)
+    images, _ = G.case_inputs(meta)
+    ims = [im.to(DEV) for im in images]
+    det_boxes, labels = _fixture_detections(z, len(ims))
+    head = torch.from_numpy(z['teacher/roi/keypoint_logits_head'])
+    nh = head.shape[0]
+    with torch.no_grad():
+        il, _ = model.transform(ims, None, None)
+        features = model.backbone(il.tensors)
+        model.roi_heads.last = {}
+        maps = model.roi_heads.keypoint_logits(features, [b.to(DEV) for b in det_boxes], il.image_sizes)
+        nchw = maps.permute(0, 3, 1, 2)
+        G.compare(z, 'teacher/roi/keypoint_logits', nchw, 1e-3)
+        e = float((nchw[:nh].cpu() - head).norm() / head.norm())
+        assert e < 1e-4, e
+        # (b) the fixture's heatmaps -> the reference's keypoints for those RoIs (before the resize to the original frame)
+        ref_xy, ref_sc = TV.heatmaps_to_keypoints(head, det_boxes[0][:nh])
+        L = load()
+        xy = torch.empty(nh, 17, 3, device=DEV)
+        sc = torch.empty(nh, 17, device=DEV)
+        nhwc = head.permute(0, 2, 3, 1).contiguous().to(DEV)
+        assert L.hnd_heatmaps_to_keypoints(nhwc.data_ptr(), nh, 56, 56, 17, 17, det_boxes[0][:nh].contiguous().to(DEV)
+                                           .data_ptr(), xy.data_ptr(), sc.data_ptr(), ops.stream_ptr()) == 0
+        same = (xy.cpu() == ref_xy).all(2).float().mean()
+        assert float(same) >= 0.95, float(same)
+        assert float((sc.cpu() - ref_sc).abs().max()) < 1e-5
+        # (c)
+        dets = model(ims)
+    for i, d in enumerate(dets):
+        assert sorted(d.keys()) == ['boxes', 'keypoints', 'keypoints_scores', 'labels', 'scores']
+        rb = torch.from_numpy(z['teacher/det/%d/boxes' % i])
+        rk = torch.from_numpy(z['teacher/det/%d/keypoints' % i])
+        rs = torch.from_numpy(z['teacher/det/%d/keypoints_scores' % i])
+        assert tuple(d['keypoints'].shape) == (len(d['scores']), 17, 3)
+        hit = tot = 0
+        for j in range(len(rb)):
+            m = ((d['boxes'].cpu() - rb[j]).abs().max(1)[0] < 0.05).nonzero()
+            if len(m):
+                q = int(m[0])
+                ok = ((d['keypoints'][q].cpu() - rk[j]).abs().max(1)[0] < 0.51) & \
+                     ((d['keypoints_scores'][q].cpu() - rs[j]).abs() < 1e-4)
+                hit += int(ok.sum())
+                tot += 17
+        assert tot >= 0.8 * 17 * len(rb) and hit >= 0.9 * tot, (hit, tot, len(rb))
