@@ -76,9 +76,10 @@ def warmup_lr_scheduler(optimizer, warmup_iters, warmup_factor):
 
 @torch.no_grad()
 def evaluate(model, data_loader, device):
-    """COCO bbox evaluation of `model` over `data_loader` (reference :75-113): eval-mode detector forward
-    (RPN -> RoI box head -> NMS on the HIP path), predictions keyed by image_id into CocoEvaluator, gathered over
-    ranks, accumulated and summarised.  Returns the evaluator (``coco_eval['bbox'].stats[0]`` = mAP)."""
+    """COCO evaluation of `model` over `data_loader` (reference :75-113): eval-mode detector forward (RPN -> RoI heads
+    -> NMS, + mask / keypoint branches for Mask / Keypoint R-CNN, all on the HIP path), predictions keyed by image_id
+    into CocoEvaluator (bbox, + segm / keypoints), gathered over ranks, accumulated and summarised.  Returns the
+    evaluator (``coco_eval['bbox'].stats[0]`` = the mAP mimic_runner selects the checkpoint on)."""
     import time
     from . import misc_util
     from .coco_eval_util import CocoEvaluator, get_coco_api_from_dataset, get_iou_types
@@ -92,7 +93,9 @@ def evaluate(model, data_loader, device):
         torch.cuda.synchronize()
         model_time = time.time()
         outputs = model(image)
-        outputs = [{k: v.to(cpu_device) for k, v in t.items()} for t in outputs]
+        # pasted masks are [n, 1, H, W] floats (0.4 GB per full-size image): the evaluator only ever looks at
+        # `masks > 0.5` (coco_eval_util.py:101), so the threshold is taken on the device and bools cross the bus
+        outputs = [{k: (v > 0.5 if k == 'masks' else v).to(cpu_device) for k, v in t.items()} for t in outputs]
         model_time = time.time() - model_time
         res = {int(target['image_id']): output for target, output in zip(targets, outputs)}
         evaluator_time = time.time()

@@ -1,5 +1,6 @@
-"""Restatement of the pycocotools (2.0.x) pieces the reference's evaluator drives: ``COCO`` (index + lookups),
-``COCOeval`` for ``iouType='bbox'`` and ``mask.iou`` on boxes.
+"""Restatement of the pycocotools (2.0.x) pieces the reference's evaluator drives: ``COCO`` (index + lookups,
+``annToRLE``), ``COCOeval`` for ``iouType`` 'bbox' / 'segm' / 'keypoints', and the ``mask`` module (RLE encode / decode /
+area / toBbox / iou / merge / frPyObjects incl. the polygon rasteriser and the compressed-string codec of maskApi.c).
 
 TEST INFRASTRUCTURE (see oracle/__init__.py).  pycocotools is a third-party dependency of the reference
 (``Pipfile`` / ``src/utils/coco_eval_util.py:5-10``), absent from this image: PARITY UNPINNED for its arithmetic,
@@ -7,7 +8,7 @@ restated here from the published ``pycocotools/coco.py`` / ``cocoeval.py`` / ``_
 reference's OWN evaluator code -- ``CocoEvaluator``, its copies of ``loadRes`` / ``evaluate`` / ``createIndex``,
 ``convert_to_coco_api`` (``src/utils/coco_eval_util.py``) -- runs unmodified when tests/golden/make_golden.py writes
 ``tiny_coco_eval.npz``; the product evaluator (hnd_ghnd_object_detectors_amd/utils/coco_eval_util.py) is then checked
-against those statistics.  Only what the bbox path touches exists; segm / keypoints raise.
+against those statistics.
 """
 import copy
 import datetime  # noqa: F401  (pycocotools imports it; kept for fidelity of the module surface)
@@ -42,17 +43,225 @@ def bb_iou(dt, gt, iscrowd):
     return o
 
 
+# ------------------------------------------------------------------------------------------------- maskApi.c (RLE)
+# An RLE is {'size': [h, w], 'counts': bytes | str}: run lengths of the COLUMN-MAJOR mask, starting with a run of
+# zeros, compressed by rleToString.  Internally: the list of run lengths.
+def _rle_counts_of_mask(m):
+    """rleEncode: m [h, w] (any memory order) -> run lengths over the column-major flattening"""
+    flat = np.asarray(m, dtype=np.uint8).reshape(m.shape[0], m.shape[1]).flatten(order='F')
+    if flat.size == 0:
+        return [0]
+    change = np.flatnonzero(flat[1:] != flat[:-1]) + 1
+    bounds = np.concatenate([[0], change, [flat.size]])
+    runs = np.diff(bounds).tolist()
+    if flat[0] != 0:
+        runs = [0] + runs
+    return [int(r) for r in runs]
+
+
+def _rle_to_string(cnts):
+    """rleToString: LEB128-like, 5 data bits + continuation bit per char, chars offset by 48; counts from the third
+    on are stored as the difference to the count two places earlier"""
+    out = bytearray()
+    for i, c in enumerate(cnts):
+        x = int(c)
+        if i > 2:
+            x -= int(cnts[i - 2])
+        more = True
+        while more:
+            ch = x & 0x1f
+            x >>= 5
+            more = (x != -1) if (ch & 0x10) else (x != 0)
+            if more:
+                ch |= 0x20
+            out.append(ch + 48)
+    return bytes(out)
+
+
+def _rle_from_string(s):
+    if isinstance(s, str):
+        s = s.encode('ascii')
+    cnts, p = [], 0
+    while p < len(s):
+        x, k, more = 0, 0, True
+        while more:
+            c = s[p] - 48
+            x |= (c & 0x1f) << (5 * k)
+            more = bool(c & 0x20)
+            p += 1
+            k += 1
+            if not more and (c & 0x10):
+                x |= -1 << (5 * k)
+        if len(cnts) > 2:
+            x += cnts[-2]
+        cnts.append(x)
+    return cnts
+
+
+def _counts(rle):
+    c = rle['counts']
+    return [int(v) for v in c] if isinstance(c, (list, tuple, np.ndarray)) else _rle_from_string(c)
+
+
+def _rle_of_counts(cnts, h, w):
+    return {'size': [int(h), int(w)], 'counts': _rle_to_string(cnts)}
+
+
+def _decode_one(rle):
+    h, w = rle['size']
+    cnts = _counts(rle)
+    flat = np.zeros(h * w, dtype=np.uint8)
+    pos, v = 0, 0
+    for c in cnts:
+        if v:
+            flat[pos:pos + c] = 1
+        pos += c
+        v ^= 1
+    return flat.reshape((h, w), order='F')
+
+
+def _fr_poly(xy, h, w):
+    """rleFrPoly: polygon [x0, y0, x1, y1, ...] -> run lengths.  Upsample x5, walk every edge densely, keep the
+    points where x changes, downsample to pixel-column crossings, difference-encode."""
+    k = len(xy) // 2
+    scale = 5.0
+    x = [int(scale * xy[2 * j] + .5) for j in range(k)]
+    y = [int(scale * xy[2 * j + 1] + .5) for j in range(k)]
+    x.append(x[0])
+    y.append(y[0])
+    u, v = [], []
+    for j in range(k):
+        xs, xe, ys, ye = x[j], x[j + 1], y[j], y[j + 1]
+        dx, dy = abs(xe - xs), abs(ys - ye)
+        flip = (dx >= dy and xs > xe) or (dx < dy and ys > ye)
+        if flip:
+            xs, xe, ys, ye = xe, xs, ye, ys
+        if dx >= dy:
+            sl = (ye - ys) / dx if dx else 0.0       # dx == dy == 0: C divides 0/0 -> NaN cast; a single point
+            for d in range(dx + 1):
+                t = dx - d if flip else d
+                u.append(t + xs)
+                v.append(int(ys + sl * t + .5))
+        else:
+            sl = (xe - xs) / dy
+            for d in range(dy + 1):
+                t = dy - d if flip else d
+                v.append(t + ys)
+                u.append(int(xs + sl * t + .5))
+    xs_, ys_ = [], []
+    for j in range(1, len(u)):
+        if u[j] != u[j - 1]:
+            xd = float(u[j] if u[j] < u[j - 1] else u[j] - 1)
+            xd = (xd + .5) / scale - .5
+            if np.floor(xd) != xd or xd < 0 or xd > w - 1:
+                continue
+            yd = float(v[j] if v[j] < v[j - 1] else v[j - 1])
+            yd = (yd + .5) / scale - .5
+            yd = 0.0 if yd < 0 else (float(h) if yd > h else yd)
+            yd = np.ceil(yd)
+            xs_.append(int(xd))
+            ys_.append(int(yd))
+    a = sorted([xx * int(h) + yy for xx, yy in zip(xs_, ys_)] + [int(h * w)])
+    p = 0
+    for j in range(len(a)):
+        t = a[j]
+        a[j] -= p
+        p = t
+    b, j = [a[0]], 1
+    while j < len(a):
+        if a[j] > 0:
+            b.append(a[j])
+            j += 1
+        else:
+            j += 1
+            if j < len(a):
+                b[-1] += a[j]
+                j += 1
+    return b
+
+
 class _MaskModule(object):
+    """pycocotools/mask.py over _mask.pyx"""
+
+    @staticmethod
+    def encode(bimask):
+        bimask = np.asarray(bimask)
+        if bimask.ndim == 3:
+            h, w, n = bimask.shape
+            return [_rle_of_counts(_rle_counts_of_mask(bimask[:, :, i]), h, w) for i in range(n)]
+        h, w = bimask.shape
+        return _rle_of_counts(_rle_counts_of_mask(bimask), h, w)
+
+    @staticmethod
+    def decode(rleObjs):
+        if isinstance(rleObjs, list):
+            return np.stack([_decode_one(r) for r in rleObjs], axis=2) if len(rleObjs) else np.zeros((0, 0, 0), np.uint8)
+        return _decode_one(rleObjs)
+
+    @staticmethod
+    def area(rleObjs):
+        def one(r):
+            return int(sum(_counts(r)[1::2]))
+        if isinstance(rleObjs, list):
+            return np.array([one(r) for r in rleObjs], dtype=np.uint32)
+        return np.uint32(one(rleObjs))
+
+    @staticmethod
+    def toBbox(rleObjs):
+        def one(r):
+            m = _decode_one(r)
+            ys, xs = np.nonzero(m)
+            if len(xs) == 0:
+                return [0.0, 0.0, 0.0, 0.0]
+            return [float(xs.min()), float(ys.min()), float(xs.max() - xs.min() + 1), float(ys.max() - ys.min() + 1)]
+        if isinstance(rleObjs, list):
+            return np.array([one(r) for r in rleObjs], dtype=np.double).reshape(-1, 4)
+        return np.array(one(rleObjs), dtype=np.double)
+
+    @staticmethod
+    def merge(rleObjs, intersect=0):
+        masks = [_decode_one(r) for r in rleObjs]
+        h, w = rleObjs[0]['size']
+        m = masks[0].astype(bool)
+        for o in masks[1:]:
+            m = (m & o.astype(bool)) if intersect else (m | o.astype(bool))
+        return _rle_of_counts(_rle_counts_of_mask(m.astype(np.uint8)), h, w)
+
+    @staticmethod
+    def frPyObjects(pyobj, h, w):
+        def fr_bbox(bb):
+            xs, ys, xe, ye = bb[0], bb[1], bb[0] + bb[2], bb[1] + bb[3]
+            return _rle_of_counts(_fr_poly([xs, ys, xs, ye, xe, ye, xe, ys], h, w), h, w)
+        if isinstance(pyobj, np.ndarray):
+            return [fr_bbox(bb) for bb in pyobj.reshape(-1, 4)]
+        if isinstance(pyobj, list) and len(pyobj) and isinstance(pyobj[0], dict):
+            return [_rle_of_counts([int(c) for c in o['counts']], o['size'][0], o['size'][1]) for o in pyobj]
+        if isinstance(pyobj, list) and len(pyobj) and len(pyobj[0]) == 4:
+            return [fr_bbox(bb) for bb in pyobj]
+        if isinstance(pyobj, list) and len(pyobj) and len(pyobj[0]) > 4:
+            return [_rle_of_counts(_fr_poly([float(v) for v in poly], h, w), h, w) for poly in pyobj]
+        if isinstance(pyobj, dict) and 'counts' in pyobj and 'size' in pyobj:
+            return _rle_of_counts([int(c) for c in pyobj['counts']], pyobj['size'][0], pyobj['size'][1])
+        raise Exception('input type is not supported.')
+
     @staticmethod
     def iou(dt, gt, iscrowd):
         if len(dt) == 0 or len(gt) == 0:
             return []
+        if isinstance(dt[0], dict):                          # rleIou: crowd ground truth -> union = area(dt)
+            D = [_decode_one(r).astype(bool) for r in dt]
+            Gm = [_decode_one(r).astype(bool) for r in gt]
+            o = np.zeros((len(D), len(Gm)), dtype=np.float64)
+            for g, gm in enumerate(Gm):
+                crowd = iscrowd is not None and len(iscrowd) and iscrowd[g]
+                ga = int(gm.sum())
+                for d, dm in enumerate(D):
+                    da = int(dm.sum())
+                    i = int((dm & gm).sum())
+                    u = da if crowd else da + ga - i
+                    o[d, g] = (i / u) if u > 0 else 0.0         # rleIou: u==0 cannot occur for i>0; 0/0 guarded as 0
+            return o
         return bb_iou(dt, gt, iscrowd)
-
-    @staticmethod
-    def _unsupported(*a, **k):
-        raise NotImplementedError('pycocotools.mask: only box IoU is restated (bbox evaluation)')
-    encode = decode = area = toBbox = frPyObjects = merge = _unsupported
 
 
 mask = _MaskModule()
@@ -133,6 +342,19 @@ class COCO(object):
         if type(ids) == int:
             return [self.anns[ids]]
 
+    def annToRLE(self, ann):
+        t = self.imgs[ann['image_id']]
+        h, w = t['height'], t['width']
+        segm = ann['segmentation']
+        if type(segm) == list:                              # polygons: one object may have several parts
+            return mask.merge(mask.frPyObjects(segm, h, w))
+        if type(segm['counts']) == list:                    # uncompressed RLE
+            return mask.frPyObjects(segm, h, w)
+        return ann['segmentation']
+
+    def annToMask(self, ann):
+        return mask.decode(self.annToRLE(ann))
+
 
 # ------------------------------------------------------------------------------------------------- cocoeval.py
 class Params(object):
@@ -145,10 +367,24 @@ class Params(object):
         self.areaRngLbl = ['all', 'small', 'medium', 'large']
         self.useCats = 1
 
+    def setKpParams(self):
+        self.imgIds, self.catIds = [], []
+        self.iouThrs = np.linspace(.5, 0.95, int(np.round((0.95 - .5) / .05)) + 1, endpoint=True)
+        self.recThrs = np.linspace(.0, 1.00, int(np.round((1.00 - .0) / .01)) + 1, endpoint=True)
+        self.maxDets = [20]
+        self.areaRng = [[0 ** 2, 1e5 ** 2], [32 ** 2, 96 ** 2], [96 ** 2, 1e5 ** 2]]
+        self.areaRngLbl = ['all', 'medium', 'large']
+        self.useCats = 1
+        self.kpt_oks_sigmas = np.array([.26, .25, .25, .35, .35, .79, .79, .72, .72, .62, .62, 1.07, 1.07, .87, .87,
+                                        .89, .89]) / 10.0
+
     def __init__(self, iouType='segm'):
-        if iouType not in ('segm', 'bbox'):
-            raise NotImplementedError('iouType %s is not restated (bbox evaluation only)' % iouType)
-        self.setDetParams()
+        if iouType == 'segm' or iouType == 'bbox':
+            self.setDetParams()
+        elif iouType == 'keypoints':
+            self.setKpParams()
+        else:
+            raise Exception('iouType not supported')
         self.iouType = iouType
         self.useSegm = None
 
@@ -175,9 +411,15 @@ class COCOeval(object):
         else:
             gts = self.cocoGt.loadAnns(self.cocoGt.getAnnIds(imgIds=p.imgIds))
             dts = self.cocoDt.loadAnns(self.cocoDt.getAnnIds(imgIds=p.imgIds))
+        if p.iouType == 'segm':                                 # _toMask: every annotation's segmentation -> RLE
+            for anns, coco in ((gts, self.cocoGt), (dts, self.cocoDt)):
+                for ann in anns:
+                    ann['segmentation'] = coco.annToRLE(ann)
         for gt in gts:
             gt['ignore'] = gt['ignore'] if 'ignore' in gt else 0
             gt['ignore'] = 'iscrowd' in gt and gt['iscrowd']
+            if p.iouType == 'keypoints':
+                gt['ignore'] = (gt['num_keypoints'] == 0) or gt['ignore']
         self._gts, self._dts = defaultdict(list), defaultdict(list)
         for gt in gts:
             self._gts[gt['image_id'], gt['category_id']].append(gt)
@@ -199,10 +441,51 @@ class COCOeval(object):
         dt = [dt[i] for i in inds]
         if len(dt) > p.maxDets[-1]:
             dt = dt[0:p.maxDets[-1]]
-        g = [g['bbox'] for g in gt]
-        d = [d['bbox'] for d in dt]
+        if p.iouType == 'segm':
+            g = [g['segmentation'] for g in gt]
+            d = [d['segmentation'] for d in dt]
+        elif p.iouType == 'bbox':
+            g = [g['bbox'] for g in gt]
+            d = [d['bbox'] for d in dt]
+        else:
+            raise Exception('unknown iouType for iou computation')
         iscrowd = [int(o['iscrowd']) for o in gt]
         return mask.iou(d, g, iscrowd)
+
+    def computeOks(self, imgId, catId):
+        p = self.params
+        gts, dts = self._gts[imgId, catId], self._dts[imgId, catId]
+        inds = np.argsort([-d['score'] for d in dts], kind='mergesort')
+        dts = [dts[i] for i in inds]
+        if len(dts) > p.maxDets[-1]:
+            dts = dts[0:p.maxDets[-1]]
+        if len(gts) == 0 or len(dts) == 0:
+            return []
+        ious = np.zeros((len(dts), len(gts)))
+        sigmas = p.kpt_oks_sigmas
+        vars = (sigmas * 2) ** 2
+        k = len(sigmas)
+        for j, gt in enumerate(gts):
+            g = np.array(gt['keypoints'])
+            xg, yg, vg = g[0::3], g[1::3], g[2::3]
+            k1 = np.count_nonzero(vg > 0)
+            bb = gt['bbox']
+            x0, x1 = bb[0] - bb[2], bb[0] + bb[2] * 2
+            y0, y1 = bb[1] - bb[3], bb[1] + bb[3] * 2
+            for i, dt in enumerate(dts):
+                d = np.array(dt['keypoints'])
+                xd, yd = d[0::3], d[1::3]
+                if k1 > 0:
+                    dx, dy = xd - xg, yd - yg
+                else:                                           # no labelled keypoint: distance to the doubled box
+                    z = np.zeros((k))
+                    dx = np.max((z, x0 - xd), axis=0) + np.max((z, xd - x1), axis=0)
+                    dy = np.max((z, y0 - yd), axis=0) + np.max((z, yd - y1), axis=0)
+                e = (dx ** 2 + dy ** 2) / vars / (gt['area'] + np.spacing(1)) / 2
+                if k1 > 0:
+                    e = e[vg > 0]
+                ious[i, j] = np.sum(np.exp(-e)) / e.shape[0]
+        return ious
 
     def evaluateImg(self, imgId, catId, aRng, maxDet):
         p = self.params
@@ -342,6 +625,13 @@ class COCOeval(object):
 
         if not self.eval:
             raise Exception('Please run accumulate() first')
+        if self.params.iouType == 'keypoints':
+            self.stats = np.array([_summarize(1, maxDets=20), _summarize(1, maxDets=20, iouThr=.5),
+                                   _summarize(1, maxDets=20, iouThr=.75), _summarize(1, maxDets=20, areaRng='medium'),
+                                   _summarize(1, maxDets=20, areaRng='large'), _summarize(0, maxDets=20),
+                                   _summarize(0, maxDets=20, iouThr=.5), _summarize(0, maxDets=20, iouThr=.75),
+                                   _summarize(0, maxDets=20, areaRng='medium'), _summarize(0, maxDets=20, areaRng='large')])
+            return
         stats = np.zeros((12,))
         stats[0] = _summarize(1)
         stats[1] = _summarize(1, iouThr=.5, maxDets=self.params.maxDets[2])

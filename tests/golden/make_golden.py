@@ -386,16 +386,25 @@ class _ListDataset(torch.utils.data.Dataset):
         return img.clone(), {k: v.clone() for k, v in t.items()}
 
 
+VAL_CASES = {'tiny_val_map': ('tiny_detect_faster', 'bbox'), 'tiny_val_map_mask': ('tiny_detect_mask', 'segm'),
+             'tiny_val_map_keypoint': ('tiny_detect_keypoint', 'keypoints')}
+
+
 def run_validation_case(name='tiny_val_map'):
     """The reference's whole validation path, unmodified: utils/main_util.evaluate (src/utils/main_util.py:75-113)
-    drives the eval-mode detector (rcnn.py:124-127) over a batch-1 loader and its CocoEvaluator.  Ground truth = the
-    first detections of the model itself (so the mAP is far from 0 with random weights and moves if detections do)."""
+    drives the eval-mode detector (rcnn.py:124-127) over a batch-1 loader and its CocoEvaluator (iou_types from
+    models.get_iou_types: bbox, + segm for Mask R-CNN, + keypoints for Keypoint R-CNN).  Ground truth = the first
+    detections of the model itself, perturbed (masks shifted, keypoints jittered), so the metrics are far from 0 with
+    random weights and move if detections do."""
     print('== %s' % name)
     from utils import main_util as ref_main                # reference
     from utils import misc_util as ref_misc                # reference
-    case = dict(yaml='ghnd/faster_rcnn-backbone_resnet50-b3ch.yaml', model='faster_rcnn',
-                sizes=[(120, 180), (112, 200), (128, 160), (100, 190)], min_size=128, max_size=256, steps=0, seed=31)
-    t_sd = O.scale_detector_heads(O.init_teacher_state(case['seed']))
+    det_case, kind = VAL_CASES[name]
+    case = dict(DETECT_CASES[det_case])
+    case['sizes'] = [(120, 180), (112, 200), (128, 160), (100, 190)]
+    if kind == 'bbox':
+        case['seed'] = 31
+    t_sd, _ = detect_states(case)
     config, teacher, _ = build_reference_models(case)
     teacher.load_state_dict(t_sd, strict=True)
     teacher.eval()
@@ -405,6 +414,7 @@ def run_validation_case(name='tiny_val_map'):
         dets = teacher([im.clone() for im in images])
     items, out = [], OrderedDict()
     out['meta'] = np.array(json.dumps(case))
+    g = torch.Generator().manual_seed(900 + case['seed'])
     for i, (im, d) in enumerate(zip(images, dets)):
         order = torch.argsort(d['scores'], descending=True)[:12]
         boxes, labels = d['boxes'][order].clone(), d['labels'][order].clone()
@@ -414,8 +424,19 @@ def run_validation_case(name='tiny_val_map'):
         wh = wh[ok]
         tgt = {'image_id': torch.tensor([500 + i]), 'boxes': boxes, 'labels': labels, 'area': wh[:, 0] * wh[:, 1],
                'iscrowd': torch.zeros(len(boxes), dtype=torch.int64)}
-        items.append((im, tgt))
         out['gt/%d/boxes' % i], out['gt/%d/labels' % i] = boxes.numpy(), labels.numpy()
+        if kind == 'segm':
+            m = (d['masks'][order][ok][:, 0] > 0.5)
+            m = torch.roll(m, shifts=(1, 2), dims=(1, 2)).to(torch.uint8)
+            tgt['masks'] = m
+            out['gt/%d/masks_bits' % i] = np.packbits(m.numpy().reshape(len(m), -1), axis=1)
+        if kind == 'keypoints':
+            kp = d['keypoints'][order][ok].clone()
+            kp[..., :2] += (torch.rand(kp[..., :2].shape, generator=g) - 0.5) * 4.0
+            kp[..., 2] = torch.randint(0, 3, kp[..., 2].shape, generator=g).float()
+            tgt['keypoints'] = kp
+            out['gt/%d/keypoints' % i] = kp.numpy()
+        items.append((im, tgt))
     loader = torch.utils.data.DataLoader(_ListDataset(items), batch_size=1, shuffle=False,
                                          collate_fn=ref_misc.collate_fn)
     real_sync = torch.cuda.synchronize
@@ -428,6 +449,12 @@ def run_validation_case(name='tiny_val_map'):
     out['stats'] = stats
     print('   stats', np.round(stats, 4).tolist())
     assert 0.1 < stats[0] < 1.0
+    if kind != 'bbox':
+        assert sorted(ev.coco_eval) == sorted(['bbox', kind])
+        ks = np.array(ev.coco_eval[kind].stats, dtype=np.float64)
+        out['stats_' + kind] = ks
+        print('   %s stats' % kind, np.round(ks, 4).tolist())
+        assert 0.1 < ks[0] < 1.0
     path = os.path.join(HERE, name + '.npz')
     np.savez_compressed(path, **out)
     print('   wrote %s (%.1f KB)' % (path, os.path.getsize(path) / 1024.0))
@@ -464,17 +491,23 @@ def coco_eval_case_inputs(seed=51):
     return dataset, preds
 
 
-def run_coco_eval_case(name='tiny_coco_eval'):
+def run_coco_eval_case(name='tiny_coco_eval', kind='bbox'):
     """The reference's own evaluator code -- utils/coco_util.convert_to_coco_api, utils/coco_eval_util.CocoEvaluator
     with its copies of loadRes / evaluate / createIndex (src/utils/coco_eval_util.py:15-150,198-345) -- over the
     restated pycocotools (oracle/pycoco_r.py): ground truth from a dataset of targets, predictions fed in two
-    update() calls, synchronize / accumulate / summarize -> the twelve COCO statistics."""
+    update() calls, synchronize / accumulate / summarize -> the COCO statistics.  kind 'segm' / 'keypoints': the
+    iou_types the reference uses for Mask / Keypoint R-CNN (coco_eval_util.py:225-233: bbox + segm / bbox + keypoints)."""
     print('== %s' % name)
     from utils import coco_eval_util as ref_eval          # reference
     from utils import coco_util as ref_coco               # reference
     dataset, preds = coco_eval_case_inputs()
+    iou_types = ['bbox']
+    if kind != 'bbox':
+        from tests import golden_util
+        dataset, preds = golden_util.coco_eval_case_extras(dataset, preds, kind)
+        iou_types.append(kind)
     coco = ref_coco.convert_to_coco_api([(img, {k: v.clone() for k, v in t.items()}) for img, t in dataset])
-    ev = ref_eval.CocoEvaluator(coco, ['bbox'])
+    ev = ref_eval.CocoEvaluator(coco, iou_types)
     ids = sorted(preds)
     ev.update({i: preds[i] for i in ids[:4]})
     ev.update({i: preds[i] for i in ids[4:]})
@@ -486,6 +519,12 @@ def run_coco_eval_case(name='tiny_coco_eval'):
                       precision_checksum=np.float64(ev.coco_eval['bbox'].eval['precision'].clip(min=0).sum()))
     print('   stats', np.round(stats, 4).tolist())
     assert 0.05 < stats[0] < 0.95 and stats[1] > stats[0] >= 0      # a non-trivial case
+    if kind != 'bbox':
+        ks = np.array(ev.coco_eval[kind].stats, dtype=np.float64)
+        out['stats_' + kind] = ks
+        out['precision_checksum_' + kind] = np.float64(ev.coco_eval[kind].eval['precision'].clip(min=0).sum())
+        print('   %s stats' % kind, np.round(ks, 4).tolist())
+        assert 0.05 < ks[0] < 0.95 and ks[1] >= ks[0]
     path = os.path.join(HERE, name + '.npz')
     np.savez_compressed(path, **out)
     print('   wrote %s (%.1f KB)' % (path, os.path.getsize(path) / 1024.0))
@@ -657,8 +696,12 @@ def main():
             run_detect_case(name)
     if not args.only or args.only == 'tiny_coco_eval':
         run_coco_eval_case()
-    if not args.only or args.only == 'tiny_val_map':
-        run_validation_case()
+    for kind in ('segm', 'keypoints'):
+        if not args.only or args.only == 'tiny_coco_eval_' + kind:
+            run_coco_eval_case('tiny_coco_eval_' + kind, kind)
+    for name in VAL_CASES:
+        if not args.only or args.only == name:
+            run_validation_case(name)
     if not args.only or args.only == 'tiny_input_pipeline':
         run_input_pipeline_case()
     if not args.only or args.only == 'tiny_ext_filter':

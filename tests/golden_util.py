@@ -121,3 +121,56 @@ def coco_eval_case_inputs(seed=51):
         ps = torch.rand(len(pb), generator=g)
         preds[200 + i] = {'boxes': pb, 'labels': pl, 'scores': ps}
     return dataset, preds
+
+
+def coco_eval_case_extras(dataset, preds, kind, seed=77):
+    """Masks or keypoints on top of coco_eval_case_inputs (its random stream is left untouched): elliptical instance
+    masks inside each box, probabilities for the predictions; 17 keypoints per instance with visibility 0 / 1 / 2
+    (one ground-truth instance without any labelled keypoint), jittered copies for the predictions.  Used by
+    tests/golden/make_golden.py (reference evaluator -> fixture) and by the product evaluator's tests."""
+    assert kind in ('segm', 'keypoints')
+    g = torch.Generator().manual_seed(seed)
+
+    def ellipse(box, h, w, shrink=1.0):
+        yy, xx = torch.meshgrid(torch.arange(h).float() + 0.5, torch.arange(w).float() + 0.5, indexing='ij')
+        cx, cy = (box[0] + box[2]) / 2, (box[1] + box[3]) / 2
+        rx, ry = (box[2] - box[0]) / 2 * shrink, (box[3] - box[1]) / 2 * shrink
+        return ((xx - cx) / rx.clamp(min=0.5)) ** 2 + ((yy - cy) / ry.clamp(min=0.5)) ** 2 <= 1.0
+
+    out_ds, out_preds = [], {}
+    for img, tgt in dataset:
+        h, w = img.shape[-2:]
+        t = {k: v.clone() for k, v in tgt.items()}
+        n = len(t['boxes'])
+        if kind == 'keypoints' and n == 0:
+            continue            # the reference's convert_to_coco_api cannot reshape an empty keypoint tensor (:175)
+        if kind == 'segm':
+            t['masks'] = torch.stack([ellipse(b, h, w) for b in t['boxes']]).to(torch.uint8) if n else \
+                torch.zeros(0, h, w, dtype=torch.uint8)
+            t['area'] = t['masks'].flatten(1).sum(1).float() if n else t['area']
+        else:
+            kp = torch.rand(n, 17, 3, generator=g)
+            wh = (t['boxes'][:, 2:] - t['boxes'][:, :2])[:, None]
+            kp[..., :2] = t['boxes'][:, None, :2] + kp[..., :2] * wh
+            kp[..., 2] = torch.randint(0, 3, (n, 17), generator=g).float()
+            if n > 2:
+                kp[2, :, 2] = 0                                          # an instance with num_keypoints == 0
+            t['keypoints'] = kp
+        out_ds.append((img, t))
+        p = {k: v.clone() for k, v in preds[int(tgt['image_id'])].items()}
+        m = len(p['boxes'])
+        if kind == 'segm':
+            probs = torch.stack([ellipse(b, h, w, 0.9).float() * 0.8 + 0.1 for b in p['boxes']])[:, None]
+            p['masks'] = (probs + (torch.rand(probs.shape, generator=g) - 0.5) * 0.3).clamp(0, 1)
+        else:
+            wh = (p['boxes'][:, 2:] - p['boxes'][:, :2])[:, None]
+            kp = torch.rand(m, 17, 3, generator=g)
+            kp[..., :2] = p['boxes'][:, None, :2] + kp[..., :2] * wh
+            # detections that copy a ground-truth instance: its keypoints, jittered by a few percent of the box
+            for j in range(min(m, n)):
+                if float((p['boxes'][j] - t['boxes'][j]).abs().max()) < 0.25 * float(wh[j].max()):
+                    kp[j, :, :2] = t['keypoints'][j, :, :2] + (torch.rand(17, 2, generator=g) - 0.5) * 0.08 * wh[j]
+            kp[..., 2] = 1
+            p['keypoints'] = kp
+        out_preds[int(tgt['image_id'])] = p
+    return out_ds, out_preds

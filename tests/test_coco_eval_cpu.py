@@ -79,8 +79,8 @@ def test_evaluator_surface_and_image_without_predictions():
     ev.accumulate()
     ev.summarize()
     assert abs(ev.coco_eval['bbox'].stats[0] - 51.0 / 101.0) < 1e-12          # 1 of 2 ground truths found
-    with pytest.raises(NotImplementedError):
-        CocoEvaluator(gt, ['bbox', 'segm'])
+    with pytest.raises(AssertionError):
+        CocoEvaluator(gt, ['bbox', 'caption'])
 
 
 def test_ground_truth_from_a_dataset_of_targets():
@@ -157,3 +157,116 @@ def test_restated_pycocotools_agrees_on_the_hand_cases():
     e.accumulate()
     e.summarize()
     assert np.abs(np.asarray(e.stats) - mine).max() < 1e-12
+
+
+# ------------------------------------------------------------------------------------------ segm / keypoints
+def _evaluate_case(kind):
+    from tests import golden_util as G
+    from hnd_ghnd_object_detectors_amd.utils.coco_eval_util import get_coco_api_from_dataset
+    z = G.load_raw('tiny_coco_eval_' + kind)
+    dataset, preds = G.coco_eval_case_inputs(int(z['seed']))
+    dataset, preds = G.coco_eval_case_extras(dataset, preds, kind)
+
+    class DS(torch.utils.data.Dataset):
+        def __len__(self):
+            return len(dataset)
+
+        def __getitem__(self, i):
+            img, t = dataset[i]
+            return img, {k: v.clone() for k, v in t.items()}
+    ev = CocoEvaluator(get_coco_api_from_dataset(DS()), ['bbox', kind])
+    ids = sorted(preds)
+    ev.update({i: preds[i] for i in ids[:3]})
+    ev.update({i: preds[i] for i in ids[3:]})
+    ev.synchronize_between_processes()
+    ev.accumulate()
+    ev.summarize()
+    return z, ev
+
+
+@pytest.mark.parametrize('kind', ['segm', 'keypoints'])
+def test_segm_and_keypoint_evaluation_match_the_reference_evaluator_fixtures(kind):
+    """tiny_coco_eval_{segm,keypoints}.npz: the REFERENCE's CocoEvaluator with iou_types bbox + segm / bbox + keypoints
+    (what src/models/__init__.py:60-70 selects for Mask / Keypoint R-CNN) -- prepare_for_coco_segmentation's 0.5
+    threshold and RLE encoding, loadRes's mask areas / keypoint extents, COCOeval's mask IoU / OKS -- over the
+    restated pycocotools.  The product evaluator (binary-mask IoU on its own run lengths, OKS) must reproduce the
+    statistics of both metrics."""
+    z, ev = _evaluate_case(kind)
+    assert np.abs(ev.coco_eval['bbox'].stats - z['stats']).max() < 1e-12
+    got, ref = ev.coco_eval[kind].stats, z['stats_' + kind]
+    assert got.shape == ref.shape == ((12,) if kind == 'segm' else (10,))
+    assert np.abs(got - ref).max() < 1e-12, (got, ref)
+    chk = float(np.clip(ev.coco_eval[kind].eval['precision'], 0, None).sum())
+    assert abs(chk - float(z['precision_checksum_' + kind])) < 1e-9
+
+
+def test_mask_util_matches_the_restated_mask_api():
+    """utils/mask_util.py (vectorised) vs oracle/pycoco_r.py (maskApi.c line by line): polygon rasteriser, run-length
+    codec, compressed strings -- on random polygons incl. integer vertices, vertices outside the image, repeated
+    vertices -- and the two documented conventions: a w x h box covers exactly w*h pixels, runs are column-major"""
+    from oracle import pycoco_r as P
+    from hnd_ghnd_object_detectors_amd.utils import mask_util as MU
+    rng = np.random.RandomState(5)
+    for t in range(120):
+        h, w = rng.randint(5, 70), rng.randint(5, 70)
+        pts = rng.rand(rng.randint(3, 9), 2) * [w * 1.3, h * 1.3] - [w * 0.15, h * 0.15]
+        if t % 3 == 0:
+            pts = np.round(pts)
+        if t % 7 == 0:
+            pts[1] = pts[0]
+        poly = pts.flatten().tolist()
+        ref = P.mask.decode(P.mask.frPyObjects([poly], h, w)[0]).astype(bool)
+        got = MU.polygons_to_mask([poly], h, w)
+        assert (ref == got).all(), t
+        rle = P.mask.encode(np.asfortranarray(ref.astype(np.uint8)))
+        counts = MU.encode(got)
+        assert MU.counts_to_string(counts) == rle['counts']
+        assert (MU.string_to_counts(rle['counts'].decode('ascii')) == counts).all()
+        assert (MU.decode(counts, h, w) == got).all() and MU.area(counts) == int(got.sum()) == int(P.mask.area(rle))
+    assert int(MU.bbox_to_mask([2, 1, 5, 4], 8, 10).sum()) == 20
+    m = np.zeros((3, 4), dtype=bool)
+    m[1:, 0] = True                                          # column-major: 1 zero, 2 ones, 9 zeros
+    assert MU.encode(m).tolist() == [1, 2, 9]
+    two_parts = MU.polygons_to_mask([[0, 0, 0, 2, 2, 2, 2, 0], [3, 3, 3, 5, 5, 5, 5, 3]], 6, 6)
+    assert int(two_parts.sum()) == 8                          # parts of one object are OR-ed (annToRLE merge)
+    assert (MU.segmentation_to_mask({'counts': [1, 2, 9], 'size': [3, 4]}, 3, 4) == m).all()
+    assert (MU.segmentation_to_mask({'counts': MU.counts_to_string([1, 2, 9]), 'size': [3, 4]}, 3, 4) == m).all()
+
+
+def test_keypoint_similarity_known_answers():
+    """OKS by hand: identical keypoints -> 1; every labelled keypoint displaced by d -> mean exp(-d^2 / (2 area
+    (2 sigma_i)^2)); a ground truth without labelled keypoints scores 1 while the detection stays inside its box
+    doubled in size; such a ground truth is ignored by the evaluation (num_keypoints == 0)."""
+    from hnd_ghnd_object_detectors_amd.utils.coco_eval_util import keypoint_oks, KPT_OKS_SIGMAS, CocoEval
+    kp = np.zeros(51)
+    kp[0::3], kp[1::3], kp[2::3] = np.arange(17) * 3.0 + 20, np.arange(17) * 2.0 + 30, 2
+    g = {'keypoints': kp.tolist(), 'bbox': [20.0, 30.0, 50.0, 34.0], 'area': 1700.0}
+    assert abs(keypoint_oks([kp.tolist()], [g])[0, 0] - 1.0) < 1e-15
+    moved = kp.copy()
+    moved[0::3] += 4.0
+    want = np.mean(np.exp(-16.0 / (2 * (1700.0 + np.spacing(1)) * (2 * KPT_OKS_SIGMAS) ** 2)))
+    assert abs(keypoint_oks([moved.tolist()], [g])[0, 0] - want) < 1e-15
+    unl = dict(g, keypoints=(kp * np.tile([1, 1, 0], 17)).tolist())
+    assert abs(keypoint_oks([moved.tolist()], [unl])[0, 0] - 1.0) < 1e-15
+    gt = CocoGT()
+    gt.add(1, g['bbox'], 1, g['area'], 0, 100, 100, keypoints=g['keypoints'])
+    gt.add(1, [60.0, 10.0, 20.0, 20.0], 1, 400.0, 0, 100, 100, keypoints=unl['keypoints'])
+    assert [a['num_keypoints'] for a in gt.anns[1]] == [17, 0]
+    ev = CocoEval(gt, 'keypoints')
+    ev.add_detections([{'image_id': 1, 'category_id': 1, 'keypoints': kp.tolist(), 'score': 0.9}])
+    ev.evaluate()
+    ev.accumulate()
+    stats = ev.summarize()
+    assert stats.shape == (10,) and abs(stats[0] - 1.0) < 1e-12 and abs(stats[5] - 1.0) < 1e-12
+
+
+def test_mask_iou_and_crowd_known_answers():
+    from hnd_ghnd_object_detectors_amd.utils.coco_eval_util import mask_iou
+    from hnd_ghnd_object_detectors_amd.utils import mask_util as MU
+    a = np.zeros((10, 10), dtype=bool)
+    b = np.zeros((10, 10), dtype=bool)
+    a[:4, :5] = True                                          # 20 px
+    b[2:6, :5] = True                                         # 20 px, 10 shared
+    iou = mask_iou([MU.encode(a)], [MU.encode(b), MU.encode(b)], [0, 1], 10, 10)
+    assert abs(iou[0, 0] - 10.0 / 30.0) < 1e-15 and abs(iou[0, 1] - 10.0 / 20.0) < 1e-15
+    assert mask_iou([MU.encode(np.zeros((10, 10), bool))], [MU.encode(b)], [0], 10, 10)[0, 0] == 0.0

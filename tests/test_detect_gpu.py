@@ -242,22 +242,32 @@ def _match(rb, rl, rs, db, dl, ds, frac, score_tol, box_tol):
     assert hit >= frac * len(rs), (hit, len(rs))
 
 
-def test_validation_map_matches_the_reference_validation_run():
-    """tiny_val_map.npz: the reference's own main_util.evaluate (src/utils/main_util.py:75-113) on its eval-mode
-    detector, batch-1 loader, CocoEvaluator -> the twelve statistics.  The HIP path's main_util.evaluate over the same
-    images / ground truth must land on the same validation mAP (what mimic_runner compares for the checkpoint,
-    :94-100): detections agree to fp32 noise, so the statistics agree to a few 1e-3."""
+@pytest.mark.parametrize('name,kind', [('tiny_val_map', 'bbox'), ('tiny_val_map_mask', 'segm'),
+                                       ('tiny_val_map_keypoint', 'keypoints')])
+def test_validation_map_matches_the_reference_validation_run(name, kind):
+    """tiny_val_map*.npz: the reference's own main_util.evaluate (src/utils/main_util.py:75-113) on its eval-mode
+    Faster / Mask / Keypoint R-CNN, batch-1 loader, CocoEvaluator (bbox, + segm, + keypoints) -> the statistics.  The
+    HIP path's main_util.evaluate over the same images / ground truth must land on the same validation mAP (what
+    mimic_runner compares for the checkpoint, :94-100): detections agree to fp32 noise, so the statistics agree to a
+    few 1e-3 (a detection reordered by a near-tie moves a statistic by about that much on 4 images)."""
     import numpy as np
     from hnd_ghnd_object_detectors_amd.utils import main_util, misc_util
-    z, meta = G.load('tiny_val_map')
+    z, meta = G.load(name)
     model = _detector('teacher', meta)
     images, _ = G.case_inputs(meta)
     items = []
     for i, im in enumerate(images):
         boxes, labels = torch.from_numpy(z['gt/%d/boxes' % i]), torch.from_numpy(z['gt/%d/labels' % i])
         wh = boxes[:, 2:] - boxes[:, :2]
-        items.append((im, {'image_id': torch.tensor([500 + i]), 'boxes': boxes, 'labels': labels,
-                           'area': wh[:, 0] * wh[:, 1], 'iscrowd': torch.zeros(len(boxes), dtype=torch.int64)}))
+        t = {'image_id': torch.tensor([500 + i]), 'boxes': boxes, 'labels': labels,
+             'area': wh[:, 0] * wh[:, 1], 'iscrowd': torch.zeros(len(boxes), dtype=torch.int64)}
+        if kind == 'segm':
+            h, w = im.shape[-2:]
+            bits = np.unpackbits(z['gt/%d/masks_bits' % i], axis=1)[:, :h * w]
+            t['masks'] = torch.from_numpy(bits.reshape(len(boxes), h, w).astype(np.uint8))
+        if kind == 'keypoints':
+            t['keypoints'] = torch.from_numpy(z['gt/%d/keypoints' % i])
+        items.append((im, t))
 
     class DS(torch.utils.data.Dataset):
         def __len__(self):
@@ -271,6 +281,11 @@ def test_validation_map_matches_the_reference_validation_run():
     got, ref = np.asarray(ev.coco_eval['bbox'].stats), z['stats']
     assert got.shape == (12,) and np.abs(got - ref).max() < 5e-3, (got.tolist(), ref.tolist())
     assert abs(got[0] - ref[0]) < 2e-3
+    if kind != 'bbox':
+        assert sorted(ev.coco_eval) == sorted(['bbox', kind])
+        got, ref = np.asarray(ev.coco_eval[kind].stats), z['stats_' + kind]
+        assert got.shape == ref.shape and np.abs(got - ref).max() < 1e-2, (got.tolist(), ref.tolist())
+        assert abs(got[0] - ref[0]) < 4e-3, (got[0], ref[0])
 
 
 # ------------------------------------------------------------------------------- mask / keypoint branch operators
