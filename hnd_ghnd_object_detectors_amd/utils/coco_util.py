@@ -56,15 +56,18 @@ class FilterAndRemapCocoCategories(object):
 
 
 def convert_coco_poly_to_mask(segmentations, height, width):
+    """reference :32-45: ``frPyObjects(polygons) -> decode -> any over the parts`` per object; rasterised by
+    utils/mask_util.py (maskApi's polygon rule: a w x h rectangle covers exactly w*h pixels)"""
+    from . import mask_util
     masks = []
     for polygons in segmentations:
-        canvas = Image.new('L', (width, height), 0)
         if isinstance(polygons, list):
-            draw = ImageDraw.Draw(canvas)
-            for poly in polygons:
-                if len(poly) >= 6:
-                    draw.polygon([(poly[i], poly[i + 1]) for i in range(0, len(poly) - 1, 2)], outline=1, fill=1)
-        masks.append(torch.from_numpy(np.array(canvas, dtype=np.uint8)))
+            m = mask_util.polygons_to_mask(polygons, height, width)
+        elif polygons:
+            m = mask_util.segmentation_to_mask(polygons, height, width)
+        else:
+            m = np.zeros((height, width), dtype=bool)
+        masks.append(torch.from_numpy(m.astype(np.uint8)))
     if masks:
         return torch.stack(masks, dim=0)
     return torch.zeros((0, height, width), dtype=torch.uint8)

@@ -270,3 +270,38 @@ def test_mask_iou_and_crowd_known_answers():
     iou = mask_iou([MU.encode(a)], [MU.encode(b), MU.encode(b)], [0, 1], 10, 10)
     assert abs(iou[0, 0] - 10.0 / 30.0) < 1e-15 and abs(iou[0, 1] - 10.0 / 20.0) < 1e-15
     assert mask_iou([MU.encode(np.zeros((10, 10), bool))], [MU.encode(b)], [0], 10, 10)[0, 0] == 0.0
+
+
+def test_ground_truth_from_a_coco_annotation_file(tmp_path):
+    """a dataset exposing ``.coco`` annotations (reference: get_coco_api_from_dataset returns dataset.coco for
+    CocoDetection datasets): polygons and the crowd region's uncompressed RLE become masks like COCO.annToRLE, keypoints
+    and num_keypoints are carried; perfect predictions then score AP 1 on all three metrics"""
+    from tests.coco_fixture import write_tiny_coco
+    from hnd_ghnd_object_detectors_amd.utils import coco_util, data_util, mask_util
+    from hnd_ghnd_object_detectors_amd.utils.coco_eval_util import get_coco_api_from_dataset
+    img_dir, ann_file = write_tiny_coco(str(tmp_path))
+    ds = coco_util.get_coco(img_dir, ann_file, data_util.get_transform(False), remove_non_annotated_imgs=False)
+    gt = get_coco_api_from_dataset(ds)
+    person, crowd = gt.anns[100]
+    assert crowd['iscrowd'] == 1 and mask_util.area(crowd['rle']) == 4 and crowd['num_keypoints'] == 0
+    m = mask_util.decode(person['rle'], 48, 64)
+    assert int(m.sum()) == 32 * 24 and m[12:36, 8:40].all() and person['num_keypoints'] == 17
+    assert gt.anns[105][0]['num_keypoints'] == 4
+    preds = {}
+    for img_id, anns in gt.anns.items():
+        anns = [a for a in anns if not a['iscrowd']]
+        info = gt.images[img_id]
+        boxes = torch.tensor([[a['bbox'][0], a['bbox'][1], a['bbox'][0] + a['bbox'][2], a['bbox'][1] + a['bbox'][3]]
+                              for a in anns])
+        masks = torch.stack([torch.from_numpy(mask_util.decode(a['rle'], info['height'], info['width'])).float()
+                             for a in anns])[:, None]
+        kps = torch.tensor([a['keypoints'] for a in anns]).view(len(anns), 17, 3)
+        preds[img_id] = {'boxes': boxes, 'labels': torch.ones(len(anns), dtype=torch.int64),
+                         'scores': torch.full((len(anns),), 0.9), 'masks': masks, 'keypoints': kps}
+    ev = CocoEvaluator(gt, ['bbox', 'segm', 'keypoints'])
+    ev.update(preds)
+    ev.synchronize_between_processes()
+    ev.accumulate()
+    ev.summarize()
+    for kind in ('bbox', 'segm', 'keypoints'):
+        assert abs(ev.coco_eval[kind].stats[0] - 1.0) < 1e-12, kind

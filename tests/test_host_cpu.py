@@ -183,7 +183,8 @@ def test_coco_format_loaders_without_pycocotools(tmp_path):
     assert isinstance(img, DecodedImage) and tuple(img.shape) == (3, 48, 64) and img.data.dtype == torch.uint8
     assert t['boxes'].tolist() == [[8.0, 12.0, 40.0, 36.0]] and t['labels'].tolist() == [1]     # crowd anno dropped
     assert t['keypoints'].shape == (1, 17, 3) and t['image_id'].tolist() == [100]
-    assert t['masks'].shape == (1, 48, 64) and abs(int(t['masks'].sum()) - 33 * 25) <= 60        # filled rectangle
+    assert t['masks'].shape == (1, 48, 64) and int(t['masks'].sum()) == 32 * 24     # maskApi: w x h pixels exactly
+    assert bool(t['masks'][0, 12:36, 8:40].all())
     assert t['area'].numel() == 1 and t['iscrowd'].tolist() == [0]
     _, t3 = ds[3]
     assert t3['boxes'].shape == (0, 4) and t3['masks'].shape == (0, 56, 56)                      # no annotations
