@@ -429,6 +429,53 @@ EXT_CONVS = ((1, 64, 64, 4, 2), (4, 64, 32, 3, 2), (7, 32, 16, 2, 1))      # (id
 EXT_BNS = ((2, 64), (5, 32), (8, 16))
 
 
+class DetectOracle(object):
+    """The eval-mode detector of the validation path (src/models/org/rcnn.py:103-134 with distill_backbone_only off:
+    transform -> backbone -> rpn -> roi_heads -> transform.postprocess) composed from this module's functional backbone
+    and the restated torchvision 0.4.2 heads (oracle/tv042_det.py, oracle/tv042.py), driven by a state dict.  The
+    reference-generated fixtures (tiny_detect_*) pin those pieces; this composition lets tests run them at sizes no
+    fixture stores (3x800x1333)."""
+
+    def __init__(self, sd, model_name='faster_rcnn', student=False, min_size=(800,), max_size=1333):
+        from oracle import tv042 as T
+        from oracle import tv042_det as D
+        self.sd, self.student = sd, student
+        self.min_size = tuple(min_size) if isinstance(min_size, (list, tuple)) else (min_size,)
+        self.max_size = max_size
+        ncls = sd['roi_heads.box_predictor.cls_score.weight'].shape[0]
+        ag = D.AnchorGenerator(((32,), (64,), (128,), (256,), (512,)), ((0.5, 1.0, 2.0),) * 5)
+        top_n = dict(training=2000, testing=1000)
+        self.rpn = D.RegionProposalNetwork(ag, D.RPNHead(256, 3), 0.7, 0.3, 256, 0.5, dict(top_n), dict(top_n), 0.7)
+        kw = {}
+        if model_name == 'mask_rcnn':
+            kw = dict(mask_roi_pool=D.MultiScaleRoIAlign([0, 1, 2, 3], 14, 2),
+                      mask_head=T.MaskRCNNHeads(256, (256, 256, 256, 256), 1),
+                      mask_predictor=T.MaskRCNNPredictor(256, 256, ncls))
+        elif model_name == 'keypoint_rcnn':
+            nkp = sd['roi_heads.keypoint_predictor.kps_score_lowres.weight'].shape[1]
+            kw = dict(keypoint_roi_pool=D.MultiScaleRoIAlign([0, 1, 2, 3], 14, 2),
+                      keypoint_head=T.KeypointRCNNHeads(256, (512,) * 8),
+                      keypoint_predictor=T.KeypointRCNNPredictor(512, nkp))
+        self.roi_heads = D.RoIHeads(D.MultiScaleRoIAlign([0, 1, 2, 3], 7, 2), D.TwoMLPHead(256 * 7 * 7, 1024),
+                                    D.FastRCNNPredictor(1024, ncls), 0.5, 0.5, 512, 0.25, None, 0.05, 0.5, 100, **kw)
+        for mod, prefix in ((self.rpn, 'rpn.'), (self.roi_heads, 'roi_heads.')):
+            mod.load_state_dict(OrderedDict((k[len(prefix):], v) for k, v in sd.items() if k.startswith(prefix)),
+                                strict=True)
+            mod.eval()
+        self.transform = T.GeneralizedRCNNTransform(self.min_size, max_size, IMAGE_MEAN, IMAGE_STD)
+        self.transform.eval()
+        self.image_list = T.ImageList
+
+    @torch.no_grad()
+    def __call__(self, images):
+        original = [tuple(im.shape[-2:]) for im in images]
+        batch, sizes = transform_images(images, self.min_size, self.max_size)
+        _, features = backbone_forward(batch, self.sd, self.student, training=False, update_buffers=False)
+        proposals, _ = self.rpn(self.image_list(batch, sizes), features)
+        dets, _ = self.roi_heads(features, proposals, sizes)
+        return self.transform.postprocess(dets, sizes, original)
+
+
 def init_ext_state(seed, dtype=torch.float32):
     """Seeded init of Ext4ResNet(64) with torch's default nn.Conv2d / nn.Linear distributions; BatchNorm buffers
     are perturbed away from (0, 1) so that eval mode is a non-trivial check."""

@@ -467,3 +467,78 @@ def test_keypoint_branch_matches_the_reference_fixture():
                 hit += int(ok.sum())
                 tot += 17
         assert tot >= 0.8 * 17 * len(rb) and hit >= 0.9 * tot, (hit, tot, len(rb))
+
+
+# ------------------------------------------------------------------------------- full size (3 x 800 x 1333 class)
+@pytest.mark.parametrize('model_name', ['faster_rcnn', 'mask_rcnn', 'keypoint_rcnn'])
+def test_full_size_detector_matches_the_oracle(model_name):
+    """BASELINE-size inputs (resized to 800 x 1200 and 800 x 1024, padded to one batch): the HIP eval-mode detector
+    against O.DetectOracle (pinned bit-exactly to the reference's forward by tests/test_oracle_golden.py).  ~240 000
+    anchors per image, 1000 proposals, 100 detections, masks pasted into the original-size images."""
+    import numpy as np
+    from hnd_ghnd_object_detectors_amd.configs import make_config
+    kw = {'num_classes': 2} if model_name == 'keypoint_rcnn' else {}
+    t_sd = O.scale_detector_heads(O.init_teacher_state(71, model_name, **kw))
+    s_sd = O.init_student_state(t_sd, 1071)
+    cfg = make_config(model_name, 'ghnd', 3, pretrained=False, ckpt_root='/nonexistent')
+    teacher, _ = MU.build_pair(cfg, t_sd, s_sd, DEV)
+    teacher.eval()
+    teacher.distill_backbone_only = False
+    g = gen(72)
+    images = [torch.rand(3, 600, 900, generator=g), torch.rand(3, 500, 640, generator=g)]
+    ref = O.DetectOracle(t_sd, model_name)(images)
+    with torch.no_grad():
+        dets = teacher([im.to(DEV) for im in images])
+    for i, (d, r) in enumerate(zip(dets, ref)):
+        assert sorted(d.keys()) == sorted(r.keys())
+        db, dl, ds = d['boxes'].cpu(), d['labels'].cpu(), d['scores'].cpu()
+        assert abs(len(ds) - len(r['scores'])) <= 2
+        pairs = []
+        for j in range(len(r['scores'])):
+            m = ((dl == r['labels'][j]) & ((ds - r['scores'][j]).abs() < 1e-3 * max(1.0, float(r['scores'][j]))) &
+                 ((db - r['boxes'][j]).abs().max(1)[0] < 0.25)).nonzero()
+            if len(m):
+                pairs.append((int(m[0]), j))
+        assert len(pairs) >= 0.95 * len(r['scores']), (len(pairs), len(r['scores']))
+        if 'masks' in r:
+            assert tuple(d['masks'].shape) == tuple(r['masks'].shape)
+            got, want = (d['masks'] > 0.5).cpu().flatten(1), (r['masks'] > 0.5).flatten(1)
+            ok = sum(int((got[a] != want[b]).sum()) <= max(2, 0.01 * int(want[b].sum())) for a, b in pairs)
+            assert ok >= 0.95 * len(pairs), (ok, len(pairs))
+        if 'keypoints' in r:
+            kp, ks = d['keypoints'].cpu(), d['keypoints_scores'].cpu()
+            close = torch.stack([((kp[a] - r['keypoints'][b]).abs().max(1)[0] < 0.51) &
+                                 ((ks[a] - r['keypoints_scores'][b]).abs() < 1e-3) for a, b in pairs])
+            assert float(close.float().mean()) >= 0.9, float(close.float().mean())
+
+
+def test_full_size_paste_and_keypoints_with_large_boxes():
+    """random-weight detectors only emit small boxes; the per-box operators at BASELINE image size with boxes up to the
+    whole image: hnd_paste_masks into 800 x 1333 canvases, hnd_heatmaps_to_keypoints with RoIs up to 1333 x 800"""
+    from hnd_ghnd_object_detectors_amd import detection as D
+    from hnd_ghnd_object_detectors_amd._lib import load
+    from hnd_ghnd_object_detectors_amd import ops
+    g = gen(73)
+    im_h, im_w, n = 800, 1333, 12
+    xy = torch.rand(n, 2, generator=g) * torch.tensor([im_w * 0.6, im_h * 0.6]) - 20
+    wh = torch.rand(n, 2, generator=g) ** 2 * torch.tensor([im_w * 1.0, im_h * 1.0]) + 3
+    boxes = torch.cat([xy, xy + wh], 1)
+    boxes[0] = torch.tensor([0.0, 0.0, float(im_w), float(im_h)])
+    masks = torch.rand(n, 1, 28, 28, generator=g)
+    ref = TV.paste_masks_in_image(masks, boxes, (im_h, im_w))
+    got = D.paste_masks_in_image(masks.to(DEV), boxes.to(DEV), (im_h, im_w)).cpu()
+    assert torch.equal(got == 0, ref == 0)
+    assert float((got - ref).abs().max()) < 2e-6
+    assert int(((got > 0.5) != (ref > 0.5)).sum()) <= 1e-6 * got.numel() + 2
+    L = load()
+    maps = torch.randn(n, 17, 56, 56, generator=g)
+    rois = boxes.clone()
+    rois[1] = torch.tensor([0.0, 0.0, 1333.0, 800.0])
+    ref_xy, ref_sc = TV.heatmaps_to_keypoints(maps, rois)
+    xyd, scd = torch.empty(n, 17, 3, device=DEV), torch.empty(n, 17, device=DEV)
+    nhwc = maps.permute(0, 2, 3, 1).contiguous().to(DEV)
+    assert L.hnd_heatmaps_to_keypoints(nhwc.data_ptr(), n, 56, 56, 17, 17, rois.to(DEV).data_ptr(), xyd.data_ptr(),
+                                       scd.data_ptr(), ops.stream_ptr()) == 0
+    same = (xyd.cpu() == ref_xy).all(2).float().mean()
+    assert float(same) >= 0.97, float(same)
+    assert float((scd.cpu() - ref_sc).abs().max()) < 1e-4 * float(ref_sc.abs().max())

@@ -151,3 +151,23 @@ def test_filter_oracle_matches_reference_fixture():
             G.compare(z, k, orc.s[k[len('buffers/'):]].float(), 1e-6)
     G.compare(z, 'eval/probs', orc.forward(images, training=False), 1e-6)
     G.compare(z, 'eval/probs_single', orc.forward(images[:1], training=False), 1e-6)
+
+
+@pytest.mark.parametrize('name', ['tiny_detect_faster', 'tiny_detect_mask', 'tiny_detect_keypoint'])
+def test_detect_oracle_reproduces_the_reference_detections(name):
+    """O.DetectOracle (functional backbone + restated torchvision heads, state-dict driven) against what the
+    REFERENCE's CustomRCNN.forward produced in eval mode: boxes / labels / scores / keypoints identical, pasted-mask
+    bits identical -- the composition the full-size GPU tests use as their checker is the pinned one"""
+    import numpy as np
+    z, meta = G.load(name)
+    kw = {'num_classes': 2} if meta['model'] == 'keypoint_rcnn' else {}
+    t_sd = O.scale_detector_heads(O.init_teacher_state(meta['seed'], meta['model'], **kw))
+    det = O.DetectOracle(t_sd, meta['model'], False, meta['min_size'], meta['max_size'])
+    images, _ = G.case_inputs(meta)
+    for i, d in enumerate(det(images)):
+        for k, v in d.items():
+            if k == 'masks':
+                bits = np.packbits((v > 0.5).numpy().reshape(len(v), -1), axis=1)
+                assert np.array_equal(bits, z['teacher/det/%d/masks_bits' % i])
+            else:
+                assert torch.equal(v, torch.from_numpy(z['teacher/det/%d/%s' % (i, k)])), (i, k)
