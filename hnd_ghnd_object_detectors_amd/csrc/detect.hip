@@ -127,19 +127,43 @@ __global__ void nms_mask_kernel(const float* __restrict__ boxes, const long long
   mask[(size_t)i * words + cbk] = bits;
 }
 
-// greedy scan in score order (one wave): keep[order[i]] = 1 unless an earlier kept box suppressed position i
-__global__ void nms_scan_kernel(const unsigned long long* __restrict__ mask, const long long* __restrict__ order, int n,
-                                int words, unsigned char* __restrict__ keep) {
+// greedy scan in score order: keep[order[i]] = 1 unless an earlier kept box suppressed position i.  One workgroup
+// walks the positions 64 at a time: wave 0 resolves the block's own chain from its 64 diagonal words held one per
+// lane (64 register steps, v_readlane broadcasts -- no memory access on the serial path), then all 256 threads OR
+// the rows of the block's survivors into the words to its right (independent, coalesced loads).  Same greedy
+// result as one position at a time (round 2: 1.0 -> ~0.1 ms at 4800 boxes).
+constexpr int NMS_SCAN_THREADS = 256;
+__global__ void __launch_bounds__(NMS_SCAN_THREADS) nms_scan_kernel(const unsigned long long* __restrict__ mask,
+                                                                    const long long* __restrict__ order, int n,
+                                                                    int words, unsigned char* __restrict__ keep) {
   extern __shared__ unsigned long long remv[];
+  __shared__ unsigned long long kept_s;
   const int t = threadIdx.x;
-  for (int k = t; k < words; k += 64) remv[k] = 0;
-  for (int k = t; k < n; k += 64) keep[k] = 0;
+  for (int k = t; k < words; k += NMS_SCAN_THREADS) remv[k] = 0;
+  for (int k = t; k < n; k += NMS_SCAN_THREADS) keep[k] = 0;
   __syncthreads();
-  for (int i = 0; i < n; ++i) {
-    const bool dead = (remv[i >> 6] >> (i & 63)) & 1ull;       // uniform
-    if (!dead) {
-      if (t == 0) keep[order[i]] = 1;
-      for (int k = (i >> 6) + t; k < words; k += 64) remv[k] |= mask[(size_t)i * words + k];
+  for (int b = 0; b < words; ++b) {
+    const int base = b * 64, cnt = min(64, n - base);
+    if (t < 64) {                                               // wave 0
+      const unsigned long long d = t < cnt ? mask[(size_t)(base + t) * words + b] : 0ull;   // bits j > t only
+      unsigned long long cur = remv[b];
+      for (int j = 0; j < cnt; ++j) {
+        const unsigned long long dj = __shfl(d, j);
+        if (!((cur >> j) & 1ull)) cur |= dj;
+      }
+      if (t == 0) kept_s = ~cur & (cnt == 64 ? ~0ull : ((1ull << cnt) - 1ull));
+    }
+    __syncthreads();
+    const unsigned long long kept = kept_s;
+    if (t < cnt && ((kept >> t) & 1ull)) keep[order[base + t]] = 1;
+    for (int k = b + 1 + t; k < words; k += NMS_SCAN_THREADS) {
+      unsigned long long acc = 0, m = kept;
+      while (m) {
+        const int j = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        acc |= mask[(size_t)(base + j) * words + k];
+      }
+      remv[k] |= acc;
     }
     __syncthreads();
   }
@@ -293,7 +317,7 @@ int hnd_nms(const float* boxes, const int64_t* order, int64_t n, float iou_thres
   if (hipMemsetAsync(workspace, 0, hnd_nms_workspace(n), hnd::as_stream(stream)) != hipSuccess) return hnd::check_launch("hnd_nms(memset)");
   hipLaunchKernelGGL(nms_mask_kernel, dim3(words, words), dim3(64), 0, hnd::as_stream(stream), boxes,
                      (const long long*)order, (int)n, iou_threshold, (unsigned long long*)workspace, words);
-  hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(64), words * sizeof(unsigned long long), hnd::as_stream(stream),
+  hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(NMS_SCAN_THREADS), words * sizeof(unsigned long long), hnd::as_stream(stream),
                      (const unsigned long long*)workspace, (const long long*)order, (int)n, words, keep);
   return hnd::check_launch("hnd_nms");
 }

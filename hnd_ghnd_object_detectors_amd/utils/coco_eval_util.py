@@ -374,9 +374,9 @@ class CocoEvaluator(object):
         for image_id, pred in predictions.items():
             if len(pred) == 0 or len(pred['scores']) == 0:
                 continue
-            bits = (pred['masks'] > 0.5)[:, 0].cpu().numpy()
-            for m, s, l in zip(bits, pred['scores'].tolist(), pred['labels'].tolist()):
-                out.append({'image_id': image_id, 'category_id': l, 'rle': mask_util.encode(m), 'score': s})
+            rles = mask_util.encode_batch((pred['masks'] > 0.5)[:, 0])          # on the masks' own device
+            for rle, s, l in zip(rles, pred['scores'].tolist(), pred['labels'].tolist()):
+                out.append({'image_id': image_id, 'category_id': l, 'rle': rle, 'score': s})
         return out
 
     @staticmethod

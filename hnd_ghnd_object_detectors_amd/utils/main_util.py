@@ -94,8 +94,9 @@ def evaluate(model, data_loader, device):
         model_time = time.time()
         outputs = model(image)
         # pasted masks are [n, 1, H, W] floats (0.4 GB per full-size image): the evaluator only ever looks at
-        # `masks > 0.5` (coco_eval_util.py:101), so the threshold is taken on the device and bools cross the bus
-        outputs = [{k: (v > 0.5 if k == 'masks' else v).to(cpu_device) for k, v in t.items()} for t in outputs]
+        # `masks > 0.5` (coco_eval_util.py:101) and run-length encodes it, so the masks stay on the device and only
+        # their run boundaries cross the bus (mask_util.encode_batch)
+        outputs = [{k: (v if k == 'masks' else v.to(cpu_device)) for k, v in t.items()} for t in outputs]
         model_time = time.time() - model_time
         res = {int(target['image_id']): output for target, output in zip(targets, outputs)}
         evaluator_time = time.time()

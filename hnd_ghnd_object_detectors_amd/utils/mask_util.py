@@ -30,6 +30,28 @@ def encode(mask):
     return runs.astype(np.uint32)
 
 
+def encode_batch(bits):
+    """torch bool masks [n, h, w] on any device -> list of uint32 run lengths, equal to ``encode`` of each mask.  The
+    run boundaries are found where the masks live (a 100 x 800 x 1333 stack is 107 MB; its boundaries a few thousand
+    indices), so only those cross PCIe on the validation path."""
+    import torch
+    n, h, w = bits.shape
+    if n == 0:
+        return []
+    flat = bits.transpose(1, 2).reshape(n, h * w)               # column-major order of every mask
+    idx = (flat[:, 1:] != flat[:, :-1]).nonzero()               # sorted by (mask, position)
+    rows, pos = idx[:, 0].cpu().numpy(), idx[:, 1].cpu().numpy() + 1
+    first = flat[:, 0].cpu().numpy()
+    splits = np.searchsorted(rows, np.arange(n + 1))
+    out = []
+    for i in range(n):
+        runs = np.diff(np.concatenate(([0], pos[splits[i]:splits[i + 1]], [h * w])))
+        if first[i]:
+            runs = np.concatenate(([0], runs))
+        out.append(runs.astype(np.uint32))
+    return out
+
+
 def decode(counts, h, w):
     """run lengths -> bool mask [h, w]"""
     counts = np.asarray(counts, dtype=np.int64)

@@ -224,6 +224,12 @@ def test_mask_util_matches_the_restated_mask_api():
         assert (MU.string_to_counts(rle['counts'].decode('ascii')) == counts).all()
         assert (MU.decode(counts, h, w) == got).all() and MU.area(counts) == int(got.sum()) == int(P.mask.area(rle))
     assert int(MU.bbox_to_mask([2, 1, 5, 4], 8, 10).sum()) == 20
+    stack = torch.from_numpy(rng.rand(7, 23, 31) > 0.6)
+    stack[2] = False
+    stack[3] = True
+    for got, m in zip(MU.encode_batch(stack), stack.numpy()):
+        assert got.dtype == np.uint32 and got.tolist() == MU.encode(m).tolist()
+    assert MU.encode_batch(torch.zeros(0, 4, 4, dtype=torch.bool)) == []
     m = np.zeros((3, 4), dtype=bool)
     m[1:, 0] = True                                          # column-major: 1 zero, 2 ones, 9 zeros
     assert MU.encode(m).tolist() == [1, 2, 9]
