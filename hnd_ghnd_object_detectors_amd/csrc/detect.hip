@@ -128,42 +128,47 @@ __global__ void nms_mask_kernel(const float* __restrict__ boxes, const long long
 }
 
 // greedy scan in score order: keep[order[i]] = 1 unless an earlier kept box suppressed position i.  One workgroup
-// walks the positions 64 at a time: wave 0 resolves the block's own chain from its 64 diagonal words held one per
-// lane (64 register steps, v_readlane broadcasts -- no memory access on the serial path), then all 256 threads OR
-// the rows of the block's survivors into the words to its right (independent, coalesced loads).  Same greedy
-// result as one position at a time (round 2: 1.0 -> ~0.1 ms at 4800 boxes).
-constexpr int NMS_SCAN_THREADS = 256;
+// walks the positions 64 at a time.  For block b: (1) GATHER -- every thread ORs word b of the rows of earlier
+// survivors (their bitmap sits in LDS; loads are independent across the 256 threads), one workgroup-wide OR gives the
+// positions of block b already dead; (2) CHAIN -- wave 0 holds the block's 64 diagonal words one per lane and
+// resolves the in-block dependency with 64 register steps (v_readlane, no memory access on the serial path).
+// Same greedy result as one position at a time (1.0 ms -> 0.28 ms at ~4800 boxes: profiles/r02_eval_mask_kernel_stats.md).
+constexpr int NMS_SCAN_THREADS = 1024;
+__device__ __forceinline__ unsigned long long readlane64(unsigned long long v, int lane) {   // lane is wave-uniform
+  const unsigned lo = __builtin_amdgcn_readlane((unsigned)v, lane);
+  const unsigned hi = __builtin_amdgcn_readlane((unsigned)(v >> 32), lane);
+  return ((unsigned long long)hi << 32) | lo;
+}
 __global__ void __launch_bounds__(NMS_SCAN_THREADS) nms_scan_kernel(const unsigned long long* __restrict__ mask,
                                                                     const long long* __restrict__ order, int n,
                                                                     int words, unsigned char* __restrict__ keep) {
-  extern __shared__ unsigned long long remv[];
-  __shared__ unsigned long long kept_s;
-  const int t = threadIdx.x;
-  for (int k = t; k < words; k += NMS_SCAN_THREADS) remv[k] = 0;
+  extern __shared__ unsigned long long keptw[];                 // [words] survivors of the blocks done so far
+  __shared__ unsigned long long part[NMS_SCAN_THREADS / 64];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   for (int k = t; k < n; k += NMS_SCAN_THREADS) keep[k] = 0;
-  __syncthreads();
   for (int b = 0; b < words; ++b) {
     const int base = b * 64, cnt = min(64, n - base);
-    if (t < 64) {                                               // wave 0
-      const unsigned long long d = t < cnt ? mask[(size_t)(base + t) * words + b] : 0ull;   // bits j > t only
-      unsigned long long cur = remv[b];
+    // the block's diagonal words: issued first so the load is in flight during the gather (wave 0 only)
+    const unsigned long long d = (wave == 0 && lane < cnt) ? mask[(size_t)(base + lane) * words + b] : 0ull;  // bits j > lane
+    unsigned long long acc = 0;
+    for (int r = t; r < base; r += NMS_SCAN_THREADS)            // rows of earlier blocks; r >> 6 < b
+      if ((keptw[r >> 6] >> (r & 63)) & 1ull) acc |= mask[(size_t)r * words + b];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc |= __shfl_xor(acc, o);
+    if (lane == 0) part[wave] = acc;
+    __syncthreads();
+    if (wave == 0) {
+      unsigned long long cur = lane < NMS_SCAN_THREADS / 64 ? part[lane] : 0ull;
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) cur |= __shfl_xor(cur, o);
+      cur = readlane64(cur, 0);
       for (int j = 0; j < cnt; ++j) {
-        const unsigned long long dj = __shfl(d, j);
+        const unsigned long long dj = readlane64(d, j);
         if (!((cur >> j) & 1ull)) cur |= dj;
       }
-      if (t == 0) kept_s = ~cur & (cnt == 64 ? ~0ull : ((1ull << cnt) - 1ull));
-    }
-    __syncthreads();
-    const unsigned long long kept = kept_s;
-    if (t < cnt && ((kept >> t) & 1ull)) keep[order[base + t]] = 1;
-    for (int k = b + 1 + t; k < words; k += NMS_SCAN_THREADS) {
-      unsigned long long acc = 0, m = kept;
-      while (m) {
-        const int j = __ffsll((long long)m) - 1;
-        m &= m - 1;
-        acc |= mask[(size_t)(base + j) * words + k];
-      }
-      remv[k] |= acc;
+      const unsigned long long kept = ~cur & (cnt == 64 ? ~0ull : ((1ull << cnt) - 1ull));
+      if (lane == 0) keptw[b] = kept;
+      if (lane < cnt && ((kept >> lane) & 1ull)) keep[order[base + lane]] = 1;
     }
     __syncthreads();
   }
