@@ -459,16 +459,36 @@ class RoIHeads(nn.Module):
         return wc
 
     def _conv3x3_relu_chain(self, x, convs, tag):
-        """[Conv2d(3x3, pad 1) + bias + ReLU] * len(convs) on an NHWC buffer, one hnd_conv2d_igemm launch each"""
+        """[Conv2d(3x3, pad 1) + bias + ReLU] * len(convs) on an NHWC buffer: Winograd F(4x4,3x3) (input transform ->
+        36 GEMMs in one hnd_conv2d_igemm launch -> output transform with bias + ReLU) where engine.use_winograd says it
+        pays (>= 128 channels: every branch conv of torchvision's heads), one direct launch otherwise"""
         for i, conv in enumerate(convs):
             assert conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) \
                 and conv.dilation == (1, 1), 'the branch convs of torchvision 0.4.2 are 3x3 / stride 1 / pad 1'
-            wc = self._cache((tag, i), conv.weight)
-            pk = wc.get()
-            wc.refresh()
-            k, h, w, _ = x.shape
-            y = torch.empty((k, h, w, conv.weight.shape[0]), dtype=torch.float32, device=x.device)
-            E._run(ops.conv_forward(x, pk, y, 3, 1, 1, epi_shift=conv.bias.detach(), relu=True), '%s.conv%d' % (tag, i))
+            k, h, w, cin = x.shape
+            cout = conv.weight.shape[0]
+            y = torch.empty((k, h, w, cout), dtype=torch.float32, device=x.device)
+            tile = E.use_winograd(cin, cout, 1)
+            if tile:
+                if self._wc is None:
+                    self._wc = {}
+                wn = self._wc.get((tag, i, 'wino'))
+                if wn is None or wn.weight is not conv.weight:
+                    wn = self._wc[(tag, i, 'wino')] = E.WinoCache(conv.weight, tile)
+                ww = wn.get(False)
+                wn.refresh()
+                nv, nm = ops.WinoConv.scratch_elems(k, h, w, cin, cout, tile)
+                v = torch.empty(nv, dtype=torch.float32, device=x.device)
+                m = torch.empty(nm, dtype=torch.float32, device=x.device)
+                for l, t in ops.WinoConv(x, ww, y, v, m, epi_shift=conv.bias.detach(),
+                                         relu=True).launches('%s.conv%d' % (tag, i)):
+                    E._run(l, t)
+            else:
+                wc = self._cache((tag, i), conv.weight)
+                pk = wc.get()
+                wc.refresh()
+                E._run(ops.conv_forward(x, pk, y, 3, 1, 1, epi_shift=conv.bias.detach(), relu=True),
+                       '%s.conv%d' % (tag, i))
             x = y
         return x
 
