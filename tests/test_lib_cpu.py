@@ -38,3 +38,23 @@ def test_invalid_arguments_are_reported_not_thrown():
     assert lib.hnd_conv2d_igemm(None, None) == -1
     assert b'null descriptor' in lib.hnd_last_error_string()
     assert lib.hnd_adam_step_flat(None, None, None, None, 0, 0.0, 0.0, 0.0, 0.0, 0, 1.0, None) == -1
+
+
+def test_detection_operators_validate_their_arguments():
+    """the validation-path entry points (ABI 3 / 4) reject null pointers and bad geometry with HND_ERR_INVALID and a
+    message, and treat an empty problem (k = 0) as a successful no-op -- all before any HIP call, so this runs on CPU"""
+    from hnd_ghnd_object_detectors_amd import _lib
+    lib = _lib.load()
+    assert lib.hnd_mask_probs(None, None, 0, 28, 91, None, None) == 0
+    assert lib.hnd_mask_probs(None, None, 5, 28, 91, None, None) == -1
+    assert b'hnd_mask_probs' in lib.hnd_last_error_string()
+    assert lib.hnd_paste_masks(None, None, 0, 28, 800, 1333, None, None) == 0
+    assert lib.hnd_paste_masks(None, None, 3, 28, 800, 1333, None, None) == -1
+    assert lib.hnd_upsample_bilinear_nhwc(None, 2, 28, 28, 17, 2, None, None) == -1
+    assert lib.hnd_heatmaps_to_keypoints(None, 0, 56, 56, 17, 17, None, None, None, None) == 0
+    assert lib.hnd_heatmaps_to_keypoints(None, 4, 56, 56, 17, 17, None, None, None, None) == -1
+    assert b'hnd_heatmaps_to_keypoints' in lib.hnd_last_error_string()
+    assert lib.hnd_nms(None, None, 0, 0.5, None, None, None) == 0
+    assert lib.hnd_nms(None, None, 10, 0.5, None, None, None) == -1
+    assert lib.hnd_roi_align(None, 1, 8, 8, 64, None, None, 3, 0.25, 7, 7, 2, None, None) == -1
+    assert lib.hnd_nms_workspace(4800) == 4800 * 75 * 8
