@@ -2,13 +2,16 @@
 
 What runs here is what ``src/models/org/rcnn.py:124-127`` reaches when ``distill_backbone_only`` is False:
 ``self.rpn(images, features)`` -> ``self.roi_heads(features, proposals, image_sizes)`` -> ``transform.postprocess``,
-i.e. torchvision 0.4.2's RegionProposalNetwork / RoIHeads box branch (restated for the CPU oracle in
+i.e. torchvision 0.4.2's RegionProposalNetwork / RoIHeads (box branch, and for Mask / Keypoint R-CNN the mask /
+keypoint branches with ``paste_masks_in_image`` / ``heatmaps_to_keypoints``; restated for the CPU oracle in
 oracle/tv042_det.py, which states the version-sensitive details this file follows: ascending-index ``nms`` result,
-float anchor strides, no empty-box removal in ``postprocess_detections``).
+float anchor strides, no empty-box removal in ``postprocess_detections``, the Python-loop mask paste, bicubic keypoint
+heat-map resize).
 
 Arithmetic is libhnd_hip.so: the RPN head convs, fc6 (as a 7x7 valid conv over the pooled map), fc7 and the two
-predictors on ``hnd_conv2d_igemm``; anchors + box decoding, clipping, NMS (bit-exact kept set), RoIAlign, softmax as
-the kernels of csrc/detect.hip.  torch is used for storage and for variable-length INDEX bookkeeping only (top-k /
+predictors on ``hnd_conv2d_igemm``, the branch convs on its Winograd form and the transposed convs on its data-gradient
+form; anchors + box decoding, clipping, NMS (bit-exact kept set), RoIAlign, softmax as the kernels of csrc/detect.hip,
+mask probabilities / paste / bilinear x2 / heat-maps-to-keypoints as those of csrc/detect_heads.hip.  torch is used for storage and for variable-length INDEX bookkeeping only (top-k /
 sort orders, ``nonzero`` compaction, gathers), never for box or feature arithmetic beyond single exactly-rounded
 adds that are part of the reference's own index trick (``batched_nms`` coordinate offsets).
 

@@ -7,9 +7,10 @@ behaviour is restated here in plain torch.  Call sites in the reference:
 
 Only the pieces that EXECUTE on the distillation step are behaviourally faithful
 (ResNet Bottleneck, FrozenBatchNorm2d without eps, IntermediateLayerGetter, FPN,
-GeneralizedRCNNTransform.normalize/batch_images, ImageList).  The eval-mode RPN / RoI box
-branch of the validation path (SURVEY.md 8f row f4) is restated in oracle/tv042_det.py;
-mask / keypoint predictors are parameter holders with the 0.4.2 names and shapes.
+GeneralizedRCNNTransform.normalize/batch_images, ImageList).  The eval-mode RPN / RoI heads
+(box, mask and keypoint branches) of the validation path are restated in
+oracle/tv042_det.py; the mask / keypoint head modules below are plain nn.Sequential / nn.Module
+stacks with the 0.4.2 names and shapes.
 """
 import math
 from collections import OrderedDict
