@@ -1004,3 +1004,28 @@ def test_distill_step_edge_geometries_match_oracle(sizes, min_size, max_size):
         if n.endswith(G.ZERO_GRAD_SUFFIXES):
             continue
         _grad_check(n, p.grad, g32[n], g64[n], tol=6e-3)
+
+
+@pytest.mark.parametrize('native', [False, True])
+def test_rccl_exchange_world_of_one(tmp_path, native):
+    """the gradient exchange on a REAL RCCL communicator (one rank: the one GPU of a test box): the hook-fired async
+    all-reduce of the flat arena -> stream-side wait in FusedAdam -> mean folded into the launch, through
+    torch.distributed ('nccl' == RCCL) and through the C ABI's own communicator (hnd_comm_*).  One rank sums to the
+    identity, so two steps must reproduce the plain loop bit for bit; the 2-rank arithmetic is
+    test_two_ranks_take_the_oracle_step_on_the_mean_gradient (gloo, shared device)."""
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    out = str(tmp_path / 'r.pt')
+    cmd = [sys.executable, os.path.join(root, 'tests', 'rccl_world1_worker.py'), out] + (['native'] if native else [])
+    res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    r = torch.load(out, weights_only=False)
+    assert r['plain']['losses'] == r['rccl']['losses']
+    for k, v in r['plain']['params'].items():
+        assert torch.equal(v, r['rccl']['params'][k]), k
