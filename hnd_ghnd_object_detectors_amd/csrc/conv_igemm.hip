@@ -55,6 +55,16 @@ constexpr int blocks_per_cu() {
                   : ((BM == 64 && BN == 64) ? 4 : 2);
 }
 
+// Sum of squares of the BN statistics on the CHECKED epilogue path (tile edges, cout = 3): product and sum are two
+// roundings, spelled out so that the vector-ALU kernel for cout <= 4 (thin_n_kernel) reproduces the partials bit for
+// bit.  Under -ffp-contract=fast the backend fuses any fmul + fadd it sees (a source-level contract(off) pragma does
+// not stop it), so the product is hidden behind an empty asm.
+__device__ __forceinline__ float sq_acc(float s2, float x) {
+  float sq = x * x;
+  asm volatile("" : "+v"(sq));
+  return s2 + sq;
+}
+
 // Epilogue of one 16-row group of a wave: the lane holds rows 4*(lane>>4)+i (i = 0..3) and, thanks to the channel
 // interleave of the packed weights (hnd::chan_of_row), NI CONSECUTIVE output channels starting at col0 -- so residual /
 // mask loads and the stores are 16-byte (NI = 4) or 8-byte (NI = 2) vector accesses, 16 lanes covering 64 consecutive
@@ -123,7 +133,7 @@ __device__ __forceinline__ void epilogue_rows(const hnd_conv_desc& d, const f32x
         x = d.relu ? fmaxf(x, 0.f) : x;
         d.y[o] = x;
         s1[ni] += x;
-        s2[ni] += x * x;
+        s2[ni] = sq_acc(s2[ni], x);
       }
     }
   }
@@ -414,6 +424,169 @@ igemm_kernel(const hnd_conv_desc d, const int ntiles) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// cout <= 4: the 3-channel bottleneck of the b3ch head (layer1.conv3 forward: 2x2x64 -> 3, and the data gradient of
+// conv4: 2x2x64 -> 3).  On the 128 x 64 MFMA tile 60 of 64 output columns are padding (4.6 TFLOP/s "useful"); here one
+// thread owns one output pixel and its <= 4 channels on the vector ALU, weights broadcast from LDS.
+// BIT-IDENTICAL to the MFMA path by construction (tests/test_ops_gpu.py compares the two bit for bit):
+//   * v_mfma_f32_16x16x4_f32 is an fmaf chain over its 4 k values; the MFMA kernel feeds MFMA s of a 16-deep k group
+//     with k = 4g + s (g = 0..3), so an accumulator sees k in the order 0,4,8,12, 1,5,9,13, ... -- the loop below;
+//   * prologue / epilogue are the same expressions compiled in this translation unit (same FMA contraction);
+//   * the BN-statistics partials are folded in the MFMA epilogue's tree: per (row half, row group 4g..4g+3) a serial
+//     sum over the 16 rows a lane owns, then (A0 + A1) + (A2 + A3), then the two halves.
+constexpr int THIN_LDA = 68;      // LDS row stride (floats) of the staged 128 x 64 activation chunk: 64 + 4 pad
+template <bool PRO>
+__global__ void __launch_bounds__(128, 4) thin_n_kernel(const hnd_conv_desc d) {
+  extern __shared__ __attribute__((aligned(16))) float tsm[];
+  float* as = tsm;                                // [128][THIN_LDA] one 64-channel chunk of the tile's 128 pixels
+  int* pnb = (int*)(as + 128 * THIN_LDA);         // [128] image base (pixels), ih0, iw0 of every row of the tile
+  int* pih = pnb + 128;
+  int* piw = pih + 128;
+  float* xs = as;                                 // epilogue: [4][128] values of this tile (aliases the chunk buffer)
+  float* part = xs + 4 * 128;                     // [4][2][4][2] partial (sum, sumsq) per channel / half / group
+  const int tid = threadIdx.x;
+  const int mt = blockIdx.x, m0 = mt * 128;
+  const int M = d.n * d.oh * d.ow;
+  // packed row of channel c is 16 * c (hnd::chan_of_row(16 c) == c for c < 4).  The weight addresses are uniform over
+  // the workgroup and the packed weights are read-only while this kernel runs: read through the constant address
+  // space they are fetched by scalar loads (s_load_dwordx16 per channel and k group) and feed the fmas as SGPR
+  // operands -- as plain global loads hipcc issued 16 vector loads + waits per k group, the kernel's whole time.
+  typedef const __attribute__((address_space(4))) float* cptr;   // constant address space: uniform loads go to SMEM
+  const cptr w0 = (cptr)(d.w);
+  const cptr w1 = (cptr)(d.w + (size_t)16 * d.kdim);
+  const cptr w2 = (cptr)(d.w + (size_t)32 * d.kdim);
+  const cptr w3 = (cptr)(d.w + (size_t)48 * d.kdim);
+  const int m = m0 + tid;
+  const bool rok = m < M;
+  const int mm = rok ? m : 0;
+  const int ow_ = mm % d.ow, t_ = mm / d.ow, oh_ = t_ % d.oh, n_ = t_ / d.oh;
+  pnb[tid] = rok ? n_ * d.h * d.w_ : -1;
+  pih[tid] = oh_ * d.sh + d.bh;
+  piw[tid] = ow_ * d.sw + d.bw;
+  const float relu_floor = d.pro_relu ? 0.f : -INFINITY;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  // Per (tap, 64-channel chunk): the 128 x 64 activation block is gathered COALESCED -- 16 consecutive lanes fetch the
+  // 256 contiguous bytes of one pixel -- with the prologue applied, written to LDS, and every thread then reads back
+  // its own pixel's row (one lane per pixel straight from global memory touched 64 cache lines per load instruction
+  // and ran at the L1's line rate).
+  const int piece = tid & 15, prow = tid >> 4;    // this thread stages float4 `piece` of rows prow, prow + 8, ...
+  const int cpt = d.cin >> 6;                     // cin % 64 == 0 on this path (thin_n_applies)
+  int kbase = 0;
+  for (int khi = 0; khi < d.kh; ++khi)
+    for (int kwi = 0; kwi < d.kw; ++kwi)
+      for (int cc = 0; cc < cpt; ++cc, kbase += 64) {
+        const int c0 = cc << 6;
+        f32x4 rps = {1.f, 1.f, 1.f, 1.f}, rpb = {0.f, 0.f, 0.f, 0.f};
+        if (PRO) {
+          rps = *(const f32x4*)(d.pro_scale + c0 + 4 * piece);
+          rpb = *(const f32x4*)(d.pro_shift + c0 + 4 * piece);
+        }
+        __syncthreads();                          // the row tables are written / the previous chunk has been read
+        f32x4 st[16];
+        unsigned okm = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const int r = prow + 8 * j;
+          const int ih = pih[r] + khi * d.dh, iw = piw[r] + kwi * d.dw, nb = pnb[r];
+          const bool ok = nb >= 0 && (unsigned)ih < (unsigned)d.h && (unsigned)iw < (unsigned)d.w_;
+          const float* px = d.x + (ok ? (size_t)(unsigned)(nb + ih * d.w_ + iw) * (unsigned)d.cin + c0 + 4 * piece : 0);
+          st[j] = *(const f32x4*)px;
+          okm |= (ok ? 1u : 0u) << j;
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          f32x4 a = st[j];
+          if (PRO) {
+            a = a * rps + rpb;
+            a.x = fmaxf(a.x, relu_floor); a.y = fmaxf(a.y, relu_floor);
+            a.z = fmaxf(a.z, relu_floor); a.w = fmaxf(a.w, relu_floor);
+          }
+          const bool ok = (okm >> j) & 1;         // padding is a zero of the NORMALISED tensor
+          a.x = ok ? a.x : 0.f; a.y = ok ? a.y : 0.f; a.z = ok ? a.z : 0.f; a.w = ok ? a.w : 0.f;
+          *(f32x4*)(as + (prow + 8 * j) * THIN_LDA + 4 * piece) = a;
+        }
+        __syncthreads();
+        const float* row = as + tid * THIN_LDA;
+        // (a register prefetch of the next chunk behind these fmas spilled SGPRs and ran 15 % slower: four resident
+        // workgroups per CU already cover one another's gather)
+#pragma unroll 1
+        for (int G = 0; G < 4; ++G) {              // 16-deep k groups of this chunk, in order
+          f32x4 v[4];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) v[g] = *(const f32x4*)(row + 16 * G + 4 * g);
+#pragma unroll
+          for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const float a = v[g][s_];
+              const int k = kbase + 16 * G + 4 * g + s_;
+              acc[0] = fmaf(a, w0[k], acc[0]);
+              acc[1] = fmaf(a, w1[k], acc[1]);
+              acc[2] = fmaf(a, w2[k], acc[2]);
+              acc[3] = fmaf(a, w3[k], acc[3]);
+            }
+        }
+      }
+  __syncthreads();                                // every thread is done with the chunk buffer (xs aliases it)
+  // ---- epilogue (the scalar path of epilogue_rows)
+  int po = -1;
+  if (rok) po = (n_ * d.yh + oh_ * d.y_sh + d.y_oh) * d.yw + ow_ * d.y_sw + d.y_ow;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    float x = 0.f;
+    if (po >= 0 && c < d.cout) {
+      const float es = d.epi_scale ? d.epi_scale[c] : 1.f, eb = d.epi_shift ? d.epi_shift[c] : 0.f;
+      const size_t o = (size_t)po * d.ldc + c;
+      x = acc[c] * es + eb;
+      if (d.res1) x += d.res1[o];
+      if (d.res2) x += d.res2[o];
+      if (d.mask) x = d.mask[o] > 0.f ? x : 0.f;
+      x = d.relu ? fmaxf(x, 0.f) : x;
+      d.y[o] = x;
+    }
+    xs[c * 128 + tid] = x;                        // rows outside the problem contribute an exact +0
+  }
+  if (!d.stats) return;
+  __syncthreads();
+  if (tid < 32) {                                 // (channel, row half, row group): a lane's 16 rows, serially
+    const int c = tid >> 3, wm = (tid >> 2) & 1, g4 = tid & 3;
+    float s1 = 0.f, s2 = 0.f;
+    for (int mi = 0; mi < 4; ++mi)
+      for (int i = 0; i < 4; ++i) {
+        const float x = xs[c * 128 + wm * 64 + mi * 16 + 4 * g4 + i];
+        s1 += x;
+        s2 = sq_acc(s2, x);
+      }
+    part[((c * 2 + wm) * 4 + g4) * 2 + 0] = s1;
+    part[((c * 2 + wm) * 4 + g4) * 2 + 1] = s2;
+  }
+  __syncthreads();
+  if (tid < 2 * d.cout) {
+    const int c = tid >> 1, q = tid & 1;
+    float h[2];
+    for (int wm = 0; wm < 2; ++wm) {
+      const float* pp = part + ((c * 2 + wm) * 4) * 2 + q;
+      h[wm] = (pp[0] + pp[2]) + (pp[4] + pp[6]);
+    }
+    d.stats[(size_t)mt * 2 * d.cout + (size_t)q * d.cout + c] = h[0] + h[1];
+  }
+}
+
+bool thin_n_applies(const hnd_conv_desc& d) {
+  static const int on = getenv("HND_THIN_N") ? atoi(getenv("HND_THIN_N")) : 1;
+  return on && d.cin != 4 && d.cin % 64 == 0 && d.cout <= 4 && d.res1_mode == 0 && d.w_group_rows == 0 &&
+         d.kdim == d.kh * d.kw * d.cin && d.kdim <= 4096;
+}
+
+int launch_thin_n(const hnd_conv_desc& d, hipStream_t stream) {
+  const long long M = (long long)d.n * d.oh * d.ow;
+  const int mtiles = (int)((M + 127) / 128);
+  const size_t lds = ((size_t)128 * THIN_LDA + 3 * 128) * sizeof(float);
+  if (d.pro_scale) hipLaunchKernelGGL(thin_n_kernel<true>, dim3(mtiles), dim3(128), lds, stream, d);
+  else hipLaunchKernelGGL(thin_n_kernel<false>, dim3(mtiles), dim3(128), lds, stream, d);
+  return hnd::check_launch("hnd_conv2d_igemm(thin)");
+}
+
 // tuning knob: cap the resident blocks per CU below what registers / LDS allow by padding the dynamic LDS request
 // (160 KB per CU).  The matrix pipe serves two waves per SIMD at 99 % and three at 95 % (16x16x4), four at 79 %.
 int bpc_cap() {
@@ -532,6 +705,7 @@ extern "C" int hnd_conv2d_igemm(const hnd_conv_desc* desc, void* stream) {
   if (d.cin == 4) {
     return launch<128, 64, 32, true>(d, s);   // stem (cout 64) and the 3->64 decoder conv
   }
+  if (thin_n_applies(d)) return launch_thin_n(d, s);
   const int bk16 = bk16_mask();
   switch (pick_tile(d)) {
     case 0: return (bk16 & 1) ? launch<128, 128, 16, false>(d, s) : launch<128, 128, 32, false>(d, s);
@@ -544,5 +718,6 @@ extern "C" int hnd_conv2d_igemm(const hnd_conv_desc* desc, void* stream) {
 extern "C" int hnd_conv2d_igemm_tile(const hnd_conv_desc* desc) {
   if (!desc) return -1;
   if (desc->cin == 4) return 1;
+  if (thin_n_applies(*desc)) return 4;
   return pick_tile(*desc);
 }

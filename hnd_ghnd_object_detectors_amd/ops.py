@@ -99,7 +99,7 @@ class ConvLaunch(object):
         self.ref = C.byref(desc)
         # which kernel instantiation hnd_conv2d_igemm dispatches to (mirrors csrc/conv_igemm.hip)
         self.variant = 'igemm_c4_128x64' if desc.cin == 4 else \
-            ('igemm_128x128', 'igemm_128x64', 'igemm_64x128', 'igemm_64x64')[_L.hnd_conv2d_igemm_tile(self.ref)]
+            ('igemm_128x128', 'igemm_128x64', 'igemm_64x128', 'igemm_64x64', 'thin_n4')[_L.hnd_conv2d_igemm_tile(self.ref)]
 
     def run(self, stream=None):
         rc = _L.hnd_conv2d_igemm(self.ref, stream if stream is not None else stream_ptr())

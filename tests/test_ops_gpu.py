@@ -4,6 +4,7 @@ Tolerances are written per test; convs are fp32 MFMA (exact fp32 products, diffe
 order than oneDNN) so 1e-4 relative-to-max is generous; the north-star bar is 1e-3.
 """
 import math
+import os
 
 import pytest
 import torch
@@ -786,3 +787,30 @@ def test_native_rccl_communicator_world_of_one(ops):
     assert L.hnd_allreduce_avg_flat(comm, None, 5, None) == -1                  # argument errors are reported
     assert L.hnd_comm_init(3, 2, uid.raw, nbytes, C.byref(C.c_void_p())) == -1
     assert L.hnd_comm_destroy(comm) == 0
+
+
+def test_thin_n_kernel_is_bit_identical_to_the_mfma_path(tmp_path):
+    """cout <= 4 launches (the 3-channel bottleneck: layer1.conv3 forward with BN prologue + statistics, conv4 data
+    gradient) run on a vector-ALU kernel that reproduces the MFMA kernel's accumulation order, epilogue expressions
+    and statistics tree: every output, every statistics partial, and two whole distillation steps (losses, updated
+    parameters, BN buffers) must be IDENTICAL BITS with the kernel switched off (HND_THIN_N=0: MFMA tiles) and on."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for mode in ('0', '1'):
+        out = str(tmp_path / ('thin%s.pt' % mode))
+        env = dict(os.environ, HND_THIN_N=mode)
+        res = subprocess.run([sys.executable, os.path.join(root, 'tests', 'thin_worker.py'), out], cwd=root, env=env,
+                             capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+        outs[mode] = torch.load(out, weights_only=False)
+    assert all(v != 'thin_n4' for v in outs['0']['variants'])
+    assert all(v == 'thin_n4' for v in outs['1']['variants']), outs['1']['variants']
+    assert outs['0']['losses'] == outs['1']['losses']
+    for k, v in outs['0'].items():
+        if isinstance(v, torch.Tensor):
+            assert torch.equal(v, outs['1'][k]), k
+    for grp in ('params', 'buffers'):
+        for k, v in outs['0'][grp].items():
+            assert torch.equal(v, outs['1'][grp][k]), (grp, k)
