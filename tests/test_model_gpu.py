@@ -737,7 +737,7 @@ def test_mimic_runner_two_ranks_share_one_gpu(tmp_path):
            '127.0.0.1', '--master-port', str(port), '-m', 'hnd_ghnd_object_detectors_amd.mimic_runner', '--config',
            cfg_path, '--json', json.dumps(override), '-distill', '--synthetic_batches', '3', '--image_size', '64x96',
            '--num_epochs', '1', '--world_size', '2']
-    res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=2400)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     assert 'distributed init (rank 0)' in res.stdout and 'Updating ckpt' in res.stdout
     ck = torch.load(ckpt, weights_only=False)
@@ -763,7 +763,7 @@ def test_two_ranks_take_the_oracle_step_on_the_mean_gradient(tmp_path):
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
            '127.0.0.1', '--master-port', str(port), os.path.join(root, 'tests', 'ddp_worker.py'), str(tmp_path),
            str(steps)]
-    res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=2400)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
     r0 = torch.load(str(tmp_path / 'rank0.pt'), weights_only=False)
     r1 = torch.load(str(tmp_path / 'rank1.pt'), weights_only=False)
@@ -1023,7 +1023,7 @@ def test_rccl_exchange_world_of_one(tmp_path, native):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     out = str(tmp_path / 'r.pt')
     cmd = [sys.executable, os.path.join(root, 'tests', 'rccl_world1_worker.py'), out] + (['native'] if native else [])
-    res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=2400)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
     r = torch.load(out, weights_only=False)
     assert r['plain']['losses'] == r['rccl']['losses']

@@ -73,7 +73,7 @@ def test_world2_gloo_gradient_allreduce_and_parameter_broadcast():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=300) for _ in range(2))
+    res = sorted(q.get(timeout=900) for _ in range(2))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -125,7 +125,7 @@ def test_world2_gloo_neural_filter_gradient_allreduce():
     procs = [ctx.Process(target=_ext_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=300) for _ in range(2))
+    res = sorted(q.get(timeout=900) for _ in range(2))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
