@@ -728,7 +728,10 @@ def test_mimic_runner_two_ranks_share_one_gpu(tmp_path):
                 'student_model': {'backbone': {'params': {'pretrained': False}},
                                   'params': {'pretrained': False, 'min_size': 64, 'max_size': 128}, 'ckpt': ckpt},
                 'train': {'batch_size': 2, 'log_freq': 1}}
-    env = dict(os.environ, HND_DIST_BACKEND='gloo', HND_SHARE_DEVICE='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    # two processes time-share the one GPU of a test box: one HIP stream each (no teacher side stream), so the pair
+    # stays within the hardware queues and the time slicing cannot degenerate (seen once: 15+ min instead of 5 s)
+    env = dict(os.environ, HND_DIST_BACKEND='gloo', HND_SHARE_DEVICE='1', HSA_ENABLE_IPC_MODE_LEGACY='0',
+               HND_TEACHER_STREAM='0')
     import socket
     with socket.socket() as sock:
         sock.bind(('127.0.0.1', 0))
@@ -759,7 +762,7 @@ def test_two_ranks_take_the_oracle_step_on_the_mean_gradient(tmp_path):
     with socket.socket() as sock:
         sock.bind(('127.0.0.1', 0))
         port = sock.getsockname()[1]
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', HND_TEACHER_STREAM='0')      # see the shared-GPU note above
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
            '127.0.0.1', '--master-port', str(port), os.path.join(root, 'tests', 'ddp_worker.py'), str(tmp_path),
            str(steps)]
