@@ -3,13 +3,17 @@
 The reference applies them ONLY at evaluation time with ``-transform_bottleneck`` (src/models/mimic/base.py:54-57;
 mimic_runner.py:90 disables them while distilling).  ``Quantizer`` / ``Dequantizer`` run as fused HIP kernels
 (global min/max -> affine uint8 quantise; dequantise) on the NHWC bottleneck buffer; the 16-bit variants are a
-half round trip.  JPEG codecs and the DataLogger of the reference are deployment/analysis tools outside the path.
+half round trip.  ``JpegCompressor`` / ``JpegDecompressor`` (:94-128: the uint8 bottleneck image through a JPEG file)
+and ``DataLogger`` (:58-91: pickled sizes of the bottleneck for the reference's cost analysis) are host-side file /
+bookkeeping utilities: the quantisation they contain runs on the same HIP kernel, the rest is PIL / pickle as in the
+reference.
 
 Input pipeline (reference :32-55): ``ToTensor`` keeps the decoded uint8 image as a
 ``DecodedImage`` instead of materialising a float CHW copy on the host, ``RandomHorizontalFlip`` only flips the
 (tiny) targets and marks the image; the /255, the flip and the model's normalise/resize/pad then run as ONE HIP
 kernel inside ``CustomRCNNTransform`` (hnd_transform_image_u8): 4x fewer host->device bytes, no host float work.
 """
+import os
 import random
 
 import numpy as np
@@ -125,8 +129,93 @@ class ToTensor(object):
 
 
 class DataLogger(object):
+    """reference :58-91: records, per call, the pickled size (KB) of the bottleneck tensor as it is, as int16
+    (``z.short()``, the reference's "fp16" figure) and quantised to ``num_bits``, plus its C / H / W; passes z through.
+    A bottleneck transformer for analysis runs (``models.get_model(..., bottleneck_transformer=DataLogger())``)."""
+
     def __init__(self, num_bits=8):
         self.num_bits4quant = num_bits
+        self.data_size_list, self.fp16_data_size_list = [], []
+        self.quantized_data_size_list, self.tensor_shape_list = [], []
+
+    def get_data(self):
+        return (self.data_size_list.copy(), self.fp16_data_size_list, self.quantized_data_size_list.copy(),
+                self.tensor_shape_list.copy())
+
+    def clear(self):
+        for lst in (self.data_size_list, self.fp16_data_size_list, self.quantized_data_size_list,
+                    self.tensor_shape_list):
+            lst.clear()
+
+    def __call__(self, z, target):
+        from ..myutils.common import file_util
+        if z is None:
+            sizes = (0.0, 0.0, 0.0)
+        elif not isinstance(z, torch.Tensor):
+            sizes = (file_util.get_binary_object_size(z), None, None)
+        else:
+            plain = z.detach().cpu().contiguous()               # logical NCHW values, as the reference pickles them
+            qz, _ = Quantizer(self.num_bits4quant)(z, None) if self.num_bits4quant == 8 else (plain.half(), None)
+            if isinstance(qz, QuantizedTensor):                  # what crosses the link: uint8 tensor + scale + zero point
+                qz = _HostQuantized(qz.tensor.cpu().contiguous(), float(qz.scale), int(qz.zero_point))
+            sizes = (file_util.get_binary_object_size(plain), file_util.get_binary_object_size(plain.short()),
+                     file_util.get_binary_object_size(qz))
+        self.data_size_list.append(sizes[0])
+        self.fp16_data_size_list.append(sizes[1])
+        self.quantized_data_size_list.append(sizes[2])
+        self.tensor_shape_list.append([0, 0, 0] if z is None else [z.shape[1], z.shape[2], z.shape[3]])
+        return z, target
+
+
+class _HostQuantized(object):
+    """host copy of a quantised bottleneck (uint8 tensor, python scale / zero point): what myutils' QuantizedTensor
+    pickles to"""
+
+    def __init__(self, tensor, scale, zero_point):
+        self.tensor, self.scale, self.zero_point = tensor, scale, zero_point
+
+
+class JpegCompressor(object):
+    """reference :94-114: a 3-channel bottleneck ([3, H, W] or [1, 3, H, W]) is quantised to uint8 (HIP kernel),
+    written as a JPEG file and replaced by ``(file path, quantised tensor)``; anything else passes through"""
+
+    def __init__(self, jpeg_quality=95, tmp_dir_path='./tmp/'):
+        self.jpeg_quality, self.tmp_dir_path = jpeg_quality, tmp_dir_path
+        os.makedirs(tmp_dir_path, exist_ok=True)
+        self._quantizer = Quantizer(8)
+
+    def save_image(self, z, output_file_path):
+        from PIL import Image
+        qz, _ = self._quantizer(z if z.dim() == 4 else z.unsqueeze(0), None)
+        hwc = qz.tensor[0].permute(1, 2, 0).cpu().numpy()
+        Image.fromarray(np.ascontiguousarray(hwc)).save(output_file_path, format='jpeg', quality=self.jpeg_quality)
+        return qz
+
+    def __call__(self, z, target):
+        if isinstance(z, torch.Tensor) and ((z.dim() == 3 and z.shape[0] == 3) or
+                                            (z.dim() == 4 and z.shape[0] == 1 and z.shape[1] == 3)):
+            file_path = os.path.join(self.tmp_dir_path, '{}.jpg'.format(hash(z)))
+            return (file_path, self.save_image(z, file_path)), target
+        return z, target
+
+
+class JpegDecompressor(object):
+    """reference :117-128: ``(file path, quantised tensor)`` -> decoded RGB * 255 de-quantised with the stored scale /
+    zero point: ``scale * (pixel - zero_point)``, as [1, 3, H, W] (target_dim 4) or [3, H, W], on the device the
+    quantised tensor lives on"""
+
+    def __init__(self, tmp_dir_path='./tmp/', target_dim=4):
+        self.tmp_dir_path, self.target_dim = tmp_dir_path, target_dim
+
+    def __call__(self, z, target):
+        if isinstance(z, tuple) and isinstance(z[0], str):
+            from PIL import Image
+            qz = z[1]
+            arr = np.array(Image.open(z[0]).convert("RGB"), dtype=np.uint8)          # a writable copy
+            pix = torch.from_numpy(np.ascontiguousarray(arr)).permute(2, 0, 1).float().div(255).to(qz.tensor.device)
+            img = qz.scale * (pix * 255.0 - qz.zero_point)      # functional.to_tensor(img) * 255.0 in the reference
+            return (img if self.target_dim != 4 else img.unsqueeze(0)), target
+        return z, target
 
 
 class QuantizedTensor(object):
@@ -176,7 +265,8 @@ class Dequantizer(object):
         return attach(z, out), target
 
 
-TRANSFORMER_CLASS_DICT = {'quantizer': Quantizer, 'dequantizer': Dequantizer}
+TRANSFORMER_CLASS_DICT = {'jpeg_compressor': JpegCompressor, 'jpeg_decompressor': JpegDecompressor,
+                          'quantizer': Quantizer, 'dequantizer': Dequantizer}
 
 
 def get_bottleneck_transformer(transformer_config):

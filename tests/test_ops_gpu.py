@@ -814,3 +814,45 @@ def test_thin_n_kernel_is_bit_identical_to_the_mfma_path(tmp_path):
     for grp in ('params', 'buffers'):
         for k, v in outs['0'][grp].items():
             assert torch.equal(v, outs['1'][grp][k]), (grp, k)
+
+
+def test_jpeg_codec_and_data_logger_follow_the_reference(tmp_path):
+    """structure/transformer.py JpegCompressor / JpegDecompressor / DataLogger (reference :58-128): the 3-channel
+    bottleneck is quantised by the HIP codec (byte-exact to myutils' quantize_tensor), written as a JPEG with PIL and
+    de-quantised with the stored scale / zero point -- identical bytes in give an identical file and an identical
+    reconstruction to the restated reference chain on the CPU; DataLogger records the reference's three sizes."""
+    import numpy as np
+    from PIL import Image
+    from oracle import myutils_r as MR
+    from hnd_ghnd_object_detectors_amd.structure import transformer as T
+    g = torch.Generator().manual_seed(3)
+    z = torch.randn(1, 3, 51, 68, generator=g) * 2.0 + 0.3
+    comp = T.JpegCompressor(jpeg_quality=90, tmp_dir_path=str(tmp_path / 'jpg'))
+    dec = T.JpegDecompressor(tmp_dir_path=str(tmp_path / 'jpg'), target_dim=4)
+    (path, qz), _ = comp(z.to(DEV), None)
+    out, _ = dec((path, qz), None)
+    # the reference chain on the CPU
+    rq = MR.quantize_tensor(z.squeeze(0))
+    ref_file = str(tmp_path / 'ref.jpg')
+    Image.fromarray(rq.tensor.permute(1, 2, 0).numpy()).save(ref_file, format='jpeg', quality=90)
+    assert open(path, 'rb').read() == open(ref_file, 'rb').read()
+    pix = torch.from_numpy(np.asarray(Image.open(ref_file).convert('RGB'))).permute(2, 0, 1).float().div(255)
+    ref = (rq.scale * (pix * 255.0 - rq.zero_point)).unsqueeze(0)
+    assert tuple(out.shape) == (1, 3, 51, 68) and torch.equal(out.cpu(), ref)
+    passthrough, _ = comp(torch.zeros(2, 5, 4, 4, device=DEV), None)            # not a 3-channel image: untouched
+    assert isinstance(passthrough, torch.Tensor)
+    tr = T.get_bottleneck_transformer({'order': ['jpeg_compressor', 'jpeg_decompressor'], 'components': {
+        'jpeg_compressor': {'params': {'jpeg_quality': 90, 'tmp_dir_path': str(tmp_path / 'j2')}},
+        'jpeg_decompressor': {'params': {'tmp_dir_path': str(tmp_path / 'j2'), 'target_dim': 4}}}})
+    again, _ = tr(z.to(DEV), None)
+    assert torch.equal(again.cpu(), ref)
+    log = T.DataLogger()
+    same, _ = log(z.to(DEV), None)
+    log(None, None)
+    sizes, fp16, quant, shapes = log.get_data()
+    assert same.data_ptr() == same.data_ptr() and shapes == [[3, 51, 68], [0, 0, 0]] and sizes[1] == 0.0
+    assert abs(sizes[0] - MR.get_binary_object_size(z)) < 0.01                  # KB of the pickled fp32 tensor
+    assert abs(fp16[0] - MR.get_binary_object_size(z.short())) < 0.01
+    assert 3 * 51 * 68 / 1024 < quant[0] < 3 * 51 * 68 / 1024 + 1.5             # uint8 payload + a small header
+    log.clear()
+    assert log.get_data() == ([], [], [], [])
