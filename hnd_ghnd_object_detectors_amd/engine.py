@@ -541,7 +541,10 @@ class HeadEngine(object):
                 z._hnd = self.y[i]
                 z2, _ = codec(z, None)
                 if getattr(z2, '_hnd', None) is not self.y[i]:
-                    raise RuntimeError('bottleneck transformer must return the (de)quantised tensor in place')
+                    # a transformer that builds a new tensor (the JPEG pair): lay it back into the plan's buffer
+                    if not isinstance(z2, torch.Tensor) or tuple(z2.shape) != tuple(z.shape):
+                        raise RuntimeError('bottleneck transformer must return a tensor of the bottleneck\'s shape')
+                    self.y[i][..., :hc.cout].copy_(z2.to(self.y[i].device).permute(0, 2, 3, 1))
             if training:
                 bn = hc.bn
                 m = self.count[i]

@@ -44,7 +44,8 @@ class BottleneckBase4Ext(nn.Module):
         self.bottleneck_transformer = bottleneck_transformer
         self.use_bottleneck_transformer = False
         self.uses_ext_encoder = isinstance(encoder, ExtEncoder) and encoder.ext_classifier is not None
-        self.data_logging = False
+        from ...structure.transformer import DataLogger
+        self.data_logging = isinstance(bottleneck_transformer, DataLogger)       # reference :34
         self._engine = None
 
     def head_layers(self):
@@ -61,6 +62,8 @@ class BottleneckBase4Ext(nn.Module):
         if self.uses_ext_encoder:                       # reference :38-48 via ExtEncoder.forward_with_ext
             go_on, ext_z = self.encoder.filter(x)
             if not go_on:
+                if self.data_logging:                   # reference :40-42: a rejected image logs an empty bottleneck
+                    self.bottleneck_transformer(None, target=None)
                 return None, ext_z
         use_codec = self.use_bottleneck_transformer and not self.training and self.bottleneck_transformer is not None
         out = self.head_engine().forward(to_nhwc(x), self.training,

@@ -1032,3 +1032,36 @@ def test_rccl_exchange_world_of_one(tmp_path, native):
     assert r['plain']['losses'] == r['rccl']['losses']
     for k, v in r['plain']['params'].items():
         assert torch.equal(v, r['rccl']['params'][k]), k
+
+
+def test_jpeg_bottleneck_and_data_logger_run_inside_the_eval_model(tmp_path):
+    """get_model(..., bottleneck_transformer=...) with the file's other transformers (reference transformer.py:58-128,
+    base.py:34,54-57): a DataLogger leaves the features untouched and records one entry per eval forward; the JPEG
+    compressor / decompressor pair changes the features a little (lossy) but not much"""
+    from hnd_ghnd_object_detectors_amd.structure import transformer as T
+    z, meta = G.load('tiny_eval_quantized')
+    cfg = MU.config_for(meta)
+    t_sd, s_sd = MU.oracle_states(meta['seed'])
+    _, student = MU.build_pair(cfg, t_sd, s_sd, DEV)
+    student.eval()
+    images, _ = G.case_inputs(meta)
+    ims = [im.to(DEV) for im in images[:1]]             # one image: the JPEG codec takes [1, 3, H, W]
+    layer1 = student.backbone.body.layer1
+    with torch.no_grad():
+        layer1.use_bottleneck_transformer = False
+        plain = OrderedDict((k, v.clone()) for k, v in student(ims).items())
+        log = T.DataLogger()
+        layer1.bottleneck_transformer, layer1.data_logging = log, True
+        layer1.use_bottleneck_transformer = True
+        logged = student(ims)
+        for k in plain:
+            assert torch.equal(logged[k], plain[k]), k
+        sizes, _, quant, shapes = log.get_data()
+        assert len(sizes) == 1 and shapes[0][0] == 3 and 0 < quant[0] < sizes[0]
+        layer1.bottleneck_transformer = T.Compose([T.JpegCompressor(95, str(tmp_path / 'jpg')),
+                                                   T.JpegDecompressor(str(tmp_path / 'jpg'), 4)])
+        layer1.data_logging = False
+        lossy = student(ims)
+        k0 = list(plain)[0]
+        rel = float((lossy[k0] - plain[k0]).norm() / plain[k0].norm())
+        assert 0.0 < rel < 0.25, rel
