@@ -82,3 +82,16 @@ def make_ext_config(bch=3, batch_size=2, pretrained=True, min_size=None, max_siz
                       'optimizer': {'type': 'SGD', 'params': {'lr': 0.001, 'momentum': 0.9, 'weight_decay': 0.0001}},
                       'scheduler': {'type': 'MultiStepLR', 'params': {'milestones': [15, 25], 'gamma': 0.1}}},
             'test': {'batch_size': 1}}
+
+
+def make_org_config(model='faster_rcnn', pretrained=True, min_size=None, max_size=None, ckpt_root='./resource/ckpt'):
+    """the schema of the reference's config/org/<model>-backbone_resnet50.yaml (the original detectors: what
+    src/coco_runner.py trains / evaluates and the hnd/ghnd teachers are loaded from)"""
+    base = make_config(model, 'ghnd', 3, 2, pretrained, min_size, max_size, ckpt_root)
+    keypoint = model == 'keypoint_rcnn'
+    return {'dataset': base['dataset'], 'model': base['teacher_model'],
+            'train': {'num_epochs': 46 if keypoint else 26, 'batch_size': 2, 'log_freq': 1000,
+                      'optimizer': {'type': 'SGD', 'params': {'lr': 0.0075, 'momentum': 0.9, 'weight_decay': 0.0001}},
+                      'scheduler': {'type': 'MultiStepLR',
+                                    'params': {'milestones': [36, 43] if keypoint else [16, 22], 'gamma': 0.1}}},
+            'test': {'batch_size': 1}}

@@ -69,6 +69,11 @@ def test_generated_yaml_equals_builder_and_reference_yaml_loads():
             gen = make_config(name, method, 3)
             for section in ('teacher_model', 'student_model', 'train', 'test', 'dataset'):
                 assert ref[section] == gen[section], (method, name, section)
+        from hnd_ghnd_object_detectors_amd.configs import make_org_config
+        for name in ('faster_rcnn', 'mask_rcnn', 'keypoint_rcnn'):       # config/org: what coco_runner evaluates
+            ref = yaml_util.load_yaml_file('%s/org/%s-backbone_resnet50.yaml' % (REF_CONFIG, name))
+            assert ref == make_org_config(name) == yaml_util.load_yaml_file(
+                os.path.join(root, 'config/org/%s-backbone_resnet50.yaml' % name)), name
 
 
 def test_json_override_and_warmup_schedule():

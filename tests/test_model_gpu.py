@@ -1065,3 +1065,29 @@ def test_jpeg_bottleneck_and_data_logger_run_inside_the_eval_model(tmp_path):
         k0 = list(plain)[0]
         rel = float((lossy[k0] - plain[k0]).norm() / plain[k0].norm())
         assert 0.0 < rel < 0.25, rel
+
+
+def test_coco_runner_evaluates_an_original_detector(tmp_path, capsys):
+    """src/coco_runner.py without -train (:131-132): config/org yaml -> get_model -> main_util.evaluate on the test
+    split.  Keypoint R-CNN on a COCO-format folder with person keypoints: the eval-mode detector incl. its keypoint
+    branch runs on the HIP path, both metrics are summarised; -train is refused (detector losses are not built)."""
+    import json
+    import os
+    from tests.coco_fixture import write_tiny_coco
+    from hnd_ghnd_object_detectors_amd import coco_runner
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    img_dir, ann_file = write_tiny_coco(str(tmp_path / 'coco'))
+    cfg_path = os.path.join(root, 'config', 'org', 'keypoint_rcnn-backbone_resnet50.yaml')
+    split = {'images': img_dir, 'annotations': ann_file}
+    override = {'dataset': {'num_workers': 0, 'splits': {'train': split, 'val': split, 'test': split}},
+                'model': {'backbone': {'params': {'pretrained': False}}, 'ckpt': str(tmp_path / 'none.pt'),
+                          'params': {'pretrained': False, 'min_size': [48, 56, 64], 'max_size': 128}}}
+    torch.manual_seed(0)
+    ev = coco_runner.main(coco_runner.get_argparser().parse_args(['--config', cfg_path, '--json', json.dumps(override)]))
+    out = capsys.readouterr().out
+    assert sorted(ev.coco_eval) == ['bbox', 'keypoints'] and 'IoU metric: keypoints' in out
+    assert ev.coco_eval['bbox'].stats.shape == (12,) and ev.coco_eval['keypoints'].stats.shape == (10,)
+    assert -1.0 <= ev.coco_eval['keypoints'].stats[0] <= 1.0
+    with pytest.raises(NotImplementedError):
+        coco_runner.main(coco_runner.get_argparser().parse_args(['--config', cfg_path, '--json', json.dumps(override),
+                                                                  '-train']))
