@@ -164,3 +164,15 @@ def get_coco(img_dir_path, ann_file_path, transforms, remove_non_annotated_imgs,
     if remove_non_annotated_imgs:
         dataset = remove_images_without_annotations(dataset)
     return dataset
+
+
+def get_coco_api_from_dataset(dataset):
+    """reference :198-206 lives in this module; the ground-truth index it returns is built by coco_eval_util"""
+    from .coco_eval_util import get_coco_api_from_dataset as build
+    return build(dataset)
+
+
+def convert_to_coco_api(ds):
+    """reference :148-195: a dataset of (image, target) pairs -> ground-truth index (same builder: a dataset without
+    ``.coco`` annotations is walked target by target)"""
+    return get_coco_api_from_dataset(ds)
