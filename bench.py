@@ -3,8 +3,14 @@
 batch 16 per GPU of synthetic 3x800x1333 images (network sees 800x1344), fp32, on 1..8 MI355X.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 8 --steps 20 --warmup 5          # starts its own 8 ranks (child processes), one per GPU
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W              # or ranks started by a launcher (RANK/WORLD_SIZE in env)
+
+With --gpus N > 1 and no RANK in the environment the process becomes a LAUNCHER: it never touches the GPU, starts N
+copies of itself as child processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT set, the
+reference's env:// rendezvous, src/utils/main_util.py:43-62), relays rank 0's JSON line and exits with the worst
+child exit code.  It refuses (non-zero) when the node has fewer than N GPUs unless --share_device is given.
 
 One "step" = what mimic_runner.distill_model does per batch (reference src/mimic_runner.py:48-58):
 DistillationBox forward (teacher + student incl. the FPN both run, as written), zero_grad, backward,
@@ -22,9 +28,6 @@ import os
 import re
 import sys
 import time
-
-import torch
-import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -54,6 +57,85 @@ def parse():
     ap.add_argument('--share_device', action='store_true', help='testing: every rank uses cuda:0')
     ap.add_argument('--detail', default=None, help='write the per-launch table of the profiled step to this file')
     return ap.parse_args()
+
+
+def free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(args):
+    """--gpus N without a launcher: become one.  The parent makes no HIP call (torch.cuda.device_count() does not
+    initialise the runtime on this image) and execs nothing: the ranks are plain child processes."""
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()
+    if have < args.gpus and not args.share_device:
+        sys.stderr.write('bench.py: --gpus %d but this node exposes %d GPU(s); refusing to report a %d-GPU number '
+                         '(--share_device puts every rank on cuda:0 for plumbing tests only)\n'
+                         % (args.gpus, have, args.gpus))
+        return 2
+    if have < 1:
+        sys.stderr.write('bench.py needs an MI355X: the HIP path has no CPU fallback\n')
+        return 2
+    port = free_port()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HND_BENCH_LAUNCHED='1')
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')        # dmabuf IPC: required by RCCL on this pool
+        env.setdefault('OMP_NUM_THREADS', '8')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    raw = procs[0].stdout.read().decode()      # rank 0 prints the JSON line; native libraries (gloo, RCCL
+    line = ''.join(l + '\n' for l in raw.splitlines() if l.startswith('{"metric"'))      # debug) may add their own
+    sys.stderr.write(''.join(l + '\n' for l in raw.splitlines() if l.strip() and not l.startswith('{"metric"')))
+    codes, deadline = [], None
+    for r, pr in enumerate(procs):
+        try:
+            codes.append(pr.wait(timeout=None if deadline is None else max(1.0, deadline - time.time())))
+        except subprocess.TimeoutExpired:      # a rank outlived a failed sibling by a minute: stop THAT pid
+            pr.kill()
+            codes.append(pr.wait())
+        if codes[-1] != 0 and deadline is None:
+            deadline = time.time() + 60.0
+    sys.stdout.write(line)
+    sys.stdout.flush()
+    bad = [c for c in codes if c != 0]
+    if bad:
+        sys.stderr.write('bench.py: rank exit codes %s\n' % codes)
+        return bad[0] if bad[0] > 0 else 1
+    return 0
+
+
+def gpu_cpu_affinity(local_rank):
+    """bind this rank to the CPUs of the NUMA node its GPU hangs off (KFD topology -> PCI local_cpulist), before
+    torch spins its thread pools up.  Best effort: returns the description that goes into the JSON line."""
+    try:
+        gpus = []
+        top = '/sys/class/kfd/kfd/topology/nodes'
+        for node in sorted(os.listdir(top), key=int):
+            props = dict(l.split() for l in open(os.path.join(top, node, 'properties')) if len(l.split()) == 2)
+            if int(props.get('simd_count', 0)) > 0:
+                gpus.append(props)
+        props = gpus[local_rank]
+        loc, dom = int(props['location_id']), int(props.get('domain', 0))
+        bdf = '%04x:%02x:%02x.%d' % (dom, (loc >> 8) & 0xff, (loc >> 3) & 0x1f, loc & 7)
+        cpus = open('/sys/bus/pci/devices/%s/local_cpulist' % bdf).read().strip()
+        ids = set()
+        for part in cpus.split(','):
+            lo, _, hi = part.partition('-')
+            ids.update(range(int(lo), int(hi or lo) + 1))
+        ids &= os.sched_getaffinity(0)
+        if not ids:
+            return 'unbound (empty local_cpulist for %s)' % bdf
+        os.sched_setaffinity(0, ids)
+        node = open('/sys/bus/pci/devices/%s/numa_node' % bdf).read().strip()
+        return 'gpu %d @ %s -> numa node %s, cpus %s' % (local_rank, bdf, node, cpus)
+    except Exception as exc:            # unknown topology layout: stay unbound rather than guess
+        return 'unbound (%s: %s)' % (type(exc).__name__, exc)
 
 
 def physical_cores():
@@ -95,25 +177,36 @@ def cpu_baseline(teacher, student, args, terms):
 
 
 def first_loss_reference(args, rank):
-    """the CPU oracle's loss for this run's first step (same seeded weights and batch), or None if the
-    configuration is not one of the pinned ones"""
+    """the CPU oracle's losses (total per method + per term) for this run's first step (same seeded weights and
+    batch), or None if the configuration is not one of the pinned ones"""
     if (args.height, args.width) != (800, 1333):
         return None
     try:
         cases = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'bench_first_loss.json')))['cases']
     except (OSError, ValueError, KeyError):
         return None
-    case = cases.get('%s/batch%d/rank%d' % (args.model, args.batch, rank))
-    return None if case is None else case[args.method]
+    return cases.get('%s/batch%d/rank%d' % (args.model, args.batch, rank))
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        sys.exit(launch_ranks(args))            # this process stays off the GPU; the ranks are its children
+    run_rank(args)
+
+
+def run_rank(args):
+    global torch, dist
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
-    if world != args.gpus and world > 1:
-        raise SystemExit('WORLD_SIZE=%d but --gpus %d' % (world, args.gpus))
+    if world != args.gpus:
+        raise SystemExit('WORLD_SIZE=%d but --gpus %d: the line would be mislabelled' % (world, args.gpus))
+    affinity = gpu_cpu_affinity(0 if args.share_device else local_rank) if world > 1 else 'unbound (single rank)'
+    import torch
+    import torch.distributed as dist
+    if not args.share_device and torch.cuda.device_count() < world:
+        raise SystemExit('bench.py: %d ranks but %d visible GPU(s)' % (world, torch.cuda.device_count()))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the HIP path has no CPU fallback')
     if args.share_device:
@@ -150,8 +243,13 @@ def main():
     targets = [{'boxes': torch.tensor([[0.125 * w, 0.125 * h, 0.5 * w, 0.5 * h]], device=dev),
                 'labels': torch.tensor([1], device=dev)} for _ in range(args.batch)]
 
-    def step(sync=True):
+    term_names = list(config['train']['criterion']['terms'].keys())
+    term_values = {}
+
+    def step(sync=True, keep_terms=False):
         loss = box(images, [dict(t) for t in targets])
+        if keep_terms:                                          # the fused loss launch's per-term sums (fp64)
+            term_values.update(zip(term_names, (float(v) for v in loss.per_term.tolist())))
         optimizer.zero_grad()
         loss.backward()                                         # N > 1: fires the flat gradient all-reduce (RCCL)
         optimizer.step()                                        # waits for it stream-side, applies the 1/world mean
@@ -163,27 +261,42 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- parity gate, outside the timed region: this run's very first step against the CPU oracle's loss
-    first = step()
-    ref_first = first_loss_reference(args, rank)
+    # ---- parity gate, outside the timed region: this run's very first step against the CPU oracle -- the total AND
+    # every term (layer1 is 96 % of the GHND total: a gate on the total alone could not see layer3 / layer4 at all)
+    first = step(keep_terms=True)
+    ref_case = first_loss_reference(args, rank)
     loss_check, bad = None, 0
-    if ref_first is not None:
+    if ref_case is not None:
+        ref_first = ref_case[args.method]
         rel = abs(first - ref_first) / abs(ref_first)
-        loss_check = {'first_step_loss': first, 'oracle': ref_first, 'rel_err': rel, 'tol': 1e-3,
-                      'source': 'tests/golden/bench_first_loss.json'}
-        bad = 0 if rel < 1e-3 else 1
+        terms_chk = {k: {'got': term_values[k], 'oracle': ref_case['terms'][k],
+                         'rel_err': abs(term_values[k] - ref_case['terms'][k]) / abs(ref_case['terms'][k])}
+                     for k in term_names}
+        worst = max([rel] + [t['rel_err'] for t in terms_chk.values()])
+        loss_check = {'first_step_loss': first, 'oracle': ref_first, 'rel_err': rel, 'terms': terms_chk,
+                      'worst_rel_err': worst, 'tol': 1e-3, 'source': 'tests/golden/bench_first_loss.json'}
+        bad = 0 if worst < 1e-3 else 1
+    elif (args.height, args.width, args.model) == (800, 1333, 'faster_rcnn') and args.batch == 16:
+        bad = 1                     # the benchmarked configuration must never run ungated
     if world > 1:                   # every rank learns the verdict, so nobody is left waiting in a collective
-        flag = torch.tensor([bad], dtype=torch.int32, device=dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-        any_bad = int(flag.item())
+        flag = torch.tensor([bad, 0 if loss_check is None else 1], dtype=torch.int32, device=dev)
+        worst_t = torch.tensor([0.0 if loss_check is None else loss_check['worst_rel_err']], dtype=torch.float64,
+                               device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.SUM)
+        dist.all_reduce(worst_t, op=dist.ReduceOp.MAX)
+        any_bad, gated_ranks, worst_all = int(flag[0].item()), int(flag[1].item()), float(worst_t.item())
     else:
-        any_bad = bad
+        any_bad, gated_ranks = bad, 0 if loss_check is None else 1
+        worst_all = None if loss_check is None else loss_check['worst_rel_err']
     if any_bad:
         if world > 1:
             dist.destroy_process_group()
-        raise SystemExit('bench.py: first-step loss differs from the CPU oracle\'s by more than 1e-3 on rank(s) of this '
-                         'run (rank %d: got %r, oracle %r): the HIP path is wrong at the benchmarked configuration'
-                         % (rank, first, ref_first))
+        raise SystemExit('bench.py: first-step loss (total or a term) differs from the CPU oracle\'s by more than 1e-3 '
+                         'on %d rank(s) of this run, or the benchmarked configuration has no pinned loss (rank %d: %r): '
+                         'the HIP path is wrong at the benchmarked configuration' % (any_bad, rank, loss_check))
+    if loss_check is not None:
+        loss_check['ranks_gated'] = gated_ranks
+        loss_check['worst_rel_err_all_ranks'] = worst_all
     last = first
     for _ in range(args.warmup - 1):
         last = step()
@@ -193,10 +306,19 @@ def main():
         last = step()
     fence()
     elapsed = time.perf_counter() - t0
+    rank_ms = [elapsed / args.steps * 1e3]
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        t = torch.zeros(world, dtype=torch.float64, device=dev)
+        t[rank] = elapsed
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        rank_ms = [round(v / args.steps * 1e3, 3) for v in t.tolist()]
+        elapsed = float(t.max().item())                          # MAX over ranks
+    rccl_ranks = dist.get_world_size() if (world > 1 and dist.get_backend() == 'nccl') else (1 if world == 1 else 0)
+    exchange = 'none (1 rank)'
+    if world > 1:
+        exchange = '%s all-reduce of the flat %d-float gradient arena, %d fired in %d steps on this rank' % (
+            'RCCL (torch.distributed nccl)' if dist.get_backend() == 'nccl' else dist.get_backend(),
+            student.backbone.body._grad_arena.total, student_w.reductions, args.warmup + args.steps)
 
     # ---- untimed extras (every rank runs them: the steps contain the all-reduce)
     # host enqueue cost: wall time to ISSUE a step with no host sync in it (what one Python process per GPU pays)
@@ -319,6 +441,10 @@ def main():
         'conv3x3_roofline': conv3x3,
         'head2x2_roofline': head2x2,
         'loss_check': loss_check,
+        'ranks': {'world': world, 'rccl_ranks': rccl_ranks, 'backend': dist.get_backend() if world > 1 else None,
+                  'ms_per_step_per_rank': rank_ms, 'exchange': exchange, 'rank0_affinity': affinity,
+                  'launched_by': 'bench.py' if os.environ.get('HND_BENCH_LAUNCHED') else
+                                 ('external launcher' if world > 1 else 'single process')},
         'run_cfg': run_cfg,
         'host_enqueue_ms_per_step': round(host_enqueue_ms, 3),
         'step_conv_tflops': round(gflop_img * args.batch / (ms_per_step / 1e3) / 1e3, 2),

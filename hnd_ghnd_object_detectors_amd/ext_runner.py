@@ -207,6 +207,8 @@ def main(args):
         train(model, ext_classifier, train_loader, val_loader, device, distributed, config, args, ckpt_file_path)
         load_ckpt(ckpt_file_path, model=ext_classifier)         # evaluate the best classifier, not the last
     evaluate(model, test_loader, device=device, min_recall=args.min_recall, split_name='Test')
+    if isinstance(model, DistributedStudent):
+        model.close()
 
 
 if __name__ == '__main__':

@@ -187,6 +187,8 @@ def main(args):
         evaluate(teacher_model, student_model, test_loader, device, args.skip_teacher_eval, args.transform_bottleneck)
     else:
         print('no dataset (--synthetic_batches): COCO evaluation skipped; checkpoint: {}'.format(student_config['ckpt']))
+    if isinstance(student_model, DistributedStudent):
+        student_model.close()               # native RCCL communicator + its stream, before the process group goes
 
 
 if __name__ == '__main__':

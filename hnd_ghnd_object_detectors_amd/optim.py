@@ -79,7 +79,7 @@ class FusedAdam(torch.optim.Adam):
             flat_g = self._grads_are_flat(flat, plist) if not flat.get('per_tensor') else None
             # gradient all-reduces fired from inside backward (parallel.DistributedStudent): wait stream-side, and
             # fold the 1/world mean of a sum all-reduce into this launch
-            grad_scale = self.grad_scale * parallel.finish_pending(flat_g)
+            grad_scale = self.grad_scale * parallel.finish_pending(flat_g if flat_g is not None else [p.grad for p in plist], plist)
             if flat_g is not None and all(p.data_ptr() == flat['p'].data_ptr() + o * 4
                                           for o, p in zip(flat['offsets'], plist)):
                 step = int(self.state[plist[0]]['step']) + 1
@@ -150,7 +150,7 @@ class FusedSGD(torch.optim.SGD):
                 flat = self._flatten(plist)
                 self._flat = flat
             flat_g = FusedAdam._grads_are_flat(self, flat, plist) if not flat.get('per_tensor') else None
-            grad_scale = self.grad_scale * parallel.finish_pending(flat_g)
+            grad_scale = self.grad_scale * parallel.finish_pending(flat_g if flat_g is not None else [p.grad for p in plist], plist)
             if flat_g is not None and all(p.data_ptr() == flat['p'].data_ptr() + o * 4
                                           for o, p in zip(flat['offsets'], plist)):
                 ops.sgd_step_flat(flat['p'], flat_g, flat['b'], *hyper, first_step=not flat['started'],

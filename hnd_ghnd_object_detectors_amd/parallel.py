@@ -28,21 +28,58 @@ import torch
 import torch.distributed as dist
 from torch import nn
 
-# reductions in flight: (flat tensor, waiter, scale) -- consumed by finish_pending() from the fused optimizers
-_PENDING = []
+# reductions in flight, keyed by the arena they belong to: id(arena) -> (flat tensor, waiter, scale).  Each fused
+# optimizer group consumes ONLY the entry whose flat arena holds the gradients it is about to apply.
+_PENDING = {}
+# id(parameter) of every tensor a DistributedStudent of world > 1 is responsible for: an optimizer step over one of
+# them with no exchanged gradient is an unsynchronised step and is refused
+_GUARDED = set()
 
 
-def finish_pending(flat_grad=None):
-    """Called by FusedAdam / FusedSGD right before their launch: make the current stream wait for every gradient
-    all-reduce in flight and return the factor the summed gradients still have to be multiplied by (1/world for a
-    sum all-reduce, 1.0 when nothing was pending or the exchange already averaged)."""
-    scale = 1.0
-    while _PENDING:
-        flat, waiter, s = _PENDING.pop()
+def _covers(flat, grad):
+    lo = flat.data_ptr()
+    return lo <= grad.data_ptr() < lo + flat.numel() * 4
+
+
+def finish_pending(grads=None, params=()):
+    """Called by FusedAdam / FusedSGD right before their launch with the gradients they are about to consume (the
+    flat arena view, or the per-tensor gradients): make the current stream wait for the all-reduce of THAT arena and
+    return the factor the summed gradients still have to be multiplied by (1/world for a sum all-reduce, 1.0 when the
+    exchange already averaged or the tensors are not data-parallel).  Entries of other arenas stay pending for their
+    own optimizer.  Raises when only part of the gradients was exchanged, or when a parameter guarded by a
+    DistributedStudent is stepped without any exchange (it would train unsynchronised across ranks)."""
+    if grads is None:
+        grads = []
+    elif isinstance(grads, torch.Tensor):
+        grads = [grads]
+    scale, hit = 1.0, 0
+    for key in list(_PENDING):
+        flat, waiter, s = _PENDING[key]
+        inside = [_covers(flat, g) for g in grads]
+        if not any(inside):
+            continue
+        if not all(inside):
+            raise RuntimeError('finish_pending: only %d of %d gradients of this optimizer group lie in the all-reduced '
+                               'arena; the group would mix averaged and local gradients' % (sum(inside), len(inside)))
+        del _PENDING[key]
         waiter()
-        if flat_grad is None or flat.data_ptr() == flat_grad.data_ptr():
-            scale = s
+        scale, hit = s, hit + 1
+    if hit > 1:
+        raise RuntimeError('finish_pending: the gradients of one optimizer group matched %d exchanged arenas' % hit)
+    if not hit and any(id(p) in _GUARDED for p in params):
+        raise RuntimeError('optimizer.step() on data-parallel parameters whose gradients were not all-reduced in this '
+                           'step: loss.backward() must run through the DistributedStudent-wrapped model (the exchange '
+                           'fires from inside its backward)')
     return scale
+
+
+def _post(arena, flat, waiter, scale):
+    """register the exchange of `arena`; a previous, never consumed one of the same arena (backward without an
+    optimizer step) is completed and dropped first so entries cannot pile up"""
+    old = _PENDING.pop(id(arena), None)
+    if old is not None:
+        old[1]()
+    _PENDING[id(arena)] = (flat, waiter, scale)
 
 
 class _NativeComm(object):
@@ -102,6 +139,22 @@ class DistributedStudent(nn.Module):
             ext = body.get_ext_classifier() if hasattr(body, 'get_ext_classifier') else None
             if ext is not None:                    # neural-filter training: its 14 tensors have their own arena
                 ext._post_backward = self._on_backward_done
+            self._guarded = [id(p) for p in module.parameters() if p.requires_grad]
+            _GUARDED.update(self._guarded)
+
+    def close(self):
+        """release the native RCCL communicator (before dist.destroy_process_group) and the step guard"""
+        _GUARDED.difference_update(getattr(self, '_guarded', ()))
+        self._guarded = []
+        if self.native is not None:
+            self.native.close()
+            self.native = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:        # interpreter teardown: the library may already be gone
+            pass
 
     def attach_optimizer(self, optimizer):
         """kept for callers of the round-1 API; the fused optimizers pick the mean factor up by themselves"""
@@ -131,20 +184,24 @@ class DistributedStudent(nn.Module):
                                    'mimic_runner.distill_model does -- gradient accumulation is not supported')
         self.reductions += 1
         if self.native is not None:
-            _PENDING.append((flat, self.native.all_reduce_avg(flat), 1.0))
+            _post(arena, flat, self.native.all_reduce_avg(flat), 1.0)
             return
         work = dist.all_reduce(flat, async_op=True)              # sum; 1/world is folded into the optimizer launch
-        _PENDING.append((flat, work.wait, 1.0 / self.world))
+        _post(arena, flat, work.wait, 1.0 / self.world)
 
     def reduce_gradients(self):
         """explicit form of round 1's loop (between loss.backward() and optimizer.step()).  The exchange now fires
         from inside backward, so this only covers models whose gradients did not come from a flat arena."""
-        if self.world == 1 or _PENDING or self.reductions:
+        if self.world == 1:
             return
         for p in self.module.parameters():
-            if p.grad is not None:
-                dist.all_reduce(p.grad)
-                p.grad.mul_(1.0 / self.world)
+            if p.grad is None or any(_covers(f, p.grad) for f, _, _ in _PENDING.values()):
+                continue                     # exchanged (or being exchanged) through its arena
+            if id(p) in _GUARDED:
+                raise RuntimeError('reduce_gradients: a data-parallel parameter has a gradient outside every '
+                                   'exchanged arena; its backward bypassed the DistributedStudent hook')
+            dist.all_reduce(p.grad)
+            p.grad.mul_(1.0 / self.world)
 
 
 def all_reduce_flat_(flat, world):

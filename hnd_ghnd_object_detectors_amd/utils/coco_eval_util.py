@@ -342,7 +342,9 @@ class CocoEvaluator(object):
         self.results = {t: [] for t in self.iou_types}
 
     def update(self, predictions):
-        self.img_ids.extend(sorted(set(predictions.keys())))
+        have = set(self.img_ids)          # a sampler-padded repeat of an image already scored here is dropped whole
+        predictions = {k: v for k, v in predictions.items() if k not in have}
+        self.img_ids.extend(sorted(predictions.keys()))
         for t in self.iou_types:
             self.results[t].extend(self.prepare(predictions, t))
 
@@ -392,24 +394,15 @@ class CocoEvaluator(object):
 
     def synchronize_between_processes(self):
         gathered = misc_util.all_gather((self.img_ids, self.results))
-        img_ids = []
-        merged = {t: [] for t in self.iou_types}
-        for ids, res in gathered:
-            img_ids.extend(ids)
-            for t in self.iou_types:
-                merged[t].extend(res[t])
-        # keep one copy per image (DistributedSampler may pad a shard with repeats): the reference keeps the first
-        # occurrence of each image id (merge: np.unique(..., return_index=True))
-        self.img_ids = sorted(set(img_ids))
+        # keep one copy per IMAGE (DistributedSampler pads the last shards with repeats): like the reference's merge
+        # (np.unique(img_ids, return_index=True)) the first rank that reports an image id owns all its detections
+        owner = {}
+        for rank, (ids, _) in enumerate(gathered):
+            for i in ids:
+                owner.setdefault(i, rank)
+        self.img_ids = sorted(owner)
         for t, ev in self.coco_eval.items():
-            seen, uniq = set(), []
-            for r in merged[t]:
-                body = r.get('bbox') or r.get('keypoints')
-                key = (r['image_id'], r['category_id'], tuple(body) if body is not None else r['rle'].tobytes(),
-                       r['score'])
-                if key not in seen:
-                    seen.add(key)
-                    uniq.append(r)
+            uniq = [r for rank, (_, res) in enumerate(gathered) for r in res[t] if owner.get(r['image_id']) == rank]
             self.results[t] = uniq
             ev.dts = defaultdict(list)
             ev.add_detections(uniq)

@@ -2,7 +2,7 @@
 """Pin bench.py's first-step loss: the CPU oracle (oracle/hnd_oracle.py, itself pinned to the reference by
 make_golden.py) evaluates the distillation loss of bench.py's EXACT first step -- same seeded weights
 (synthetic.build_distillation_pair(seed=0)), same seeded batch (torch.rand, seed 1234 + rank), batch 16 at
-3x800x1333 -- forward only (no autograd graph, so batch 16 fits the build container), FPN skipped (dead w.r.t. the
+3x800x1333, every rank 0..7 of an 8-GPU run -- forward only (no autograd graph, so batch 16 fits the build container), FPN skipped (dead w.r.t. the
 loss).  bench.py asserts its warm-up step 0 against these numbers outside the timed region.
 
 usage:  python tests/golden/make_bench_loss.py        -> tests/golden/bench_first_loss.json
@@ -26,7 +26,7 @@ def main():
     from hnd_ghnd_object_detectors_amd.synthetic import build_distillation_pair
     torch.set_num_threads(8)
     out = {'script': 'tests/golden/make_bench_loss.py', 'torch': torch.__version__, 'cases': {}}
-    for model, batch, ranks in (('faster_rcnn', 16, (0, 1)), ('faster_rcnn', 4, (0,)), ('mask_rcnn', 8, (0,)),
+    for model, batch, ranks in (('faster_rcnn', 16, tuple(range(8))), ('faster_rcnn', 4, (0,)), ('mask_rcnn', 8, (0,)),
                                 ('keypoint_rcnn', 8, (0,))):
         config = make_config(model, 'ghnd', 3, batch_size=batch, pretrained=False, ckpt_root='/nonexistent')
         with contextlib.redirect_stdout(sys.stderr):

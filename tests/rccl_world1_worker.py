@@ -42,10 +42,10 @@ def main():
 
         def hook(arena, flat):
             if comm is not None:                                   # hnd_comm_init / hnd_allreduce_avg_flat (ncclAvg)
-                parallel._PENDING.append((flat, comm.all_reduce_avg(flat), 1.0))
+                parallel._post(arena, flat, comm.all_reduce_avg(flat), 1.0)
             else:                                                  # torch.distributed over RCCL, sum; mean folded later
                 work = dist.all_reduce(flat, async_op=True)
-                parallel._PENDING.append((flat, work.wait, 1.0 / dist.get_world_size()))
+                parallel._post(arena, flat, work.wait, 1.0 / dist.get_world_size())
             fired.append(flat.numel())
         if mode == 'rccl':
             student.backbone.body._post_backward = hook

@@ -1,0 +1,75 @@
+"""bench.py as the driver runs it: `python bench.py --gpus N` with NO launcher environment must start its own N
+ranks (row e2 of VERDICT r2), gate every rank on the pinned per-term losses and label the line with the real rank
+count; asking for more GPUs than the node has must fail, not measure one GPU."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LAUNCH_ENV = ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT', 'LOCAL_WORLD_SIZE',
+              'HND_BENCH_LAUNCHED', 'GROUP_RANK', 'TORCHELASTIC_RUN_ID')
+
+
+def _run(argv, timeout=1500, extra_env=None):
+    env = {k: v for k, v in os.environ.items() if k not in LAUNCH_ENV}
+    env.update(extra_env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + argv, env=env, cwd=ROOT,
+                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+
+
+def test_launcher_refuses_more_gpus_than_the_node_has():
+    """runs everywhere (no GPU call in the launcher): 64 GPUs exist on no node"""
+    r = _run(['--gpus', '64', '--steps', '1', '--warmup', '1'], timeout=300)
+    assert r.returncode != 0 and r.stdout.strip() == b''
+    assert b'refusing' in r.stderr or b'needs an MI355X' in r.stderr
+
+
+def test_mislabelled_world_size_is_refused():
+    """a launcher that started 1 rank for --gpus 8 must not produce an `n_gpus: 1` line (bench.py r2 :112-116 did)"""
+    r = _run(['--gpus', '8', '--steps', '1', '--warmup', '1'], timeout=300,
+             extra_env={'RANK': '0', 'WORLD_SIZE': '1', 'LOCAL_RANK': '0'})
+    assert r.returncode != 0 and r.stdout.strip() == b'' and b'WORLD_SIZE=1 but --gpus 8' in r.stderr
+
+
+def test_affinity_probe_never_raises():
+    sys.path.insert(0, ROOT)
+    import bench
+    before = os.sched_getaffinity(0)
+    try:
+        msg = bench.gpu_cpu_affinity(0)
+        assert isinstance(msg, str) and msg
+        assert os.sched_getaffinity(0)            # never an empty set
+    finally:
+        os.sched_setaffinity(0, before)
+
+
+@pytest.mark.gpu
+def test_bench_launches_its_own_two_ranks_and_gates_both():
+    r = _run(['--gpus', '2', '--share_device', '--dist_backend', 'gloo', '--steps', '2', '--warmup', '1',
+              '--no_cpu_baseline'])
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['config']['global_batch'] == 32 and out['config']['parallelism'] == 'dp2'
+    assert out['ranks']['world'] == 2 and out['ranks']['launched_by'] == 'bench.py'
+    assert out['ranks']['backend'] == 'gloo' and out['ranks']['rccl_ranks'] == 0
+    assert len(out['ranks']['ms_per_step_per_rank']) == 2
+    lc = out['loss_check']
+    assert lc['ranks_gated'] == 2 and lc['worst_rel_err_all_ranks'] < 1e-3
+    assert sorted(lc['terms']) == ['layer1', 'layer2', 'layer3', 'layer4']
+    assert all(t['rel_err'] < 1e-3 for t in lc['terms'].values())
+    print('\n[bench --gpus 2, shared device] %.1f img/s, per-rank ms %s, worst first-step rel err %.1e'
+          % (out['value'], out['ranks']['ms_per_step_per_rank'], lc['worst_rel_err_all_ranks']))
+
+
+@pytest.mark.gpu
+def test_bench_refuses_eight_gpus_on_a_smaller_node():
+    if torch.cuda.device_count() >= 8:
+        pytest.skip('this node has 8 GPUs')
+    r = _run(['--gpus', '8', '--steps', '1', '--warmup', '1'], timeout=300)
+    assert r.returncode != 0 and r.stdout.strip() == b''

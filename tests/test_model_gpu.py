@@ -500,6 +500,105 @@ def test_batch16_is_the_reference_batch4_replicated():
             G.compare(z, 'after/param/' + n, sd[n], 2e-3, atol=1e-6)
 
 
+def test_batch16_hnd_is_the_reference_batch2_replicated():
+    """BASELINE config 2 (HND, batch 16 per GPU) at the benchmarked batch: the reference's HND batch of 2
+    (fixture full_hnd_faster_b2, layer1 loss only) replicated 8x.  Same invariances as the GHND test above: maps of
+    images 0..1 match the reference's fingerprints, images 2k..2k+1 equal them bit for bit, loss and gradients are
+    8x the reference's, Adam's update is scale-invariant."""
+    z, meta = G.load('full_hnd_faster_b2')
+    cfg, teacher, student, box, opt, warm, ims, tgs, loss = _full_step(z, meta, repeat=8)
+    assert len(ims) == 16 and list(MU.terms_of(cfg)) == ['layer1']
+    ref = 8.0 * float(z['step0/loss'])
+    assert abs(loss.item() - ref) / ref < LOSS_TOL
+    assert abs(float(loss.per_term.cpu()[0]) - 8.0 * float(z['step0/term/layer1'])) / ref < LOSS_TOL
+    for who, model in (('teacher', teacher), ('student', student)):
+        out = _hooked(model, 'backbone.body.layer1')
+        assert out.shape[0] == 16
+        G.compare(z, 'step0/%s/layer1' % who, out[:2].contiguous(), FEAT_TOL)
+        for r in range(1, 8):
+            assert torch.equal(out[2 * r:2 * r + 2], out[:2]), (who, r)
+    opt.zero_grad()
+    loss.backward()
+    for n, p in student.named_parameters():
+        if p.requires_grad and not n.endswith(G.ZERO_GRAD_SUFFIXES):
+            G.compare(z, 'step0/grad/' + n, p.grad * 0.125, 5e-3)
+    opt.step()
+    sd = student.state_dict()
+    for n in O.trainable_keys(sd):
+        if not n.endswith(G.ZERO_GRAD_SUFFIXES):
+            G.compare(z, 'after/param/' + n, sd[n], 2e-3, atol=1e-6)
+
+
+DENSE = {   # name -> (fixture whose seeded inputs / weights are reused, number of images taken from it)
+    'ghnd_faster_b2': ('full_ghnd_faster_b4', 2),
+    'hnd_faster_b2': ('full_hnd_faster_b2', 2),
+    'ghnd_keypoint_b2': ('full_ghnd_keypoint_b2', 2),
+}
+
+
+@pytest.mark.parametrize('case', sorted(DENSE))
+def test_full_size_dense_parity_every_element(case):
+    """at 3x800x1333 (Keypoint: 1248x1120 padded, sizes drawn per image) EVERY element of every
+    hooked map of both networks, every loss term and every gradient is compared -- not a fingerprint.  The CPU oracle
+    (pinned to the reference by tests/golden; it travels to the GPU box) runs the same step on the host in fp32 and,
+    for the gradients, in fp64; the HIP maps must agree with the oracle's to 1e-3 relative L2 per map AND per image,
+    with the worst absolute element difference bounded in units of the map's rms so an edge-tile / tail-tile error in
+    any image fails; gradients by _grad_check (vs fp64, no worse than 2x the reference arithmetic's own error)."""
+    fixture, nimg = DENSE[case]
+    z, meta = G.load(fixture)
+    meta = dict(meta, sizes=meta['sizes'][:nimg])
+    cfg, t_sd, s_sd, teacher, student, box, opt, warm = _setup(meta)
+    terms = MU.terms_of(cfg)
+    images, targets = G.case_inputs(meta)
+    fixed = None
+    if meta['model'] == 'keypoint_rcnn':
+        random.seed(100)
+        fixed = [random.choice(teacher.transform.min_size) for _ in images]
+        random.seed(100)                   # the box draws the same sizes again (tool.py:45-48)
+    ims, tgs = _to_dev(images, targets)
+    loss = box(ims, tgs)
+    opt.zero_grad()
+    loss.backward()
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    ms = meta['min_size'] if isinstance(meta['min_size'], list) else [meta['min_size']]
+    orc32 = O.DistillOracle(t_sd, s_sd, terms=terms, min_size=tuple(ms), max_size=meta['max_size'])
+    o_loss, o_terms, t_hooked, s_hooked, _, _, x = orc32.forward(images, fixed)
+    o_loss.backward()
+    g32 = OrderedDict((k, orc32.s[k].grad.detach().clone()) for k in orc32.keys)
+    report = []
+    for i, k in enumerate(terms):
+        assert abs(float(loss.per_term[i]) - float(o_terms[k])) / abs(float(o_terms[k])) < LOSS_TOL, k
+        for who, model, hooked in (('teacher', teacher, t_hooked), ('student', student, s_hooked)):
+            got = _hooked(model, 'backbone.body.' + k).cpu().double()
+            ref = hooked[k].detach().double()
+            assert got.shape == ref.shape, (k, who, got.shape, ref.shape)
+            diff = got - ref
+            rel = float(diff.norm() / ref.norm())
+            per_img = (diff.flatten(1).norm(dim=1) / ref.flatten(1).norm(dim=1)).max().item()
+            rms = float(ref.pow(2).mean().sqrt())
+            worst_abs = float(diff.abs().max())
+            # borders (first / last two rows and columns of the padded map: where a tail-tile bug would live)
+            edge = torch.zeros_like(ref, dtype=torch.bool)
+            edge[..., :2, :] = edge[..., -2:, :] = edge[..., :, :2] = edge[..., :, -2:] = True
+            rel_edge = float(diff[edge].norm() / ref[edge].norm().clamp_min(1e-30))
+            report.append('%s/%s rel %.1e img %.1e edge %.1e max|d| %.1e (rms %.2e)'
+                          % (who, k, rel, per_img, rel_edge, worst_abs, rms))
+            assert rel < FEAT_TOL and per_img < FEAT_TOL and rel_edge < FEAT_TOL, report[-1]
+            assert worst_abs < 2e-2 * rms + 1e-6, report[-1]
+    assert abs(loss.item() - float(o_loss)) / abs(float(o_loss)) < LOSS_TOL
+    del t_hooked, s_hooked, o_loss
+    orc64 = O.DistillOracle(t_sd, s_sd, terms=terms, min_size=tuple(ms), max_size=meta['max_size'],
+                            dtype=torch.float64, with_fpn=False)
+    l64, *_ = orc64.forward(images, fixed)
+    l64.backward()
+    worst_g = 0.0
+    for n, p in student.named_parameters():
+        if p.requires_grad and not n.endswith(G.ZERO_GRAD_SUFFIXES):
+            worst_g = max(worst_g, _grad_check(n, p.grad, g32[n], orc64.s[n].grad))
+    print('\n[dense %s, batched %s] %s\n  loss rel %.1e; worst gradient rel-L2 vs fp64 %.2e'
+          % (case, tuple(x.shape), '\n  '.join(report), abs(loss.item() - float(l64)) / abs(float(l64)), worst_g))
+
+
 def test_batch16_teacher_maps_equal_batch1_maps_bitwise_and_steps_are_reproducible():
     """Two batch-16 properties that need no CPU run.  (i) the frozen teacher has no cross-image coupling: the hooked
     maps of image i inside a batch of 16 distinct images equal the maps of the same image alone, bit for bit --

@@ -51,7 +51,40 @@ def _worker(rank, world, port, q):
     body._post_backward(arena, flat)                  # what _DistillLossFn.backward calls after its last kernel
     assert len(parallel._PENDING) == 1
     scale = parallel.finish_pending(flat)             # what FusedAdam.step does before its launch
-    assert not parallel._PENDING and parallel.finish_pending(flat) == 1.0
+    assert not parallel._PENDING and parallel.finish_pending(flat) == 1.0         # nothing pending: no factor
+    # (1) stepping data-parallel parameters with NO exchange in flight is refused (was: silently 1.0)
+    try:
+        parallel.finish_pending(flat, params)
+        unsynced_refused = False
+    except RuntimeError:
+        unsynced_refused = True
+    # (2) an optimizer group consumes only the entry of ITS arena; another arena's exchange stays pending
+    other = GradArena(params[:2])
+    oflat = other.pick()
+    oflat.fill_(float(rank + 1))
+    parallel._post(other, oflat, lambda: None, 0.25)
+    body._post_backward(arena, flat)
+    assert len(parallel._PENDING) == 2
+    assert parallel.finish_pending(flat, params) == 0.5 and list(parallel._PENDING) == [id(other)]
+    # (3) a group whose gradients only partly lie in an exchanged arena is refused
+    try:
+        parallel.finish_pending([oflat[:4], torch.zeros(4)])
+        partial_refused = False
+    except RuntimeError:
+        partial_refused = True
+    assert parallel.finish_pending(oflat) == 0.25 and not parallel._PENDING
+    # (4) backward twice without a step: the older exchange of the same arena is completed and dropped, not piled up
+    flat.fill_(float(rank + 1))
+    body._post_backward(arena, flat)
+    flat2 = arena.flat[1 - arena.cur]
+    flat2.fill_(float(rank + 1))
+    body._post_backward(arena, flat2)
+    assert len(parallel._PENDING) == 1 and float(flat.min()) == 3.0
+    assert parallel.finish_pending(flat2, params) == 0.5 and float(flat2.max()) == 3.0
+    wrapped.close()
+    assert parallel.finish_pending(flat, params) == 1.0          # guard released with the wrapper
+    wrapped._guarded = [id(q_) for q_ in params]
+    parallel._GUARDED.update(wrapped._guarded)
     # a gradient left alive in the other arena (no zero_grad) must be refused, not silently mis-reduced
     params[0].grad = arena.views(arena.flat[1 - arena.cur])[0]
     try:
@@ -61,7 +94,7 @@ def _worker(rank, world, port, q):
         refused = True
     params[0].grad = None
     q.put((rank, float(w0.sum()), float(rm.sum()), float(flat.min()), float(flat.max()), scale,
-           len(params), arena.total, misc_util.is_main_process() and refused))
+           len(params), arena.total, misc_util.is_main_process() and refused and unsynced_refused and partial_refused))
     dist.barrier()
     dist.destroy_process_group()
 
