@@ -1,0 +1,320 @@
+// B-resident persistent GEMM on fp32 MFMA for gfx950 (MI355X): the K <= 256 (BN = 128) / K <= 512 (BN = 64) class of
+// hnd_conv2d_igemm launches with no taps -- every 1x1 convolution and data gradient of the frozen ResNet / FPN and
+// every Winograd component GEMM  M_f[tiles x cout] = V_f[tiles x cin] * U_f^T  (34 ms of the 107 ms round-2 step,
+// where the tiled kernel sat at 105-115 TFLOP/s: a 16-k-step tile pays its exposed first-load latency and its
+// store burst once per 8 MFLOP, profiles/r02_igemm_sq_counters.txt: matrix pipe 68 % busy, waves parked 25 %).
+//
+// Structure (one workgroup of 8 waves per CU, 256 workgroups, each alive for the whole launch):
+//   * the [BN x K] slice of the packed weight matrix a workgroup needs is loaded ONCE into LDS (128 KB for
+//     128 x 256, XOR-swizzled 16-byte chunks -> conflict-free ds_read_b128 fragments) and stays there;
+//   * A is never staged: a wave reads its MFMA A-fragments straight from global memory into registers (a lane
+//     owns row l16 of a 16-row group and 4 consecutive k = one 16-byte load per (row group, 16-deep k group));
+//     the fragment of k group g+4 is requested while group g is on the matrix pipe (a 4-deep register ring), and
+//     the first groups of the wave's NEXT 64-row chunk are requested before this chunk's epilogue -- so there is
+//     no tile prologue, no LDS write, and NO barrier anywhere in the main loop: the 8 waves free-run, two per SIMD,
+//     each filling the other's waits;
+//   * work split: `nsl = cout / BN` workgroups that share one L2 (same XCD) form a team, one per weight slice; the
+//     64-row chunks are divided statically and evenly among the 256 / nsl teams (persistent: no grid quantisation),
+//     inside a team's range the wave rows take chunks round-robin.  A chunk read by one member of a team is an L2 hit
+//     for the others, so A crosses HBM once.
+// The accumulation order per output element is the implicit-GEMM kernel's (k groups ascending; inside a group MFMA s
+// sums k = s, 4+s, 8+s, 12+s), the prologue / epilogue expressions are the same code (conv_epilogue.h): results are
+// BIT-IDENTICAL to igemm_kernel's (tests/test_ops_gpu.py::test_bres_kernel_is_bit_identical_to_the_tiled_kernel).
+//
+// Roofline: fp32 MFMA (157.3 TFLOP/s).  Per wave and k group: 64 MFMAs (2048 cycles of its SIMD's pipe at two
+// waves per SIMD: 4096) against 4 global_load_dwordx4 + 4 ds_read_b128 -- 8 B/clk/CU from L2, 4 % of the LDS.
+#include <atomic>
+
+#include "common.h"
+#include "conv_epilogue.h"
+
+#include <stdlib.h>
+
+namespace {
+
+using hnd::f32x4;
+using hnd::FastDiv;
+
+struct BresArgs {
+  FastDiv div_ow, div_oh;     // m -> (n, oh, ow)
+  int nsl;                    // weight slices = workgroups per team
+  int nchunks;                // ceil(M / 64)
+  int cpg;                    // chunks per weight group (Winograd component), 0 = one group
+  int dbg;                    // tuning experiments (HND_BRES_DBG): 1 = no epilogue, 2 = A always from chunk 0
+};
+
+// WN = wave columns (BN = 64 * WN); the 8 / WN wave rows take 64-row chunks round-robin.  K = 64 * KQ is a template
+// parameter and the k loop is fully unrolled: with a loop back edge inside the chunk hipcc drains every load in
+// flight (`s_waitcnt vmcnt(0)`) at the loop header, which empties the register ring every four k groups.
+template <int WN, int KQ, bool PRO>
+__global__ void __launch_bounds__(512, 1) bres_kernel(const hnd_conv_desc d, const BresArgs a) {
+  constexpr int WM = 8 / WN, BN = 64 * WN, MI = 4, NI = 4, RING = 4;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int K = 64 * KQ, KG = 4 * KQ;
+  float* Bs = smem;                                   // [BN][K]: chunk c of row r at position c ^ (r & 15)
+  float* pro = Bs + BN * K;                           // [2][K] prologue scale, shift
+  int* tabs = (int*)(pro + (PRO ? 2 * K : 0));        // [8 waves][2][64]: output / res1 pixel of the wave's rows
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave % WN, wm = wave / WN;
+  const int l16 = lane & 15, g4 = lane >> 4;
+  int* rowoff = tabs + wave * 128;
+  int* resoff = rowoff + 64;
+
+  // team (shares an XCD / L2) and weight slice of this workgroup
+  const int b = blockIdx.x, xcd = b & 7, idx = b >> 3, per_xcd = gridDim.x >> 3;
+  const int slice = idx % a.nsl, tpx = per_xcd / a.nsl;
+  const int team = xcd * tpx + idx / a.nsl, nteams = 8 * tpx;
+  const int n0 = slice * BN;
+  const int M = d.n * d.oh * d.ow;
+  const int c_lo = (int)((long long)a.nchunks * team / nteams);
+  const int c_hi = (int)((long long)a.nchunks * (team + 1) / nteams);
+
+  // A row m -> element offset of its input pixel (1x1 taps, no padding: always in range)
+  auto a_off = [&](int m) -> unsigned {
+    m = m < M ? m : M - 1;
+    if (a.dbg & 2) m &= 63;
+    const unsigned t = hnd::fdiv((unsigned)m, a.div_ow), ow_ = (unsigned)m - t * (unsigned)d.ow;
+    const unsigned n_ = hnd::fdiv(t, a.div_oh), oh_ = t - n_ * (unsigned)d.oh;
+    return ((n_ * (unsigned)d.h + oh_ * (unsigned)d.sh) * (unsigned)d.w_ + ow_ * (unsigned)d.sw) * (unsigned)d.cin +
+           (unsigned)(g4 * 4);
+  };
+
+  // epilogue constants of this wave's 4 consecutive channels
+  const int col0 = n0 + wn * 64 + l16 * 4;
+  float es[NI], eb[NI], s1[NI], s2[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    es[ni] = d.epi_scale ? d.epi_scale[col0 + ni] : 1.f;
+    eb[ni] = d.epi_shift ? d.epi_shift[col0 + ni] : 0.f;
+    s1[ni] = 0.f;
+    s2[ni] = 0.f;
+  }
+  const uintptr_t align_bits = (uintptr_t)d.y | (uintptr_t)d.res1 | (uintptr_t)d.res2 | (uintptr_t)d.mask;
+  const bool vec_ok = (d.ldc % NI == 0) && (align_bits % (4 * NI) == 0);
+  const float relu_floor = d.pro_relu ? 0.f : -INFINITY;
+  if (PRO) {
+    for (int k = tid; k < K; k += 512) {
+      pro[k] = d.pro_scale[k];
+      pro[K + k] = d.pro_shift[k];
+    }
+  }
+  // LDS offsets (floats) of this lane's B fragment chunk for k group u of an unrolled quartet: the logical chunk
+  // 4*kg + g4 sits at (4*kg + g4) ^ l16 = 4*(kg & ~3) + ((4*(kg & 3) + g4) ^ l16)
+  int bsw[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) bsw[u] = ((4 * u + g4) ^ l16) * 4;
+  const float* Bw = Bs + (wn * 64 + l16) * K;
+
+  int c = c_lo;
+  while (c < c_hi) {            // one pass per weight group met by this team's range (1 or 2, rarely 3)
+    const int grp = a.cpg > 0 ? c / a.cpg : 0;
+    const int seg_hi = a.cpg > 0 ? min(c_hi, (grp + 1) * a.cpg) : c_hi;
+    __syncthreads();                                  // every wave is done with the previous slice
+    {
+      const float* wsrc = d.w + (size_t)grp * (size_t)d.w_group_stride + (size_t)n0 * K;
+      const int cpr = K >> 2;                         // 16-byte chunks per row
+      for (int e = tid; e < BN * cpr; e += 512) {
+        const int r = e / cpr, ck = e - r * cpr;
+        *(f32x4*)(Bs + r * K + ((ck ^ (r & 15)) << 2)) = *(const f32x4*)(wsrc + (size_t)r * K + (ck << 2));
+      }
+    }
+    __syncthreads();
+
+    int cc = c + wm;
+    if (cc < seg_hi) {
+      unsigned aoff[MI];
+      f32x4 ring[RING][MI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) aoff[mi] = a_off(cc * 64 + mi * 16 + l16);
+#pragma unroll
+      for (int u = 0; u < RING; ++u)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) ring[u][mi] = *(const f32x4*)(d.x + aoff[mi] + u * 16);
+      for (; cc < seg_hi; cc += WM) {
+        const int cn = cc + WM < seg_hi ? cc + WM : cc;     // the wave's next chunk (itself at the end: harmless)
+        unsigned noff[MI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) noff[mi] = a_off(cn * 64 + mi * 16 + l16);
+        f32x4 acc[MI][NI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 bcur[NI], bnxt[NI], ps = {1.f, 1.f, 1.f, 1.f}, pb = {0.f, 0.f, 0.f, 0.f}, psn = ps, pbn = pb;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) bcur[ni] = *(const f32x4*)(Bw + ni * 16 * K + bsw[0]);
+        if (PRO) {
+          ps = *(const f32x4*)(pro + g4 * 4);
+          pb = *(const f32x4*)(pro + K + g4 * 4);
+        }
+#pragma unroll
+        for (int kg0 = 0; kg0 < KG; kg0 += 4) {
+          const bool more = kg0 + 4 < KG;
+          unsigned poff[MI];                          // where the ring is refilled from: 4 groups ahead
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) poff[mi] = more ? aoff[mi] + (unsigned)((kg0 + 4) * 16) : noff[mi];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            // B fragments (and prologue constants) of the following k group; past the end: group 0 again, unused
+            // ((kg0 + u + 1) & 3 == (u + 1) & 3 whether or not the quartet wraps: kg0 and KG are multiples of 4)
+            const int kn = u < 3 ? kg0 + u + 1 : (more ? kg0 + 4 : 0);
+            const int bo = (kn & ~3) * 16 + bsw[(u + 1) & 3];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+              f32x4 av = ring[u][mi];
+              if (PRO) {
+                av = av * ps + pb;
+                av.x = fmaxf(av.x, relu_floor); av.y = fmaxf(av.y, relu_floor);
+                av.z = fmaxf(av.z, relu_floor); av.w = fmaxf(av.w, relu_floor);
+              }
+#pragma unroll
+              for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+                  acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bcur[ni][s], acc[mi][ni], 0, 0, 0);
+                if (mi == 0) {
+                  bnxt[s] = *(const f32x4*)(Bw + s * 16 * K + bo);
+                  if (PRO && s == 3) {
+                    psn = *(const f32x4*)(pro + kn * 16 + g4 * 4);
+                    pbn = *(const f32x4*)(pro + K + kn * 16 + g4 * 4);
+                  }
+                }
+                if (s == 3) ring[u][mi] = *(const f32x4*)(d.x + poff[mi] + u * 16);
+                __builtin_amdgcn_sched_barrier(0);
+              }
+            }
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) bcur[ni] = bnxt[ni];
+            if (PRO) { ps = psn; pb = pbn; }
+          }
+        }
+        // ---- epilogue of this 64 x 64 wave tile (the next chunk's first k groups are already in flight)
+        if (!(a.dbg & 1) || acc[0][0][0] == 1234.5f) {
+          const int m = cc * 64 + lane;
+          int po = -1, pr = 0;
+          if (m < M) {
+            const unsigned t = hnd::fdiv((unsigned)m, a.div_ow), ow_ = (unsigned)m - t * (unsigned)d.ow;
+            const unsigned n_ = hnd::fdiv(t, a.div_oh), oh_ = t - n_ * (unsigned)d.oh;
+            const int yr = (int)oh_ * d.y_sh + d.y_oh, yc = (int)ow_ * d.y_sw + d.y_ow;
+            po = ((int)n_ * d.yh + yr) * d.yw + yc;
+            if (d.res1_mode == 1)
+              pr = ((int)n_ * d.res1_h + (yr * d.res1_h) / d.yh) * d.res1_w + (yc * d.res1_w) / d.yw;
+          }
+          __builtin_amdgcn_wave_barrier();            // the wave's previous epilogue has read its tables
+          rowoff[lane] = po;
+          resoff[lane] = pr;
+          __builtin_amdgcn_wave_barrier();            // LDS executes one wave's accesses in order
+          const bool full = vec_ok && (cc * 64 + 64 <= M);
+          hnd::epilogue_tile<MI, NI>(d, acc, rowoff, resoff, 4 * g4, col0, es, eb, s1, s2, full);
+        }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) aoff[mi] = noff[mi];
+      }
+    }
+    c = seg_hi;
+  }
+}
+
+int bres_kmax() {
+  const char* e = getenv("HND_BRES");          // 0 = off, else the largest K taken (read per call: in-process A/B)
+  return e ? atoi(e) : 512;
+}
+
+int cu_count() {
+  static std::atomic<int> cached{0};
+  int v = cached.load(std::memory_order_relaxed);
+  if (v == 0) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    cached.store(v, std::memory_order_relaxed);
+  }
+  return v;
+}
+
+template <int WN, int KQ, bool PRO>
+int launch_bres_t(const hnd_conv_desc& d, const BresArgs& a, size_t lds, int grid, hipStream_t stream) {
+  static std::atomic<unsigned long long> attr_set{0};
+  auto kern = bres_kernel<WN, KQ, PRO>;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (!(attr_set.load(std::memory_order_relaxed) & bit)) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) {
+      hnd::set_error("hipFuncSetAttribute(bres<%d,%d>) failed: %s", WN, KQ, hipGetErrorString(e));
+      return HND_ERR_LAUNCH;
+    }
+    attr_set.fetch_or(bit, std::memory_order_relaxed);
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, d, a);
+  return hnd::check_launch("hnd_conv2d_igemm(bres)");
+}
+
+template <int WN, int KQ>
+int launch_bres_p(const hnd_conv_desc& d, const BresArgs& a, size_t lds, int grid, hipStream_t stream) {
+  return d.pro_scale ? launch_bres_t<WN, KQ, true>(d, a, lds, grid, stream)
+                     : launch_bres_t<WN, KQ, false>(d, a, lds, grid, stream);
+}
+
+}  // namespace
+
+namespace hnd {
+
+// 0 = not taken; 2 = the 128-column slice (K <= 256), 1 = the 64-column slice (K <= 512)
+int bres_variant(const hnd_conv_desc& d) {
+  const int kmax = bres_kmax();
+  if (kmax <= 0 || d.kh != 1 || d.kw != 1 || d.bh != 0 || d.bw != 0 || d.stats != nullptr) return 0;
+  if (d.cin != d.kdim || d.kdim > kmax) return 0;
+  if (d.w_group_rows % 64 != 0) return 0;
+  const int wn = (d.kdim <= 256 && d.cout % 128 == 0) ? 2 : 1;
+  // instantiated depths: 64 / 128 / 256 with the 128-column slice, 256 / 512 with the 64-column slice
+  if (wn == 2 ? (d.kdim != 64 && d.kdim != 128 && d.kdim != 256) : (d.kdim != 256 && d.kdim != 512)) return 0;
+  const int bn = 64 * wn;
+  if (d.cout % bn != 0) return 0;
+  const int per_xcd = cu_count() / 8, nsl = d.cout / bn;
+  if (per_xcd < 1 || nsl > per_xcd || per_xcd % nsl != 0) return 0;
+  const long long M = (long long)d.n * d.oh * d.ow;
+  const long long nchunks = (M + 63) / 64, nteams = 8ll * (per_xcd / nsl);
+  const long long per_team = nchunks / nteams;
+  if (per_team < 2ll * (8 / wn)) return 0;              // every wave row gets at least two chunks
+  if (!getenv("HND_BRES_ALL")) {
+    // where the free-running waves beat the tiled kernel (profiles/r03_bres_vs_tiled.txt, both with the specialised
+    // epilogue): long runs of chunks per weight slice.  A Winograd launch whose components are short reloads its
+    // slice every few chunks; an epilogue with residual / mask loads drains the wave's prefetch ring (one wave cannot
+    // hold both in 256 registers), which only the K = 512 launches amortise.
+    if (d.w_group_rows > 0 && per_team < 64) return 0;
+    if ((d.res1 || d.res2 || d.mask) && d.kdim < 512) return 0;
+    if (d.kdim == 128 && d.cout >= 512) return 0;
+  }
+  if ((long long)(d.oh - 1) * d.sh >= d.h || (long long)(d.ow - 1) * d.sw >= d.w_) return 0;
+  return wn;
+}
+
+int launch_bres(const hnd_conv_desc& d, hipStream_t stream) {
+  const int wn = bres_variant(d);
+  if (wn == 0) {
+    set_error("launch_bres: descriptor not eligible");
+    return HND_ERR_INVALID;
+  }
+  const long long M = (long long)d.n * d.oh * d.ow;
+  BresArgs a;
+  a.div_ow = make_fastdiv((unsigned)d.ow);
+  a.div_oh = make_fastdiv((unsigned)d.oh);
+  a.nsl = d.cout / (64 * wn);
+  a.nchunks = (int)((M + 63) / 64);
+  a.cpg = d.w_group_rows / 64;
+  a.dbg = getenv("HND_BRES_DBG") ? atoi(getenv("HND_BRES_DBG")) : 0;
+  const bool pro = d.pro_scale != nullptr;
+  const size_t lds = ((size_t)64 * wn * d.kdim + (pro ? 2 * (size_t)d.kdim : 0) + 8 * 128) * sizeof(float);
+  const int grid = (cu_count() / 8) * 8;
+  if (wn == 2) {
+    if (d.kdim == 64) return launch_bres_p<2, 1>(d, a, lds, grid, stream);
+    if (d.kdim == 128) return launch_bres_p<2, 2>(d, a, lds, grid, stream);
+    return launch_bres_p<2, 4>(d, a, lds, grid, stream);
+  }
+  if (d.kdim == 256) return launch_bres_p<1, 4>(d, a, lds, grid, stream);
+  return launch_bres_p<1, 8>(d, a, lds, grid, stream);
+}
+
+}  // namespace hnd

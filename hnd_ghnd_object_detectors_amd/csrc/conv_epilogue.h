@@ -1,0 +1,139 @@
+// Epilogue shared by the implicit-GEMM kernels (conv_igemm.hip, conv_bres.hip): one 16-row group of a wave's
+// accumulator tiles -> scale/shift, residuals, ReLU-backward mask, ReLU, store (+ BN-statistics partials).
+#pragma once
+#include "common.h"
+
+namespace hnd {
+
+// Sum of squares of the BN statistics on the CHECKED epilogue path (tile edges, cout = 3): product and sum are two
+// roundings, spelled out so that the vector-ALU kernel for cout <= 4 (thin_n_kernel) reproduces the partials bit for
+// bit.  Under -ffp-contract=fast the backend fuses any fmul + fadd it sees (a source-level contract(off) pragma does
+// not stop it), so the product is hidden behind an empty asm.
+__device__ __forceinline__ float sq_acc(float s2, float x) {
+  float sq = x * x;
+  asm volatile("" : "+v"(sq));
+  return s2 + sq;
+}
+
+// Epilogue of one 16-row group of a wave: the lane holds rows 4*(lane>>4)+i (i = 0..3) and, thanks to the channel
+// interleave of the packed weights (hnd::chan_of_row), NI CONSECUTIVE output channels starting at col0 -- so residual /
+// mask loads and the stores are 16-byte (NI = 4) or 8-byte (NI = 2) vector accesses, 16 lanes covering 64 consecutive
+// channels of a pixel.
+//
+// epilogue_rows_full: the whole tile is in range and every pointer / ldc is vector-aligned.  WHICH optional operands
+// exist (R1 residual / FPN top-down, R2 second residual, MK ReLU-backward mask) is a TEMPLATE parameter: as a run-time
+// `if (d.res1) load else zero` hipcc branches around each group of loads and puts `s_waitcnt vmcnt(0)` on the
+// no-operand side (the zeros overwrite registers that are load destinations on the other side) -- three full drains of
+// the memory pipe per 16-row group, i.e. twelve per tile, which stalled every store burst and every prefetch in flight
+// (round 3: the Winograd component GEMMs, which have no optional operand at all, went 115 -> 140 TFLOP/s with the
+// epilogue compiled out; profiles/r03_bres_ablation.txt).  The callers switch ONCE per tile (epilogue_tile).
+template <int NI, bool R1, bool R2, bool MK>
+__device__ __forceinline__ void epilogue_rows_full(const hnd_conv_desc& d, const f32x4 (&acc)[NI], const int* rowoff,
+                                                   const int* resoff, int rbase, int col0, const float (&es)[NI],
+                                                   const float (&eb)[NI], float (&s1)[NI], float (&s2)[NI]) {
+  typedef float vec __attribute__((ext_vector_type(NI)));
+  unsigned off[4];
+  vec r1v[4], r2v[4], mkv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    off[i] = (unsigned)rowoff[rbase + i] * (unsigned)d.ldc + (unsigned)col0;
+    r1v[i] = 0.f; r2v[i] = 0.f; mkv[i] = 1.f;
+  }
+  if (R1) {
+    if (d.res1_mode == 1) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        r1v[i] = *(const vec*)(d.res1 + (size_t)resoff[rbase + i] * d.ldc + col0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) r1v[i] = *(const vec*)(d.res1 + off[i]);
+    }
+  }
+  if (R2) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r2v[i] = *(const vec*)(d.res2 + off[i]);
+  }
+  if (MK) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) mkv[i] = *(const vec*)(d.mask + off[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    vec v;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      float x = acc[ni][i] * es[ni] + eb[ni];
+      if (R1) x += r1v[i][ni];
+      if (R2) x += r2v[i][ni];
+      if (MK) x = mkv[i][ni] > 0.f ? x : 0.f;
+      x = d.relu ? fmaxf(x, 0.f) : x;
+      v[ni] = x;
+      s1[ni] += x;
+      s2[ni] += x * x;
+    }
+    *(vec*)(d.y + off[i]) = v;
+  }
+  asm volatile("" ::: "memory");
+}
+
+// tile edges, odd ldc (91-class logits), unaligned views: scalar, fully checked
+template <int NI>
+__device__ __forceinline__ void epilogue_rows_checked(const hnd_conv_desc& d, const f32x4 (&acc)[NI], const int* rowoff,
+                                                      const int* resoff, int rbase, int col0, const float (&es)[NI],
+                                                      const float (&eb)[NI], float (&s1)[NI], float (&s2)[NI]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int po = rowoff[rbase + i];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int col = col0 + ni;
+      if (po < 0 || col >= d.cout) continue;
+      const size_t o = (size_t)po * d.ldc + col;
+      float x = acc[ni][i] * es[ni] + eb[ni];
+      if (d.res1) x += d.res1_mode == 1 ? d.res1[(size_t)resoff[rbase + i] * d.ldc + col] : d.res1[o];
+      if (d.res2) x += d.res2[o];
+      if (d.mask) x = d.mask[o] > 0.f ? x : 0.f;
+      x = d.relu ? fmaxf(x, 0.f) : x;
+      d.y[o] = x;
+      s1[ni] += x;
+      s2[ni] = sq_acc(s2[ni], x);
+    }
+  }
+}
+
+// The wave's MI row groups (rows rbase0 + 16*mi + 0..3 of the tables), dispatched once on the operand set.
+template <int MI, int NI, bool R1, bool R2, bool MK>
+__device__ __forceinline__ void epilogue_tile_full(const hnd_conv_desc& d, const f32x4 (&acc)[MI][NI], const int* rowoff,
+                                                   const int* resoff, int rbase0, int col0, const float (&es)[NI],
+                                                   const float (&eb)[NI], float (&s1)[NI], float (&s2)[NI]) {
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+    epilogue_rows_full<NI, R1, R2, MK>(d, acc[mi], rowoff, resoff, rbase0 + 16 * mi, col0, es, eb, s1, s2);
+}
+
+template <int MI, int NI>
+__device__ __forceinline__ void epilogue_tile(const hnd_conv_desc& d, const f32x4 (&acc)[MI][NI], const int* rowoff,
+                                              const int* resoff, int rbase0, int col0, const float (&es)[NI],
+                                              const float (&eb)[NI], float (&s1)[NI], float (&s2)[NI], bool full) {
+  if (!full) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+      epilogue_rows_checked<NI>(d, acc[mi], rowoff, resoff, rbase0 + 16 * mi, col0, es, eb, s1, s2);
+    return;
+  }
+  const int sel = (d.res1 ? 1 : 0) | (d.res2 ? 2 : 0) | (d.mask ? 4 : 0);
+#define HND_EPI(R1, R2, MK) epilogue_tile_full<MI, NI, R1, R2, MK>(d, acc, rowoff, resoff, rbase0, col0, es, eb, s1, s2)
+  switch (sel) {
+    case 0: HND_EPI(false, false, false); break;
+    case 1: HND_EPI(true, false, false); break;
+    case 2: HND_EPI(false, true, false); break;
+    case 3: HND_EPI(true, true, false); break;
+    case 4: HND_EPI(false, false, true); break;
+    case 5: HND_EPI(true, false, true); break;
+    case 6: HND_EPI(false, true, true); break;
+    default: HND_EPI(true, true, true); break;
+  }
+#undef HND_EPI
+}
+
+}  // namespace hnd

@@ -28,6 +28,7 @@
 #include <atomic>
 
 #include "common.h"
+#include "conv_epilogue.h"
 
 #include <stdlib.h>
 
@@ -41,6 +42,7 @@ namespace {
 
 using hnd::f32x16;
 using hnd::f32x4;
+using hnd::sq_acc;
 
 
 template <int BM, int BN, int BK, bool PRO>
@@ -53,90 +55,6 @@ template <int BM, int BN, int BK>
 constexpr int blocks_per_cu() {
   return BK == 16 ? ((BM == 64 && BN == 64) ? 5 : ((BM == 128 && BN == 128) ? HND_BPC_128 : 4))
                   : ((BM == 64 && BN == 64) ? 4 : 2);
-}
-
-// Sum of squares of the BN statistics on the CHECKED epilogue path (tile edges, cout = 3): product and sum are two
-// roundings, spelled out so that the vector-ALU kernel for cout <= 4 (thin_n_kernel) reproduces the partials bit for
-// bit.  Under -ffp-contract=fast the backend fuses any fmul + fadd it sees (a source-level contract(off) pragma does
-// not stop it), so the product is hidden behind an empty asm.
-__device__ __forceinline__ float sq_acc(float s2, float x) {
-  float sq = x * x;
-  asm volatile("" : "+v"(sq));
-  return s2 + sq;
-}
-
-// Epilogue of one 16-row group of a wave: the lane holds rows 4*(lane>>4)+i (i = 0..3) and, thanks to the channel
-// interleave of the packed weights (hnd::chan_of_row), NI CONSECUTIVE output channels starting at col0 -- so residual /
-// mask loads and the stores are 16-byte (NI = 4) or 8-byte (NI = 2) vector accesses, 16 lanes covering 64 consecutive
-// channels of a pixel.  FULL = the block's whole BM x BN tile is in range and every pointer / ldc is vector-aligned:
-// then there is no per-element control flow, hipcc issues the loads of the 4 rows back to back (uniform branches only)
-// and the stores stream behind counted waits.  Otherwise a scalar, fully checked path runs (tile edges, ldc = 91 ...).
-template <int NI, bool FULL>
-__device__ __forceinline__ void epilogue_rows(const hnd_conv_desc& d, const f32x4 (&acc)[NI], const int* rowoff,
-                                              const int* resoff, int rbase, int col0, const float (&es)[NI],
-                                              const float (&eb)[NI], float (&s1)[NI], float (&s2)[NI]) {
-  typedef float vec __attribute__((ext_vector_type(NI)));
-  if (FULL) {
-    unsigned off[4];
-    vec r1v[4], r2v[4], mkv[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      off[i] = (unsigned)rowoff[rbase + i] * (unsigned)d.ldc + (unsigned)col0;
-      r1v[i] = 0.f; r2v[i] = 0.f; mkv[i] = 1.f;
-    }
-    if (d.res1) {
-      if (d.res1_mode == 1) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-          r1v[i] = *(const vec*)(d.res1 + (size_t)resoff[rbase + i] * d.ldc + col0);
-      } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) r1v[i] = *(const vec*)(d.res1 + off[i]);
-      }
-    }
-    if (d.res2) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) r2v[i] = *(const vec*)(d.res2 + off[i]);
-    }
-    if (d.mask) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) mkv[i] = *(const vec*)(d.mask + off[i]);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      vec v;
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) {
-        float x = acc[ni][i] * es[ni] + eb[ni] + r1v[i][ni] + r2v[i][ni];
-        x = mkv[i][ni] > 0.f ? x : 0.f;
-        x = d.relu ? fmaxf(x, 0.f) : x;
-        v[ni] = x;
-        s1[ni] += x;
-        s2[ni] += x * x;
-      }
-      *(vec*)(d.y + off[i]) = v;
-    }
-    asm volatile("" ::: "memory");
-  } else {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int po = rowoff[rbase + i];
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) {
-        const int col = col0 + ni;
-        if (po < 0 || col >= d.cout) continue;
-        const size_t o = (size_t)po * d.ldc + col;
-        float x = acc[ni][i] * es[ni] + eb[ni];
-        if (d.res1) x += d.res1_mode == 1 ? d.res1[(size_t)resoff[rbase + i] * d.ldc + col] : d.res1[o];
-        if (d.res2) x += d.res2[o];
-        if (d.mask) x = d.mask[o] > 0.f ? x : 0.f;
-        x = d.relu ? fmaxf(x, 0.f) : x;
-        d.y[o] = x;
-        s1[ni] += x;
-        s2[ni] = sq_acc(s2[ni], x);
-      }
-    }
-  }
 }
 
 template <int BM, int BN, int BK, bool CIN4, bool PRO>
@@ -396,12 +314,7 @@ igemm_kernel(const hnd_conv_desc d, const int ntiles) {
     s1[ni] = 0.f;
     s2[ni] = 0.f;
   }
-#pragma unroll
-  for (int mi = 0; mi < MI; ++mi) {
-    const int rbase = wm * WTM + mi * 16 + 4 * g4;
-    if (tile_full) epilogue_rows<NI, true>(d, acc[mi], rowoff, resoff, rbase, col0, es, eb, s1, s2);
-    else epilogue_rows<NI, false>(d, acc[mi], rowoff, resoff, rbase, col0, es, eb, s1, s2);
-  }
+  hnd::epilogue_tile<MI, NI>(d, acc, rowoff, resoff, wm * WTM + 4 * g4, col0, es, eb, s1, s2, tile_full);
   if (d.stats) {
     // per 128-row tile and channel: fold the four row groups of the wave (lane>>4), then the two row-waves
     const int cl = col0 - n0;                  // channel index inside the block tile
@@ -680,6 +593,11 @@ int pick_tile(const hnd_conv_desc& d) {
 
 }  // namespace
 
+namespace hnd {
+int bres_variant(const hnd_conv_desc& d);                      // conv_bres.hip: B-resident persistent GEMM
+int launch_bres(const hnd_conv_desc& d, hipStream_t stream);
+}  // namespace hnd
+
 extern "C" int hnd_conv2d_igemm(const hnd_conv_desc* desc, void* stream) {
   HND_REQUIRE(desc != nullptr, "hnd_conv2d_igemm: null descriptor");
   const hnd_conv_desc& d = *desc;
@@ -706,6 +624,7 @@ extern "C" int hnd_conv2d_igemm(const hnd_conv_desc* desc, void* stream) {
     return launch<128, 64, 32, true>(d, s);   // stem (cout 64) and the 3->64 decoder conv
   }
   if (thin_n_applies(d)) return launch_thin_n(d, s);
+  if (hnd::bres_variant(d)) return hnd::launch_bres(d, s);
   const int bk16 = bk16_mask();
   switch (pick_tile(d)) {
     case 0: return (bk16 & 1) ? launch<128, 128, 16, false>(d, s) : launch<128, 128, 32, false>(d, s);
@@ -719,5 +638,6 @@ extern "C" int hnd_conv2d_igemm_tile(const hnd_conv_desc* desc) {
   if (!desc) return -1;
   if (desc->cin == 4) return 1;
   if (thin_n_applies(*desc)) return 4;
+  if (const int v = hnd::bres_variant(*desc)) return v == 2 ? 5 : 6;
   return pick_tile(*desc);
 }

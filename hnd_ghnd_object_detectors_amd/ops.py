@@ -98,8 +98,13 @@ class ConvLaunch(object):
         self.alg_flops = flops      # 2*MAC of the convolution this launch stands for (== flops unless Winograd)
         self.ref = C.byref(desc)
         # which kernel instantiation hnd_conv2d_igemm dispatches to (mirrors csrc/conv_igemm.hip)
-        self.variant = 'igemm_c4_128x64' if desc.cin == 4 else \
-            ('igemm_128x128', 'igemm_128x64', 'igemm_64x128', 'igemm_64x64', 'thin_n4')[_L.hnd_conv2d_igemm_tile(self.ref)]
+        self.refresh_variant()
+
+    def refresh_variant(self):
+        """call again after editing the descriptor (grouped weights): the dispatch may change"""
+        self.variant = 'igemm_c4_128x64' if self.desc.cin == 4 else \
+            ('igemm_128x128', 'igemm_128x64', 'igemm_64x128', 'igemm_64x64', 'thin_n4', 'bres_128',
+             'bres_64')[_L.hnd_conv2d_igemm_tile(self.ref)]
 
     def run(self, stream=None):
         rc = _L.hnd_conv2d_igemm(self.ref, stream if stream is not None else stream_ptr())
@@ -460,6 +465,7 @@ class WinoConv(object):
                               dw=1, bw=0, cout=self.cout)
         self.gemm.desc.w_group_rows = self.tiles_pad
         self.gemm.desc.w_group_stride = ww.rows_pad * ww.depth
+        self.gemm.refresh_variant()
         tiles = n * ((h + tile - 1) // tile) * ((w + tile - 1) // tile)
         self.gemm.flops = 2 * nc * tiles * ww.rows * ww.depth          # multiplies actually executed
         self.gemm.alg_flops = 2 * n * h * w * ww.rows * 9 * ww.depth   # the direct 3x3 convolution it computes
@@ -545,6 +551,7 @@ class Wino2Conv(object):
                               dw=1, bw=0, cout=self.cout)
         self.gemm.desc.w_group_rows = self.tiles_pad
         self.gemm.desc.w_group_stride = ww.rows_pad * ww.depth
+        self.gemm.refresh_variant()
         tiles = n * ((oh + 3) // 4) * ((ow + 3) // 4)
         self.gemm.flops = 2 * 25 * tiles * ww.rows * ww.depth
         self.gemm.alg_flops = 2 * n * oh * ow * ww.rows * 4 * ww.depth  # the direct 2x2 convolution it computes

@@ -816,6 +816,81 @@ def test_thin_n_kernel_is_bit_identical_to_the_mfma_path(tmp_path):
             assert torch.equal(v, outs['1'][grp][k]), (grp, k)
 
 
+@pytest.mark.parametrize('case', [
+    # cin, h, w, cout, stride, residual, mask, prologue, groups, batch
+    (256, 200, 336, 256, 1, False, False, False, 1, 2),      # bres_128, K = 256
+    (256, 200, 336, 128, 2, False, False, False, 1, 8),      # stride-2 rows (downsample)
+    (64, 200, 336, 256, 1, True, False, False, 1, 2),        # K = 64, residual epilogue
+    (128, 100, 168, 512, 1, True, True, True, 1, 8),         # K = 128, residual + mask + prologue
+    (512, 100, 168, 64, 1, False, False, True, 1, 16),       # bres_64, K = 512, prologue
+    (256, 201, 337, 64, 1, True, False, False, 1, 4),        # bres_64 with K = 256, ragged last chunk
+    (256, 37, 53, 256, 1, False, False, False, 9, 64),       # grouped (Winograd-style) weights
+])
+def test_bres_kernel_is_bit_identical_to_the_tiled_kernel(ops, case, monkeypatch):
+    """The B-resident persistent GEMM (csrc/conv_bres.hip: weight slice resident in LDS, A fragments straight from
+    global memory, no barrier in the main loop) keeps the tiled kernel's accumulation order and shares its prologue /
+    epilogue code, so every output must be IDENTICAL BITS -- and both must match a torch fp32 convolution."""
+    cin, h, w, cout, s, res, msk, pro, groups, n = case
+    g = torch.Generator().manual_seed(11)
+    monkeypatch.setenv('HND_BRES_ALL', '1')
+    if groups > 1:
+        tiles_pad = (n * h * w + 127) // 128 * 128
+        x = torch.randn(1, 1, groups * tiles_pad, cin, generator=g).to(DEV)
+        y = torch.empty(1, 1, groups * tiles_pad, cout, device=DEV)
+        ws = [torch.randn(cout, cin, 1, 1, generator=g).to(DEV) / cin ** 0.5 for _ in range(groups)]
+        pks = [ops.pack_weights(wt) for wt in ws]
+        pk = ops.PackedWeight.__new__(ops.PackedWeight)
+        pk.buf = torch.cat([p.buf for p in pks])
+        pk.kdim, pk.rows, pk.chan_pad, pk.chan_real = pks[0].kdim, cout, cin, cin
+    else:
+        x = torch.randn(n, h, w, cin, generator=g).to(DEV)
+        oh, ow = ops.conv_out_size(h, 1, s, 0), ops.conv_out_size(w, 1, s, 0)
+        y = torch.empty(n, oh, ow, cout, device=DEV)
+        wt = torch.randn(cout, cin, 1, 1, generator=g).to(DEV) / cin ** 0.5
+        pk = ops.pack_weights(wt)
+    sc, sh = torch.rand(cout, generator=g).to(DEV) + 0.5, torch.randn(cout, generator=g).to(DEV)
+    r = torch.randn(y.shape, generator=g).to(DEV) if res else None
+    mk = (torch.rand(y.shape, generator=g).to(DEV) - 0.3).clamp_min(0) if msk else None
+    ps = (torch.rand(cin, generator=g).to(DEV) + 0.5) if pro else None
+    pb = torch.randn(cin, generator=g).to(DEV) if pro else None
+    outs, variants = {}, {}
+    for mode in ('0', '512'):
+        monkeypatch.setenv('HND_BRES', mode)
+        if groups > 1:
+            l = ops.conv_desc(x, pk, y, kh=1, kw=1, oh=1, ow=groups * tiles_pad, sh=1, dh=1, bh=0, sw=1, dw=1, bw=0,
+                              cout=cout)
+            l.desc.w_group_rows, l.desc.w_group_stride = tiles_pad, pks[0].buf.numel()
+        else:
+            l = ops.conv_forward(x, pk, y, 1, s, 0, epi_scale=sc, epi_shift=sh, res1=r, mask=mk, relu=not msk,
+                                 pro_scale=ps, pro_shift=pb, pro_relu=pro)
+        l.refresh_variant()
+        y.fill_(float('nan'))
+        l.run()
+        torch.cuda.synchronize()
+        outs[mode], variants[mode] = y.clone(), l.variant
+    assert variants['0'].startswith('igemm') and variants['512'].startswith('bres'), variants
+    assert not bool(torch.isnan(outs['512']).any())
+    assert torch.equal(outs['0'], outs['512']), float((outs['0'] - outs['512']).abs().max())
+    if groups == 1:
+        xin = x.permute(0, 3, 1, 2)
+        if pro:
+            xin = torch.relu(xin * ps.view(1, -1, 1, 1) + pb.view(1, -1, 1, 1))
+        ref = torch.nn.functional.conv2d(xin, wt, stride=s) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+        if res:
+            ref = ref + r.permute(0, 3, 1, 2)
+        if msk:
+            ref = torch.where(mk.permute(0, 3, 1, 2) > 0, ref, torch.zeros_like(ref))
+        else:
+            ref = torch.relu(ref)
+        got = outs['512'].permute(0, 3, 1, 2)
+        assert float((got - ref).norm() / ref.norm()) < 1e-5
+    else:
+        for gi in (0, groups - 1):
+            rows = slice(gi * tiles_pad, (gi + 1) * tiles_pad)
+            ref = x[0, 0, rows] @ ws[gi].view(cout, cin).t()
+            assert float((outs['512'][0, 0, rows] - ref).norm() / ref.norm()) < 1e-5
+
+
 def test_jpeg_codec_and_data_logger_follow_the_reference(tmp_path):
     """structure/transformer.py JpegCompressor / JpegDecompressor / DataLogger (reference :58-128): the 3-channel
     bottleneck is quantised by the HIP codec (byte-exact to myutils' quantize_tensor), written as a JPEG with PIL and
