@@ -30,6 +30,9 @@
 
 #include <stdlib.h>
 
+#include <type_traits>
+#include <utility>
+
 namespace {
 
 using hnd::f32x4;
@@ -215,6 +218,230 @@ __global__ void __launch_bounds__(512, 1) bres_kernel(const hnd_conv_desc d, con
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// bres2: the same data flow with ONE wave per SIMD (256 threads, 512 registers per lane) for launches whose epilogue
+// has no residual / mask operand (every Winograd component GEMM, conv1 / downsample 1x1 convs).  What the 8-wave kernel
+// above cannot do in 256 registers, and what it loses 10 % to (profiles/r03_bres_ablation.txt):
+//   * the finished tile is copied to a second register set and its scale/shift/ReLU + 16 stores are issued one row
+//     per group of 4 MFMAs INSIDE the first k group of the next tile -- no store burst, the matrix pipe never waits;
+//   * the A ring is 8 k groups deep (16 K floats in flight per wave) and its loads are inline asm with hand-counted
+//     `s_waitcnt vmcnt(28)`: hipcc drains `vmcnt(0)` at every loop header for loads it can see, i.e. once per tile
+//     for the youngest prefetch AND the tile's stores.  The count is safe whatever else the wave has in flight: a
+//     ring slot is consumed 8 k groups after it was requested, by then at least 7 x 4 younger ring loads exist, and
+//     memory operations retire in issue order, so "at most 28 outstanding" implies the slot has landed; stores or
+//     compiler-issued loads in between only make the wait stronger.  (Audit: tools/audit_bres_asm.py checks in the
+//     disassembly that no instruction touches a ring register between its load and the wait that names it.)
+template <int N, class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl<N>(f, std::make_integer_sequence<int, N>{});
+}
+
+// ACC = the slot lives in the accumulator half of the register file ("a": VMEM can target it and an MFMA reads its A
+// operand from it).  Half of the ring's slots do: with all 128 ring registers in architectural VGPRs hipcc ran out of
+// those and shuffled just-requested ring registers into AGPRs (copies of data that had not landed yet); with all of
+// them in AGPRs, beside the two accumulator sets, it ran out of these instead.
+template <int OFF, bool ACC>
+__device__ __forceinline__ void ring_load(f32x4& dst, const float* p) {
+  if (ACC) asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=a"(dst) : "v"(p), "n"(OFF));
+  else asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(dst) : "v"(p), "n"(OFF));
+}
+template <int N, bool ACC>
+__device__ __forceinline__ void ring_wait(f32x4& a0, f32x4& a1, f32x4& a2, f32x4& a3) {
+  if (ACC) asm volatile("s_waitcnt vmcnt(%4)" : "+a"(a0), "+a"(a1), "+a"(a2), "+a"(a3) : "n"(N));
+  else asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "n"(N));
+}
+
+template <int WN, int KQ, bool PRO>
+__global__ void __launch_bounds__(256, 1) bres2_kernel(const hnd_conv_desc d, const BresArgs a) {
+  constexpr int WM = 4 / WN, BN = 64 * WN, MI = 4, NI = 4, RING = 8;
+  constexpr int K = 64 * KQ, KG = 4 * KQ;
+  static_assert(KG >= RING, "the ring reaches at most one tile ahead");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Bs = smem;                                   // [BN][K]: chunk c of row r at position c ^ (r & 15)
+  float* pro = Bs + BN * K;                           // [2][K] prologue scale, shift
+  int* tabs = (int*)(pro + (PRO ? 2 * K : 0));        // [4 waves][2][64]: output pixel of the rows of a tile
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave % WN, wm = wave / WN;
+  const int l16 = lane & 15, g4 = lane >> 4;
+  int* rowoff = tabs + wave * 128;
+
+  const int b = blockIdx.x, xcd = b & 7, idx = b >> 3, per_xcd = gridDim.x >> 3;
+  const int slice = idx % a.nsl, tpx = per_xcd / a.nsl;
+  const int team = xcd * tpx + idx / a.nsl, nteams = 8 * tpx;
+  const int n0 = slice * BN;
+  const int M = d.n * d.oh * d.ow;
+  const int c_lo = (int)((long long)a.nchunks * team / nteams);
+  const int c_hi = (int)((long long)a.nchunks * (team + 1) / nteams);
+
+  auto a_ptr = [&](int m) -> const float* {
+    m = m < M ? m : M - 1;
+    const unsigned t = hnd::fdiv((unsigned)m, a.div_ow), ow_ = (unsigned)m - t * (unsigned)d.ow;
+    const unsigned n_ = hnd::fdiv(t, a.div_oh), oh_ = t - n_ * (unsigned)d.oh;
+    const size_t pix = ((size_t)n_ * d.h + oh_ * (unsigned)d.sh) * (size_t)d.w_ + ow_ * (unsigned)d.sw;
+    return d.x + pix * (size_t)d.cin + (size_t)(g4 * 4);
+  };
+  auto out_pix = [&](int m) -> int {
+    if (m >= M) return -1;
+    const unsigned t = hnd::fdiv((unsigned)m, a.div_ow), ow_ = (unsigned)m - t * (unsigned)d.ow;
+    const unsigned n_ = hnd::fdiv(t, a.div_oh), oh_ = t - n_ * (unsigned)d.oh;
+    return ((int)n_ * d.yh + (int)oh_ * d.y_sh + d.y_oh) * d.yw + (int)ow_ * d.y_sw + d.y_ow;
+  };
+
+  const int col0 = n0 + wn * 64 + l16 * 4;
+  float es[NI], eb[NI], s1[NI], s2[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    es[ni] = d.epi_scale ? d.epi_scale[col0 + ni] : 1.f;
+    eb[ni] = d.epi_shift ? d.epi_shift[col0 + ni] : 0.f;
+    s1[ni] = 0.f;
+    s2[ni] = 0.f;
+  }
+  const bool vec_ok = (d.ldc % NI == 0) && ((uintptr_t)d.y % (4 * NI) == 0);
+  const float relu_floor = d.pro_relu ? 0.f : -INFINITY;
+  if (PRO) {
+    for (int k = tid; k < K; k += 256) {
+      pro[k] = d.pro_scale[k];
+      pro[K + k] = d.pro_shift[k];
+    }
+  }
+  int bsw[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) bsw[u] = ((4 * u + g4) ^ l16) * 4;
+  const float* Bw = Bs + (wn * 64 + l16) * K;
+
+  int c = c_lo;
+  while (c < c_hi) {
+    const int grp = a.cpg > 0 ? c / a.cpg : 0;
+    const int seg_hi = a.cpg > 0 ? min(c_hi, (grp + 1) * a.cpg) : c_hi;
+    __syncthreads();
+    {
+      const float* wsrc = d.w + (size_t)grp * (size_t)d.w_group_stride + (size_t)n0 * K;
+      constexpr int cpr = K >> 2;
+      for (int e = tid; e < BN * cpr; e += 256) {
+        const int r = e / cpr, ck = e - r * cpr;
+        *(f32x4*)(Bs + r * K + ((ck ^ (r & 15)) << 2)) = *(const f32x4*)(wsrc + (size_t)r * K + (ck << 2));
+      }
+    }
+    __syncthreads();
+
+    int cc = c + wm;
+    if (cc < seg_hi) {
+      const float* aptr[MI];
+      f32x4 ring[RING][MI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) aptr[mi] = a_ptr(cc * 64 + mi * 16 + l16);
+      static_for<RING>([&](auto U) __attribute__((always_inline)) {
+        constexpr int u = decltype(U)::value;
+        static_for<MI>([&](auto I) __attribute__((always_inline)) {
+          ring_load<u * 64, (u & 1) != 0>(ring[u][decltype(I)::value], aptr[decltype(I)::value]);
+        });
+      });
+      f32x4 out[MI][NI];                 // the finished tile, stored during the next tile's first k group
+      bool have_out = false;
+      for (; cc < seg_hi; cc += WM) {
+        const int cn = cc + WM < seg_hi ? cc + WM : cc;
+        const float* nptr[MI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) nptr[mi] = a_ptr(cn * 64 + mi * 16 + l16);
+        f32x4 acc[MI][NI];
+        f32x4 bcur[NI], bnxt[NI], ps = {1.f, 1.f, 1.f, 1.f}, pb = {0.f, 0.f, 0.f, 0.f}, psn = ps, pbn = pb;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) bcur[ni] = *(const f32x4*)(Bw + ni * 16 * K + bsw[0]);
+        if (PRO) {
+          ps = *(const f32x4*)(pro + g4 * 4);
+          pb = *(const f32x4*)(pro + K + g4 * 4);
+        }
+        static_for<KG>([&](auto G) __attribute__((always_inline)) {
+          constexpr int g = decltype(G)::value, slot = g % RING;
+          constexpr int kn = g + 1 < KG ? g + 1 : 0;
+          const int bo = (kn & ~3) * 16 + bsw[kn & 3];
+          ring_wait<4 * (RING - 1), (slot & 1) != 0>(ring[slot][0], ring[slot][1], ring[slot][2], ring[slot][3]);
+          static_for<MI>([&](auto MIc) __attribute__((always_inline)) {
+            constexpr int mi = decltype(MIc)::value;
+            f32x4 av = ring[slot][mi];
+            if (PRO) {
+              av = av * ps + pb;
+              av.x = fmaxf(av.x, relu_floor); av.y = fmaxf(av.y, relu_floor);
+              av.z = fmaxf(av.z, relu_floor); av.w = fmaxf(av.w, relu_floor);
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+#pragma unroll
+              for (int ni = 0; ni < NI; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                    av[s], bcur[ni][s], (g == 0 && s == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[mi][ni], 0, 0, 0);
+              if (mi == 0) {
+                bnxt[s] = *(const f32x4*)(Bw + s * 16 * K + bo);
+                if (PRO && s == 3) {
+                  psn = *(const f32x4*)(pro + kn * 16 + g4 * 4);
+                  pbn = *(const f32x4*)(pro + K + kn * 16 + g4 * 4);
+                }
+              }
+              if (g == 0 && have_out) {              // row 4*g4 + s of row group mi of the previous tile
+                f32x4 v;
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                  const float x = out[mi][ni][s] * es[ni] + eb[ni];
+                  v[ni] = d.relu ? fmaxf(x, 0.f) : x;
+                }
+                *(f32x4*)(d.y + (size_t)(unsigned)rowoff[mi * 16 + 4 * g4 + s] * (unsigned)d.ldc + col0) = v;
+              }
+              __builtin_amdgcn_sched_barrier(0);
+            }
+            // refill this slot's row group for the k group RING ahead (in this tile or the wave's next one)
+            if (g + RING < KG) ring_load<(g + RING) * 64, (slot & 1) != 0>(ring[slot][mi], aptr[mi]);
+            else ring_load<(g + RING - KG) * 64, (slot & 1) != 0>(ring[slot][mi], nptr[mi]);
+            __builtin_amdgcn_sched_barrier(0);
+          });
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) bcur[ni] = bnxt[ni];
+          if (PRO) { ps = psn; pb = pbn; }
+        });
+        // ---- hand the tile over: table of its output rows, accumulators -> `out`
+        {
+          const int po = out_pix(cc * 64 + lane);
+          __builtin_amdgcn_wave_barrier();
+          rowoff[lane] = po;
+          __builtin_amdgcn_wave_barrier();
+          const bool full = vec_ok && (cc * 64 + 64 <= M);
+          if (full) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+              for (int ni = 0; ni < NI; ++ni) out[mi][ni] = acc[mi][ni];
+            have_out = true;
+          } else {                                     // ragged / unaligned tile: checked path, not deferred
+            hnd::epilogue_tile<MI, NI>(d, acc, rowoff, rowoff, 4 * g4, col0, es, eb, s1, s2, false);
+            have_out = false;
+          }
+        }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) aptr[mi] = nptr[mi];
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the ring's last (unused) prefetches land before reuse
+      if (have_out) {                                    // the segment's last tile
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            f32x4 v;
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+              const float x = out[mi][ni][s] * es[ni] + eb[ni];
+              v[ni] = d.relu ? fmaxf(x, 0.f) : x;
+            }
+            *(f32x4*)(d.y + (size_t)(unsigned)rowoff[mi * 16 + 4 * g4 + s] * (unsigned)d.ldc + col0) = v;
+          }
+      }
+    }
+    c = seg_hi;
+  }
+}
+
 int bres_kmax() {
   const char* e = getenv("HND_BRES");          // 0 = off, else the largest K taken (read per call: in-process A/B)
   return e ? atoi(e) : 512;
@@ -257,11 +484,37 @@ int launch_bres_p(const hnd_conv_desc& d, const BresArgs& a, size_t lds, int gri
                      : launch_bres_t<WN, KQ, false>(d, a, lds, grid, stream);
 }
 
+template <int WN, int KQ, bool PRO>
+int launch_bres2_t(const hnd_conv_desc& d, const BresArgs& a, size_t lds, int grid, hipStream_t stream) {
+  static std::atomic<unsigned long long> attr_set{0};
+  auto kern = bres2_kernel<WN, KQ, PRO>;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (!(attr_set.load(std::memory_order_relaxed) & bit)) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) {
+      hnd::set_error("hipFuncSetAttribute(bres2<%d,%d>) failed: %s", WN, KQ, hipGetErrorString(e));
+      return HND_ERR_LAUNCH;
+    }
+    attr_set.fetch_or(bit, std::memory_order_relaxed);
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, d, a);
+  return hnd::check_launch("hnd_conv2d_igemm(bres2)");
+}
+
+template <int WN, int KQ>
+int launch_bres2_p(const hnd_conv_desc& d, const BresArgs& a, size_t lds, int grid, hipStream_t stream) {
+  return d.pro_scale ? launch_bres2_t<WN, KQ, true>(d, a, lds, grid, stream)
+                     : launch_bres2_t<WN, KQ, false>(d, a, lds, grid, stream);
+}
+
 }  // namespace
 
 namespace hnd {
 
-// 0 = not taken; 2 = the 128-column slice (K <= 256), 1 = the 64-column slice (K <= 512)
+// 0 = not taken; 1 / 2 = the 8-wave kernel with a 64- / 128-column weight slice (K <= 512 / 256); 3 / 4 = the
+// one-wave-per-SIMD kernel (bres2) with a 64- / 128-column slice, for epilogues without residual / mask operands
 int bres_variant(const hnd_conv_desc& d) {
   const int kmax = bres_kmax();
   if (kmax <= 0 || d.kh != 1 || d.kw != 1 || d.bh != 0 || d.bw != 0 || d.stats != nullptr) return 0;
@@ -274,9 +527,18 @@ int bres_variant(const hnd_conv_desc& d) {
   if (d.cout % bn != 0) return 0;
   const int per_xcd = cu_count() / 8, nsl = d.cout / bn;
   if (per_xcd < 1 || nsl > per_xcd || per_xcd % nsl != 0) return 0;
+  if ((long long)(d.oh - 1) * d.sh >= d.h || (long long)(d.ow - 1) * d.sw >= d.w_) return 0;
   const long long M = (long long)d.n * d.oh * d.ow;
   const long long nchunks = (M + 63) / 64, nteams = 8ll * (per_xcd / nsl);
   const long long per_team = nchunks / nteams;
+  const bool plain = !d.res1 && !d.res2 && !d.mask;
+  const char* v2 = getenv("HND_BRES2");                   // 0 = never the one-wave kernel (A/B)
+  if (plain && d.kdim >= 128 && !(v2 && atoi(v2) == 0) && per_team >= 2ll * (4 / wn)) {
+    // measured (profiles/r03_bres_vs_tiled.txt): the one-wave kernel wins on long runs of chunks; its prologue form
+    // (8 VALU per A fragment beside a single wave's MFMAs) does not, and K = 512 needs >= 48 chunks per team
+    if (getenv("HND_BRES_ALL") && !(d.pro_scale && d.kdim == 512)) return 2 + wn;
+    if (!d.pro_scale && per_team >= (d.w_group_rows > 0 || d.kdim == 512 ? 48 : 8)) return 2 + wn;
+  }
   if (per_team < 2ll * (8 / wn)) return 0;              // every wave row gets at least two chunks
   if (!getenv("HND_BRES_ALL")) {
     // where the free-running waves beat the tiled kernel (profiles/r03_bres_vs_tiled.txt, both with the specialised
@@ -287,16 +549,17 @@ int bres_variant(const hnd_conv_desc& d) {
     if ((d.res1 || d.res2 || d.mask) && d.kdim < 512) return 0;
     if (d.kdim == 128 && d.cout >= 512) return 0;
   }
-  if ((long long)(d.oh - 1) * d.sh >= d.h || (long long)(d.ow - 1) * d.sw >= d.w_) return 0;
   return wn;
 }
 
 int launch_bres(const hnd_conv_desc& d, hipStream_t stream) {
-  const int wn = bres_variant(d);
-  if (wn == 0) {
+  const int var = bres_variant(d);
+  if (var == 0) {
     set_error("launch_bres: descriptor not eligible");
     return HND_ERR_INVALID;
   }
+  const bool v2 = var > 2;
+  const int wn = v2 ? var - 2 : var;
   const long long M = (long long)d.n * d.oh * d.ow;
   BresArgs a;
   a.div_ow = make_fastdiv((unsigned)d.ow);
@@ -308,6 +571,11 @@ int launch_bres(const hnd_conv_desc& d, hipStream_t stream) {
   const bool pro = d.pro_scale != nullptr;
   const size_t lds = ((size_t)64 * wn * d.kdim + (pro ? 2 * (size_t)d.kdim : 0) + 8 * 128) * sizeof(float);
   const int grid = (cu_count() / 8) * 8;
+  if (v2) {
+    if (wn == 2) return d.kdim == 128 ? launch_bres2_p<2, 2>(d, a, lds, grid, stream)
+                                      : launch_bres2_p<2, 4>(d, a, lds, grid, stream);
+    return d.kdim == 256 ? launch_bres2_p<1, 4>(d, a, lds, grid, stream) : launch_bres2_p<1, 8>(d, a, lds, grid, stream);
+  }
   if (wn == 2) {
     if (d.kdim == 64) return launch_bres_p<2, 1>(d, a, lds, grid, stream);
     if (d.kdim == 128) return launch_bres_p<2, 2>(d, a, lds, grid, stream);

@@ -638,6 +638,6 @@ extern "C" int hnd_conv2d_igemm_tile(const hnd_conv_desc* desc) {
   if (!desc) return -1;
   if (desc->cin == 4) return 1;
   if (thin_n_applies(*desc)) return 4;
-  if (const int v = hnd::bres_variant(*desc)) return v == 2 ? 5 : 6;
+  if (const int v = hnd::bres_variant(*desc)) return v == 2 ? 5 : (v == 1 ? 6 : (v == 4 ? 7 : 8));
   return pick_tile(*desc);
 }

@@ -104,7 +104,7 @@ class ConvLaunch(object):
         """call again after editing the descriptor (grouped weights): the dispatch may change"""
         self.variant = 'igemm_c4_128x64' if self.desc.cin == 4 else \
             ('igemm_128x128', 'igemm_128x64', 'igemm_64x128', 'igemm_64x64', 'thin_n4', 'bres_128',
-             'bres_64')[_L.hnd_conv2d_igemm_tile(self.ref)]
+             'bres_64', 'bres2_128', 'bres2_64')[_L.hnd_conv2d_igemm_tile(self.ref)]
 
     def run(self, stream=None):
         rc = _L.hnd_conv2d_igemm(self.ref, stream if stream is not None else stream_ptr())

@@ -823,6 +823,8 @@ def test_thin_n_kernel_is_bit_identical_to_the_mfma_path(tmp_path):
     (64, 200, 336, 256, 1, True, False, False, 1, 2),        # K = 64, residual epilogue
     (128, 100, 168, 512, 1, True, True, True, 1, 8),         # K = 128, residual + mask + prologue
     (512, 100, 168, 64, 1, False, False, True, 1, 16),       # bres_64, K = 512, prologue
+    (128, 100, 168, 128, 1, False, False, True, 1, 16),      # K = 128 with prologue (one-wave kernel: ring = tile)
+    (256, 101, 169, 256, 1, False, False, False, 1, 8),      # ragged last chunk on the deferred-epilogue kernel
     (256, 201, 337, 64, 1, True, False, False, 1, 4),        # bres_64 with K = 256, ragged last chunk
     (256, 37, 53, 256, 1, False, False, False, 9, 64),       # grouped (Winograd-style) weights
 ])
@@ -854,8 +856,12 @@ def test_bres_kernel_is_bit_identical_to_the_tiled_kernel(ops, case, monkeypatch
     ps = (torch.rand(cin, generator=g).to(DEV) + 0.5) if pro else None
     pb = torch.randn(cin, generator=g).to(DEV) if pro else None
     outs, variants = {}, {}
-    for mode in ('0', '512'):
-        monkeypatch.setenv('HND_BRES', mode)
+    plain = not (res or msk)
+    for mode in ('0', '512', 'one_wave'):
+        if mode == 'one_wave' and not plain:
+            continue
+        monkeypatch.setenv('HND_BRES', '0' if mode == '0' else '512')
+        monkeypatch.setenv('HND_BRES2', '1' if mode == 'one_wave' else '0')
         if groups > 1:
             l = ops.conv_desc(x, pk, y, kh=1, kw=1, oh=1, ow=groups * tiles_pad, sh=1, dh=1, bh=0, sw=1, dw=1, bw=0,
                               cout=cout)
@@ -868,9 +874,12 @@ def test_bres_kernel_is_bit_identical_to_the_tiled_kernel(ops, case, monkeypatch
         l.run()
         torch.cuda.synchronize()
         outs[mode], variants[mode] = y.clone(), l.variant
-    assert variants['0'].startswith('igemm') and variants['512'].startswith('bres'), variants
+    assert variants['0'].startswith('igemm') and variants['512'] in ('bres_128', 'bres_64'), variants
     assert not bool(torch.isnan(outs['512']).any())
     assert torch.equal(outs['0'], outs['512']), float((outs['0'] - outs['512']).abs().max())
+    if plain and cin >= 128:        # the one-wave-per-SIMD kernel (asm register ring, deferred epilogue)
+        assert variants['one_wave'] in ('bres2_128', 'bres2_64'), variants
+        assert torch.equal(outs['0'], outs['one_wave']), float((outs['0'] - outs['one_wave']).abs().max())
     if groups == 1:
         xin = x.permute(0, 3, 1, 2)
         if pro:

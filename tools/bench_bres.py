@@ -41,7 +41,8 @@ def main():
     args = ap.parse_args()
     dev = 'cuda:0'
     os.environ['HND_BRES_ALL'] = '1'            # A/B on every eligible shape, not only where the picker takes it
-    tot = {'0': [0.0, 0.0], '512': [0.0, 0.0]}
+    modes = (('tiled', '0', '1'), ('bres', '512', '0'), ('bres2', '512', '1'))      # name, HND_BRES, HND_BRES2
+    tot = {m[0]: [0.0, 0.0] for m in modes}
     for name, (cin, h, w, cout, s, res, pro, groups) in SHAPES.items():
         if args.only and args.only not in name:
             continue
@@ -66,8 +67,8 @@ def main():
         ps = (torch.rand(cin, device=dev) + 0.5) if pro else None
         pb = torch.randn(cin, device=dev) if pro else None
         outs, line = {}, '%-38s' % name
-        for mode in ("0", "512"):
-            os.environ['HND_BRES'] = mode
+        for mode, e1, e2 in modes:
+            os.environ['HND_BRES'], os.environ['HND_BRES2'] = e1, e2
             if groups > 1:
                 l = ops.conv_desc(x, pk, y, kh=1, kw=1, oh=1, ow=groups * tiles_pad, sh=1, dh=1, bh=0, sw=1, dw=1, bw=0,
                                   cout=cout)
@@ -90,14 +91,16 @@ def main():
             outs[mode] = y.clone()
             tot[mode][0] += ms
             tot[mode][1] += l.flops
-            line += '  %-13s %7.3f ms %6.1f TF' % (l.variant, ms, l.flops / ms / 1e9)
-        same = torch.equal(outs['0'], outs['512']) and not bool(torch.isnan(outs['512']).any())
+            line += '  %-13s %6.3f ms %5.1f TF' % (l.variant, ms, l.flops / ms / 1e9)
+        same = all(torch.equal(outs['tiled'], outs[m]) for m in ('bres', 'bres2')) and \
+            not bool(torch.isnan(outs['bres2']).any())
         print(line + ('   bits equal' if same else '   *** DIFFERENT (max |d| %.3e)'
-                                                   % float((outs['0'] - outs['512']).abs().max())), flush=True)
+                                                   % float((outs['tiled'] - outs['bres2']).abs().max())), flush=True)
     os.environ.pop('HND_BRES', None)
+    os.environ.pop('HND_BRES2', None)
     for mode, (ms, fl) in tot.items():
         if ms:
-            print('TOTAL HND_BRES=%-4s %8.3f ms  %7.1f TFLOP/s' % (mode, ms, fl / ms / 1e9))
+            print('TOTAL %-6s %8.3f ms  %7.1f TFLOP/s' % (mode, ms, fl / ms / 1e9))
 
 
 if __name__ == '__main__':
