@@ -330,9 +330,11 @@ def run_rank(args):
     host_enqueue_ms = (time.perf_counter() - h0) / nh * 1e3
     fence()
     # per-launch HIP events: one extra single-stream step (kernels timed running alone)
+    from hnd_ghnd_object_detectors_amd import ops as OPS
     E.PROFILE['enabled'], E.PROFILE['records'] = True, []
+    OPS.HBM_PROFILE['enabled'], OPS.HBM_PROFILE['records'] = True, []
     step()
-    E.PROFILE['enabled'] = False
+    E.PROFILE['enabled'] = OPS.HBM_PROFILE['enabled'] = False
     fence()
     if rank != 0:
         if world > 1:
@@ -341,11 +343,21 @@ def run_rank(args):
         return
 
     # ---- roofline of the dominant kernel from the per-launch HIP events of the profiled step
-    per, groups = {}, {}
+    per, groups, hbm = {}, {}, {}
+
+    def hbm_add(kernel, nbytes, ms):
+        h_ = hbm.setdefault(kernel, {'launches': 0, 'ms': 0.0, 'bytes': 0})
+        h_['launches'] += 1
+        h_['ms'] += ms
+        h_['bytes'] += nbytes
+    for kernel, nbytes, e0, e1 in OPS.HBM_PROFILE['records']:
+        hbm_add(kernel, nbytes, e0.elapsed_time(e1))
     re_3x3 = re.compile(r'^(layer\d\.\d+\.conv2|fpn\.layer\d)(\.dgrad)?(\.wino_(in|out))?$')
     re_head = re.compile(r'^(layer1\.conv\d)(\.dgrad|\.wgrad)?(\.wino_(in|out|dy))?$')
     for tag, launch, e0, e1 in E.PROFILE['records']:
         ms = e0.elapsed_time(e1)
+        if getattr(launch, 'hbm_bytes', 0):              # Winograd transforms: HBM-bound plan entries
+            hbm_add(launch.kernel, launch.hbm_bytes, ms)
         if launch.flops:
             d = per.setdefault(launch.variant, {'ms': 0.0, 'flop': 0.0, 'n': 0})
             d['ms'] += ms
@@ -396,12 +408,23 @@ def run_rank(args):
     if g3 and g3['ms'] > 0:
         tf3 = g3['alg'] / g3['ms'] / 1e9
         conv3x3 = {'algorithmic_gflop': round(g3['alg'] / 1e9, 1), 'ms': round(g3['ms'], 3),
-                   'tflops': round(tf3, 2), 'frac': round(tf3 / FP32_MFMA_PEAK_TFLOPS, 4)}
+                   'algorithmic_tflops': round(tf3, 2),
+                   'algorithmic_speed_vs_direct_at_peak': round(tf3 / FP32_MFMA_PEAK_TFLOPS, 4),
+                   'note': 'direct-convolution 2*MAC / kernel time incl. the Winograd transforms; NOT a roofline '
+                           'fraction (Winograd executes 4x fewer multiplies): > 1 means faster than a direct conv at peak'}
     head2x2 = {k[1]: {'algorithmic_gflop': round(v['alg'] / 1e9, 2), 'ms': round(v['ms'], 3),
-                      'tflops': round(v['alg'] / v['ms'] / 1e9, 2),
-                      'frac': round(v['alg'] / v['ms'] / 1e9 / FP32_MFMA_PEAK_TFLOPS, 4)}
+                      'algorithmic_tflops': round(v['alg'] / v['ms'] / 1e9, 2),
+                      'algorithmic_speed_vs_direct_at_peak': round(v['alg'] / v['ms'] / 1e9 / FP32_MFMA_PEAK_TFLOPS, 4)}
                for k, v in sorted(groups.items()) if k[0] == 'head2x2' and v['ms'] > 0}
     conv_ms = sum(v['ms'] for v in per.values())
+    # HBM side: algorithmic bytes / in-run HIP-event time of the bandwidth-bound kernels, against the 8 TB/s spec
+    # and the ~6.3 TB/s a streaming kernel reaches on this part (MI355X_MICROARCH.md)
+    hbm_roofline = {k: {'launches': v['launches'], 'ms': round(v['ms'], 3), 'gbytes': round(v['bytes'] / 1e9, 3),
+                        'tb_per_s': round(v['bytes'] / v['ms'] / 1e9, 3),
+                        'frac_of_8.0': round(v['bytes'] / v['ms'] / 1e9 / 8.0, 3),
+                        'frac_of_6.3': round(v['bytes'] / v['ms'] / 1e9 / 6.3, 3)}
+                    for k, v in sorted(hbm.items(), key=lambda kv: -kv[1]['ms']) if v['ms'] > 0}
+    hbm_ms = sum(v['ms'] for v in hbm.values())
     E.PROFILE['records'] = [r for r in E.PROFILE['records'] if r[1].flops]      # --detail lists the MFMA launches
     if args.detail:
         agg = {}
@@ -449,6 +472,8 @@ def run_rank(args):
         'host_enqueue_ms_per_step': round(host_enqueue_ms, 3),
         'step_conv_tflops': round(gflop_img * args.batch / (ms_per_step / 1e3) / 1e3, 2),
         'conv_kernel_ms_per_step': round(conv_ms, 2),
+        'hbm_kernel_ms_per_step': round(hbm_ms, 2),
+        'hbm_roofline': hbm_roofline,
         'kernels': kernels,
         'last_loss': last,
         'max_mem_gb': round(torch.cuda.max_memory_allocated() / 1e9, 2),

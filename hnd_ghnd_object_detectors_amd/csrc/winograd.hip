@@ -364,6 +364,192 @@ __global__ void wino4_output_kernel(const float* __restrict__ m, float* __restri
 }
 
 
+// ================================================================================== F(6x6, 3x3)
+// Interpolation points {0, +-1, +-2, +-1/2, inf}: 64 products per 6x6 output tile = 5.06x fewer multiplies than direct
+// (F(4x4,3x3): 4x) and transformed tensors of 64/36 = 1.78x the activation (F(4x4,3x3): 2.25x) -- 21 % fewer GEMM
+// flops AND 21 % fewer transform bytes than F(4x4,3x3).  fp32 error against exact convolution on post-ReLU data,
+// K = 256: rel-L2 5e-6 (F(4x4,3x3): 2.6e-6; direct fp32 summation: 2e-7) -- far inside the 1e-3 parity bar.  Used
+// where the 6x6 tiling wastes little (>= 50x84 maps); matrices (Cook-Toom, checked against direct correlation in
+// fp64 to 3e-14):
+//   B^T = [1 0 -21/4 0 21/4 0 -1 0; 0 1 1 -17/4 -17/4 1 1 0; 0 -1 1 17/4 -17/4 -1 1 0; 0 1/2 1/4 -5/2 -5/4 2 1 0;
+//          0 -1/2 1/4 5/2 -5/4 -2 1 0; 0 2 4 -5/2 -5 1/2 1 0; 0 -2 4 5/2 -5 -1/2 1 0; 0 -1 0 21/4 0 -21/4 0 1]
+//   G   = [1 0 0; -2/9 -2/9 -2/9; -2/9 2/9 -2/9; 1/90 1/45 2/45; 1/90 -1/45 2/45; 32/45 16/45 8/45;
+//          32/45 -16/45 8/45; 0 0 1]
+//   A^T = [1 1 1 1 1 1 1 0; 0 1 -1 2 -2 1/2 -1/2 0; 0 1 1 4 4 1/4 1/4 0; 0 1 -1 8 -8 1/8 -1/8 0;
+//          0 1 1 16 16 1/16 1/16 0; 0 1 -1 32 -32 1/32 -1/32 1]
+#define HND_WINO6_G(a, b, c, o)                                          \
+  do {                                                                   \
+    o[0] = a;                                                            \
+    o[1] = -(a + b + c) * (2.f / 9.f);                                   \
+    o[2] = (-a + b - c) * (2.f / 9.f);                                   \
+    o[3] = a * (1.f / 90.f) + b * (1.f / 45.f) + c * (2.f / 45.f);       \
+    o[4] = a * (1.f / 90.f) - b * (1.f / 45.f) + c * (2.f / 45.f);       \
+    o[5] = a * (32.f / 45.f) + b * (16.f / 45.f) + c * (8.f / 45.f);     \
+    o[6] = a * (32.f / 45.f) - b * (16.f / 45.f) + c * (8.f / 45.f);     \
+    o[7] = c;                                                            \
+  } while (0)
+
+__global__ void wino6_weights_kernel(const float* __restrict__ w, float* __restrict__ u, int cout, int cin, int dgrad,
+                                     int rows, int rows_pad, int kdim) {
+  const long long total = (long long)rows_pad * kdim;
+  const int kreal = dgrad ? cout : cin;
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    const int pr = (int)(e / kdim), k = (int)(e - (long long)pr * kdim);      // packed row pr holds channel r
+    const int r = hnd::chan_of_row(pr);
+    const bool ok = r < rows && k < kreal;
+    float g[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        float v = 0.f;
+        if (ok) v = dgrad ? w[(((size_t)k * cin + r) * 3 + (2 - i)) * 3 + (2 - j)]
+                          : w[(((size_t)r * cin + k) * 3 + i) * 3 + j];
+        g[i][j] = v;
+      }
+    float t[3][8];                          // t[j][i] = (G g)[i][j]
+#pragma unroll
+    for (int j = 0; j < 3; ++j) HND_WINO6_G(g[0][j], g[1][j], g[2][j], t[j]);
+    const size_t fs = (size_t)rows_pad * kdim;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float o[8];
+      HND_WINO6_G(t[0][i], t[1][i], t[2][i], o);
+      float* dst = u + ((size_t)(i * 8) * rows_pad + pr) * kdim + k;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dst[(size_t)j * fs] = o[j];
+    }
+  }
+}
+
+#define HND_WINO6_BT(d0, d1, d2, d3, d4, d5, d6, d7, o0, o1, o2, o3, o4, o5, o6, o7) \
+  do {                                                                               \
+    const f32x2 e26_ = d2 + d6 - 4.25f * d4, o15_ = d1 + d5 - 4.25f * d3;            \
+    const f32x2 e3_ = 0.25f * d2 - 1.25f * d4 + d6, o3_ = 0.5f * d1 - 2.5f * d3 + 2.f * d5; \
+    const f32x2 e5_ = 4.f * d2 - 5.f * d4 + d6, o5_ = 2.f * d1 - 2.5f * d3 + 0.5f * d5;     \
+    const f32x2 t0_ = d0 - d6 + 5.25f * (d4 - d2), t7_ = d7 - d1 + 5.25f * (d3 - d5);       \
+    o0 = t0_; o1 = e26_ + o15_; o2 = e26_ - o15_; o3 = e3_ + o3_; o4 = e3_ - o3_;     \
+    o5 = e5_ + o5_; o6 = e5_ - o5_; o7 = t7_;                                         \
+  } while (0)
+
+// 8x8 input patch of tile t (rows 6ty-1.., cols 6tx-1..), two channels per thread: 128 VGPRs of patch
+__global__ void __launch_bounds__(256) wino6_input_kernel(const float* __restrict__ x, float* __restrict__ v,
+                                                          const WinoGeom g, const float* __restrict__ pro_scale,
+                                                          const float* __restrict__ pro_shift, int pro_relu) {
+  const int c2n = g.c >> 1;
+  const long long tiles = (long long)g.n * g.th * g.tw;
+  const long long total = tiles * c2n;
+  const size_t fs = (size_t)g.tiles_pad * g.c;
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    const int c2 = (int)(e % c2n);
+    long long t = e / c2n;
+    const int tx = (int)(t % g.tw);
+    long long q = t / g.tw;
+    const int ty = (int)(q % g.th), b = (int)(q / g.th);
+    f32x2 ps = {1.f, 1.f}, pb = {0.f, 0.f};
+    if (pro_scale) {
+      ps = *(const f32x2*)(pro_scale + c2 * 2);
+      pb = *(const f32x2*)(pro_shift + c2 * 2);
+    }
+    const float floor_ = pro_relu ? 0.f : -INFINITY;
+    f32x2 d[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int iy = 6 * ty - 1 + i;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int ix = 6 * tx - 1 + j;
+        const bool ok = (unsigned)iy < (unsigned)g.h && (unsigned)ix < (unsigned)g.w;
+        const size_t off = ok ? (((size_t)b * g.h + iy) * g.w + ix) * g.c + c2 * 2 : 0;
+        f32x2 a = *(const f32x2*)(x + off);
+        if (pro_scale) {
+          a = a * ps + pb;
+          a.x = fmaxf(a.x, floor_); a.y = fmaxf(a.y, floor_);
+        }
+        const f32x2 z = {0.f, 0.f};
+        d[i][j] = ok ? a : z;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)            // B^T d (down the columns, in place)
+      HND_WINO6_BT(d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j], d[6][j], d[7][j], d[0][j], d[1][j], d[2][j],
+                   d[3][j], d[4][j], d[5][j], d[6][j], d[7][j]);
+    float* dst = v + (size_t)t * g.c + c2 * 2;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {          // (.) B (along the rows), straight to memory
+      f32x2 o[8];
+      HND_WINO6_BT(d[i][0], d[i][1], d[i][2], d[i][3], d[i][4], d[i][5], d[i][6], d[i][7], o[0], o[1], o[2], o[3], o[4],
+                   o[5], o[6], o[7]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) *(f32x2*)(dst + (size_t)(i * 8 + j) * fs) = o[j];
+    }
+  }
+}
+
+#define HND_WINO6_AT(m0, m1, m2, m3, m4, m5, m6, m7, o0, o1, o2, o3, o4, o5)            \
+  do {                                                                                  \
+    const f32x2 p12 = m1 + m2, q12 = m1 - m2, p34 = m3 + m4, q34 = m3 - m4, p56 = m5 + m6, q56 = m5 - m6; \
+    o0 = m0 + p12 + p34 + p56;                                                          \
+    o1 = q12 + 2.f * q34 + 0.5f * q56;                                                  \
+    o2 = p12 + 4.f * p34 + 0.25f * p56;                                                 \
+    o3 = q12 + 8.f * q34 + 0.125f * q56;                                                \
+    o4 = p12 + 16.f * p34 + 0.0625f * p56;                                              \
+    o5 = q12 + 32.f * q34 + 0.03125f * q56 + m7;                                        \
+  } while (0)
+
+__global__ void __launch_bounds__(256) wino6_output_kernel(const float* __restrict__ m, float* __restrict__ y,
+                                                           const WinoGeom g, int cout, const WinoEpilogue ep) {
+  const int c2n = cout >> 1;
+  const long long tiles = (long long)g.n * g.th * g.tw;
+  const long long total = tiles * c2n;
+  const size_t fs = (size_t)g.tiles_pad * cout;
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    const int c2 = (int)(e % c2n);
+    long long t = e / c2n;
+    const int tx = (int)(t % g.tw);
+    long long q = t / g.tw;
+    const int ty = (int)(q % g.th), b = (int)(q / g.th);
+    const float* src = m + (size_t)t * cout + c2 * 2;
+    f32x2 s[6][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {          // A^T m (down the columns)
+      f32x2 mm[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) mm[i] = *(const f32x2*)(src + (size_t)(i * 8 + j) * fs);
+      HND_WINO6_AT(mm[0], mm[1], mm[2], mm[3], mm[4], mm[5], mm[6], mm[7], s[0][j], s[1][j], s[2][j], s[3][j], s[4][j],
+                   s[5][j]);
+    }
+    f32x2 es = {1.f, 1.f}, eb = {0.f, 0.f};
+    if (ep.epi_scale) es = *(const f32x2*)(ep.epi_scale + c2 * 2);
+    if (ep.epi_shift) eb = *(const f32x2*)(ep.epi_shift + c2 * 2);
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      const int oy = 6 * ty + a;
+      f32x2 o[6];
+      HND_WINO6_AT(s[a][0], s[a][1], s[a][2], s[a][3], s[a][4], s[a][5], s[a][6], s[a][7], o[0], o[1], o[2], o[3], o[4],
+                   o[5]);
+#pragma unroll
+      for (int bb = 0; bb < 6; ++bb) {
+        const int ox = 6 * tx + bb;
+        if (oy >= g.h || ox >= g.w) continue;
+        f32x2 v = o[bb] * es + eb;
+        const size_t off = (((size_t)b * g.h + oy) * g.w + ox) * g.c + c2 * 2;
+        if (ep.res1) v += *(const f32x2*)(ep.res1 + off);
+        if (ep.mask) {
+          const f32x2 k = *(const f32x2*)(ep.mask + off);
+          v.x = k.x > 0.f ? v.x : 0.f; v.y = k.y > 0.f ? v.y : 0.f;
+        }
+        if (ep.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); }
+        *(f32x2*)(y + off) = v;
+      }
+    }
+  }
+}
+
+
 // ================================================================================== F(4x4, 2x2)
 // The student head's 2x2 convolutions (src/models/mimic/resnet_layer.py:43-62) and their data gradients: points
 // {0, 1, -1, 2, inf}, 25 products per 4x4 output tile instead of 64 (2.56x fewer), transformed tensors 25/16 = 1.56x.
@@ -647,28 +833,32 @@ __global__ void wino2_wgrad_out_kernel(const float* __restrict__ s, float* __res
 extern "C" {
 
 int64_t hnd_wino_tiles_pad(int n, int h, int w, int tile) {
-  if (tile != 2 && tile != 4) return -1;
+  if (tile != 2 && tile != 4 && tile != 6) return -1;
   const long long t = (long long)n * ((h + tile - 1) / tile) * ((w + tile - 1) / tile);
   return (t + 127) / 128 * 128;
 }
 
 int hnd_wino_weights(const float* weight, float* u, int cout, int cin, int dgrad, int tile, void* stream) {
-  HND_REQUIRE(weight && u && cout > 0 && cin > 0 && (tile == 2 || tile == 4), "hnd_wino_weights: bad arguments");
+  HND_REQUIRE(weight && u && cout > 0 && cin > 0 && (tile == 2 || tile == 4 || tile == 6),
+              "hnd_wino_weights: bad arguments");
   const int rows = dgrad ? cin : cout, kreal = dgrad ? cout : cin;
   HND_REQUIRE(kreal % 32 == 0, "hnd_wino_weights: GEMM depth %d must be a multiple of 32", kreal);
   const int rows_pad = (rows + 63) / 64 * 64;
   if (tile == 2)
     hipLaunchKernelGGL(wino_weights_kernel, dim3(grid_for((long long)rows_pad * kreal)), dim3(256), 0,
                        hnd::as_stream(stream), weight, u, cout, cin, dgrad, rows, rows_pad, kreal);
-  else
+  else if (tile == 4)
     hipLaunchKernelGGL(wino4_weights_kernel, dim3(grid_for((long long)rows_pad * kreal)), dim3(256), 0,
+                       hnd::as_stream(stream), weight, u, cout, cin, dgrad, rows, rows_pad, kreal);
+  else
+    hipLaunchKernelGGL(wino6_weights_kernel, dim3(grid_for((long long)rows_pad * kreal)), dim3(256), 0,
                        hnd::as_stream(stream), weight, u, cout, cin, dgrad, rows, rows_pad, kreal);
   return hnd::check_launch("hnd_wino_weights");
 }
 
 int hnd_wino_input(const float* x, float* v, int n, int h, int w, int c, const float* pro_scale,
                    const float* pro_shift, int pro_relu, int tile, void* stream) {
-  HND_REQUIRE(x && v && n > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0 && (tile == 2 || tile == 4),
+  HND_REQUIRE(x && v && n > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0 && (tile == 2 || tile == 4 || tile == 6),
               "hnd_wino_input: bad arguments");
   HND_REQUIRE(pro_scale == nullptr || pro_shift != nullptr, "hnd_wino_input: pro_shift is required with pro_scale");
   WinoGeom g{n, h, w, c, (h + tile - 1) / tile, (w + tile - 1) / tile, (int)hnd_wino_tiles_pad(n, h, w, tile)};
@@ -676,8 +866,11 @@ int hnd_wino_input(const float* x, float* v, int n, int h, int w, int c, const f
   if (tile == 2)
     hipLaunchKernelGGL(wino_input_kernel, dim3(grid_for(tiles * (c / 4))), dim3(256), 0, hnd::as_stream(stream), x, v,
                        g, pro_scale, pro_shift, pro_relu);
-  else
+  else if (tile == 4)
     hipLaunchKernelGGL(wino4_input_kernel, dim3(grid_for(tiles * (c / 2))), dim3(256), 0, hnd::as_stream(stream), x, v,
+                       g, pro_scale, pro_shift, pro_relu);
+  else
+    hipLaunchKernelGGL(wino6_input_kernel, dim3(grid_for(tiles * (c / 2))), dim3(256), 0, hnd::as_stream(stream), x, v,
                        g, pro_scale, pro_shift, pro_relu);
   return hnd::check_launch("hnd_wino_input");
 }
@@ -685,15 +878,18 @@ int hnd_wino_input(const float* x, float* v, int n, int h, int w, int c, const f
 int hnd_wino_output(const float* m, float* y, int n, int h, int w, int cout, int ldc, const float* epi_scale,
                     const float* epi_shift, const float* res1, const float* mask, int relu, int tile, void* stream) {
   HND_REQUIRE(m && y && n > 0 && h > 0 && w > 0 && cout > 0 && cout % 4 == 0 && ldc >= cout && ldc % 4 == 0 &&
-                  (tile == 2 || tile == 4), "hnd_wino_output: bad arguments");
+                  (tile == 2 || tile == 4 || tile == 6), "hnd_wino_output: bad arguments");
   WinoGeom g{n, h, w, ldc, (h + tile - 1) / tile, (w + tile - 1) / tile, (int)hnd_wino_tiles_pad(n, h, w, tile)};
   WinoEpilogue ep{epi_scale, epi_shift, res1, mask, relu};
   const long long tiles = (long long)n * g.th * g.tw;
   if (tile == 2)
     hipLaunchKernelGGL(wino_output_kernel, dim3(grid_for(tiles * (cout / 4))), dim3(256), 0, hnd::as_stream(stream), m,
                        y, g, cout, ep);
-  else
+  else if (tile == 4)
     hipLaunchKernelGGL(wino4_output_kernel, dim3(grid_for(tiles * (cout / 2))), dim3(256), 0, hnd::as_stream(stream), m,
+                       y, g, cout, ep);
+  else
+    hipLaunchKernelGGL(wino6_output_kernel, dim3(grid_for(tiles * (cout / 2))), dim3(256), 0, hnd::as_stream(stream), m,
                        y, g, cout, ep);
   return hnd::check_launch("hnd_wino_output");
 }

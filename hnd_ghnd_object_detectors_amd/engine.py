@@ -139,10 +139,12 @@ class WinoCache(object):
     def __init__(self, weight, tile):
         self.weight, self.tile, self.packs, self.ver = weight, tile, {}, None
 
-    def get(self, dgrad=False):
-        ww = self.packs.get(dgrad)
+    def get(self, dgrad=False, tile=None):
+        """tile: the output tile the launch will use (wino_tile_for picks it per geometry); default = the cache's own"""
+        tile = tile or self.tile
+        ww = self.packs.get((dgrad, tile))
         if ww is None:
-            ww = self.packs[dgrad] = ops.WinoWeights(self.weight.detach(), dgrad, self.tile)
+            ww = self.packs[(dgrad, tile)] = ops.WinoWeights(self.weight.detach(), dgrad, tile)
             self.ver = weight_version(self.weight)
         return ww
 
@@ -187,6 +189,22 @@ def use_winograd(cin, cout, stride):
     if WINOGRAD not in (2, 4) or not WINOGRAD_FROZEN or stride != 1 or cin % 32 != 0 or cout % 4 != 0:
         return 0
     return WINOGRAD if min(cin, cout) >= (128 if WINOGRAD == 4 else 256) else 0
+
+
+WINOGRAD6 = os.environ.get('HND_WINOGRAD6', '1') != '0'
+WINOGRAD6_MIN_TILES = int(os.environ.get('HND_WINOGRAD6_MIN_TILES', '32'))      # 6x6 tiles per IMAGE
+
+
+def wino_tile_for(tile, n, h, w):
+    """F(6x6,3x3) instead of F(4x4,3x3) where the map is large enough: 64 products per 36 outputs instead of 36 per
+    16 (21 % fewer GEMM flops) and transformed tensors of 1.78x instead of 2.25x the activation (21 % fewer transform
+    bytes), at twice F(4x4)'s -- still ~5e-6 -- fp32 error (measured: tools/bench_wino.py, profiles/r03_bench_wino.txt:
+    x1.12-1.19 over F(4x4) from 200x336 down to 25x42 at 512 channels).  Tiny maps keep 4x4 tiles (border waste of
+    the 6x6 tiling).  The choice depends on the map size only, never on the batch: the arithmetic of one image is the
+    same alone and inside a batch (tests: batch-16 maps == batch-1 maps bit for bit)."""
+    if tile != 4 or not WINOGRAD6:
+        return tile
+    return 6 if ((h + 5) // 6) * ((w + 5) // 6) >= WINOGRAD6_MIN_TILES else 4
 
 
 # =========================================================================================== transform
@@ -385,8 +403,9 @@ class FrozenLayerEngine(object):
             self.fwd.append((ops.conv_forward(cur, b.w1.get(), a1, 1, 1, 0, epi_scale=a1f[0], epi_shift=a1f[1],
                                               relu=True), tagp + '.conv1'))
             if b.wino is not None:      # stride-1 3x3, >= 256 channels: Winograd F(2x2,3x3)
-                v, m = self._wino_scratch(n, h, w, b.planes, b.planes)
-                self.fwd += ops.WinoConv(a1, b.wino.get(False), a2, v, m, epi_scale=a2f[0], epi_shift=a2f[1],
+                tile = wino_tile_for(b.wino.tile, n, h, w)
+                v, m = self._wino_scratch(n, h, w, b.planes, b.planes, tile)
+                self.fwd += ops.WinoConv(a1, b.wino.get(False, tile), a2, v, m, epi_scale=a2f[0], epi_shift=a2f[1],
                                          relu=True).launches(tagp + '.conv2')
             else:
                 self.fwd.append((ops.conv_forward(a1, b.w2.get(), a2, 3, b.stride, 1, epi_scale=a2f[0],
@@ -408,9 +427,9 @@ class FrozenLayerEngine(object):
         self.out = cur
         self.flops_fwd = flops
 
-    def _wino_scratch(self, n, h, w, cin, cout):
+    def _wino_scratch(self, n, h, w, cin, cout, tile=None):
         """V / M scratch of the Winograd launches of this engine (they run one after another on one stream)."""
-        nv, nm = ops.WinoConv.scratch_elems(n, h, w, cin, cout, WINOGRAD)
+        nv, nm = ops.WinoConv.scratch_elems(n, h, w, cin, cout, tile or WINOGRAD)
         self._wino_need = (max(nv, getattr(self, '_wino_need', (0, 0))[0]), max(nm, getattr(self, '_wino_need', (0, 0))[1]))
         return self.bufs.get('wino_v', (self._wino_need[0],)), self.bufs.get('wino_m', (self._wino_need[1],))
 
@@ -449,8 +468,9 @@ class FrozenLayerEngine(object):
             self.bwd += [(l, tagp + '.conv3.dgrad') for l in ls]
             # conv2 (3x3, stride s): g_a1 = [a1>0] * dgrad(g_a2 * s2)
             if b.wino is not None:
-                v, m = self._wino_scratch(n, h, w, b.planes, b.planes)
-                self.bwd += ops.WinoConv(g_a2, b.wino.get(True), g_a1, v, m, pro_scale=s2,
+                tile = wino_tile_for(b.wino.tile, n, h, w)
+                v, m = self._wino_scratch(n, h, w, b.planes, b.planes, tile)
+                self.bwd += ops.WinoConv(g_a2, b.wino.get(True, tile), g_a1, v, m, pro_scale=s2,
                                          mask=a1).launches(tagp + '.conv2.dgrad')
             else:
                 ls, _ = ops.conv_dgrad(g_a2, b.w2, g_a1, 3, b.stride, 1, pro_scale=s2, mask=a1)
@@ -806,7 +826,7 @@ class FpnEngine(object):
             # Winograd scratch sized for the finest level up front (the loop runs coarse -> fine)
             n0, h0, w0, _ = feats[0].shape
             oc = self.layer[0][0].weight.shape[0]
-            need = (ops.WinoConv.scratch_elems(n0, h0, w0, oc, oc, WINOGRAD)
+            need = (ops.WinoConv.scratch_elems(n0, h0, w0, oc, oc, wino_tile_for(WINOGRAD, n0, h0, w0))
                     if any(w is not None for w in self.wino) else (0, 0))
             for i in range(nlev - 1, -1, -1):
                 f = feats[i]
@@ -819,10 +839,11 @@ class FpnEngine(object):
                 ml, wl = self.layer[i]
                 self.results[i] = self.bufs.get('p%d' % i, (n, h, w, ml.weight.shape[0]))
                 if self.wino[i] is not None:            # 3x3 256->256 output conv: Winograd F(2x2,3x3)
-                    nv, nm = ops.WinoConv.scratch_elems(n, h, w, ml.weight.shape[1], ml.weight.shape[0], WINOGRAD)
+                    tile = wino_tile_for(self.wino[i].tile, n, h, w)
+                    nv, nm = ops.WinoConv.scratch_elems(n, h, w, ml.weight.shape[1], ml.weight.shape[0], tile)
                     need = (max(nv, need[0]), max(nm, need[1]))
                     v, mm = self.bufs.get('wino_v', (need[0],)), self.bufs.get('wino_m', (need[1],))
-                    self.fwd += ops.WinoConv(inner[i], self.wino[i].get(False), self.results[i], v, mm,
+                    self.fwd += ops.WinoConv(inner[i], self.wino[i].get(False, tile), self.results[i], v, mm,
                                              epi_shift=ml.bias.detach()).launches('fpn.layer%d' % i)
                 else:
                     self.fwd.append((ops.conv_forward(inner[i], wl.get(), self.results[i], 3, 1, 1,

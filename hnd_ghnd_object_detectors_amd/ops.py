@@ -283,8 +283,9 @@ def transform_image(src, dst, index, out_h, out_w, rscale_h, rscale_w, mean, std
     assert c == 3 and src.is_contiguous() and dst.shape[3] == 4
     m = (C.c_float * 3)(*mean)
     s = (C.c_float * 3)(*std)
-    check(_L.hnd_transform_image(ptr(src), h, w, ptr(dst), index, out_h, out_w, dst.shape[1], dst.shape[2],
-                                 float(rscale_h), float(rscale_w), m, s, stream_ptr()), 'hnd_transform_image')
+    _hbm('transform_image', 12 * h * w + 16 * dst.shape[1] * dst.shape[2], lambda: check(
+        _L.hnd_transform_image(ptr(src), h, w, ptr(dst), index, out_h, out_w, dst.shape[1], dst.shape[2],
+                               float(rscale_h), float(rscale_w), m, s, stream_ptr()), 'hnd_transform_image'))
 
 
 def transform_image_u8(src, dst, index, out_h, out_w, rscale_h, rscale_w, mean, std, hwc, flip=False):
@@ -300,17 +301,35 @@ def transform_image_u8(src, dst, index, out_h, out_w, rscale_h, rscale_w, mean, 
           'hnd_transform_image_u8')
 
 
+# bench.py's hbm_roofline: HIP events (torch's current stream == the launch stream) around the HBM-bound launches
+# that do not go through an engine plan entry, with the bytes each of them must move
+HBM_PROFILE = {'enabled': False, 'records': []}
+
+
+def _hbm(kernel, nbytes, call):
+    if HBM_PROFILE['enabled']:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        call()
+        e1.record()
+        HBM_PROFILE['records'].append((kernel, int(nbytes), e0, e1))
+    else:
+        call()
+
+
 def maxpool_fwd(x, y, idx):
     n, h, w, c = x.shape
-    check(_L.hnd_maxpool3x3s2_fwd(ptr(x), ptr(y), ptr(idx), n, h, w, c, y.shape[1], y.shape[2], stream_ptr()),
-          'hnd_maxpool3x3s2_fwd')
+    _hbm('maxpool_fwd', x.numel() * 4 + y.numel() * 4 + idx.numel() * idx.element_size(), lambda: check(
+        _L.hnd_maxpool3x3s2_fwd(ptr(x), ptr(y), ptr(idx), n, h, w, c, y.shape[1], y.shape[2], stream_ptr()),
+        'hnd_maxpool3x3s2_fwd'))
 
 
 def maxpool_bwd_relu_scale(dy, idx, act, scale, dx):
     n, h, w, c = act.shape
-    check(_L.hnd_maxpool3x3s2_bwd_relu_scale(ptr(dy), ptr(idx), ptr(act), ptr(scale), ptr(dx), n, h, w, c,
-                                             dy.shape[1], dy.shape[2], stream_ptr()),
-          'hnd_maxpool3x3s2_bwd_relu_scale')
+    nbytes = dy.numel() * 4 + idx.numel() * idx.element_size() + act.numel() * 4 + dx.numel() * 4
+    _hbm('maxpool_bwd', nbytes, lambda: check(
+        _L.hnd_maxpool3x3s2_bwd_relu_scale(ptr(dy), ptr(idx), ptr(act), ptr(scale), ptr(dx), n, h, w, c,
+                                           dy.shape[1], dy.shape[2], stream_ptr()), 'hnd_maxpool3x3s2_bwd_relu_scale'))
 
 
 def bn_finalize(partials, ntiles, c, cs, count, gamma, beta, running_mean, running_var, nbt, momentum, eps,
@@ -322,8 +341,9 @@ def bn_finalize(partials, ntiles, c, cs, count, gamma, beta, running_mean, runni
 
 def affine_relu(x, scale, shift, y, relu):
     cs = x.shape[-1]
-    check(_L.hnd_affine_relu(ptr(x), ptr(scale), ptr(shift), ptr(y), x.numel() // cs, cs, int(relu), stream_ptr()),
-          'hnd_affine_relu')
+    _hbm('affine_relu', 8 * x.numel(), lambda: check(
+        _L.hnd_affine_relu(ptr(x), ptr(scale), ptr(shift), ptr(y), x.numel() // cs, cs, int(relu), stream_ptr()),
+        'hnd_affine_relu'))
 
 
 def bn_bwd_ntiles(npix):
@@ -332,8 +352,9 @@ def bn_bwd_ntiles(npix):
 
 def bn_bwd_reduce(g, x, scale, shift, mean, rstd, relu, partials):
     cs = x.shape[-1]
-    check(_L.hnd_bn_bwd_reduce(ptr(g), ptr(x), ptr(scale), ptr(shift), ptr(mean), ptr(rstd), int(relu),
-                               x.numel() // cs, cs, ptr(partials), stream_ptr()), 'hnd_bn_bwd_reduce')
+    _hbm('bn_bwd_reduce', 8 * x.numel(), lambda: check(
+        _L.hnd_bn_bwd_reduce(ptr(g), ptr(x), ptr(scale), ptr(shift), ptr(mean), ptr(rstd), int(relu),
+                             x.numel() // cs, cs, ptr(partials), stream_ptr()), 'hnd_bn_bwd_reduce'))
 
 
 def bn_bwd_finalize(partials, ntiles, c, cs, count, gamma, mean, rstd, dgamma, dbeta, k123):
@@ -343,8 +364,9 @@ def bn_bwd_finalize(partials, ntiles, c, cs, count, gamma, mean, rstd, dgamma, d
 
 def bn_bwd_apply(g, x, scale, shift, k123, relu, dx):
     cs = x.shape[-1]
-    check(_L.hnd_bn_bwd_apply(ptr(g), ptr(x), ptr(scale), ptr(shift), ptr(k123), int(relu), ptr(dx),
-                              x.numel() // cs, cs, stream_ptr()), 'hnd_bn_bwd_apply')
+    _hbm('bn_bwd_apply', 12 * x.numel(), lambda: check(
+        _L.hnd_bn_bwd_apply(ptr(g), ptr(x), ptr(scale), ptr(shift), ptr(k123), int(relu), ptr(dx),
+                            x.numel() // cs, cs, stream_ptr()), 'hnd_bn_bwd_apply'))
 
 
 class MseLaunch(object):
@@ -363,8 +385,10 @@ class MseLaunch(object):
         self.scratch = torch.empty(_L.hnd_mse_scratch_elems(), dtype=torch.float64, device=device)
 
     def run(self):
-        check(_L.hnd_mse_sum_fwd_bwd(self.arr, self.n, ptr(self.out), ptr(self.scratch), stream_ptr()),
-              'hnd_mse_sum_fwd_bwd')
+        nbytes = sum(4 * t.numel() * (3 if g is not None else 2) for t, s, g, f, rm in self.keep)
+        _hbm('mse', nbytes, lambda: check(
+            _L.hnd_mse_sum_fwd_bwd(self.arr, self.n, ptr(self.out), ptr(self.scratch), stream_ptr()),
+            'hnd_mse_sum_fwd_bwd'))
         return self.out
 
 
@@ -374,9 +398,10 @@ def scale_by_device_scalar(x, scalar_dev):
 
 
 def adam_step_flat(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, grad_scale=1.0):
-    check(_L.hnd_adam_step_flat(ptr(param), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), param.numel(), float(lr),
-                                float(beta1), float(beta2), float(eps), int(step), float(grad_scale), stream_ptr()),
-          'hnd_adam_step_flat')
+    _hbm('adam', 28 * param.numel(), lambda: check(
+        _L.hnd_adam_step_flat(ptr(param), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), param.numel(), float(lr),
+                              float(beta1), float(beta2), float(eps), int(step), float(grad_scale), stream_ptr()),
+        'hnd_adam_step_flat'))
     PARAM_EPOCH[0] += 1
 
 
@@ -416,11 +441,11 @@ def wino_tiles_pad(n, h, w, tile=2):
 
 class WinoWeights(object):
     """U = G g G^T of one 3x3 conv weight in packed GEMM-operand layout [(tile+2)^2][rows_pad][depth]; dgrad:
-    transposed conv.  tile = 2 (F(2x2,3x3)) or 4 (F(4x4,3x3))."""
+    transposed conv.  tile = 2 (F(2x2,3x3)), 4 (F(4x4,3x3)) or 6 (F(6x6,3x3))."""
 
     def __init__(self, weight, dgrad=False, tile=2):
         cout, cin, kh, kw = weight.shape
-        assert kh == 3 and kw == 3 and weight.is_contiguous() and tile in (2, 4)
+        assert kh == 3 and kw == 3 and weight.is_contiguous() and tile in (2, 4, 6)
         self.src, self.dgrad, self.tile, self.ncomp = weight, dgrad, tile, (tile + 2) ** 2
         self.rows, self.depth = (cin, cout) if dgrad else (cout, cin)
         assert self.depth % 32 == 0, 'Winograd path needs a GEMM depth that is a multiple of 32'
@@ -492,7 +517,13 @@ class WinoConv(object):
     def launches(self, tag):
         """[(launch, tag)] for an engine plan: the two transforms carry no flops (not event-timed by bench.py), the
         GEMM launch is an ordinary igemm launch with the multiplies it really executes."""
-        return [(_Step(self._run_input), tag + '.wino_in'), (self.gemm, tag), (_Step(self._run_output), tag + '.wino_out')]
+        n, h, w, c = self.geom
+        nc, tiles = self.ww.ncomp, n * ((h + self.tile - 1) // self.tile) * ((w + self.tile - 1) // self.tile)
+        extra = sum(1 for t in (self.epi[2], self.epi[3]) if t is not None)
+        b_in = 4 * (n * h * w * c + nc * tiles * c)                                 # read x once, write V
+        b_out = 4 * (nc * tiles * self.cout + (1 + extra) * n * h * w * self.cout)  # read M (+ res / mask), write y
+        return [(_Step(self._run_input, 'wino_input', b_in), tag + '.wino_in'), (self.gemm, tag),
+                (_Step(self._run_output, 'wino_output', b_out), tag + '.wino_out')]
 
     def run(self, stream=None):
         self._run_input(stream)
@@ -578,7 +609,12 @@ class Wino2Conv(object):
                                   stream if stream is not None else stream_ptr()), 'hnd_wino2_output')
 
     def launches(self, tag):
-        return [(_Step(self._run_input), tag + '.wino_in'), (self.gemm, tag), (_Step(self._run_output), tag + '.wino_out')]
+        n, h, w, c, oh, ow = self.geom
+        tiles = n * ((oh + 3) // 4) * ((ow + 3) // 4)
+        b_in = 4 * (n * h * w * c + 25 * tiles * c)
+        b_out = 4 * (25 * tiles * self.cout + n * oh * ow * self.cout)
+        return [(_Step(self._run_input, 'wino2_input', b_in), tag + '.wino_in'), (self.gemm, tag),
+                (_Step(self._run_output, 'wino2_output', b_out), tag + '.wino_out')]
 
     def run(self, stream=None):
         self._run_input(stream)
@@ -628,7 +664,10 @@ class Wino2Wgrad(object):
                                         stream if stream is not None else stream_ptr()), 'hnd_wino2_wgrad_output')
 
     def launches(self, tag):
-        return [(_Step(self._run_dy), tag + '.wino_dy'), (self.gemm, tag), (_Step(self._run_out), tag + '.wino_out')]
+        n, oh, ow, cout, ldy, cin = self.geom
+        tiles = n * ((oh + 3) // 4) * ((ow + 3) // 4)
+        return [(_Step(self._run_dy, 'wino2_dy', 4 * (n * oh * ow * cout + 25 * tiles * cout)), tag + '.wino_dy'),
+                (self.gemm, tag), (_Step(self._run_out, 'wino2_wgrad_output', 4 * 29 * cout * cin), tag + '.wino_out')]
 
     def run(self, stream=None):
         self._run_dy(stream)
@@ -637,11 +676,12 @@ class Wino2Wgrad(object):
 
 
 class _Step(object):
-    """a plan entry without MFMA work"""
-    __slots__ = ('fn', 'flops', 'alg_flops', 'variant')
+    """a plan entry without MFMA work: HBM-bound; `hbm_bytes` = the bytes it must move (bench.py's hbm_roofline)"""
+    __slots__ = ('fn', 'flops', 'alg_flops', 'variant', 'kernel', 'hbm_bytes')
 
-    def __init__(self, fn):
+    def __init__(self, fn, kernel='transform', hbm_bytes=0):
         self.fn, self.flops, self.alg_flops, self.variant = fn, 0, 0, 'transform'
+        self.kernel, self.hbm_bytes = kernel, int(hbm_bytes)
 
     def run(self, stream=None):
         self.fn(stream)

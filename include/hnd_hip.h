@@ -165,12 +165,13 @@ int hnd_transform_image_u8(const uint8_t* src, int h, int w, int hwc, int flip, 
                            int out_w, int hp, int wp, float scale_h, float scale_w, const float mean[3],
                            const float std[3], void* stream);
 
-/* ---- Winograd F(tile x tile, 3x3), tile = 2 or 4, for stride-1 pad-1 3x3 convolutions (torchvision Bottleneck.conv2
+/* ---- Winograd F(tile x tile, 3x3), tile = 2, 4 or 6, for stride-1 pad-1 3x3 convolutions (torchvision Bottleneck.conv2
  * and the FPN output convs built at src/models/org/rcnn.py:391-414; forward and data gradient) ----------------------
  * y = out_transform( GEMM_f( in_transform(x), U_f ) ), f = 0..(tile+2)^2-1, with all GEMMs issued as ONE
  * hnd_conv2d_igemm launch (1x1 conv over ncomp*tiles_pad "pixels", w_group_rows = tiles_pad, w_group_stride =
  * rows_pad*depth).  tile 2: 16 products per 2x2 outputs (2.25x fewer multiplies than direct, transformed tensors 4x);
- * tile 4: 36 per 4x4 outputs (4x fewer, tensors 2.25x, points 0, +-1, +-2, inf: ~1e-5 relative fp32 error).
+ * tile 4: 36 per 4x4 outputs (4x fewer, tensors 2.25x, points 0, +-1, +-2, inf: ~1e-5 relative fp32 error);
+ * tile 6: 64 per 6x6 outputs (5.06x fewer, tensors 1.78x, points 0, +-1, +-2, +-1/2, inf: twice tile 4's error).
  * hnd_wino_tiles_pad: rows per component = n*ceil(h/tile)*ceil(w/tile) rounded up to 128.
  * hnd_wino_weights:   OIHW [cout][cin][3][3] -> u [ncomp][round_up(rows,64)][depth] (forward: rows = cout, depth = cin;
  *                     dgrad != 0: rows = cin, depth = cout, taps flipped -- the transposed convolution).

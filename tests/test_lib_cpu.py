@@ -58,3 +58,17 @@ def test_detection_operators_validate_their_arguments():
     assert lib.hnd_nms(None, None, 10, 0.5, None, None, None) == -1
     assert lib.hnd_roi_align(None, 1, 8, 8, 64, None, None, 3, 0.25, 7, 7, 2, None, None) == -1
     assert lib.hnd_nms_workspace(4800) == 4800 * 75 * 8
+
+
+def test_bres2_inline_asm_ring_is_untouched_between_load_and_wait():
+    """csrc/conv_bres.hip hides the A-fragment ring loads of bres2_kernel from hipcc (inline asm `global_load_dwordx4`
+    + hand-counted `s_waitcnt vmcnt(28)`); the compiler is then free to copy / spill / reuse a ring register before
+    its data has landed.  tools/audit_bres_asm.py walks the generated assembly (loop back edges included) and must
+    find no instruction touching a ring register between its asm load and the wait that releases it."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, os.path.join(root, 'tools', 'audit_bres_asm.py')], capture_output=True,
+                         text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
+    assert 'bres2_kernel' in res.stdout and '0 problem(s)' in res.stdout

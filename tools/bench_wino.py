@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Direct implicit-GEMM vs Winograd F(2x2,3x3) on the 3x3 stride-1 shapes of the step (batch 16)."""
+"""Direct implicit-GEMM vs Winograd F(4x4,3x3) and F(6x6,3x3) on the 3x3 stride-1 shapes of the step (batch 16)."""
 import os
 import sys
 
@@ -36,7 +36,7 @@ def main():
         direct = ops.conv_forward(x, ops.pack_weights(wt), y0, 3, 1, 1, epi_shift=sh, relu=True)
         td = timed(direct.run)
         line = '%-26s direct %7.3f ms (%5.1f TF)' % (name, td, direct.flops / td / 1e9)
-        for tile in (2, 4):
+        for tile in (4, 6):
             ww = ops.WinoWeights(wt, tile=tile)
             nv, nm = ops.WinoConv.scratch_elems(n, h, w, cin, cout, tile)
             v, m = torch.empty(nv, device=dev), torch.empty(nm, device=dev)
@@ -44,7 +44,7 @@ def main():
             tw, tg = timed(wino.run), timed(wino.gemm.run)
             err = float((y0 - y1).abs().max() / y0.abs().max())
             line += ' | F(%d,3) %7.3f ms (gemm %6.3f ms %5.1f TF %s) x%.2f err %.1e' % (
-                tile, tw, tg, wino.gemm.flops / tg / 1e9, wino.variant.split('_')[-1], td / tw, err)
+                tile, tw, tg, wino.gemm.flops / tg / 1e9, wino.gemm.variant, td / tw, err)
             del v, m
         print(line, flush=True)
 
