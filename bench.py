@@ -382,12 +382,14 @@ def run_rank(args):
                 'traffic_measured_in_run': False,
                 'launches_per_step': per[dom]['n'], 'avg_launch_ms': round(per[dom]['ms'] / per[dom]['n'], 4),
                 'algorithmic_gflop_per_launch': round(per[dom]['flop'] / per[dom]['n'] / 1e9, 3),
-                'flops_basis': ('multiplies the launches execute: implicit-GEMM convs 2*M*Cout*K; the Winograd '
-                                'F(%dx%d,3x3) GEMMs 2*%d*tiles*Cin*Cout (%.2fx fewer than the direct 3x3 they replace)'
-                                % (E.WINOGRAD, E.WINOGRAD, (E.WINOGRAD + 2) ** 2,
-                                   9.0 * E.WINOGRAD ** 2 / (E.WINOGRAD + 2) ** 2))
-                               if E.WINOGRAD else 'implicit-GEMM convs 2*M*Cout*K'}
+                'flops_basis': ('multiplies the launches execute: implicit-GEMM / B-resident GEMM convs 2*M*Cout*K; the '
+                                'Winograd component GEMMs 2*ncomp*tiles*Cin*Cout (F(4x4,3x3): 36 products per 16 outputs, '
+                                'F(6x6,3x3): 64 per 36, F(4x4,2x2): 25 per 16 -- 4x / 5.06x / 2.56x fewer than the direct '
+                                'convolutions they replace)') if E.WINOGRAD else 'implicit-GEMM convs 2*M*Cout*K',
+                'per_kernel_frac': {k: round(v['flop'] / v['ms'] / 1e9 / FP32_MFMA_PEAK_TFLOPS, 4)
+                                    for k, v in per.items() if v['ms'] > 0}}
     run_cfg = {'batch': args.batch, 'method': args.method, 'model': args.model, 'winograd': E.WINOGRAD,
+               'winograd6': bool(E.WINOGRAD6), 'bres': os.environ.get('HND_BRES', '512'),
                'no_fpn': bool(args.no_fpn), 'height': args.height, 'width': args.width}
     try:        # HBM bytes per launch of the dominant kernel from the newest committed PMC pass OF THIS CONFIGURATION
         import glob
@@ -457,8 +459,9 @@ def run_rank(args):
                                   'elided' if args.no_fpn else 'executed (as written)'),
                    'global_batch': args.batch * world, 'parallelism': 'dp%d' % world,
                    'weights': 'seeded random init (no network for COCO weights)',
-                   'conv3x3': ('Winograd F(%dx%d,3x3) for stride-1 3x3 convs with >=%d channels, implicit GEMM elsewhere'
-                               % (E.WINOGRAD, E.WINOGRAD, 128 if E.WINOGRAD == 4 else 256))
+                   'conv3x3': ('Winograd F(%dx%d,3x3)%s for stride-1 3x3 convs with >=%d channels, implicit GEMM elsewhere'
+                               % (E.WINOGRAD, E.WINOGRAD, ' / F(6x6,3x3) on maps of >= %d 6x6 tiles' % E.WINOGRAD6_MIN_TILES
+                                  if E.WINOGRAD6 and E.WINOGRAD == 4 else '', 128 if E.WINOGRAD == 4 else 256))
                               if E.WINOGRAD else 'implicit GEMM'},
         'roofline': roofline,
         'conv3x3_roofline': conv3x3,

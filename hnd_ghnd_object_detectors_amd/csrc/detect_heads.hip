@@ -23,6 +23,25 @@ inline int grid_for(long long work, int threads = 256) {
   return (int)(b < 1 ? 1 : (b > 65535LL * 32 ? 65535LL * 32 : b));
 }
 
+// GT-mask resize of CustomRCNNTransform.resize (reference src/models/org/rcnn.py:54-57):
+//   misc_nn_ops.interpolate(mask[None].float(), scale_factor=s)[0].byte()   -- mode 'nearest'
+// ATen: src = min((int64)floorf(dst * scale), in - 1) with scale = (float)(1.0 / scale_factor) per axis.  The float
+// round trip of a uint8 is the identity, so the kernel moves bytes.
+__global__ void resize_mask_nearest_kernel(const unsigned char* __restrict__ in, long long k, int h, int w, int oh,
+                                           int ow, float rh, float rw, unsigned char* __restrict__ out) {
+  const long long total = k * oh * ow;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const int ox = (int)(e % ow);
+    const long long t = e / ow;
+    const int oy = (int)(t % oh);
+    const long long b = t / oh;
+    int sy = (int)floorf((float)oy * rh), sx = (int)floorf((float)ox * rw);
+    sy = sy < h - 1 ? sy : h - 1;
+    sx = sx < w - 1 ? sx : w - 1;
+    out[e] = in[(b * h + sy) * w + sx];
+  }
+}
+
 __global__ void mask_probs_kernel(const float* __restrict__ logits, const long long* __restrict__ labels, long long k,
                                   int m, int ldc, float* __restrict__ probs) {
   const long long total = k * m * m;
@@ -209,6 +228,16 @@ int hnd_paste_masks(const float* probs, const int64_t* boxes, int64_t k, int m, 
   hipLaunchKernelGGL(paste_masks_kernel, dim3(grid_for(k * (long long)im_h * im_w)), dim3(256), 0, hnd::as_stream(stream),
                      probs, (const long long*)boxes, (long long)k, m, im_h, im_w, out);
   return hnd::check_launch("hnd_paste_masks");
+}
+
+int hnd_resize_mask_nearest_u8(const unsigned char* in, int64_t k, int h, int w, int oh, int ow, double scale_factor,
+                               unsigned char* out, void* stream) {
+  if (k <= 0 || oh <= 0 || ow <= 0) return HND_OK;
+  HND_REQUIRE(in && out && h > 0 && w > 0 && scale_factor > 0.0, "hnd_resize_mask_nearest_u8: bad arguments");
+  const float r = (float)(1.0 / scale_factor);                   // compute_scales_value with a given scale_factor
+  hipLaunchKernelGGL(resize_mask_nearest_kernel, dim3(grid_for(k * (long long)oh * ow)), dim3(256), 0,
+                     hnd::as_stream(stream), in, (long long)k, h, w, oh, ow, r, r, out);
+  return hnd::check_launch("hnd_resize_mask_nearest_u8");
 }
 
 int hnd_upsample_bilinear_nhwc(const float* in, int64_t k, int h, int w, int c, int factor, float* out, void* stream) {

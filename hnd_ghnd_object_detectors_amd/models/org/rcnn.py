@@ -24,6 +24,23 @@ def resize_boxes(boxes, original_size, new_size):
     return torch.stack((xmin * rw, ymin * rh, xmax * rw, ymax * rh), dim=1)
 
 
+def resize_masks_nearest(masks, scale):
+    """ground-truth masks [k, h, w] uint8 -> [k, floor(h*s), floor(w*s)] uint8: the reference's
+    ``misc_nn_ops.interpolate(mask[None].float(), scale_factor=scale)[0].byte()`` (src/models/org/rcnn.py:54-57, mode
+    'nearest') as one HIP launch that moves bytes (hnd_resize_mask_nearest_u8) -- no float copy of the masks."""
+    from ... import _lib, ops
+    if not masks.is_cuda:
+        raise RuntimeError('the HIP transform resizes ground-truth masks on the device: move the targets there first '
+                           '(mimic_runner.distill_model does, as the reference :49-50)')
+    m = masks.to(torch.uint8).contiguous()
+    k, h, w = m.shape
+    oh, ow = ops.interp_out_size(h, scale), ops.interp_out_size(w, scale)
+    out = torch.empty((k, oh, ow), dtype=torch.uint8, device=m.device)
+    _lib.check(_lib.load().hnd_resize_mask_nearest_u8(m.data_ptr(), k, h, w, oh, ow, float(scale), out.data_ptr(),
+                                                      ops.stream_ptr()), 'hnd_resize_mask_nearest_u8')
+    return out
+
+
 def resize_keypoints(keypoints, original_size, new_size):
     rh, rw = (float(s) / float(o) for s, o in zip(new_size, original_size))
     out = keypoints.clone()
@@ -56,8 +73,7 @@ class CustomRCNNTransform(nn.Module):
             return target
         target['boxes'] = resize_boxes(target['boxes'], old_hw, new_hw)
         if 'masks' in target:
-            m = target['masks']
-            target['masks'] = torch.nn.functional.interpolate(m[None].float(), scale_factor=scale)[0].byte()
+            target['masks'] = resize_masks_nearest(target['masks'], scale)
         if 'keypoints' in target:
             target['keypoints'] = resize_keypoints(target['keypoints'], old_hw, new_hw)
         return target

@@ -370,6 +370,11 @@ int hnd_mask_probs(const float* logits, const int64_t* labels, int64_t k, int m,
  * pixel, resized bilinearly (align_corners=False) to (y1-y0+1, x1-x0+1) and pasted at (y0, x0), zero elsewhere */
 int hnd_paste_masks(const float* probs, const int64_t* boxes, int64_t k, int m, int im_h, int im_w, float* out,
                     void* stream);
+/* Ground-truth mask resize of the transform (reference src/models/org/rcnn.py:54-57:
+ * interpolate(mask[None].float(), scale_factor=s)[0].byte(), mode 'nearest'): in [k][h][w] uint8 -> out [k][oh][ow]
+ * uint8 with oh = floor(h*s), ow = floor(w*s); source index min(floor(dst * (float)(1/s)), in-1) as ATen. */
+int hnd_resize_mask_nearest_u8(const unsigned char* in, int64_t k, int h, int w, int oh, int ow, double scale_factor,
+                               unsigned char* out, void* stream);
 /* F.interpolate(scale_factor=factor, mode='bilinear', align_corners=False) on an NHWC tensor in [k][h][w][c] */
 int hnd_upsample_bilinear_nhwc(const float* in, int64_t k, int h, int w, int c, int factor, float* out, void* stream);
 /* heatmaps_to_keypoints: maps [k][h][w][ldc] (keypoint j = channel j), rois [k][4] (x1, y1, x2, y2); per RoI the

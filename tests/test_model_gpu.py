@@ -210,6 +210,12 @@ def test_decoded_input_pipeline_matches_reference_fixture():
     ref = torch.from_numpy(zp['batch'])
     assert float((il.tensors.cpu() - ref).abs().max()) < 2e-5
     assert out_t[0]['masks'].shape[-2:] == tuple(il.image_sizes[0])
+    # the reference's resized targets (rcnn.py:50-62): ground-truth masks through hnd_resize_mask_nearest_u8 are the
+    # reference's bytes; boxes / keypoints to rounding
+    for got, (_, _, _, tout) in zip(out_t, G.pipeline_case(zp)):
+        assert got['masks'].dtype == torch.uint8 and torch.equal(got['masks'].cpu(), tout['masks'])
+        assert float((got['boxes'].cpu() - tout['boxes']).abs().max()) < 1e-3
+        assert float((got['keypoints'].cpu() - tout['keypoints']).abs().max()) < 1e-3
 
 
 def test_deferred_fpn_stream_changes_nothing(monkeypatch):

@@ -903,6 +903,21 @@ def test_bres_kernel_is_bit_identical_to_the_tiled_kernel(ops, case, monkeypatch
             assert float((outs['512'][0, 0, rows] - ref).norm() / ref.norm()) < 1e-5
 
 
+@pytest.mark.parametrize('h,w,scale', [(480, 640, 1.25), (800, 1333, 1.0), (375, 500, 2.1333333333333333),
+                                       (1333, 800, 0.8401500375093773), (37, 53, 1.7027027027027026), (5, 7, 0.5)])
+def test_gt_mask_nearest_resize_equals_torch_bytes(h, w, scale):
+    """reference src/models/org/rcnn.py:54-57: interpolate(mask[None].float(), scale_factor=s)[0].byte() -- the HIP
+    kernel moves uint8 and must reproduce ATen's nearest source index (floorf(dst * (float)(1 / s))) byte for byte"""
+    from hnd_ghnd_object_detectors_amd.models.org.rcnn import resize_masks_nearest
+    g = torch.Generator().manual_seed(5)
+    m = (torch.rand(3, h, w, generator=g) < 0.4).to(torch.uint8) * torch.randint(1, 255, (3, 1, 1), generator=g).to(torch.uint8)
+    ref = torch.nn.functional.interpolate(m[None].float(), scale_factor=scale)[0].byte()
+    got = resize_masks_nearest(m.to(DEV), scale)
+    assert got.dtype == torch.uint8 and tuple(got.shape) == tuple(ref.shape)
+    assert torch.equal(got.cpu(), ref)
+    assert resize_masks_nearest(torch.zeros(0, h, w, dtype=torch.uint8, device=DEV), scale).shape[0] == 0
+
+
 def test_jpeg_codec_and_data_logger_follow_the_reference(tmp_path):
     """structure/transformer.py JpegCompressor / JpegDecompressor / DataLogger (reference :58-128): the 3-channel
     bottleneck is quantised by the HIP codec (byte-exact to myutils' quantize_tensor), written as a JPEG with PIL and

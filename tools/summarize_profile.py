@@ -20,6 +20,9 @@ def short(name):
     if m:
         base = ('igemm_c4_%sx%s' if m.group(4) == 'true' else 'igemm_%sx%s') % (m.group(1), m.group(2))
         return base + ('[bn-prologue]' if m.group(5) == 'true' and FULLNAMES else '')
+    m = re.search(r'bres(2?)_kernel<(\d+), (\d+), (true|false)>', name)
+    if m:           # B-resident persistent GEMM (conv_bres.hip): wave columns -> width of the resident weight slice
+        return 'bres%s_%d' % (m.group(1), 64 * int(m.group(2))) + ('[prologue]' if m.group(4) == 'true' and FULLNAMES else '')
     m = re.search(r'wgrad_kernel<(\d+), (\d+)>', name)
     if m:
         return 'wgrad_m%s' % m.group(1)
@@ -30,7 +33,7 @@ def short(name):
                      ('wgrad_kernelILi128', 'wgrad_m128'), ('wgrad_kernelILi64', 'wgrad_m64')):
         if key in name:
             return lab
-    for key in ('wino4_input', 'wino4_output', 'wino4_weights', 'wino2_input', 'wino2_output', 'wino2_weights',
+    for key in ('wino6_input', 'wino6_output', 'wino6_weights', 'wino4_input', 'wino4_output', 'wino4_weights', 'wino2_input', 'wino2_output', 'wino2_weights',
                 'wino_input', 'wino_output', 'wino_weights'):
         if key + '_kernel' in name:
             return key
@@ -81,7 +84,7 @@ if 'FETCH_SIZE' in traffic and 'WRITE_SIZE' in traffic:
                     '--warmup 1`, summed over both steps; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts '
                     '64 B per 128-B request)', 'unit': 'bytes per launch', 'kernels': {}}
     for k, (fv, fn) in traffic['FETCH_SIZE'].items():
-        if k in traffic['WRITE_SIZE'] and ('igemm' in k or 'wgrad' in k):
+        if k in traffic['WRITE_SIZE'] and ('igemm' in k or 'wgrad' in k or 'bres' in k):
             wv, wn = traffic['WRITE_SIZE'][k]
             tj['kernels'][k] = {'dispatches': fn, 'fetch_kib_raw': fv, 'write_kib': wv,
                                 'traffic_bytes_per_launch': int((2 * fv + wv) * 1024 / fn)}
