@@ -87,6 +87,8 @@ def launch_ranks(args):
                    MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HND_BENCH_LAUNCHED='1')
         env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')        # dmabuf IPC: required by RCCL on this pool
         env.setdefault('OMP_NUM_THREADS', '8')
+        if args.share_device:                   # several processes on one GPU: the third (FPN) stream thrashes
+            env['HND_DEFER_FPN'] = '0'
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
     raw = procs[0].stdout.read().decode()      # rank 0 prints the JSON line; native libraries (gloo, RCCL

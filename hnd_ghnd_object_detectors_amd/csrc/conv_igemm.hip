@@ -596,6 +596,8 @@ int pick_tile(const hnd_conv_desc& d) {
 namespace hnd {
 int bres_variant(const hnd_conv_desc& d);                      // conv_bres.hip: B-resident persistent GEMM
 int launch_bres(const hnd_conv_desc& d, hipStream_t stream);
+bool stem7_applies(const hnd_conv_desc& d);                    // conv_stem.hip: 7x7 s2 stem from an LDS patch
+int launch_stem7(const hnd_conv_desc& d, hipStream_t stream);
 }  // namespace hnd
 
 extern "C" int hnd_conv2d_igemm(const hnd_conv_desc* desc, void* stream) {
@@ -621,7 +623,8 @@ extern "C" int hnd_conv2d_igemm(const hnd_conv_desc* desc, void* stream) {
   HND_REQUIRE((long long)d.n * d.h * d.w_ * d.cin < (1ll << 32) - 1, "hnd_conv2d_igemm: input exceeds 2^32 elements");
   hipStream_t s = hnd::as_stream(stream);
   if (d.cin == 4) {
-    return launch<128, 64, 32, true>(d, s);   // stem (cout 64) and the 3->64 decoder conv
+    if (hnd::stem7_applies(d)) return hnd::launch_stem7(d, s);
+    return launch<128, 64, 32, true>(d, s);   // the 3->64 decoder conv (and any other 4-channel-input conv)
   }
   if (thin_n_applies(d)) return launch_thin_n(d, s);
   if (hnd::bres_variant(d)) return hnd::launch_bres(d, s);
@@ -636,7 +639,7 @@ extern "C" int hnd_conv2d_igemm(const hnd_conv_desc* desc, void* stream) {
 
 extern "C" int hnd_conv2d_igemm_tile(const hnd_conv_desc* desc) {
   if (!desc) return -1;
-  if (desc->cin == 4) return 1;
+  if (desc->cin == 4) return hnd::stem7_applies(*desc) ? 9 : 1;
   if (thin_n_applies(*desc)) return 4;
   if (const int v = hnd::bres_variant(*desc)) return v == 2 ? 5 : (v == 1 ? 6 : (v == 4 ? 7 : 8));
   return pick_tile(*desc);

@@ -1,0 +1,149 @@
+// Stem convolution (7x7, stride 2, pad 3, 3 -> 64 channels, image stored NHWC4) from an LDS-staged input patch:
+// custom/resnet.py:26-30,96 / torchvision ResNet.conv1, FrozenBatchNorm + ReLU in the epilogue.
+//
+// In the generic implicit-GEMM kernel every thread gathers ONE 16-byte tap per (pixel, tap) from global memory -- 49
+// scattered reads per output pixel -- and the stem ran at 64 TFLOP/s (0.41 of the fp32 MFMA peak) although its GEMM
+// shape (M = 4.3 M pixels, N = 64, K = 196) reaches 90-95 on the same kernel without the gather.  Here a workgroup
+// owns an 8 x 32 tile of output pixels: the 21 x 69 input patch it needs (23 KB) is copied to LDS once, coalesced,
+// zero-filled outside the image; the packed weights (64 rows x 208, 54 KB, rows padded to 212 floats so the 16 rows of
+// a fragment read fall on different banks) sit beside it; an MFMA A-fragment -- lane (l16, g4) = pixel l16 of a
+// 16-pixel run, tap 4*kg + g4, 4 channels -- is then exactly ONE ds_read_b128 of the patch.  No k-loop staging, no
+// barrier after the fill.
+// The k order is the generic kernel's (k = 4*tap + channel; MFMA s of k group kg sums channel s of taps 4kg..4kg+3)
+// and the epilogue expression is the same, so the result is bit-identical (tests/test_ops_gpu.py).
+#include "common.h"
+
+#include <stdlib.h>
+
+namespace {
+
+using hnd::f32x4;
+
+constexpr int TH = 8, TW = 32;                   // output tile of a workgroup (rows x cols)
+constexpr int PH = 2 * TH + 5, PW = 2 * TW + 5;  // input patch: 21 x 69 pixels of 4 floats
+constexpr int KG = 13;                           // 16-deep k groups: 52 taps (49 real; the packed rows are zero beyond)
+constexpr int WLD = 212;                         // LDS row stride of the weights (floats): 53 sixteen-byte slots
+
+__global__ void __launch_bounds__(256, 2) stem7_kernel(const hnd_conv_desc d, const int tiles_x, const int tiles_y) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* patch = smem;                           // [PH][PW][4]
+  float* ws = smem + PH * PW * 4;                // [64][WLD]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l16 = lane & 15, g4 = lane >> 4;
+  int b = blockIdx.x;
+  const int tx = b % tiles_x;
+  b /= tiles_x;
+  const int ty = b % tiles_y, n = b / tiles_y;
+  const int oy0 = ty * TH, ox0 = tx * TW;        // first output pixel of the tile
+  const int iy0 = 2 * oy0 - 3, ix0 = 2 * ox0 - 3;
+
+  // ---- fill: weights (k < 208 of the 64 packed rows) and the zero-padded patch
+  for (int e = tid; e < 64 * (KG * 4); e += 256) {
+    const int r = e / (KG * 4), c = e - r * (KG * 4);
+    *(f32x4*)(ws + r * WLD + c * 4) = *(const f32x4*)(d.w + (size_t)r * d.kdim + c * 4);
+  }
+  const float* img = d.x + (size_t)n * d.h * d.w_ * 4;
+  for (int e = tid; e < PH * PW; e += 256) {
+    const int py = e / PW, px = e - py * PW;
+    const int iy = iy0 + py, ix = ix0 + px;
+    const bool ok = (unsigned)iy < (unsigned)d.h && (unsigned)ix < (unsigned)d.w_;
+    const f32x4 v = *(const f32x4*)(img + (ok ? ((size_t)iy * d.w_ + ix) * 4 : 0));
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    *(f32x4*)(patch + e * 4) = ok ? v : z;
+  }
+  __syncthreads();
+
+  // this lane's tap of every k group: offset (floats) inside the patch; taps >= 49 read tap 48 (their weights are 0)
+  int toff[KG];
+#pragma unroll
+  for (int kg = 0; kg < KG; ++kg) {
+    int t = 4 * kg + g4;
+    t = t < 49 ? t : 48;
+    toff[kg] = ((t / 7) * PW + (t % 7)) * 4;
+  }
+  // wave w owns output rows 2w, 2w+1 of the tile; row group mi = (row 2w + mi / 2, cols 16 * (mi & 1) + l16)
+  const float* ap[4];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+    ap[mi] = patch + ((2 * (2 * wave + (mi >> 1))) * PW + 2 * (16 * (mi & 1) + l16)) * 4;
+  const float* bp = ws + l16 * WLD + g4 * 4;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kg = 0; kg < KG; ++kg) {
+    f32x4 a[4], bq[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) bq[ni] = *(const f32x4*)(bp + ni * 16 * WLD + kg * 16);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) a[mi] = *(const f32x4*)(ap[mi] + toff[kg]);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi][s], bq[ni][s], acc[mi][ni], 0, 0, 0);
+  }
+
+  // ---- epilogue: the lane holds pixels 4*g4 + i of each 16-pixel run and channels 4*l16 .. 4*l16 + 3
+  const int col0 = l16 * 4;
+  float es[4], eb[4];
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) {
+    es[ni] = d.epi_scale ? d.epi_scale[col0 + ni] : 1.f;
+    eb[ni] = d.epi_shift ? d.epi_shift[col0 + ni] : 0.f;
+  }
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+    const int oy = oy0 + 2 * wave + (mi >> 1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int ox = ox0 + 16 * (mi & 1) + 4 * g4 + i;
+      if (oy >= d.oh || ox >= d.ow) continue;
+      f32x4 v;
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        const float x = acc[mi][ni][i] * es[ni] + eb[ni];
+        v[ni] = d.relu ? fmaxf(x, 0.f) : x;
+      }
+      *(f32x4*)(d.y + (((size_t)n * d.yh + oy) * d.yw + ox) * (size_t)d.ldc + col0) = v;
+    }
+  }
+}
+
+}  // namespace
+
+namespace hnd {
+
+bool stem7_applies(const hnd_conv_desc& d) {
+  const char* e = getenv("HND_STEM7");
+  if (e && atoi(e) == 0) return false;
+  return d.cin == 4 && d.kh == 7 && d.kw == 7 && d.sh == 2 && d.sw == 2 && d.dh == 1 && d.dw == 1 && d.bh == -3 &&
+         d.bw == -3 && d.cout == 64 && d.ldc % 4 == 0 && d.kdim >= 4 * KG * 4 && !d.pro_scale && !d.res1 && !d.res2 &&
+         !d.mask && !d.stats && d.w_group_rows == 0 && d.y_sh == 1 && d.y_sw == 1 && d.y_oh == 0 && d.y_ow == 0 &&
+         d.yh == d.oh && d.yw == d.ow && (uintptr_t)d.y % 16 == 0 && (uintptr_t)d.x % 16 == 0;
+}
+
+int launch_stem7(const hnd_conv_desc& d, hipStream_t stream) {
+  static bool attr_done[64] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const size_t lds = ((size_t)PH * PW * 4 + 64 * WLD) * sizeof(float);
+  if (!attr_done[dev & 63]) {
+    hipError_t e = hipFuncSetAttribute((const void*)stem7_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      set_error("hipFuncSetAttribute(stem7) failed: %s", hipGetErrorString(e));
+      return HND_ERR_LAUNCH;
+    }
+    attr_done[dev & 63] = true;
+  }
+  const int tiles_x = (d.ow + TW - 1) / TW, tiles_y = (d.oh + TH - 1) / TH;
+  hipLaunchKernelGGL(stem7_kernel, dim3((unsigned)(d.n * tiles_x * tiles_y)), dim3(256), lds, stream, d, tiles_x, tiles_y);
+  return check_launch("hnd_conv2d_igemm(stem7)");
+}
+
+}  // namespace hnd

@@ -7,10 +7,11 @@ drawn ``fixed_sizes``, :45-48), collects ``{loss_name: ((teacher_path, out), (st
 returns ``criterion(output_dict, org_loss_dict)``.
 MI355X specifics: the frozen teacher forward is issued on a second HIP stream (it is independent of the student
 forward, so the tails of one network's launches are filled by the other's); both models share one transformed
-batch inside a transform scope.  Opt-in (``HND_DEFER_FPN=1``): both feature pyramids -- executed as written, but
-read by nobody when ``org_loss_factor`` is 0 -- are issued on a third stream so they trail into the backward pass
-and fill the last-round gaps of its dgrad launches (joined before the next forward).  It is worth +0.6 % on a
-dedicated GPU but collapses (50x slower) when two processes time-share one GPU, so it is off by default.
+batch inside a transform scope.  Both feature pyramids -- executed as written, but read by nobody when
+``org_loss_factor`` is 0 -- are issued on a third stream so they trail into the backward pass and fill the last-round
+gaps of its dgrad launches (joined before the next forward): +0.8 % on a dedicated GPU (round 3, A/B on one box:
+101.76 -> 100.94 ms).  It collapses (50x slower) when two PROCESSES time-share one GPU, which only the 2-rank
+plumbing tests do: they, and ``bench.py --share_device``, set ``HND_DEFER_FPN=0``.
 """
 import os
 import random
@@ -48,7 +49,7 @@ class DistillationBox(nn.Module):
         self.overlap_teacher = os.environ.get('HND_TEACHER_STREAM', '1') != '0'
         self._side_stream = None
         # the criterion ignores the models' own outputs (org_loss_factor 0): their FPNs may trail into the backward
-        self.defer_fpn = (os.environ.get('HND_DEFER_FPN', '0') != '0' and
+        self.defer_fpn = (os.environ.get('HND_DEFER_FPN', '1') != '0' and
                           getattr(self.criterion, 'org_loss_factor', 1) == 0)
         self._fpn_stream = None
 

@@ -179,6 +179,7 @@ class Wino2Cache(object):
 
 
 WINOGRAD_FROZEN = os.environ.get('HND_WINOGRAD_FROZEN', '1') != '0'   # debugging knob: frozen / FPN 3x3 convs
+WINOGRAD6_ENABLED = os.environ.get('HND_WINOGRAD6', '1') != '0'
 
 
 def use_winograd(cin, cout, stride):
@@ -188,7 +189,10 @@ def use_winograd(cin, cout, stride):
     256/512 and x1.0 for 128."""
     if WINOGRAD not in (2, 4) or not WINOGRAD_FROZEN or stride != 1 or cin % 32 != 0 or cout % 4 != 0:
         return 0
-    return WINOGRAD if min(cin, cout) >= (128 if WINOGRAD == 4 else 256) else 0
+    # with F(6x6,3x3) available even the 64-channel convs of the teacher's layer1 gain (x1.20 at 200x336,
+    # profiles/r03_bench_wino.txt; F(4x4): x1.06): their 64 component GEMMs are K = 64 deep, HBM-bound like the transforms
+    floor = (64 if WINOGRAD6_ENABLED else 128) if WINOGRAD == 4 else 256
+    return WINOGRAD if min(cin, cout) >= floor else 0
 
 
 WINOGRAD6 = os.environ.get('HND_WINOGRAD6', '1') != '0'

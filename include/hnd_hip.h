@@ -103,7 +103,9 @@ int hnd_conv2d_igemm(const hnd_conv_desc* desc, void* stream);
 /* which block tile the launch above would use: 0 = 128x128, 1 = 128x64, 2 = 64x128, 3 = 64x64 (pixels x channels),
  * 4 = the vector-ALU kernel for cout <= 4 (one thread per pixel; bit-identical to the MFMA tiles),
  * 5 / 6 = the B-resident persistent GEMM (csrc/conv_bres.hip) with a 128- / 64-column weight slice held in LDS: 1x1
- * taps, K <= 256 / 512, no statistics; bit-identical to the tiled kernel.  HND_BRES=0 in the environment turns it off. */
+ * taps, K <= 256 / 512, no statistics; bit-identical to the tiled kernel.  HND_BRES=0 in the environment turns it off;
+ * 7 / 8 = its one-wave-per-SIMD build (plain epilogues); 9 = the 7x7 stride-2 stem from an LDS-staged input patch
+ * (csrc/conv_stem.hip; bit-identical to the generic 4-channel-input kernel, HND_STEM7=0 turns it off). */
 int hnd_conv2d_igemm_tile(const hnd_conv_desc* desc);
 
 /* Weight gradient (autograd conv backward(weight), src/mimic_runner.py:53) of the trainable convs:

@@ -918,6 +918,32 @@ def test_gt_mask_nearest_resize_equals_torch_bytes(h, w, scale):
     assert resize_masks_nearest(torch.zeros(0, h, w, dtype=torch.uint8, device=DEV), scale).shape[0] == 0
 
 
+@pytest.mark.parametrize('n,h,w', [(2, 800, 1344), (1, 75, 133), (3, 64, 96), (1, 1248, 1120)])
+def test_stem_conv_from_lds_patch_is_bit_identical_and_matches_torch(ops, n, h, w, monkeypatch):
+    """csrc/conv_stem.hip: the 7x7 stride-2 stem reads its MFMA A-fragments from an LDS-staged input patch instead of
+    49 scattered global reads per pixel; same k order and epilogue expression as the generic kernel -> identical bits,
+    incl. partial edge tiles and odd sizes; and both equal a torch fp32 convolution + FrozenBN + ReLU."""
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(n, 3, h, w, generator=g)
+    wt = torch.randn(64, 3, 7, 7, generator=g) * (1.0 / 147 ** 0.5)
+    sc, sh = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g)
+    xd = nhwc(x, 4)
+    pk = ops.pack_weights(wt.to(DEV).contiguous(), chan_pad=4)
+    oh, ow = ops.conv_out_size(h, 7, 2, 3), ops.conv_out_size(w, 7, 2, 3)
+    outs, variants = {}, {}
+    for mode in ('0', '1'):
+        monkeypatch.setenv('HND_STEM7', mode)
+        y = torch.full((n, oh, ow, 64), float('nan'), device=DEV)
+        l = ops.conv_forward(xd, pk, y, 7, 2, 3, epi_scale=sc.to(DEV), epi_shift=sh.to(DEV), relu=True)
+        l.run()
+        ops.sync_check()
+        outs[mode], variants[mode] = y, l.variant
+    assert variants == {'0': 'igemm_c4_128x64', '1': 'stem7_lds'}, variants
+    assert not bool(torch.isnan(outs['1']).any()) and torch.equal(outs['0'], outs['1'])
+    ref = torch.relu(F.conv2d(x, wt, stride=2, padding=3) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    assert relerr(nchw(outs['1']), ref) < 1e-5
+
+
 def test_jpeg_codec_and_data_logger_follow_the_reference(tmp_path):
     """structure/transformer.py JpegCompressor / JpegDecompressor / DataLogger (reference :58-128): the 3-channel
     bottleneck is quantised by the HIP codec (byte-exact to myutils' quantize_tensor), written as a JPEG with PIL and
