@@ -255,7 +255,10 @@ __device__ __forceinline__ void ring_wait(f32x4& a0, f32x4& a1, f32x4& a2, f32x4
   else asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "n"(N));
 }
 
-template <int WN, int KQ, bool PRO>
+// RES: the epilogue adds `res1` (identity / downsample sum of a Bottleneck, or the nearest-upsampled FPN top-down map):
+// its 16 rows per tile are requested during the tile's LAST k group into registers of their own and consumed, like the
+// accumulators, during the next tile's first k group.
+template <int WN, int KQ, bool PRO, bool RES>
 __global__ void __launch_bounds__(256, 1) bres2_kernel(const hnd_conv_desc d, const BresArgs a) {
   constexpr int WM = 4 / WN, BN = 64 * WN, MI = 4, NI = 4, RING = 8;
   constexpr int K = 64 * KQ, KG = 4 * KQ;
@@ -263,11 +266,11 @@ __global__ void __launch_bounds__(256, 1) bres2_kernel(const hnd_conv_desc d, co
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Bs = smem;                                   // [BN][K]: chunk c of row r at position c ^ (r & 15)
   float* pro = Bs + BN * K;                           // [2][K] prologue scale, shift
-  int* tabs = (int*)(pro + (PRO ? 2 * K : 0));        // [4 waves][2][64]: output pixel of the rows of a tile
+  int* tabs = (int*)(pro + (PRO ? 2 * K : 0));        // [4 waves][2 tiles][2][64]: output / res1 pixel of a tile's rows
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave % WN, wm = wave / WN;
   const int l16 = lane & 15, g4 = lane >> 4;
-  int* rowoff = tabs + wave * 128;
+  int* tab0 = tabs + wave * 256;
 
   const int b = blockIdx.x, xcd = b & 7, idx = b >> 3, per_xcd = gridDim.x >> 3;
   const int slice = idx % a.nsl, tpx = per_xcd / a.nsl;
@@ -284,11 +287,16 @@ __global__ void __launch_bounds__(256, 1) bres2_kernel(const hnd_conv_desc d, co
     const size_t pix = ((size_t)n_ * d.h + oh_ * (unsigned)d.sh) * (size_t)d.w_ + ow_ * (unsigned)d.sw;
     return d.x + pix * (size_t)d.cin + (size_t)(g4 * 4);
   };
-  auto out_pix = [&](int m) -> int {
+  // output pixel of row m (-1 beyond M) and the pixel its residual is read from (mode 1: nearest-upsampled res1)
+  auto out_pix = [&](int m, int& pr) -> int {
+    pr = 0;
     if (m >= M) return -1;
     const unsigned t = hnd::fdiv((unsigned)m, a.div_ow), ow_ = (unsigned)m - t * (unsigned)d.ow;
     const unsigned n_ = hnd::fdiv(t, a.div_oh), oh_ = t - n_ * (unsigned)d.oh;
-    return ((int)n_ * d.yh + (int)oh_ * d.y_sh + d.y_oh) * d.yw + (int)ow_ * d.y_sw + d.y_ow;
+    const int yr = (int)oh_ * d.y_sh + d.y_oh, yc = (int)ow_ * d.y_sw + d.y_ow;
+    const int po = ((int)n_ * d.yh + yr) * d.yw + yc;
+    pr = d.res1_mode == 1 ? ((int)n_ * d.res1_h + (yr * d.res1_h) / d.yh) * d.res1_w + (yc * d.res1_w) / d.yw : po;
+    return po;
   };
 
   const int col0 = n0 + wn * 64 + l16 * 4;
@@ -300,7 +308,7 @@ __global__ void __launch_bounds__(256, 1) bres2_kernel(const hnd_conv_desc d, co
     s1[ni] = 0.f;
     s2[ni] = 0.f;
   }
-  const bool vec_ok = (d.ldc % NI == 0) && ((uintptr_t)d.y % (4 * NI) == 0);
+  const bool vec_ok = (d.ldc % NI == 0) && (((uintptr_t)d.y | (uintptr_t)d.res1) % (4 * NI) == 0);
   const float relu_floor = d.pro_relu ? 0.f : -INFINITY;
   if (PRO) {
     for (int k = tid; k < K; k += 256) {
@@ -341,8 +349,20 @@ __global__ void __launch_bounds__(256, 1) bres2_kernel(const hnd_conv_desc d, co
         });
       });
       f32x4 out[MI][NI];                 // the finished tile, stored during the next tile's first k group
+      f32x4 resv[MI][4];                 // ... and its residual rows (RES), requested during its last k group
       bool have_out = false;
-      for (; cc < seg_hi; cc += WM) {
+      int par = 0;                       // row tables alternate: the previous tile's are read while this one's are written
+      for (; cc < seg_hi; cc += WM, par ^= 1) {
+        int* rowoff = tab0 + par * 128;             // this tile
+        const int* prow = tab0 + (par ^ 1) * 128;   // the previous one
+        const bool full = vec_ok && (cc * 64 + 64 <= M);
+        {
+          int pr;
+          const int po = out_pix(cc * 64 + lane, pr);
+          rowoff[lane] = po;
+          rowoff[64 + lane] = pr;
+          __builtin_amdgcn_wave_barrier();
+        }
         const int cn = cc + WM < seg_hi ? cc + WM : cc;
         const float* nptr[MI];
 #pragma unroll
@@ -385,11 +405,15 @@ __global__ void __launch_bounds__(256, 1) bres2_kernel(const hnd_conv_desc d, co
                 f32x4 v;
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) {
-                  const float x = out[mi][ni][s] * es[ni] + eb[ni];
+                  float x = out[mi][ni][s] * es[ni] + eb[ni];
+                  if (RES) x += resv[mi][s][ni];
                   v[ni] = d.relu ? fmaxf(x, 0.f) : x;
                 }
-                *(f32x4*)(d.y + (size_t)(unsigned)rowoff[mi * 16 + 4 * g4 + s] * (unsigned)d.ldc + col0) = v;
+                *(f32x4*)(d.y + (size_t)(unsigned)prow[mi * 16 + 4 * g4 + s] * (unsigned)d.ldc + col0) = v;
               }
+              if (RES && g == KG - 1 && full)        // this tile's residual rows, consumed one tile later
+                resv[mi][s] = *(const f32x4*)(d.res1 + (size_t)(unsigned)rowoff[64 + mi * 16 + 4 * g4 + s] *
+                                                           (unsigned)d.ldc + col0);
               __builtin_amdgcn_sched_barrier(0);
             }
             // refill this slot's row group for the k group RING ahead (in this tile or the wave's next one)
@@ -401,13 +425,8 @@ __global__ void __launch_bounds__(256, 1) bres2_kernel(const hnd_conv_desc d, co
           for (int ni = 0; ni < NI; ++ni) bcur[ni] = bnxt[ni];
           if (PRO) { ps = psn; pb = pbn; }
         });
-        // ---- hand the tile over: table of its output rows, accumulators -> `out`
+        // ---- hand the tile over: accumulators -> `out`
         {
-          const int po = out_pix(cc * 64 + lane);
-          __builtin_amdgcn_wave_barrier();
-          rowoff[lane] = po;
-          __builtin_amdgcn_wave_barrier();
-          const bool full = vec_ok && (cc * 64 + 64 <= M);
           if (full) {
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
@@ -415,7 +434,7 @@ __global__ void __launch_bounds__(256, 1) bres2_kernel(const hnd_conv_desc d, co
               for (int ni = 0; ni < NI; ++ni) out[mi][ni] = acc[mi][ni];
             have_out = true;
           } else {                                     // ragged / unaligned tile: checked path, not deferred
-            hnd::epilogue_tile<MI, NI>(d, acc, rowoff, rowoff, 4 * g4, col0, es, eb, s1, s2, false);
+            hnd::epilogue_tile<MI, NI>(d, acc, rowoff, rowoff + 64, 4 * g4, col0, es, eb, s1, s2, false);
             have_out = false;
           }
         }
@@ -423,7 +442,8 @@ __global__ void __launch_bounds__(256, 1) bres2_kernel(const hnd_conv_desc d, co
         for (int mi = 0; mi < MI; ++mi) aptr[mi] = nptr[mi];
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the ring's last (unused) prefetches land before reuse
-      if (have_out) {                                    // the segment's last tile
+      if (have_out) {                                    // the segment's last tile (its tables: the parity just left)
+        const int* prow = tab0 + (par ^ 1) * 128;
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -431,10 +451,11 @@ __global__ void __launch_bounds__(256, 1) bres2_kernel(const hnd_conv_desc d, co
             f32x4 v;
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
-              const float x = out[mi][ni][s] * es[ni] + eb[ni];
+              float x = out[mi][ni][s] * es[ni] + eb[ni];
+              if (RES) x += resv[mi][s][ni];
               v[ni] = d.relu ? fmaxf(x, 0.f) : x;
             }
-            *(f32x4*)(d.y + (size_t)(unsigned)rowoff[mi * 16 + 4 * g4 + s] * (unsigned)d.ldc + col0) = v;
+            *(f32x4*)(d.y + (size_t)(unsigned)prow[mi * 16 + 4 * g4 + s] * (unsigned)d.ldc + col0) = v;
           }
       }
     }
@@ -484,10 +505,10 @@ int launch_bres_p(const hnd_conv_desc& d, const BresArgs& a, size_t lds, int gri
                      : launch_bres_t<WN, KQ, false>(d, a, lds, grid, stream);
 }
 
-template <int WN, int KQ, bool PRO>
+template <int WN, int KQ, bool PRO, bool RES>
 int launch_bres2_t(const hnd_conv_desc& d, const BresArgs& a, size_t lds, int grid, hipStream_t stream) {
   static std::atomic<unsigned long long> attr_set{0};
-  auto kern = bres2_kernel<WN, KQ, PRO>;
+  auto kern = bres2_kernel<WN, KQ, PRO, RES>;
   int dev = 0;
   (void)hipGetDevice(&dev);
   const unsigned long long bit = 1ull << (dev & 63);
@@ -505,8 +526,9 @@ int launch_bres2_t(const hnd_conv_desc& d, const BresArgs& a, size_t lds, int gr
 
 template <int WN, int KQ>
 int launch_bres2_p(const hnd_conv_desc& d, const BresArgs& a, size_t lds, int grid, hipStream_t stream) {
-  return d.pro_scale ? launch_bres2_t<WN, KQ, true>(d, a, lds, grid, stream)
-                     : launch_bres2_t<WN, KQ, false>(d, a, lds, grid, stream);
+  if (d.res1) return launch_bres2_t<WN, KQ, false, true>(d, a, lds, grid, stream);      // (never with a prologue)
+  return d.pro_scale ? launch_bres2_t<WN, KQ, true, false>(d, a, lds, grid, stream)
+                     : launch_bres2_t<WN, KQ, false, false>(d, a, lds, grid, stream);
 }
 
 }  // namespace
@@ -531,13 +553,14 @@ int bres_variant(const hnd_conv_desc& d) {
   const long long M = (long long)d.n * d.oh * d.ow;
   const long long nchunks = (M + 63) / 64, nteams = 8ll * (per_xcd / nsl);
   const long long per_team = nchunks / nteams;
-  const bool plain = !d.res1 && !d.res2 && !d.mask;
+  const bool plain = !d.res2 && !d.mask && !(d.res1 && d.pro_scale);      // the one-wave kernel: optional res1 only
   const char* v2 = getenv("HND_BRES2");                   // 0 = never the one-wave kernel (A/B)
   if (plain && d.kdim >= 128 && !(v2 && atoi(v2) == 0) && per_team >= 2ll * (4 / wn)) {
     // measured (profiles/r03_bres_vs_tiled.txt): the one-wave kernel wins on long runs of chunks; its prologue form
     // (8 VALU per A fragment beside a single wave's MFMAs) does not, and K = 512 needs >= 48 chunks per team
-    if (getenv("HND_BRES_ALL") && !(d.pro_scale && d.kdim == 512)) return 2 + wn;
-    if (!d.pro_scale && per_team >= (d.w_group_rows > 0 || d.kdim == 512 ? 48 : 8)) return 2 + wn;
+    const bool spills = (d.pro_scale || d.res1) && d.kdim == 512;      // those two builds do not fit 512 registers
+    if (getenv("HND_BRES_ALL") && !spills) return 2 + wn;
+    if (!d.pro_scale && !spills && per_team >= (d.w_group_rows > 0 || d.kdim == 512 ? 48 : 8)) return 2 + wn;
   }
   if (per_team < 2ll * (8 / wn)) return 0;              // every wave row gets at least two chunks
   if (!getenv("HND_BRES_ALL")) {
@@ -569,7 +592,7 @@ int launch_bres(const hnd_conv_desc& d, hipStream_t stream) {
   a.cpg = d.w_group_rows / 64;
   a.dbg = getenv("HND_BRES_DBG") ? atoi(getenv("HND_BRES_DBG")) : 0;
   const bool pro = d.pro_scale != nullptr;
-  const size_t lds = ((size_t)64 * wn * d.kdim + (pro ? 2 * (size_t)d.kdim : 0) + 8 * 128) * sizeof(float);
+  const size_t lds = ((size_t)64 * wn * d.kdim + (pro ? 2 * (size_t)d.kdim : 0) + 8 * 256) * sizeof(float);
   const int grid = (cu_count() / 8) * 8;
   if (v2) {
     if (wn == 2) return d.kdim == 128 ? launch_bres2_p<2, 2>(d, a, lds, grid, stream)

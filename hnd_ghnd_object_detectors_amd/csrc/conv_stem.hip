@@ -4,8 +4,9 @@
 // In the generic implicit-GEMM kernel every thread gathers ONE 16-byte tap per (pixel, tap) from global memory -- 49
 // scattered reads per output pixel -- and the stem ran at 64 TFLOP/s (0.41 of the fp32 MFMA peak) although its GEMM
 // shape (M = 4.3 M pixels, N = 64, K = 196) reaches 90-95 on the same kernel without the gather.  Here a workgroup
-// owns an 8 x 32 tile of output pixels: the 21 x 69 input patch it needs (23 KB) is copied to LDS once, coalesced,
-// zero-filled outside the image; the packed weights (64 rows x 208, 54 KB, rows padded to 212 floats so the 16 rows of
+// owns an 8 x 32 tile of output pixels at a time (workgroups are persistent: two per CU walk the tiles, the patch
+// of the next tile is in flight in registers while this one is on the matrix pipe): the 21 x 69 input patch it needs
+// (23 KB) is copied to LDS once, coalesced, zero-filled outside the image; the packed weights (64 rows x 208, 54 KB, rows padded to 212 floats so the 16 rows of
 // a fragment read fall on different banks) sit beside it; an MFMA A-fragment -- lane (l16, g4) = pixel l16 of a
 // 16-pixel run, tap 4*kg + g4, 4 channels -- is then exactly ONE ds_read_b128 of the patch.  No k-loop staging, no
 // barrier after the fill.
@@ -30,29 +31,14 @@ __global__ void __launch_bounds__(256, 2) stem7_kernel(const hnd_conv_desc d, co
   float* ws = smem + PH * PW * 4;                // [64][WLD]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l16 = lane & 15, g4 = lane >> 4;
-  int b = blockIdx.x;
-  const int tx = b % tiles_x;
-  b /= tiles_x;
-  const int ty = b % tiles_y, n = b / tiles_y;
-  const int oy0 = ty * TH, ox0 = tx * TW;        // first output pixel of the tile
-  const int iy0 = 2 * oy0 - 3, ix0 = 2 * ox0 - 3;
+  const int ntiles = d.n * tiles_x * tiles_y;
 
-  // ---- fill: weights (k < 208 of the 64 packed rows) and the zero-padded patch
+  // ---- once per workgroup: the weights (k < 208 of the 64 packed rows).  Workgroups are persistent (two per CU
+  // walk the tiles with the grid's stride), so the 54 KB are not re-read for each of the 16 800 tiles of a batch.
   for (int e = tid; e < 64 * (KG * 4); e += 256) {
     const int r = e / (KG * 4), c = e - r * (KG * 4);
     *(f32x4*)(ws + r * WLD + c * 4) = *(const f32x4*)(d.w + (size_t)r * d.kdim + c * 4);
   }
-  const float* img = d.x + (size_t)n * d.h * d.w_ * 4;
-  for (int e = tid; e < PH * PW; e += 256) {
-    const int py = e / PW, px = e - py * PW;
-    const int iy = iy0 + py, ix = ix0 + px;
-    const bool ok = (unsigned)iy < (unsigned)d.h && (unsigned)ix < (unsigned)d.w_;
-    const f32x4 v = *(const f32x4*)(img + (ok ? ((size_t)iy * d.w_ + ix) * 4 : 0));
-    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    *(f32x4*)(patch + e * 4) = ok ? v : z;
-  }
-  __syncthreads();
-
   // this lane's tap of every k group: offset (floats) inside the patch; taps >= 49 read tap 48 (their weights are 0)
   int toff[KG];
 #pragma unroll
@@ -67,29 +53,6 @@ __global__ void __launch_bounds__(256, 2) stem7_kernel(const hnd_conv_desc d, co
   for (int mi = 0; mi < 4; ++mi)
     ap[mi] = patch + ((2 * (2 * wave + (mi >> 1))) * PW + 2 * (16 * (mi & 1) + l16)) * 4;
   const float* bp = ws + l16 * WLD + g4 * 4;
-
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int kg = 0; kg < KG; ++kg) {
-    f32x4 a[4], bq[4];
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) bq[ni] = *(const f32x4*)(bp + ni * 16 * WLD + kg * 16);
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi) a[mi] = *(const f32x4*)(ap[mi] + toff[kg]);
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi][s], bq[ni][s], acc[mi][ni], 0, 0, 0);
-  }
-
-  // ---- epilogue: the lane holds pixels 4*g4 + i of each 16-pixel run and channels 4*l16 .. 4*l16 + 3
   const int col0 = l16 * 4;
   float es[4], eb[4];
 #pragma unroll
@@ -97,20 +60,86 @@ __global__ void __launch_bounds__(256, 2) stem7_kernel(const hnd_conv_desc d, co
     es[ni] = d.epi_scale ? d.epi_scale[col0 + ni] : 1.f;
     eb[ni] = d.epi_shift ? d.epi_shift[col0 + ni] : 0.f;
   }
+
+  // the patch of a tile: PH * PW = 1449 pixels over 256 threads = 6 float4 per thread, zero outside the image
+  constexpr int PPT = (PH * PW + 255) / 256;
+  f32x4 pre[PPT];
+  auto fetch = [&](int tile) {                   // global -> registers (issued early, written to LDS late)
+    int b = tile;
+    const int tx = b % tiles_x;
+    b /= tiles_x;
+    const int ty = b % tiles_y, n = b / tiles_y;
+    const int iy0 = 2 * ty * TH - 3, ix0 = 2 * tx * TW - 3;
+    const float* img = d.x + (size_t)n * d.h * d.w_ * 4;
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi) {
-    const int oy = oy0 + 2 * wave + (mi >> 1);
+    for (int q = 0; q < PPT; ++q) {
+      const int e = tid + 256 * q;
+      const int py = e / PW, px = e - py * PW;
+      const int iy = iy0 + py, ix = ix0 + px;
+      const bool ok = e < PH * PW && (unsigned)iy < (unsigned)d.h && (unsigned)ix < (unsigned)d.w_;
+      const f32x4 v = *(const f32x4*)(img + (ok ? ((size_t)iy * d.w_ + ix) * 4 : 0));
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      pre[q] = ok ? v : z;
+    }
+  };
+  auto commit = [&]() {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int ox = ox0 + 16 * (mi & 1) + 4 * g4 + i;
-      if (oy >= d.oh || ox >= d.ow) continue;
-      f32x4 v;
+    for (int q = 0; q < PPT; ++q) {
+      const int e = tid + 256 * q;
+      if (e < PH * PW) *(f32x4*)(patch + e * 4) = pre[q];
+    }
+  };
+
+  int tile = blockIdx.x;
+  if (tile < ntiles) fetch(tile);
+  for (; tile < ntiles; tile += gridDim.x) {
+    __syncthreads();                             // the previous tile's fragment reads are done
+    commit();
+    __syncthreads();
+    if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);       // in flight during this tile's MFMAs
+    int b = tile;
+    const int tx = b % tiles_x;
+    b /= tiles_x;
+    const int ty = b % tiles_y, n = b / tiles_y;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+
+    f32x4 acc[4][4];
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni) {
-        const float x = acc[mi][ni][i] * es[ni] + eb[ni];
-        v[ni] = d.relu ? fmaxf(x, 0.f) : x;
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kg = 0; kg < KG; ++kg) {
+      f32x4 a[4], bq[4];
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) bq[ni] = *(const f32x4*)(bp + ni * 16 * WLD + kg * 16);
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) a[mi] = *(const f32x4*)(ap[mi] + toff[kg]);
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi][s], bq[ni][s], acc[mi][ni], 0, 0, 0);
+    }
+
+    // ---- epilogue: the lane holds pixels 4*g4 + i of each 16-pixel run and channels 4*l16 .. 4*l16 + 3
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      const int oy = oy0 + 2 * wave + (mi >> 1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ox = ox0 + 16 * (mi & 1) + 4 * g4 + i;
+        if (oy >= d.oh || ox >= d.ow) continue;
+        f32x4 v;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          const float x = acc[mi][ni][i] * es[ni] + eb[ni];
+          v[ni] = d.relu ? fmaxf(x, 0.f) : x;
+        }
+        *(f32x4*)(d.y + (((size_t)n * d.yh + oy) * d.yw + ox) * (size_t)d.ldc + col0) = v;
       }
-      *(f32x4*)(d.y + (((size_t)n * d.yh + oy) * d.yw + ox) * (size_t)d.ldc + col0) = v;
     }
   }
 }
@@ -142,7 +171,11 @@ int launch_stem7(const hnd_conv_desc& d, hipStream_t stream) {
     attr_done[dev & 63] = true;
   }
   const int tiles_x = (d.ow + TW - 1) / TW, tiles_y = (d.oh + TH - 1) / TH;
-  hipLaunchKernelGGL(stem7_kernel, dim3((unsigned)(d.n * tiles_x * tiles_y)), dim3(256), lds, stream, d, tiles_x, tiles_y);
+  int cus = 256;
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  const int ntiles = d.n * tiles_x * tiles_y;
+  const int grid = ntiles < 2 * cus ? ntiles : 2 * cus;        // persistent: two workgroups per CU walk the tiles
+  hipLaunchKernelGGL(stem7_kernel, dim3((unsigned)grid), dim3(256), lds, stream, d, tiles_x, tiles_y);
   return check_launch("hnd_conv2d_igemm(stem7)");
 }
 

@@ -826,6 +826,9 @@ def test_thin_n_kernel_is_bit_identical_to_the_mfma_path(tmp_path):
     (128, 100, 168, 128, 1, False, False, True, 1, 16),      # K = 128 with prologue (one-wave kernel: ring = tile)
     (256, 101, 169, 256, 1, False, False, False, 1, 8),      # ragged last chunk on the deferred-epilogue kernel
     (256, 201, 337, 64, 1, True, False, False, 1, 4),        # bres_64 with K = 256, ragged last chunk
+    (256, 50, 84, 1024, 1, True, False, False, 1, 16),       # residual on the one-wave kernel (layer3 conv3)
+    (512, 25, 42, 2048, 1, True, False, False, 1, 16),       # K = 512 + residual: stays on the 8-wave kernel
+    (256, 200, 336, 256, 1, 'up', False, False, 1, 2),       # FPN lateral conv: + nearest-upsampled top-down map
     (256, 37, 53, 256, 1, False, False, False, 9, 64),       # grouped (Winograd-style) weights
 ])
 def test_bres_kernel_is_bit_identical_to_the_tiled_kernel(ops, case, monkeypatch):
@@ -852,11 +855,13 @@ def test_bres_kernel_is_bit_identical_to_the_tiled_kernel(ops, case, monkeypatch
         pk = ops.pack_weights(wt)
     sc, sh = torch.rand(cout, generator=g).to(DEV) + 0.5, torch.randn(cout, generator=g).to(DEV)
     r = torch.randn(y.shape, generator=g).to(DEV) if res else None
+    if res == 'up':                 # res1_mode 1: the residual is read from the half-resolution map (FPN top-down path)
+        r = torch.randn(n, (h + 1) // 2, (w + 1) // 2, cout, generator=g).to(DEV)
     mk = (torch.rand(y.shape, generator=g).to(DEV) - 0.3).clamp_min(0) if msk else None
     ps = (torch.rand(cin, generator=g).to(DEV) + 0.5) if pro else None
     pb = torch.randn(cin, generator=g).to(DEV) if pro else None
     outs, variants = {}, {}
-    plain = not (res or msk)
+    plain = not msk and not (res and pro)        # what the one-wave kernel takes: optional res1, no mask
     for mode in ('0', '512', 'one_wave'):
         if mode == 'one_wave' and not plain:
             continue
@@ -867,8 +872,8 @@ def test_bres_kernel_is_bit_identical_to_the_tiled_kernel(ops, case, monkeypatch
                               cout=cout)
             l.desc.w_group_rows, l.desc.w_group_stride = tiles_pad, pks[0].buf.numel()
         else:
-            l = ops.conv_forward(x, pk, y, 1, s, 0, epi_scale=sc, epi_shift=sh, res1=r, mask=mk, relu=not msk,
-                                 pro_scale=ps, pro_shift=pb, pro_relu=pro)
+            l = ops.conv_forward(x, pk, y, 1, s, 0, epi_scale=sc, epi_shift=sh, res1=r, res1_up=res == 'up', mask=mk,
+                                 relu=not msk, pro_scale=ps, pro_shift=pb, pro_relu=pro)
         l.refresh_variant()
         y.fill_(float('nan'))
         l.run()
@@ -878,7 +883,7 @@ def test_bres_kernel_is_bit_identical_to_the_tiled_kernel(ops, case, monkeypatch
     assert not bool(torch.isnan(outs['512']).any())
     assert torch.equal(outs['0'], outs['512']), float((outs['0'] - outs['512']).abs().max())
     if plain and cin >= 128:        # the one-wave-per-SIMD kernel (asm register ring, deferred epilogue)
-        if pro and cin == 512:      # (its K = 512 prologue build spills: that combination stays on the 8-wave kernel)
+        if (pro or res) and cin == 512:     # (those builds spill: that combination stays on the 8-wave kernel)
             assert variants['one_wave'] == 'bres_64', variants
         else:
             assert variants['one_wave'] in ('bres2_128', 'bres2_64'), variants
@@ -888,7 +893,9 @@ def test_bres_kernel_is_bit_identical_to_the_tiled_kernel(ops, case, monkeypatch
         if pro:
             xin = torch.relu(xin * ps.view(1, -1, 1, 1) + pb.view(1, -1, 1, 1))
         ref = torch.nn.functional.conv2d(xin, wt, stride=s) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
-        if res:
+        if res == 'up':
+            ref = ref + F.interpolate(r.permute(0, 3, 1, 2), size=ref.shape[-2:], mode='nearest')
+        elif res:
             ref = ref + r.permute(0, 3, 1, 2)
         if msk:
             ref = torch.where(mk.permute(0, 3, 1, 2) > 0, ref, torch.zeros_like(ref))
