@@ -411,9 +411,12 @@ __global__ void __launch_bounds__(256, 1) bres2_kernel(const hnd_conv_desc d, co
                 }
                 *(f32x4*)(d.y + (size_t)(unsigned)prow[mi * 16 + 4 * g4 + s] * (unsigned)d.ldc + col0) = v;
               }
-              if (RES && g == KG - 1 && full)        // this tile's residual rows, consumed one tile later
-                resv[mi][s] = *(const f32x4*)(d.res1 + (size_t)(unsigned)rowoff[64 + mi * 16 + 4 * g4 + s] *
-                                                           (unsigned)d.ldc + col0);
+              // this tile's residual rows, consumed one tile later: four per k group over the last four k groups (a
+              // single k group of lead -- 2048 cycles -- is less than the memory latency under load: measured slower)
+              if (RES && g >= KG - 4 && mi == 1 && full)
+                resv[g - (KG - 4)][s] = *(const f32x4*)(d.res1 + (size_t)(unsigned)rowoff[64 + (g - (KG - 4)) * 16 +
+                                                                                         4 * g4 + s] *
+                                                                      (unsigned)d.ldc + col0);
               __builtin_amdgcn_sched_barrier(0);
             }
             // refill this slot's row group for the k group RING ahead (in this tile or the wave's next one)
@@ -560,7 +563,10 @@ int bres_variant(const hnd_conv_desc& d) {
     // (8 VALU per A fragment beside a single wave's MFMAs) does not, and K = 512 needs >= 48 chunks per team
     const bool spills = (d.pro_scale || d.res1) && d.kdim == 512;      // those two builds do not fit 512 registers
     if (getenv("HND_BRES_ALL") && !spills) return 2 + wn;
-    if (!d.pro_scale && !spills && per_team >= (d.w_group_rows > 0 || d.kdim == 512 ? 48 : 8)) return 2 + wn;
+    // the residual build (RES) is bit-exact but slower than the tiled kernel's three co-resident blocks wherever it was
+    // tried (256->1024 @50x84 + res: 104 vs 112 TF; 128->512 @100x168 + res: 81 vs 94): hipcc's own counted waits for the
+    // residual loads also retire the asm ring loads queued behind them.  Kept for the A/B tool and the tests only.
+    if (!d.pro_scale && !d.res1 && !spills && per_team >= (d.w_group_rows > 0 || d.kdim == 512 ? 48 : 8)) return 2 + wn;
   }
   if (per_team < 2ll * (8 / wn)) return 0;              // every wave row gets at least two chunks
   if (!getenv("HND_BRES_ALL")) {
