@@ -317,7 +317,9 @@ int hnd_nms(const float* boxes, const int64_t* order, int64_t n, float iou_thres
             uint8_t* keep, void* stream) {
   if (n <= 0) return HND_OK;
   HND_REQUIRE(boxes && order && workspace && keep, "hnd_nms: null pointer");
-  HND_REQUIRE(n <= 65536, "hnd_nms: at most 65536 boxes per call (got %lld)", (long long)n);
+  // (RoIHeads.postprocess_detections can reach 1000 proposals x 90 classes = 90 000 candidates with a score threshold
+  // near 0; the bit matrix is then 90 000 x 1407 words = 1 GB of caller-provided workspace)
+  HND_REQUIRE(n <= 131072, "hnd_nms: at most 131072 boxes per call (got %lld)", (long long)n);
   const int words = (int)((n + 63) / 64);
   if (hipMemsetAsync(workspace, 0, hnd_nms_workspace(n), hnd::as_stream(stream)) != hipSuccess) return hnd::check_launch("hnd_nms(memset)");
   hipLaunchKernelGGL(nms_mask_kernel, dim3(words, words), dim3(64), 0, hnd::as_stream(stream), boxes,

@@ -221,9 +221,17 @@ class CocoEval(object):
         dtind = np.argsort([-d['score'] for d in dt], kind='mergesort')
         dt = [dt[i] for i in dtind[0:max_det]]
         iscrowd = [int(g['iscrowd']) for g in gt]
-        # computeIoU uses the detections sorted by score, truncated to maxDets[-1]
-        dt_all = [self.dts.get((img_id, cat_id), [])[i] for i in dtind[0:self.max_dets[-1]]]
-        ious = self._similarity(img_id, dt_all, gt, iscrowd)
+        # COCOeval.computeIoU: ONE similarity matrix per (image, category) over the detections sorted by score and
+        # truncated to maxDets[-1] against the ground truth in annotation order; the four area ranges only permute its
+        # columns (gtind), so it is cached instead of being recomputed (for segm: re-decoding every RLE) per range
+        key = (img_id, cat_id)
+        full = self._iou_cache.get(key)
+        if full is None:
+            gt0 = [g for g in self.gt.anns.get(img_id, []) if g['category_id'] == cat_id]
+            dt_all = [self.dts.get(key, [])[i] for i in dtind[0:self.max_dets[-1]]]
+            full = self._similarity(img_id, dt_all, gt0, [int(g['iscrowd']) for g in gt0])
+            self._iou_cache[key] = full
+        ious = full[:, gtind] if len(full) != 0 else full
         T, G, D = len(self.iou_thrs), len(gt), len(dt)
         gtm, dtm = np.zeros((T, G)), np.zeros((T, D))
         gt_ig = np.array([g['_ignore'] for g in gt])
@@ -252,6 +260,7 @@ class CocoEval(object):
         return {'dtMatches': dtm, 'dtScores': [d['score'] for d in dt], 'gtIgnore': gt_ig, 'dtIgnore': dt_ig}
 
     def evaluate(self, img_ids=None):
+        self._iou_cache = {}
         self.img_ids = sorted(set(img_ids if img_ids is not None else self.gt.images.keys()))
         self.cat_ids = sorted(self.gt.categories)
         max_det = self.max_dets[-1]

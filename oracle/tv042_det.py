@@ -18,6 +18,11 @@ PARITY UNPINNED for the third-party part: no torchvision 0.4.2 binary exists her
 details are restated from the 0.4.2 sources as published and flagged below:
   * ``nms`` (CPU operator) returns the kept indices in ASCENDING INDEX order (``at::nonzero(suppressed == 0)``);
     score order came with 0.5.  Callers slice ``keep[:n]`` on that order (rpn.py, roi_heads.py).
+  * ``nms`` TIE RULE: a box is suppressed when ``ovr > iou_threshold`` (STRICT), as 0.4.2's ``nms_cpu_kernel``
+    (``if (ovr > iou_threshold) suppressed_t[j] = 1;``).  The maskrcnn-benchmark kernel it was ported from used ``>=``;
+    the two differ only on boxes whose IoU equals the threshold exactly (measure zero on real detections, reachable
+    with the duplicated / quantised boxes of the tests).  Strict is taken here AND in ``csrc/detect.hip``
+    (``if (ovr > thr)``): tests/test_detect_gpu.py holds the two to identical kept sets including exact-threshold ties.
   * anchor strides are the true quotients ``image_size / grid_size`` (floats; 800/13 for the 'pool' level).
   * ``postprocess_detections`` has no "remove empty boxes" step (added in 0.5).
   * ``roi_align`` is the non-"aligned" form (no half-pixel shift; roi width/height clamped to >= 1).

@@ -83,6 +83,31 @@ def test_evaluator_surface_and_image_without_predictions():
         CocoEvaluator(gt, ['bbox', 'caption'])
 
 
+def test_padded_sampler_repeats_are_dropped_by_image_id(monkeypatch):
+    """DistributedSampler pads the last shards with repeats; the reference's merge keeps the FIRST rank's
+    copy of each image id (np.unique(..., return_index=True)) -- by image, not by detection content: a repeat whose
+    detections differ slightly (a different batch composition) must not count as extra false positives."""
+    from hnd_ghnd_object_detectors_amd.utils import misc_util
+    gt = _gt([(7, [10, 10, 40, 40], 3, 0), (8, [20, 20, 60, 30], 3, 0)])
+
+    def pred(box, score):
+        return {'boxes': torch.tensor([box]), 'labels': torch.tensor([3]), 'scores': torch.tensor([score])}
+    rank0, rank1 = CocoEvaluator(gt, ['bbox']), CocoEvaluator(gt, ['bbox'])
+    rank0.update({7: pred([10.0, 10.0, 50.0, 50.0], 0.8)})
+    rank0.update({7: pred([11.0, 10.0, 50.0, 50.0], 0.7)})           # a repeat inside one shard: dropped at update()
+    rank1.update({8: pred([20.0, 20.0, 80.0, 50.0], 0.9)})
+    rank1.update({7: pred([10.5, 10.0, 50.0, 50.0], 0.79)})          # rank 1's padded repeat of image 7
+    assert rank0.img_ids == [7] and len(rank0.results['bbox']) == 1
+    monkeypatch.setattr(misc_util, 'all_gather', lambda _: [(rank0.img_ids, rank0.results),
+                                                            (rank1.img_ids, rank1.results)])
+    rank0.synchronize_between_processes()
+    assert rank0.img_ids == [7, 8] and len(rank0.results['bbox']) == 2
+    assert sorted((r['image_id'], r['score']) for r in rank0.results['bbox']) == [(7, 0.800000011920929), (8, 0.8999999761581421)]
+    rank0.accumulate()
+    rank0.summarize()
+    assert abs(rank0.coco_eval['bbox'].stats[0] - 1.0) < 1e-12       # both ground truths found, no false positive
+
+
 def test_ground_truth_from_a_dataset_of_targets():
     from hnd_ghnd_object_detectors_amd.utils.coco_eval_util import get_coco_api_from_dataset
 
