@@ -413,10 +413,12 @@ __global__ void __launch_bounds__(256, 1) bres2_kernel(const hnd_conv_desc d, co
               }
               // this tile's residual rows, consumed one tile later: four per k group over the last four k groups (a
               // single k group of lead -- 2048 cycles -- is less than the memory latency under load: measured slower)
-              if (RES && g >= KG - 4 && mi == 1 && full)
-                resv[g - (KG - 4)][s] = *(const f32x4*)(d.res1 + (size_t)(unsigned)rowoff[64 + (g - (KG - 4)) * 16 +
-                                                                                         4 * g4 + s] *
-                                                                      (unsigned)d.ldc + col0);
+              if constexpr (RES && g >= KG - 4 && mi == 1) {
+                constexpr int q = g - (KG - 4);
+                if (full)
+                  resv[q][s] = *(const f32x4*)(d.res1 + (size_t)(unsigned)rowoff[64 + q * 16 + 4 * g4 + s] *
+                                                            (unsigned)d.ldc + col0);
+              }
               __builtin_amdgcn_sched_barrier(0);
             }
             // refill this slot's row group for the k group RING ahead (in this tile or the wave's next one)

@@ -11,9 +11,11 @@ heat-map resize).
 Arithmetic is libhnd_hip.so: the RPN head convs, fc6 (as a 7x7 valid conv over the pooled map), fc7 and the two
 predictors on ``hnd_conv2d_igemm``, the branch convs on its Winograd form and the transposed convs on its data-gradient
 form; anchors + box decoding, clipping, NMS (bit-exact kept set), RoIAlign, softmax as the kernels of csrc/detect.hip,
-mask probabilities / paste / bilinear x2 / heat-maps-to-keypoints as those of csrc/detect_heads.hip.  torch is used for storage and for variable-length INDEX bookkeeping only (top-k /
-sort orders, ``nonzero`` compaction, gathers), never for box or feature arithmetic beyond single exactly-rounded
-adds that are part of the reference's own index trick (``batched_nms`` coordinate offsets).
+mask probabilities / paste / bilinear x2 / heat-maps-to-keypoints as those of csrc/detect_heads.hip; the variable-length
+index bookkeeping -- per-level top-k, the score order of NMS, every ``nonzero`` compaction -- as those of
+csrc/select.hip (stable descending argsort, ordered predicate compaction).  torch is used for storage, gathers by
+those indices and concatenation, never for box or feature arithmetic beyond single exactly-rounded adds that are part
+of the reference's own index trick (``batched_nms`` coordinate offsets).
 
 Training-mode branches (RPN / RoI losses) do not exist: every hnd/ghnd config trains with ``org_loss_factor: 0``
 behind ``distill_backbone_only`` (src/models/org/rcnn.py:109-110), so they never run in the reference either.
@@ -43,9 +45,52 @@ def clip_boxes_(boxes, size):
     return boxes
 
 
+def _compacted(call, n, device):
+    """run one hnd_nonzero_* launch and return the indices it kept (ascending), like torch.nonzero(p).squeeze(1);
+    the count comes back through the same kind of host read torch.nonzero needs for its output size"""
+    out = torch.empty(max(int(n), 1), dtype=torch.int64, device=device)
+    count = torch.empty(1, dtype=torch.int64, device=device)
+    call(out.data_ptr(), count.data_ptr())
+    return out[:int(count.item())]
+
+
+def nonzero_flags(flags):
+    f = flags.contiguous()
+    return _compacted(lambda o, c: _check(_L.hnd_nonzero_u8(f.data_ptr(), f.numel(), o, c, ops.stream_ptr()),
+                                          'hnd_nonzero_u8'), f.numel(), f.device)
+
+
+def nonzero_greater(x, threshold):
+    x = x.contiguous()
+    return _compacted(lambda o, c: _check(_L.hnd_nonzero_gt_f32(x.data_ptr(), x.numel(), float(threshold), o, c,
+                                                                ops.stream_ptr()), 'hnd_nonzero_gt_f32'),
+                      x.numel(), x.device)
+
+
+def nonzero_equal(x, value):
+    x = x.contiguous()
+    return _compacted(lambda o, c: _check(_L.hnd_nonzero_eq_i64(x.data_ptr(), x.numel(), int(value), o, c,
+                                                                ops.stream_ptr()), 'hnd_nonzero_eq_i64'),
+                      x.numel(), x.device)
+
+
+def argsort_descending(keys):
+    """stable descending argsort of a 1-D fp32 tensor (== torch.sort(descending=True, stable=True)[1])"""
+    keys = keys.contiguous()
+    n = keys.numel()
+    order = torch.empty(n, dtype=torch.int64, device=keys.device)
+    if n:
+        ws = torch.empty(int(_L.hnd_argsort_desc_workspace(n)), dtype=torch.uint8, device=keys.device)
+        _check(_L.hnd_argsort_desc_f32(keys.data_ptr(), n, order.data_ptr(), ws.data_ptr(), ops.stream_ptr()),
+               'hnd_argsort_desc_f32')
+    return order
+
+
 def remove_small_boxes(boxes, min_size):
-    ws, hs = boxes[:, 2] - boxes[:, 0], boxes[:, 3] - boxes[:, 1]
-    return ((ws >= min_size) & (hs >= min_size)).nonzero().squeeze(1)
+    b = boxes.contiguous()
+    return _compacted(lambda o, c: _check(_L.hnd_nonzero_min_size(b.data_ptr(), b.shape[0], float(min_size), o, c,
+                                                                  ops.stream_ptr()), 'hnd_nonzero_min_size'),
+                      b.shape[0], b.device)
 
 
 def nms(boxes, scores, iou_threshold):
@@ -54,12 +99,12 @@ def nms(boxes, scores, iou_threshold):
     if n == 0:
         return torch.empty((0,), dtype=torch.int64, device=boxes.device)
     boxes = boxes.contiguous()
-    order = torch.sort(scores, descending=True, stable=True)[1].contiguous()
+    order = argsort_descending(scores)
     ws = torch.empty(int(_L.hnd_nms_workspace(n)), dtype=torch.uint8, device=boxes.device)
     keep = torch.empty(n, dtype=torch.uint8, device=boxes.device)
     _check(_L.hnd_nms(boxes.data_ptr(), order.data_ptr(), n, float(iou_threshold), ws.data_ptr(), keep.data_ptr(),
                       ops.stream_ptr()), 'hnd_nms')
-    return keep.nonzero().squeeze(1)
+    return nonzero_flags(keep)
 
 
 def batched_nms(boxes, scores, idxs, iou_threshold):
@@ -238,7 +283,8 @@ class RegionProposalNetwork(nn.Module):
         r, offset = [], 0
         for ob in objectness.split(num_anchors_per_level, 1):       # top-k per level, independently
             k = min(self.pre_nms_top_n, ob.shape[1])
-            r.append(ob.topk(k, dim=1)[1] + offset)
+            # top-k = the head of the stable descending order (hnd_argsort_desc_f32), image by image
+            r.append(torch.stack([argsort_descending(row)[:k] for row in ob]) + offset)
             offset += ob.shape[1]
         top_n_idx = torch.cat(r, dim=1)
         batch_idx = torch.arange(num_images, device=dev)[:, None]
@@ -309,7 +355,7 @@ class MultiScaleRoIAlign(nn.Module):
         out = torch.zeros((k, ph, pw, c), dtype=torch.float32, device=dev)
         levels = self.map_levels(rois) if len(feats) > 1 else torch.zeros(k, dtype=torch.int64, device=dev)
         for level, (f, scale) in enumerate(zip(feats, self.scales)):
-            idx = torch.nonzero(levels == level).squeeze(1).contiguous()
+            idx = nonzero_equal(levels, level)
             _check(_L.hnd_roi_align(f.data_ptr(), f.shape[0], f.shape[1], f.shape[2], c, rois.data_ptr(),
                                     idx.data_ptr(), idx.numel(), float(scale), ph, pw, self.sampling_ratio,
                                     out.data_ptr(), ops.stream_ptr()), 'hnd_roi_align')
@@ -411,7 +457,7 @@ class RoIHeads(nn.Module):
             labels = torch.arange(ncls, device=dev).view(1, -1).expand_as(scores)
             boxes, scores, labels = boxes[:, 1:], scores[:, 1:], labels[:, 1:]          # drop background
             boxes, scores, labels = boxes.reshape(-1, 4), scores.flatten(), labels.flatten()
-            inds = torch.nonzero(scores > self.score_thresh).squeeze(1)
+            inds = nonzero_greater(scores, self.score_thresh)
             boxes, scores, labels = boxes[inds], scores[inds], labels[inds]
             keep = batched_nms(boxes, scores, labels, self.nms_thresh)
             keep = keep[:self.detections_per_img]

@@ -386,6 +386,23 @@ int hnd_upsample_bilinear_nhwc(const float* in, int64_t k, int h, int w, int c, 
 int hnd_heatmaps_to_keypoints(const float* maps, int64_t k, int h, int w, int ldc, int num_keypoints, const float* rois,
                               float* xy, float* scores, void* stream);
 
+/* ---- index bookkeeping of the validation path without library kernels (csrc/select.hip): what torchvision 0.4.2's
+ * rpn.py / roi_heads.py / poolers.py do with torch.nonzero, torch.topk and torch.sort.
+ * hnd_nonzero_*: out[0..count) = the indices i in [0, n) where the predicate holds, ASCENDING (== torch.nonzero(p)
+ * .squeeze(1)); out has room for n entries, *count (device) receives how many were written.
+ *   _u8: flags[i] != 0 (the NMS keep bytes);  _gt_f32: x[i] > threshold (roi_heads.py box_score_thresh);
+ *   _eq_i64: x[i] == value (poolers.py level assignment);  _min_size: boxes [n][4], width >= m and height >= m
+ *   (boxes.py remove_small_boxes).
+ * hnd_argsort_desc_f32: order[0..n) = indices sorting `keys` DESCENDING, ties in ascending index order (== torch.sort(
+ * descending=True, stable=True)[1]; the first k entries are torch.topk's index set): the RPN's per-level pre-NMS top-k
+ * and the score order of hnd_nms.  workspace: hnd_argsort_desc_workspace(n) bytes (caller-owned). */
+int hnd_nonzero_u8(const uint8_t* flags, int64_t n, int64_t* out, int64_t* count, void* stream);
+int hnd_nonzero_gt_f32(const float* x, int64_t n, float threshold, int64_t* out, int64_t* count, void* stream);
+int hnd_nonzero_eq_i64(const int64_t* x, int64_t n, int64_t value, int64_t* out, int64_t* count, void* stream);
+int hnd_nonzero_min_size(const float* boxes, int64_t n, float min_size, int64_t* out, int64_t* count, void* stream);
+size_t hnd_argsort_desc_workspace(int64_t n);
+int hnd_argsort_desc_f32(const float* keys, int64_t n, int64_t* order, void* workspace, void* stream);
+
 /* ---- generic workspace query: bytes of caller-provided scratch an op needs.  `desc` is the op's
  * descriptor where it has one (hnd_wgrad_desc for HND_OP_CONV2D_WGRAD), `arg` an op-specific integer (channels for
  * HND_OP_CHANNEL_SUM), both ignored otherwise.  The op-specific helpers above return the same numbers. */

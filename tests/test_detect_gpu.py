@@ -542,3 +542,35 @@ def test_full_size_paste_and_keypoints_with_large_boxes():
     same = (xyd.cpu() == ref_xy).all(2).float().mean()
     assert float(same) >= 0.97, float(same)
     assert float((scd.cpu() - ref_sc).abs().max()) < 1e-4 * float(ref_sc.abs().max())
+
+
+# ------------------------------------------------------------------------------------------ csrc/select.hip
+@pytest.mark.parametrize('n', [1, 5, 63, 64, 65, 1000, 4096, 4097, 10000, 201600])
+def test_argsort_descending_is_torch_stable_sort(n):
+    """hnd_argsort_desc_f32 (bitonic in LDS up to 4096 keys, 4-pass LSD radix beyond) == torch.sort(descending=True,
+    stable=True)[1] exactly: heavy ties (quantised scores), negatives, +-0, +-inf"""
+    from hnd_ghnd_object_detectors_amd import detection as D
+    g = torch.Generator().manual_seed(n)
+    x = torch.randn(n, generator=g)
+    x = torch.where(torch.rand(n, generator=g) < 0.5, (x * 4).round() / 4, x)          # many exact ties
+    if n >= 64:
+        x[3], x[7], x[11], x[12], x[20], x[21] = 0.0, -0.0, float('inf'), float('-inf'), 0.0, -0.0
+    want = torch.sort(x, descending=True, stable=True)[1]
+    got = D.argsort_descending(x.to(DEV))
+    assert got.dtype == torch.int64 and torch.equal(got.cpu(), want)
+
+
+def test_ordered_compaction_equals_torch_nonzero():
+    from hnd_ghnd_object_detectors_amd import detection as D
+    g = torch.Generator().manual_seed(9)
+    for n in (0, 1, 1023, 1024, 1025, 90000):
+        s = torch.rand(n, generator=g)
+        assert torch.equal(D.nonzero_greater(s.to(DEV), 0.05).cpu(), torch.nonzero(s > 0.05).squeeze(1))
+        f = (torch.rand(n, generator=g) < 0.3).to(torch.uint8)
+        assert torch.equal(D.nonzero_flags(f.to(DEV)).cpu(), torch.nonzero(f).squeeze(1))
+        lv = torch.randint(0, 4, (n,), generator=g)
+        assert torch.equal(D.nonzero_equal(lv.to(DEV), 2).cpu(), torch.nonzero(lv == 2).squeeze(1))
+        b = torch.rand(n, 4, generator=g) * 50
+        b[:, 2:] = b[:, :2] + torch.rand(n, 2, generator=g) * 3
+        ws, hs = b[:, 2] - b[:, 0], b[:, 3] - b[:, 1]
+        assert torch.equal(D.remove_small_boxes(b.to(DEV), 1.0).cpu(), ((ws >= 1.0) & (hs >= 1.0)).nonzero().squeeze(1))
