@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define HND_ABI_VERSION 4
+#define HND_ABI_VERSION 5
 
 typedef enum hnd_status {
   HND_OK = 0,
