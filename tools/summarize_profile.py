@@ -20,7 +20,7 @@ def short(name):
     if m:
         base = ('igemm_c4_%sx%s' if m.group(4) == 'true' else 'igemm_%sx%s') % (m.group(1), m.group(2))
         return base + ('[bn-prologue]' if m.group(5) == 'true' and FULLNAMES else '')
-    m = re.search(r'bres(2?)_kernel<(\d+), (\d+), (true|false)>', name)
+    m = re.search(r'bres(2?)_kernel<(\d+), (\d+), (true|false)(?:, (?:true|false))?>', name)
     if m:           # B-resident persistent GEMM (conv_bres.hip): wave columns -> width of the resident weight slice
         return 'bres%s_%d' % (m.group(1), 64 * int(m.group(2))) + ('[prologue]' if m.group(4) == 'true' and FULLNAMES else '')
     m = re.search(r'wgrad_kernel<(\d+), (\d+)>', name)
@@ -33,6 +33,8 @@ def short(name):
                      ('wgrad_kernelILi128', 'wgrad_m128'), ('wgrad_kernelILi64', 'wgrad_m64')):
         if key in name:
             return lab
+    if 'stem7_kernel' in name:
+        return 'stem7_lds'
     for key in ('wino6_input', 'wino6_output', 'wino6_weights', 'wino4_input', 'wino4_output', 'wino4_weights', 'wino2_input', 'wino2_output', 'wino2_weights',
                 'wino_input', 'wino_output', 'wino_weights'):
         if key + '_kernel' in name:
