@@ -16,3 +16,19 @@ def pytest_configure(config):
 @pytest.fixture(scope='session')
 def golden_dir():
     return os.path.join(ROOT, 'tests', 'golden')
+
+
+# Achieved parity figures (worst errors inside the tolerances) are collected here by the tests and printed in the
+# terminal summary, so they show up in the tail of a `pytest -q` log even when everything passes.
+ACHIEVED = []
+
+
+def record_achieved(line):
+    ACHIEVED.append(str(line))
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    if ACHIEVED:
+        terminalreporter.write_sep('-', 'achieved parity figures (inside the asserted tolerances)')
+        for line in ACHIEVED:
+            terminalreporter.write_line(line)

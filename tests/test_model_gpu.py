@@ -129,9 +129,10 @@ def test_distill_steps_match_reference_golden(name):
     # differing mask element for this fixture between two builds whose buffers otherwise agree to 4e-6).  The updated
     # parameters are therefore held to 2e-3 only when no flip happened (all gradients within 1e-4), else to 2e-2.
     ptol = 2e-2 if (gtol or worst['grad'] > 1e-4) else 2e-3
+    worst['param'] = 0.0
     for n in O.trainable_keys(s_sd):
         if not n.endswith(G.ZERO_GRAD_SUFFIXES):
-            G.compare(z, 'after/param/' + n, sd[n], ptol, atol=1e-6)
+            worst['param'] = max(worst['param'], G.compare(z, 'after/param/' + n, sd[n], ptol, atol=1e-6))
     for n in z.files:
         if n.startswith('after/buffer/'):
             key = n[len('after/buffer/'):]
@@ -139,9 +140,13 @@ def test_distill_steps_match_reference_golden(name):
             got = sd[key].cpu().double()
             assert float((got - ref).abs().max()) <= 1e-4 * (1 + float(ref.abs().max())), key
     assert worst['loss'] < LOSS_TOL, worst
-    print('\n[%s] worst rel err: features %.2e  loss %.2e  grads %.2e; worst e_hip/e_ref beyond %.0e so far: %.2f (%s)'
-          % (name, worst['feat'], worst['loss'], worst['grad'], GRAD_TOL, WORST_GRAD_RATIO['ratio'],
-             WORST_GRAD_RATIO['name']))
+    line = ('[%s] worst rel err: features %.2e (tol %.0e)  loss %.2e (%.0e)  grads vs fp64 %.2e (%.0e or 2x torch-fp32); '
+            'params after Adam %.2e (held to %.0e); worst e_hip/e_ref beyond %.0e so far: %.2f (%s)'
+            % (name, worst['feat'], FEAT_TOL, worst['loss'], LOSS_TOL, worst['grad'], gtol or GRAD_TOL, worst['param'], ptol, GRAD_TOL,
+               WORST_GRAD_RATIO['ratio'], WORST_GRAD_RATIO['name']))
+    print('\n' + line)
+    from tests.conftest import record_achieved
+    record_achieved(line)
 
 
 def test_eval_after_a_training_step_uses_the_updated_weights():
@@ -605,6 +610,11 @@ def test_full_size_dense_parity_every_element(case):
             worst_g = max(worst_g, _grad_check(n, p.grad, g32[n], orc64.s[n].grad))
     print('\n[dense %s, batched %s] %s\n  loss rel %.1e; worst gradient rel-L2 vs fp64 %.2e'
           % (case, tuple(x.shape), '\n  '.join(report), abs(loss.item() - float(l64)) / abs(float(l64)), worst_g))
+    from tests.conftest import record_achieved
+    worst_map = max(float(r.split('rel ')[1].split(' ')[0]) for r in report)
+    record_achieved('[dense %s] every element of %d maps: worst rel-L2 %.1e (tol %.0e); loss rel %.1e; worst gradient '
+                    'rel-L2 vs fp64 %.2e' % (case, len(report), worst_map, FEAT_TOL,
+                                             abs(loss.item() - float(l64)) / abs(float(l64)), worst_g))
 
 
 def test_batch16_teacher_maps_equal_batch1_maps_bitwise_and_steps_are_reproducible():
