@@ -258,9 +258,13 @@ __device__ __forceinline__ void ring_wait(f32x4& a0, f32x4& a1, f32x4& a2, f32x4
 // RES: the epilogue adds `res1` (identity / downsample sum of a Bottleneck, or the nearest-upsampled FPN top-down map):
 // its 16 rows per tile are requested during the tile's LAST k group into registers of their own and consumed, like the
 // accumulators, during the next tile's first k group.
-template <int WN, int KQ, bool PRO, bool RES>
+// NI = 16-column accumulator tiles per wave (4: the 64-column wave tile; 2: a 32-column one, so that a K = 1024 slice
+// of 32 columns still fits the LDS: the layer3 / layer4 1x1 convs with M of only 16 800 / 67 200 pixels).
+template <int WN, int KQ, bool PRO, bool RES, int NI = 4>
 __global__ void __launch_bounds__(256, 1) bres2_kernel(const hnd_conv_desc d, const BresArgs a) {
-  constexpr int WM = 4 / WN, BN = 64 * WN, MI = 4, NI = 4, RING = 8;
+  constexpr int WM = 4 / WN, WTN = 16 * NI, BN = WTN * WN, MI = 4, RING = 8;
+  typedef float vecn __attribute__((ext_vector_type(NI)));
+  static_assert(!RES || NI == 4, "the residual build keeps the 64-column wave tile");
   constexpr int K = 64 * KQ, KG = 4 * KQ;
   static_assert(KG >= RING, "the ring reaches at most one tile ahead");
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -299,7 +303,8 @@ __global__ void __launch_bounds__(256, 1) bres2_kernel(const hnd_conv_desc d, co
     return po;
   };
 
-  const int col0 = n0 + wn * 64 + l16 * 4;
+  const int rho0 = n0 + wn * WTN;                     // first packed weight row of this wave's tiles
+  const int col0 = (rho0 & ~63) + l16 * 4 + ((rho0 >> 4) & 3);      // hnd::chan_of_row: NI consecutive channels
   float es[NI], eb[NI], s1[NI], s2[NI];
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
@@ -319,7 +324,7 @@ __global__ void __launch_bounds__(256, 1) bres2_kernel(const hnd_conv_desc d, co
   int bsw[4];
 #pragma unroll
   for (int u = 0; u < 4; ++u) bsw[u] = ((4 * u + g4) ^ l16) * 4;
-  const float* Bw = Bs + (wn * 64 + l16) * K;
+  const float* Bw = Bs + (wn * WTN + l16) * K;
 
   int c = c_lo;
   while (c < c_hi) {
@@ -395,21 +400,21 @@ __global__ void __launch_bounds__(256, 1) bres2_kernel(const hnd_conv_desc d, co
                 acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(
                     av[s], bcur[ni][s], (g == 0 && s == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[mi][ni], 0, 0, 0);
               if (mi == 0) {
-                bnxt[s] = *(const f32x4*)(Bw + s * 16 * K + bo);
+                if (s < NI) bnxt[s] = *(const f32x4*)(Bw + s * 16 * K + bo);
                 if (PRO && s == 3) {
                   psn = *(const f32x4*)(pro + kn * 16 + g4 * 4);
                   pbn = *(const f32x4*)(pro + K + kn * 16 + g4 * 4);
                 }
               }
               if (g == 0 && have_out) {              // row 4*g4 + s of row group mi of the previous tile
-                f32x4 v;
+                vecn v;
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) {
                   float x = out[mi][ni][s] * es[ni] + eb[ni];
                   if (RES) x += resv[mi][s][ni];
                   v[ni] = d.relu ? fmaxf(x, 0.f) : x;
                 }
-                *(f32x4*)(d.y + (size_t)(unsigned)prow[mi * 16 + 4 * g4 + s] * (unsigned)d.ldc + col0) = v;
+                *(vecn*)(d.y + (size_t)(unsigned)prow[mi * 16 + 4 * g4 + s] * (unsigned)d.ldc + col0) = v;
               }
               // this tile's residual rows, consumed one tile later: four per k group over the last four k groups (a
               // single k group of lead -- 2048 cycles -- is less than the memory latency under load: measured slower)
@@ -453,14 +458,14 @@ __global__ void __launch_bounds__(256, 1) bres2_kernel(const hnd_conv_desc d, co
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
-            f32x4 v;
+            vecn v;
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
               float x = out[mi][ni][s] * es[ni] + eb[ni];
               if (RES) x += resv[mi][s][ni];
               v[ni] = d.relu ? fmaxf(x, 0.f) : x;
             }
-            *(f32x4*)(d.y + (size_t)(unsigned)prow[mi * 16 + 4 * g4 + s] * (unsigned)d.ldc + col0) = v;
+            *(vecn*)(d.y + (size_t)(unsigned)prow[mi * 16 + 4 * g4 + s] * (unsigned)d.ldc + col0) = v;
           }
       }
     }
@@ -529,6 +534,24 @@ int launch_bres2_t(const hnd_conv_desc& d, const BresArgs& a, size_t lds, int gr
   return hnd::check_launch("hnd_conv2d_igemm(bres2)");
 }
 
+int launch_bres2_k1024(const hnd_conv_desc& d, const BresArgs& a, size_t lds, int grid, hipStream_t stream) {
+  static std::atomic<unsigned long long> attr_set{0};
+  auto kern = bres2_kernel<1, 16, false, false, 2>;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (!(attr_set.load(std::memory_order_relaxed) & bit)) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) {
+      hnd::set_error("hipFuncSetAttribute(bres2<K=1024>) failed: %s", hipGetErrorString(e));
+      return HND_ERR_LAUNCH;
+    }
+    attr_set.fetch_or(bit, std::memory_order_relaxed);
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, d, a);
+  return hnd::check_launch("hnd_conv2d_igemm(bres2 K=1024)");
+}
+
 template <int WN, int KQ>
 int launch_bres2_p(const hnd_conv_desc& d, const BresArgs& a, size_t lds, int grid, hipStream_t stream) {
   if (d.res1) return launch_bres2_t<WN, KQ, false, true>(d, a, lds, grid, stream);      // (never with a prologue)
@@ -545,8 +568,25 @@ namespace hnd {
 int bres_variant(const hnd_conv_desc& d) {
   const int kmax = bres_kmax();
   if (kmax <= 0 || d.kh != 1 || d.kw != 1 || d.bh != 0 || d.bw != 0 || d.stats != nullptr) return 0;
-  if (d.cin != d.kdim || d.kdim > kmax) return 0;
+  if (d.cin != d.kdim) return 0;
   if (d.w_group_rows % 64 != 0) return 0;
+  if (d.kdim == 1024) {
+    // 5 = the one-wave kernel with a 32-column slice (32 x 1024 floats = 128 KB) for the K = 1024 1x1 convs of layer3 /
+    // layer4.  Measured and NOT adopted (round 3): 110 vs 106 TF (1024->256 @50x84) and 121 vs 117 (1024->512) in
+    // isolation, nothing in the step (101.1 vs 100.8 ms): with NI = 2 a wave issues one 16-byte A load per 8 MFMAs and
+    // every A row is fetched by Cout / 32 workgroups.  Opt-in: HND_BRES_K1024=1 (the tests and tools/bench_bres.py).
+    const char* e = getenv("HND_BRES_K1024");
+    const char* e2 = getenv("HND_BRES2");
+    if (!(e && atoi(e) != 0) || (e2 && atoi(e2) == 0) ||
+        kmax < 512 || d.res1 || d.res2 || d.mask || d.pro_scale || d.w_group_rows != 0) return 0;
+    const int per_xcd = cu_count() / 8, nsl = d.cout / 32;
+    if (d.cout % 32 != 0 || per_xcd < 1 || nsl > per_xcd || per_xcd % nsl != 0) return 0;
+    if ((long long)(d.oh - 1) * d.sh >= d.h || (long long)(d.ow - 1) * d.sw >= d.w_) return 0;
+    const long long M = (long long)d.n * d.oh * d.ow;
+    const long long per_team = ((M + 63) / 64) / (8ll * (per_xcd / nsl));
+    return per_team >= 8 ? 5 : 0;
+  }
+  if (d.kdim > kmax) return 0;
   const int wn = (d.kdim <= 256 && d.cout % 128 == 0) ? 2 : 1;
   // instantiated depths: 64 / 128 / 256 with the 128-column slice, 256 / 512 with the 64-column slice
   if (wn == 2 ? (d.kdim != 64 && d.kdim != 128 && d.kdim != 256) : (d.kdim != 256 && d.kdim != 512)) return 0;
@@ -588,6 +628,18 @@ int launch_bres(const hnd_conv_desc& d, hipStream_t stream) {
   if (var == 0) {
     set_error("launch_bres: descriptor not eligible");
     return HND_ERR_INVALID;
+  }
+  if (var == 5) {
+    const long long M5 = (long long)d.n * d.oh * d.ow;
+    BresArgs a5;
+    a5.div_ow = make_fastdiv((unsigned)d.ow);
+    a5.div_oh = make_fastdiv((unsigned)d.oh);
+    a5.nsl = d.cout / 32;
+    a5.nchunks = (int)((M5 + 63) / 64);
+    a5.cpg = 0;
+    a5.dbg = 0;
+    const size_t lds5 = ((size_t)32 * d.kdim + 8 * 256) * sizeof(float);
+    return launch_bres2_k1024(d, a5, lds5, (cu_count() / 8) * 8, stream);
   }
   const bool v2 = var > 2;
   const int wn = v2 ? var - 2 : var;

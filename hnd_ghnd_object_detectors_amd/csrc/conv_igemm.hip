@@ -641,6 +641,6 @@ extern "C" int hnd_conv2d_igemm_tile(const hnd_conv_desc* desc) {
   if (!desc) return -1;
   if (desc->cin == 4) return hnd::stem7_applies(*desc) ? 9 : 1;
   if (thin_n_applies(*desc)) return 4;
-  if (const int v = hnd::bres_variant(*desc)) return v == 2 ? 5 : (v == 1 ? 6 : (v == 4 ? 7 : 8));
+  if (const int v = hnd::bres_variant(*desc)) return v == 2 ? 5 : (v == 1 ? 6 : (v == 4 ? 7 : (v == 3 ? 8 : 10)));
   return pick_tile(*desc);
 }

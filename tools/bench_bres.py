@@ -30,6 +30,8 @@ SHAPES = {
     '1x1_256-1024@50 pro (conv1.dgrad)': (256, 50, 84, 1024, 1, False, True, 1),
     '1x1_512-2048@25+res (layer4.conv3)': (512, 25, 42, 2048, 1, True, False, 1),
     '1x1_512-256@100 (fpn.inner1)': (512, 100, 168, 256, 1, True, False, 1),
+    '1x1_1024-256@50 (layer3.conv1)': (1024, 50, 84, 256, 1, False, False, 1),
+    '1x1_1024-512@50 (layer4.0.conv1)': (1024, 50, 84, 512, 1, False, False, 1),
 }
 
 
@@ -40,7 +42,7 @@ def main():
     ap.add_argument('--only', default='')
     args = ap.parse_args()
     dev = 'cuda:0'
-    os.environ['HND_BRES_ALL'] = '1'            # A/B on every eligible shape, not only where the picker takes it
+    os.environ['HND_BRES_ALL'] = os.environ['HND_BRES_K1024'] = '1'            # A/B on every eligible shape, not only where the picker takes it
     modes = (('tiled', '0', '1'), ('bres', '512', '0'), ('bres2', '512', '1'))      # name, HND_BRES, HND_BRES2
     tot = {m[0]: [0.0, 0.0] for m in modes}
     for name, (cin, h, w, cout, s, res, pro, groups) in SHAPES.items():
