@@ -57,13 +57,13 @@ _SIGNATURES = {
     'hnd_wino_weights': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     'hnd_wino_input': (C.c_int, [vp, vp] + [C.c_int] * 4 + [vp, vp, C.c_int, C.c_int, vp]),
     'hnd_wino_output': (C.c_int, [vp, vp] + [C.c_int] * 5 + [vp, vp, vp, vp, C.c_int, C.c_int, vp]),
-    'hnd_wino2_tiles_pad': (C.c_int64, [C.c_int] * 3),
-    'hnd_wino2_stats_blocks': (C.c_int, [C.c_int] * 4),
-    'hnd_wino2_weights': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp]),
-    'hnd_wino2_input': (C.c_int, [vp, vp] + [C.c_int] * 5 + [vp, vp, C.c_int, vp]),
-    'hnd_wino2_output': (C.c_int, [vp, vp] + [C.c_int] * 5 + [vp, vp, C.c_int, vp, vp]),
-    'hnd_wino2_dy': (C.c_int, [vp, vp] + [C.c_int] * 5 + [vp]),
-    'hnd_wino2_wgrad_output': (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),
+    'hnd_wino2_tiles_pad': (C.c_int64, [C.c_int] * 4),
+    'hnd_wino2_stats_blocks': (C.c_int, [C.c_int] * 5),
+    'hnd_wino2_weights': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    'hnd_wino2_input': (C.c_int, [vp, vp] + [C.c_int] * 5 + [vp, vp, C.c_int, C.c_int, vp]),
+    'hnd_wino2_output': (C.c_int, [vp, vp] + [C.c_int] * 5 + [vp, vp, C.c_int, vp, C.c_int, vp]),
+    'hnd_wino2_dy': (C.c_int, [vp, vp] + [C.c_int] * 6 + [vp]),
+    'hnd_wino2_wgrad_output': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     'hnd_maxpool3x3s2_fwd': (C.c_int, [vp, vp, vp] + [C.c_int] * 6 + [vp]),
     'hnd_maxpool3x3s2_bwd_relu_scale': (C.c_int, [vp] * 5 + [C.c_int] * 6 + [vp]),
     'hnd_bn_finalize': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int64, vp, vp, vp, vp, vp,

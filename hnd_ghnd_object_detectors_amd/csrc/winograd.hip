@@ -828,6 +828,289 @@ __global__ void wino2_wgrad_out_kernel(const float* __restrict__ s, float* __res
   }
 }
 
+
+// ================================================================================== F(6x6, 2x2) / F(2x2, 6x6)
+// Round 3: the same head convolutions on 6x6 output tiles.  Points {0, 1, -1, 2, -2, 1/2, inf}: 49 products per 36
+// outputs instead of 25 per 16 (12.9 % fewer GEMM flops; transformed tensors 1.36x instead of 1.56x the activation).
+// fp32 error against exact correlation, post-ReLU data, K = 256: relative L2 4.1e-6 (F(4x4,2x2): 1.7e-6).  Matrices by
+// Cook-Toom in exact rationals (all row scalings 1 / prod_{l != j}(a_j - a_l) sit in G, so B^T depends on the points
+// only and the weight-gradient problem F(2x2, 6x6) -- the dy tile in the role of the filter -- shares the forward
+// pass's V = B^T d B); checked against direct correlation in fp64 to 1e-15.
+constexpr float W6_AT[6][7] = {{1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 0.f},
+                               {0.f, 1.f, -1.f, 2.f, -2.f, 1.f / 2.f, 0.f},
+                               {0.f, 1.f, 1.f, 4.f, 4.f, 1.f / 4.f, 0.f},
+                               {0.f, 1.f, -1.f, 8.f, -8.f, 1.f / 8.f, 0.f},
+                               {0.f, 1.f, 1.f, 16.f, 16.f, 1.f / 16.f, 0.f},
+                               {0.f, 1.f, -1.f, 32.f, -32.f, 1.f / 32.f, 1.f}};
+constexpr float W6_G[7][2] = {{-1.f / 2.f, 0.f},        {-1.f / 3.f, -1.f / 3.f}, {1.f / 9.f, -1.f / 9.f},
+                              {1.f / 36.f, 1.f / 18.f}, {-1.f / 60.f, 1.f / 30.f}, {32.f / 45.f, 16.f / 45.f},
+                              {0.f, 1.f}};
+constexpr float W6_BT[7][7] = {{-2.f, 4.f, 5.f / 2.f, -5.f, -1.f / 2.f, 1.f, 0.f},
+                               {0.f, 2.f, -2.f, -9.f / 2.f, 1.f / 2.f, 1.f, 0.f},
+                               {0.f, -2.f, 6.f, -7.f / 2.f, -3.f / 2.f, 1.f, 0.f},
+                               {0.f, 1.f, -3.f / 2.f, -2.f, 3.f / 2.f, 1.f, 0.f},
+                               {0.f, -1.f, 5.f / 2.f, 0.f, -5.f / 2.f, 1.f, 0.f},
+                               {0.f, 4.f, 0.f, -5.f, 0.f, 1.f, 0.f},
+                               {0.f, -2.f, 4.f, 5.f / 2.f, -5.f, -1.f / 2.f, 1.f}};
+constexpr float W6_G2[7][6] = {{-1.f / 2.f, 0.f, 0.f, 0.f, 0.f, 0.f},
+                               {-1.f / 3.f, -1.f / 3.f, -1.f / 3.f, -1.f / 3.f, -1.f / 3.f, -1.f / 3.f},
+                               {1.f / 9.f, -1.f / 9.f, 1.f / 9.f, -1.f / 9.f, 1.f / 9.f, -1.f / 9.f},
+                               {1.f / 36.f, 1.f / 18.f, 1.f / 9.f, 2.f / 9.f, 4.f / 9.f, 8.f / 9.f},
+                               {-1.f / 60.f, 1.f / 30.f, -1.f / 15.f, 2.f / 15.f, -4.f / 15.f, 8.f / 15.f},
+                               {32.f / 45.f, 16.f / 45.f, 8.f / 45.f, 4.f / 45.f, 2.f / 45.f, 1.f / 45.f},
+                               {0.f, 0.f, 0.f, 0.f, 0.f, 1.f}};
+constexpr float W6_A2T[2][7] = {{1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 0.f}, {0.f, 1.f, -1.f, 2.f, -2.f, 1.f / 2.f, 1.f}};
+
+// out = M in for a compile-time matrix: fully unrolled, zero entries vanish, +-1 become add / subtract
+template <int R, int C, class V>
+__device__ __forceinline__ void mat_apply(const float (&M)[R][C], const V (&in)[C], V (&out)[R]) {
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    V acc = in[0] * 0.f;
+    bool first = true;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const float m = M[r][c];
+      if (m == 0.f) continue;
+      const V term = m == 1.f ? in[c] : (m == -1.f ? -in[c] : in[c] * m);
+      acc = first ? term : acc + term;
+      first = false;
+    }
+    out[r] = acc;
+  }
+}
+
+__global__ void wino26_weights_kernel(const float* __restrict__ w, float* __restrict__ u, int cout, int cin, int dgrad,
+                                      int rows, int rows_pad, int kdim) {
+  const long long total = (long long)rows_pad * kdim;
+  const int kreal = dgrad ? cout : cin;
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    const int pr = (int)(e / kdim), k = (int)(e - (long long)pr * kdim);      // packed row pr holds channel r
+    const int r = hnd::chan_of_row(pr);
+    const bool ok = r < rows && k < kreal;
+    float g[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        float v = 0.f;
+        if (ok) v = dgrad ? w[(((size_t)k * cin + r) * 2 + (1 - i)) * 2 + (1 - j)]
+                          : w[(((size_t)r * cin + k) * 2 + i) * 2 + j];
+        g[i][j] = v;
+      }
+    float t[2][7];                          // t[j] = G g[:, j]
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const float col[2] = {g[0][j], g[1][j]};
+      mat_apply(W6_G, col, t[j]);
+    }
+    const size_t fs = (size_t)rows_pad * kdim;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      const float row[2] = {t[0][i], t[1][i]};
+      float o[7];
+      mat_apply(W6_G, row, o);
+      float* dst = u + ((size_t)(i * 7) * rows_pad + pr) * kdim + k;
+#pragma unroll
+      for (int j = 0; j < 7; ++j) dst[(size_t)j * fs] = o[j];
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) wino26_input_kernel(const float* __restrict__ x, float* __restrict__ v,
+                                                           const Wino2Geom g, const float* __restrict__ pro_scale,
+                                                           const float* __restrict__ pro_shift, int pro_relu) {
+  const int c2n = g.c >> 1;
+  const long long tiles = (long long)g.n * g.th * g.tw;
+  const long long total = tiles * c2n;
+  const size_t fs = (size_t)g.tiles_pad * g.c;
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    const int c2 = (int)(e % c2n);
+    long long t = e / c2n;
+    const int tx = (int)(t % g.tw);
+    long long q = t / g.tw;
+    const int ty = (int)(q % g.th), b = (int)(q / g.th);
+    f32x2 ps = {1.f, 1.f}, pb = {0.f, 0.f};
+    if (pro_scale) {
+      ps = *(const f32x2*)(pro_scale + c2 * 2);
+      pb = *(const f32x2*)(pro_shift + c2 * 2);
+    }
+    const float floor_ = pro_relu ? 0.f : -INFINITY;
+    f32x2 d[7][7];                          // d[j][i]: column j of the patch (so a column is one array)
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      const int iy = 6 * ty - g.pad + i;
+#pragma unroll
+      for (int j = 0; j < 7; ++j) {
+        const int ix = 6 * tx - g.pad + j;
+        const bool ok = (unsigned)iy < (unsigned)g.h && (unsigned)ix < (unsigned)g.w;
+        const size_t off = ok ? (((size_t)b * g.h + iy) * g.w + ix) * g.c + c2 * 2 : 0;
+        f32x2 a = *(const f32x2*)(x + off);
+        if (pro_scale) {
+          a = a * ps + pb;
+          a.x = fmaxf(a.x, floor_); a.y = fmaxf(a.y, floor_);
+        }
+        const f32x2 z = {0.f, 0.f};
+        d[j][i] = ok ? a : z;
+      }
+    }
+    f32x2 r[7][7];                          // r[i][j] = (B^T d)[i][j]
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      f32x2 o[7];
+      mat_apply(W6_BT, d[j], o);
+#pragma unroll
+      for (int i = 0; i < 7; ++i) r[i][j] = o[i];
+    }
+    float* dst = v + (size_t)t * g.c + c2 * 2;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      f32x2 o[7];
+      mat_apply(W6_BT, r[i], o);
+#pragma unroll
+      for (int j = 0; j < 7; ++j) *(f32x2*)(dst + (size_t)(i * 7 + j) * fs) = o[j];
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) wino26_output_kernel(const float* __restrict__ m, float* __restrict__ y,
+                                                            const Wino2Geom g, int cout, int ldc,
+                                                            const float* __restrict__ epi_scale,
+                                                            const float* __restrict__ epi_shift, int relu,
+                                                            float* __restrict__ stats) {
+  __shared__ float red[2][512];
+  const int c2n = cout >> 1;
+  const long long tiles = (long long)g.n * g.th * g.tw;
+  const long long total = tiles * c2n;
+  const size_t fs = (size_t)g.tiles_pad * cout;
+  f32x2 s1 = {0.f, 0.f}, s2 = {0.f, 0.f};
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    const int c2 = (int)(e % c2n);
+    long long t = e / c2n;
+    const int tx = (int)(t % g.tw);
+    long long q = t / g.tw;
+    const int ty = (int)(q % g.th), b = (int)(q / g.th);
+    const float* src = m + (size_t)t * cout + c2 * 2;
+    f32x2 s[6][7];                          // s[a][j] = (A^T m)[a][j]
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      f32x2 col[7], o[6];
+#pragma unroll
+      for (int i = 0; i < 7; ++i) col[i] = *(const f32x2*)(src + (size_t)(i * 7 + j) * fs);
+      mat_apply(W6_AT, col, o);
+#pragma unroll
+      for (int a = 0; a < 6; ++a) s[a][j] = o[a];
+    }
+    f32x2 es = {1.f, 1.f}, eb = {0.f, 0.f};
+    if (epi_scale) es = *(const f32x2*)(epi_scale + c2 * 2);
+    if (epi_shift) eb = *(const f32x2*)(epi_shift + c2 * 2);
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      const int oy = 6 * ty + a;
+      f32x2 o[6];
+      mat_apply(W6_AT, s[a], o);
+#pragma unroll
+      for (int bb = 0; bb < 6; ++bb) {
+        const int ox = 6 * tx + bb;
+        if (oy >= g.oh || ox >= g.ow) continue;
+        f32x2 v = o[bb] * es + eb;
+        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); }
+        *(f32x2*)(y + (((size_t)b * g.oh + oy) * g.ow + ox) * ldc + c2 * 2) = v;
+        s1 += v;
+        s2 += v * v;
+      }
+    }
+  }
+  if (stats) {
+    red[0][threadIdx.x * 2] = s1.x; red[0][threadIdx.x * 2 + 1] = s1.y;
+    red[1][threadIdx.x * 2] = s2.x; red[1][threadIdx.x * 2 + 1] = s2.y;
+    __syncthreads();
+    if ((int)threadIdx.x < cout) {
+      float a1 = 0.f, a2 = 0.f;
+      for (int k = threadIdx.x; k < 512; k += cout) { a1 += red[0][k]; a2 += red[1][k]; }
+      float* st = stats + (size_t)blockIdx.x * 2 * cout;
+      st[threadIdx.x] = a1;
+      st[cout + threadIdx.x] = a2;
+    }
+  }
+}
+
+// Z = G' dy_t G'^T of the 6x6 tiles of dy (F(2x2, 6x6): the weight gradient in the Winograd domain, see above)
+__global__ void __launch_bounds__(256) wino26_dy_kernel(const float* __restrict__ dy, float* __restrict__ z,
+                                                        const Wino2Geom g, int cout, int ldy) {
+  const int c2n = cout >> 1;
+  const long long tiles = (long long)g.n * g.th * g.tw;
+  const long long total = tiles * c2n;
+  const size_t fs = (size_t)g.tiles_pad * cout;
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    const int c2 = (int)(e % c2n);
+    long long t = e / c2n;
+    const int tx = (int)(t % g.tw);
+    long long q = t / g.tw;
+    const int ty = (int)(q % g.th), b = (int)(q / g.th);
+    f32x2 d[6][6];                          // d[bb][a]: column bb of the dy tile
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      const int oy = 6 * ty + a;
+#pragma unroll
+      for (int bb = 0; bb < 6; ++bb) {
+        const int ox = 6 * tx + bb;
+        const bool ok = oy < g.oh && ox < g.ow;
+        const size_t off = ok ? (((size_t)b * g.oh + oy) * g.ow + ox) * ldy + c2 * 2 : 0;
+        const f32x2 v = *(const f32x2*)(dy + off);
+        const f32x2 zz = {0.f, 0.f};
+        d[bb][a] = ok ? v : zz;
+      }
+    }
+    f32x2 r[7][6];                          // r[i][bb] = (G' dy)[i][bb]
+#pragma unroll
+    for (int bb = 0; bb < 6; ++bb) {
+      f32x2 o[7];
+      mat_apply(W6_G2, d[bb], o);
+#pragma unroll
+      for (int i = 0; i < 7; ++i) r[i][bb] = o[i];
+    }
+    float* dst = z + (size_t)t * cout + c2 * 2;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      f32x2 o[7];
+      mat_apply(W6_G2, r[i], o);
+#pragma unroll
+      for (int j = 0; j < 7; ++j) *(f32x2*)(dst + (size_t)(i * 7 + j) * fs) = o[j];
+    }
+  }
+}
+
+// dW[co][ci][i][j] = (A'^T S A')[i][j],  S_f[co][ci] at s[f*cout*cin + co*cin + ci], f = 0..48
+__global__ void wino26_wgrad_out_kernel(const float* __restrict__ s, float* __restrict__ dw, int cout, int cin) {
+  const long long total = (long long)cout * cin;
+  const size_t fs = (size_t)total;
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    float t[2][7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      float col[7], o[2];
+#pragma unroll
+      for (int i = 0; i < 7; ++i) col[i] = s[(size_t)(i * 7 + j) * fs + e];
+      mat_apply(W6_A2T, col, o);
+      t[0][j] = o[0];
+      t[1][j] = o[1];
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      float o[2];
+      mat_apply(W6_A2T, t[i], o);
+      dw[e * 4 + i * 2 + 0] = o[0];
+      dw[e * 4 + i * 2 + 1] = o[1];
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -894,70 +1177,97 @@ int hnd_wino_output(const float* m, float* y, int n, int h, int w, int cout, int
   return hnd::check_launch("hnd_wino_output");
 }
 
-/* ---- F(4x4, 2x2): the 2x2 convolutions of the student head ---- */
-int64_t hnd_wino2_tiles_pad(int n, int oh, int ow) {
-  const long long t = (long long)n * ((oh + 3) / 4) * ((ow + 3) / 4);
+/* ---- F(4x4, 2x2) / F(6x6, 2x2): the 2x2 convolutions of the student head; tile = 4 or 6 ---- */
+static inline bool wino2_tile_ok(int tile) { return tile == 4 || tile == 6; }
+
+int64_t hnd_wino2_tiles_pad(int n, int oh, int ow, int tile) {
+  if (!wino2_tile_ok(tile)) return -1;
+  const long long t = (long long)n * ((oh + tile - 1) / tile) * ((ow + tile - 1) / tile);
   return (t + 127) / 128 * 128;
 }
 
-int hnd_wino2_stats_blocks(int n, int oh, int ow, int cout) {
-  const long long tiles = (long long)n * ((oh + 3) / 4) * ((ow + 3) / 4);
+int hnd_wino2_stats_blocks(int n, int oh, int ow, int cout, int tile) {
+  if (!wino2_tile_ok(tile)) return -1;
+  const long long tiles = (long long)n * ((oh + tile - 1) / tile) * ((ow + tile - 1) / tile);
   long long b = (tiles * (cout / 2) + 255) / 256;
   return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
 }
 
-int hnd_wino2_weights(const float* weight, float* u, int cout, int cin, int dgrad, void* stream) {
-  HND_REQUIRE(weight && u && cout > 0 && cin > 0, "hnd_wino2_weights: bad arguments");
+int hnd_wino2_weights(const float* weight, float* u, int cout, int cin, int dgrad, int tile, void* stream) {
+  HND_REQUIRE(weight && u && cout > 0 && cin > 0 && wino2_tile_ok(tile), "hnd_wino2_weights: bad arguments");
   const int rows = dgrad ? cin : cout, kreal = dgrad ? cout : cin;
   HND_REQUIRE(kreal % 32 == 0, "hnd_wino2_weights: GEMM depth %d must be a multiple of 32", kreal);
   const int rows_pad = (rows + 63) / 64 * 64;
-  hipLaunchKernelGGL(wino2_weights_kernel, dim3(grid_for((long long)rows_pad * kreal)), dim3(256), 0,
-                     hnd::as_stream(stream), weight, u, cout, cin, dgrad, rows, rows_pad, kreal);
+  if (tile == 4)
+    hipLaunchKernelGGL(wino2_weights_kernel, dim3(grid_for((long long)rows_pad * kreal)), dim3(256), 0,
+                       hnd::as_stream(stream), weight, u, cout, cin, dgrad, rows, rows_pad, kreal);
+  else
+    hipLaunchKernelGGL(wino26_weights_kernel, dim3(grid_for((long long)rows_pad * kreal)), dim3(256), 0,
+                       hnd::as_stream(stream), weight, u, cout, cin, dgrad, rows, rows_pad, kreal);
   return hnd::check_launch("hnd_wino2_weights");
 }
 
 int hnd_wino2_input(const float* x, float* v, int n, int h, int w, int c, int pad, const float* pro_scale,
-                    const float* pro_shift, int pro_relu, void* stream) {
+                    const float* pro_shift, int pro_relu, int tile, void* stream) {
   HND_REQUIRE(x && v && n > 0 && h > 0 && w > 0 && c > 0 && c % 2 == 0 && (pad == 0 || pad == 1) &&
-                  h + 2 * pad - 1 > 0 && w + 2 * pad - 1 > 0, "hnd_wino2_input: bad arguments");
+                  h + 2 * pad - 1 > 0 && w + 2 * pad - 1 > 0 && wino2_tile_ok(tile), "hnd_wino2_input: bad arguments");
   HND_REQUIRE(pro_scale == nullptr || pro_shift != nullptr, "hnd_wino2_input: pro_shift is required with pro_scale");
   const int oh = h + 2 * pad - 1, ow = w + 2 * pad - 1;
-  Wino2Geom g{n, h, w, c, oh, ow, (oh + 3) / 4, (ow + 3) / 4, (int)hnd_wino2_tiles_pad(n, oh, ow), pad};
+  Wino2Geom g{n, h, w, c, oh, ow, (oh + tile - 1) / tile, (ow + tile - 1) / tile,
+              (int)hnd_wino2_tiles_pad(n, oh, ow, tile), pad};
   const long long tiles = (long long)n * g.th * g.tw;
-  hipLaunchKernelGGL(wino2_input_kernel, dim3(grid_for(tiles * (c / 2))), dim3(256), 0, hnd::as_stream(stream), x, v, g,
-                     pro_scale, pro_shift, pro_relu);
+  if (tile == 4)
+    hipLaunchKernelGGL(wino2_input_kernel, dim3(grid_for(tiles * (c / 2))), dim3(256), 0, hnd::as_stream(stream), x, v,
+                       g, pro_scale, pro_shift, pro_relu);
+  else
+    hipLaunchKernelGGL(wino26_input_kernel, dim3(grid_for(tiles * (c / 2))), dim3(256), 0, hnd::as_stream(stream), x, v,
+                       g, pro_scale, pro_shift, pro_relu);
   return hnd::check_launch("hnd_wino2_input");
 }
 
 int hnd_wino2_output(const float* m, float* y, int n, int oh, int ow, int cout, int ldc, const float* epi_scale,
-                     const float* epi_shift, int relu, float* stats, void* stream) {
-  HND_REQUIRE(m && y && n > 0 && oh > 0 && ow > 0 && cout > 0 && cout % 2 == 0 && ldc >= cout && ldc % 2 == 0,
-              "hnd_wino2_output: bad arguments");
+                     const float* epi_shift, int relu, float* stats, int tile, void* stream) {
+  HND_REQUIRE(m && y && n > 0 && oh > 0 && ow > 0 && cout > 0 && cout % 2 == 0 && ldc >= cout && ldc % 2 == 0 &&
+                  wino2_tile_ok(tile), "hnd_wino2_output: bad arguments");
   HND_REQUIRE(stats == nullptr || 512 % cout == 0, "hnd_wino2_output: stats need 512 %% cout == 0 (cout=%d)", cout);
-  Wino2Geom g{n, 0, 0, 0, oh, ow, (oh + 3) / 4, (ow + 3) / 4, (int)hnd_wino2_tiles_pad(n, oh, ow), 0};
-  const int blocks = hnd_wino2_stats_blocks(n, oh, ow, cout);
-  hipLaunchKernelGGL(wino2_output_kernel, dim3(blocks), dim3(256), 0, hnd::as_stream(stream), m, y, g, cout, ldc,
-                     epi_scale, epi_shift, relu, stats);
+  Wino2Geom g{n, 0, 0, 0, oh, ow, (oh + tile - 1) / tile, (ow + tile - 1) / tile,
+              (int)hnd_wino2_tiles_pad(n, oh, ow, tile), 0};
+  const int blocks = hnd_wino2_stats_blocks(n, oh, ow, cout, tile);
+  if (tile == 4)
+    hipLaunchKernelGGL(wino2_output_kernel, dim3(blocks), dim3(256), 0, hnd::as_stream(stream), m, y, g, cout, ldc,
+                       epi_scale, epi_shift, relu, stats);
+  else
+    hipLaunchKernelGGL(wino26_output_kernel, dim3(blocks), dim3(256), 0, hnd::as_stream(stream), m, y, g, cout, ldc,
+                       epi_scale, epi_shift, relu, stats);
   return hnd::check_launch("hnd_wino2_output");
 }
 
-/* Winograd-domain weight gradient of a 2x2 head conv: z = G' dy G'^T per 4x4 tile of dy [n][oh][ow][ldy] ->
- * z [25][tiles_pad][cout]; after the 25 grouped GEMMs s[f][cout][cin] = sum_t z_f[t][co] v_f[t][ci]
- * (hnd_conv2d_wgrad, groups = 25), hnd_wino2_wgrad_output writes dW [cout][cin][2][2]. */
-int hnd_wino2_dy(const float* dy, float* z, int n, int oh, int ow, int cout, int ldy, void* stream) {
-  HND_REQUIRE(dy && z && n > 0 && oh > 0 && ow > 0 && cout > 0 && cout % 2 == 0 && ldy >= cout && ldy % 2 == 0,
-              "hnd_wino2_dy: bad arguments");
-  Wino2Geom g{n, 0, 0, 0, oh, ow, (oh + 3) / 4, (ow + 3) / 4, (int)hnd_wino2_tiles_pad(n, oh, ow), 0};
+/* Winograd-domain weight gradient of a 2x2 head conv: z = G' dy G'^T per tile of dy [n][oh][ow][ldy] ->
+ * z [(tile+1)^2][tiles_pad][cout]; after the grouped GEMMs s[f][cout][cin] = sum_t z_f[t][co] v_f[t][ci]
+ * (hnd_conv2d_wgrad, groups = (tile+1)^2), hnd_wino2_wgrad_output writes dW [cout][cin][2][2]. */
+int hnd_wino2_dy(const float* dy, float* z, int n, int oh, int ow, int cout, int ldy, int tile, void* stream) {
+  HND_REQUIRE(dy && z && n > 0 && oh > 0 && ow > 0 && cout > 0 && cout % 2 == 0 && ldy >= cout && ldy % 2 == 0 &&
+                  wino2_tile_ok(tile), "hnd_wino2_dy: bad arguments");
+  Wino2Geom g{n, 0, 0, 0, oh, ow, (oh + tile - 1) / tile, (ow + tile - 1) / tile,
+              (int)hnd_wino2_tiles_pad(n, oh, ow, tile), 0};
   const long long tiles = (long long)n * g.th * g.tw;
-  hipLaunchKernelGGL(wino2_dy_kernel, dim3(grid_for(tiles * (cout / 2))), dim3(256), 0, hnd::as_stream(stream), dy, z,
-                     g, cout, ldy);
+  if (tile == 4)
+    hipLaunchKernelGGL(wino2_dy_kernel, dim3(grid_for(tiles * (cout / 2))), dim3(256), 0, hnd::as_stream(stream), dy,
+                       z, g, cout, ldy);
+  else
+    hipLaunchKernelGGL(wino26_dy_kernel, dim3(grid_for(tiles * (cout / 2))), dim3(256), 0, hnd::as_stream(stream), dy,
+                       z, g, cout, ldy);
   return hnd::check_launch("hnd_wino2_dy");
 }
 
-int hnd_wino2_wgrad_output(const float* s, float* dw, int cout, int cin, void* stream) {
-  HND_REQUIRE(s && dw && cout > 0 && cin > 0, "hnd_wino2_wgrad_output: bad arguments");
-  hipLaunchKernelGGL(wino2_wgrad_out_kernel, dim3(grid_for((long long)cout * cin)), dim3(256), 0,
-                     hnd::as_stream(stream), s, dw, cout, cin);
+int hnd_wino2_wgrad_output(const float* s, float* dw, int cout, int cin, int tile, void* stream) {
+  HND_REQUIRE(s && dw && cout > 0 && cin > 0 && wino2_tile_ok(tile), "hnd_wino2_wgrad_output: bad arguments");
+  if (tile == 4)
+    hipLaunchKernelGGL(wino2_wgrad_out_kernel, dim3(grid_for((long long)cout * cin)), dim3(256), 0,
+                       hnd::as_stream(stream), s, dw, cout, cin);
+  else
+    hipLaunchKernelGGL(wino26_wgrad_out_kernel, dim3(grid_for((long long)cout * cin)), dim3(256), 0,
+                       hnd::as_stream(stream), s, dw, cout, cin);
   return hnd::check_launch("hnd_wino2_wgrad_output");
 }
 

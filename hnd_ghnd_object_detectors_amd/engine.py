@@ -163,10 +163,10 @@ class Wino2Cache(object):
     def __init__(self, weight):
         self.weight, self.packs, self.ver = weight, {}, None
 
-    def get(self, dgrad=False):
-        ww = self.packs.get(dgrad)
+    def get(self, dgrad=False, tile=4):
+        ww = self.packs.get((dgrad, tile))
         if ww is None:
-            ww = self.packs[dgrad] = ops.Wino2Weights(self.weight.detach(), dgrad)
+            ww = self.packs[(dgrad, tile)] = ops.Wino2Weights(self.weight.detach(), dgrad, tile)
         return ww
 
     def refresh(self, force=False):
@@ -209,6 +209,18 @@ def wino_tile_for(tile, n, h, w):
     if tile != 4 or not WINOGRAD6:
         return tile
     return 6 if ((h + 5) // 6) * ((w + 5) // 6) >= WINOGRAD6_MIN_TILES else 4
+
+
+WINOGRAD2_6 = os.environ.get('HND_WINOGRAD2_6', '1') != '0'
+
+
+def wino2_tile_for(oh, ow):
+    """F(6x6,2x2) (49 products per 36 outputs) instead of F(4x4,2x2) (25 per 16) for the deep head convs on maps of at
+    least WINOGRAD6_MIN_TILES 6x6 tiles per image: 12.9 % fewer GEMM flops, transformed tensors 1.36x instead of 1.56x
+    the activation; fp32 error 4.1e-6 vs 1.7e-6 relative L2.  Map size only, never the batch (see wino_tile_for)."""
+    if not WINOGRAD2_6:
+        return 4
+    return 6 if ((oh + 5) // 6) * ((ow + 5) // 6) >= WINOGRAD6_MIN_TILES else 4
 
 
 # =========================================================================================== transform
@@ -503,7 +515,7 @@ class FrozenLayerEngine(object):
 
 # =========================================================================================== student head
 class _HeadConv(object):
-    __slots__ = ('conv', 'bn', 'pad', 'relu', 'cin', 'cout', 'cs_in', 'cs_out', 'wc', 'wino')
+    __slots__ = ('conv', 'bn', 'pad', 'relu', 'cin', 'cout', 'cs_in', 'cs_out', 'wc', 'wino', 'wino_f', 'wino_d')
 
 
 class HeadEngine(object):
@@ -520,10 +532,18 @@ class HeadEngine(object):
             hc.cout, hc.cin = conv.weight.shape[0], conv.weight.shape[1]
             hc.cs_in, hc.cs_out = ops.chan_pad_of(hc.cin), ops.chan_pad_of(hc.cout)
             hc.wc = WeightCache(conv.weight)
-            # F(4x4,2x2) pays for the two deep decoder convs (128->256, 256->256: x1.2-1.45 forward and dgrad,
-            # tools/bench_wino2.py); with 64 channels on either side the 25 GEMMs are HBM-bound and lose
-            hc.wino = Wino2Cache(conv.weight) if (WINOGRAD and WINOGRAD_HEAD and min(hc.cin, hc.cout) >= 128 and
-                                                  512 % hc.cout == 0) else None
+            # Winograd F(6x6,2x2) / F(4x4,2x2) per DIRECTION (tools/bench_wino2.py, profiles/r03_bench_wino2.txt, batch 16):
+            #   * both sides >= 128 channels (decoder 128->256, 256->256): forward x1.4-1.7, data gradient x1.4-1.7, weight
+            #     gradient in the Winograd domain x1.5-2.0 -- everything;
+            #   * 256 -> 64 (encoder conv2): forward x1.23 and, reusing its V, the weight gradient x2.1; its data gradient
+            #     (GEMM depth 64) gains nothing -> forward + weight gradient only;
+            #   * 64 -> 256 (encoder conv1): only the data gradient (GEMM depth 256) gains, x1.29;
+            #   * 64 channels on both sides / 64 -> 128: the component GEMMs are HBM-bound and lose.
+            deep = min(hc.cin, hc.cout) >= 128
+            ok = bool(WINOGRAD and WINOGRAD_HEAD and 512 % hc.cout == 0)
+            hc.wino_f = ok and (deep or (WINOGRAD2_6 and hc.cin >= 256 and hc.cout == 64))
+            hc.wino_d = ok and (deep or (WINOGRAD2_6 and hc.cin == 64 and hc.cout >= 256))
+            hc.wino = Wino2Cache(conv.weight) if (hc.wino_f or hc.wino_d) else None
             self.layers.append(hc)
         self.bufs = None
         self.plan_key = None
@@ -535,13 +555,11 @@ class HeadEngine(object):
         if self.bufs is None:
             self.bufs = Buffers(x.device)
         for hc in self.layers:
-            if hc.wino is not None:
-                hc.wino.get(False)
+            if hc.wino is not None:         # (packs are made by the plan, for the tile its geometry picks)
                 hc.wino.refresh(force=training)
-                hc.wc.refresh(force=training)        # transposed / wgrad-side packs, if any were made
-                continue
-            hc.wc.get(False, hc.cs_in)
-            hc.wc.refresh(force=training)
+            if not hc.wino_f:
+                hc.wc.get(False, hc.cs_in)
+            hc.wc.refresh(force=training)            # forward / transposed / wgrad-side packs, whichever were made
         ptrs = tuple(t.data_ptr() for hc in self.layers
                      for t in (hc.bn.weight, hc.bn.bias, hc.bn.running_mean, hc.bn.running_var))
         key = (x.data_ptr(), tuple(x.shape), training, ptrs)
@@ -591,15 +609,17 @@ class HeadEngine(object):
             oh, ow = ops.conv_out_size(h, 2, 1, hc.pad), ops.conv_out_size(w, 2, 1, hc.pad)
             y = b.get('y%d' % i, (n, oh, ow, hc.cs_out))
             m = n * oh * ow
-            nt = ops.Wino2Conv.stats_blocks(n, oh, ow, hc.cs_out) if hc.wino is not None else ops.stats_tiles(m)
+            t2 = wino2_tile_for(oh, ow)
+            nt = ops.Wino2Conv.stats_blocks(n, oh, ow, hc.cs_out, t2) if hc.wino_f else ops.stats_tiles(m)
             st = b.get('stats%d' % i, (nt, 2, hc.cs_out)) if training else None
             sc, sh = b.get('scale%d' % i, (hc.cs_out,)), b.get('shift%d' % i, (hc.cs_out,))
             mu, rs = b.get('mean%d' % i, (hc.cs_out,)), b.get('rstd%d' % i, (hc.cs_out,))
-            if hc.wino is not None:
-                v, mm = self._wino_scratch(n, oh, ow, hc.cs_in, hc.cs_out)
+            if hc.wino_f:
+                v, mm = self._wino_scratch(n, oh, ow, hc.cs_in, hc.cs_out, t2)
                 if training:        # the transformed input is kept: the weight gradient reuses it
-                    v = b.get('wino_keep_v%d' % i, (ops.Wino2Conv.scratch_elems(n, oh, ow, hc.cs_in, hc.cs_out)[0],))
-                wl = ops.Wino2Conv(cur, hc.wino.get(False), y, v, mm, hc.pad, pro_scale=cur_scale,
+                    v = b.get('wino_keep_v%d' % i,
+                              (ops.Wino2Conv.scratch_elems(n, oh, ow, hc.cs_in, hc.cs_out, t2)[0],))
+                wl = ops.Wino2Conv(cur, hc.wino.get(False, t2), y, v, mm, hc.pad, pro_scale=cur_scale,
                                    pro_shift=cur_shift, pro_relu=cur_relu, stats=st)
                 self.wino_fwd[i] = wl
                 self.convs.append(wl.launches('layer1.conv%d' % i))
@@ -621,8 +641,8 @@ class HeadEngine(object):
         self.out = b.get('out', (n, h, w, self.layers[-1].cs_out))
         self.flops_fwd = flops
 
-    def _wino_scratch(self, n, oh, ow, cin, cout):
-        nv, nm = ops.Wino2Conv.scratch_elems(n, oh, ow, cin, cout)
+    def _wino_scratch(self, n, oh, ow, cin, cout, tile=4):
+        nv, nm = ops.Wino2Conv.scratch_elems(n, oh, ow, cin, cout, tile)
         cur = getattr(self, '_wino_need', (0, 0))
         self._wino_need = (max(nv, cur[0]), max(nm, cur[1]))
         return self.bufs.get('wino_v', (self._wino_need[0],)), self.bufs.get('wino_m', (self._wino_need[1],))
@@ -631,9 +651,9 @@ class HeadEngine(object):
         """split-K workspace of the grouped Winograd wgrad launch (sized for the largest layer that uses it)"""
         n, h, w, c, oh, ow = fw.geom
         d = ops.WgradDesc()
-        tiles = n * ((oh + 3) // 4) * ((ow + 3) // 4)
+        tiles = n * ((oh + fw.tile - 1) // fw.tile) * ((ow + fw.tile - 1) // fw.tile)
         d.n, d.h, d.w_, d.cin, d.cin_real, d.oh, d.ow, d.cout, d.ldy = 1, 1, tiles, c, hc.cin, 1, tiles, hc.cout, hc.cout
-        d.kh, d.kw, d.stride, d.pad, d.groups = 1, 1, 1, 0, 25
+        d.kh, d.kw, d.stride, d.pad, d.groups = 1, 1, 1, 0, fw.ww.ncomp
         need = (ops.wgrad_workspace_of(d) + 3) // 4
         self._wino_slab_need = max(need, getattr(self, '_wino_slab_need', 0))
         return self._wino_slab_need
@@ -654,10 +674,9 @@ class HeadEngine(object):
             self.parts = {}
         for hc in self.layers[lo:hi]:
             if hc.wino is not None:
-                hc.wino.get(False)
                 hc.wino.refresh()
-                continue
-            hc.wc.get(False, hc.cs_in)
+            if not hc.wino_f:
+                hc.wc.get(False, hc.cs_in)
             hc.wc.refresh()
         b = self.bufs
         first = max(lo - 1, 0)               # the decoder's first conv applies decoder.0 (BN of layer lo-1) on load
@@ -679,9 +698,10 @@ class HeadEngine(object):
                 oh, ow = ops.conv_out_size(h, 2, 1, hc.pad), ops.conv_out_size(w, 2, 1, hc.pad)
                 y = b.get('%s.y%d' % (part, i), (n, oh, ow, hc.cs_out))
                 tag = 'layer1.%s.conv%d' % (part, i)
-                if hc.wino is not None:          # same arithmetic as the unsplit model
-                    v, mm = self._wino_scratch(n, oh, ow, hc.cs_in, hc.cs_out)
-                    plan['convs'] += ops.Wino2Conv(cur, hc.wino.get(False), y, v, mm, hc.pad, pro_scale=pro[0],
+                if hc.wino_f:                    # same arithmetic as the unsplit model
+                    t2 = wino2_tile_for(oh, ow)
+                    v, mm = self._wino_scratch(n, oh, ow, hc.cs_in, hc.cs_out, t2)
+                    plan['convs'] += ops.Wino2Conv(cur, hc.wino.get(False, t2), y, v, mm, hc.pad, pro_scale=pro[0],
                                                    pro_shift=pro[1], pro_relu=pro[2]).launches(tag)
                 else:
                     plan['convs'].append((ops.conv_forward(cur, hc.wc.get(False, hc.cs_in), y, 2, 1, hc.pad,
@@ -763,8 +783,8 @@ class HeadEngine(object):
             if dw is not None and i in self.wino_fwd and hc.cs_out == hc.cout and hc.cs_in == hc.cin:
                 # Winograd-domain weight gradient: forward V x transformed dy, 25 grouped split-K reductions
                 fw = self.wino_fwd[i]
-                _, zbuf = self._wino_scratch(fw.geom[0], fw.geom[4], fw.geom[5], hc.cs_in, hc.cs_out)
-                sbuf = b.get('wino_s%d' % i, (25 * hc.cout * hc.cin,))
+                _, zbuf = self._wino_scratch(fw.geom[0], fw.geom[4], fw.geom[5], hc.cs_in, hc.cs_out, fw.tile)
+                sbuf = b.get('wino_s%d' % i, (fw.ww.ncomp * hc.cout * hc.cin,))
                 st['wgrad'] = ops.Wino2Wgrad(fw, gbuf[i], dw, zbuf, sbuf,
                                              b.get('wino_slabs', (self._wino_slab_elems(fw, hc),))
                                              ).launches('layer1.conv%d.wgrad' % i)
@@ -775,10 +795,11 @@ class HeadEngine(object):
                 flops += 2 * npix * hc.cout * 4 * hc.cin
             st['dgrad'] = []
             tgt = gbuf[i - 1] if i > 0 else self.g_in
-            if tgt is not None and hc.wino is not None:
+            if tgt is not None and hc.wino_d:
                 nd, hd, wd, _ = tgt.shape
-                v, mm = self._wino_scratch(nd, hd, wd, hc.cs_out, hc.cs_in)
-                st['dgrad'] = ops.Wino2Conv(gbuf[i], hc.wino.get(True), tgt, v, mm,
+                t2 = wino2_tile_for(hd, wd)
+                v, mm = self._wino_scratch(nd, hd, wd, hc.cs_out, hc.cs_in, t2)
+                st['dgrad'] = ops.Wino2Conv(gbuf[i], hc.wino.get(True, t2), tgt, v, mm,
                                             1 - hc.pad).launches('layer1.conv%d.dgrad' % i)
                 flops += 2 * npix * hc.cout * 4 * hc.cin
             elif tgt is not None:

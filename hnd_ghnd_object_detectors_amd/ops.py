@@ -533,21 +533,23 @@ class WinoConv(object):
 
 
 class Wino2Weights(object):
-    """F(4x4,2x2) weights of one 2x2 conv in packed GEMM-operand layout [25][rows_pad][depth]; dgrad: transposed conv."""
+    """F(tile x tile, 2x2) weights (tile 4 or 6) of one 2x2 conv in packed GEMM-operand layout
+    [(tile+1)^2][rows_pad][depth]; dgrad: transposed conv."""
 
-    def __init__(self, weight, dgrad=False):
+    def __init__(self, weight, dgrad=False, tile=4):
         cout, cin, kh, kw = weight.shape
-        assert kh == 2 and kw == 2 and weight.is_contiguous()
-        self.src, self.dgrad, self.ncomp = weight, dgrad, 25
+        assert kh == 2 and kw == 2 and weight.is_contiguous() and tile in (4, 6)
+        self.src, self.dgrad, self.tile, self.ncomp = weight, dgrad, tile, (tile + 1) ** 2
         self.rows, self.depth = (cin, cout) if dgrad else (cout, cin)
         assert self.depth % 32 == 0, 'Winograd path needs a GEMM depth that is a multiple of 32'
         self.rows_pad = round_up(self.rows, 64)
-        self.buf = torch.empty(25 * self.rows_pad * self.depth, dtype=torch.float32, device=weight.device)
+        self.buf = torch.empty(self.ncomp * self.rows_pad * self.depth, dtype=torch.float32, device=weight.device)
         self.repack()
 
     def repack(self):
         cout, cin = self.src.shape[0], self.src.shape[1]
-        check(_L.hnd_wino2_weights(self.src.data_ptr(), ptr(self.buf), cout, cin, int(self.dgrad), stream_ptr()),
+        check(_L.hnd_wino2_weights(self.src.data_ptr(), ptr(self.buf), cout, cin, int(self.dgrad), self.tile,
+                                   stream_ptr()),
               'hnd_wino2_weights')
 
 
@@ -563,10 +565,11 @@ class Wino2Conv(object):
         assert tuple(y.shape[:3]) == (n, oh, ow) and c == ww.depth and pad in (0, 1)
         self.x, self.y, self.ww, self.pad = x, y, ww, pad
         self.geom = (n, h, w, c, oh, ow)
-        self.tiles_pad = int(_L.hnd_wino2_tiles_pad(n, oh, ow))
+        self.tile, nc = ww.tile, ww.ncomp
+        self.tiles_pad = int(_L.hnd_wino2_tiles_pad(n, oh, ow, self.tile))
         self.cout = round_up(ww.rows, 2)
         assert self.cout <= y.shape[3]
-        need_v, need_m = 25 * self.tiles_pad * c, 25 * self.tiles_pad * self.cout
+        need_v, need_m = nc * self.tiles_pad * c, nc * self.tiles_pad * self.cout
         assert v.numel() >= need_v and m.numel() >= need_m
         if pro_scale is not None and pro_shift is None:
             pro_shift = _zeros(c, x.device)
@@ -574,46 +577,48 @@ class Wino2Conv(object):
         self.epi = (epi_scale, epi_shift, int(relu))
         self.stats = stats
         if stats is not None:
-            assert stats.numel() >= self.stats_blocks(n, oh, ow, self.cout) * 2 * self.cout
-        self.v = v[:need_v].view(1, 1, 25 * self.tiles_pad, c)
-        self.m = m[:need_m].view(1, 1, 25 * self.tiles_pad, self.cout)
+            assert stats.numel() >= self.stats_blocks(n, oh, ow, self.cout, self.tile) * 2 * self.cout
+        self.v = v[:need_v].view(1, 1, nc * self.tiles_pad, c)
+        self.m = m[:need_m].view(1, 1, nc * self.tiles_pad, self.cout)
         pw = PackedWeight.__new__(PackedWeight)
         pw.buf, pw.kdim, pw.rows, pw.chan_pad, pw.chan_real = ww.buf, ww.depth, ww.rows, c, c
-        self.gemm = conv_desc(self.v, pw, self.m, kh=1, kw=1, oh=1, ow=25 * self.tiles_pad, sh=1, dh=1, bh=0, sw=1,
+        self.gemm = conv_desc(self.v, pw, self.m, kh=1, kw=1, oh=1, ow=nc * self.tiles_pad, sh=1, dh=1, bh=0, sw=1,
                               dw=1, bw=0, cout=self.cout)
         self.gemm.desc.w_group_rows = self.tiles_pad
         self.gemm.desc.w_group_stride = ww.rows_pad * ww.depth
         self.gemm.refresh_variant()
-        tiles = n * ((oh + 3) // 4) * ((ow + 3) // 4)
-        self.gemm.flops = 2 * 25 * tiles * ww.rows * ww.depth
+        tiles = n * ((oh + self.tile - 1) // self.tile) * ((ow + self.tile - 1) // self.tile)
+        self.gemm.flops = 2 * nc * tiles * ww.rows * ww.depth
         self.gemm.alg_flops = 2 * n * oh * ow * ww.rows * 4 * ww.depth  # the direct 2x2 convolution it computes
         self.flops, self.variant = self.gemm.flops, self.gemm.variant
 
     @staticmethod
-    def scratch_elems(n, oh, ow, cin, cout):
-        tp = int(_L.hnd_wino2_tiles_pad(n, oh, ow))
-        return 25 * tp * cin, 25 * tp * round_up(cout, 2)
+    def scratch_elems(n, oh, ow, cin, cout, tile=4):
+        tp, nc = int(_L.hnd_wino2_tiles_pad(n, oh, ow, tile)), (tile + 1) ** 2
+        return nc * tp * cin, nc * tp * round_up(cout, 2)
 
     @staticmethod
-    def stats_blocks(n, oh, ow, cout):
-        return int(_L.hnd_wino2_stats_blocks(n, oh, ow, cout))
+    def stats_blocks(n, oh, ow, cout, tile=4):
+        return int(_L.hnd_wino2_stats_blocks(n, oh, ow, cout, tile))
 
     def _run_input(self, stream=None):
         n, h, w, c, oh, ow = self.geom
         check(_L.hnd_wino2_input(ptr(self.x), ptr(self.v), n, h, w, c, self.pad, ptr(self.pro[0]), ptr(self.pro[1]),
-                                 self.pro[2], stream if stream is not None else stream_ptr()), 'hnd_wino2_input')
+                                 self.pro[2], self.tile, stream if stream is not None else stream_ptr()),
+              'hnd_wino2_input')
 
     def _run_output(self, stream=None):
         n, h, w, c, oh, ow = self.geom
         check(_L.hnd_wino2_output(ptr(self.m), ptr(self.y), n, oh, ow, self.cout, self.y.shape[3], ptr(self.epi[0]),
-                                  ptr(self.epi[1]), self.epi[2], ptr(self.stats),
+                                  ptr(self.epi[1]), self.epi[2], ptr(self.stats), self.tile,
                                   stream if stream is not None else stream_ptr()), 'hnd_wino2_output')
 
     def launches(self, tag):
         n, h, w, c, oh, ow = self.geom
-        tiles = n * ((oh + 3) // 4) * ((ow + 3) // 4)
-        b_in = 4 * (n * h * w * c + 25 * tiles * c)
-        b_out = 4 * (25 * tiles * self.cout + n * oh * ow * self.cout)
+        nc = self.ww.ncomp
+        tiles = n * ((oh + self.tile - 1) // self.tile) * ((ow + self.tile - 1) // self.tile)
+        b_in = 4 * (n * h * w * c + nc * tiles * c)
+        b_out = 4 * (nc * tiles * self.cout + n * oh * ow * self.cout)
         return [(_Step(self._run_input, 'wino2_input', b_in), tag + '.wino_in'), (self.gemm, tag),
                 (_Step(self._run_output, 'wino2_output', b_out), tag + '.wino_out')]
 
@@ -634,9 +639,10 @@ class Wino2Wgrad(object):
         cout, cin = dw.shape[0], dw.shape[1]
         assert tuple(dw.shape) == (cout, cin, 2, 2) and dw.is_contiguous() and cin == c and cout % 2 == 0
         assert tuple(dy.shape[:3]) == (n, oh, ow) and dy.shape[3] >= cout
-        tp = fwd.tiles_pad
-        tiles = n * ((oh + 3) // 4) * ((ow + 3) // 4)
-        assert z.numel() >= 25 * tp * cout and s.numel() >= 25 * cout * cin
+        tp, tile, nc = fwd.tiles_pad, fwd.tile, fwd.ww.ncomp
+        self.tile, self.ncomp = tile, nc
+        tiles = n * ((oh + tile - 1) // tile) * ((ow + tile - 1) // tile)
+        assert z.numel() >= nc * tp * cout and s.numel() >= nc * cout * cin
         self.fwd, self.dy, self.dw, self.z, self.s = fwd, dy, dw, z, s
         self.geom = (n, oh, ow, cout, dy.shape[3], cin)
         d = WgradDesc()
@@ -644,31 +650,33 @@ class Wino2Wgrad(object):
         d.n, d.h, d.w_, d.cin, d.cin_real = 1, 1, tiles, c, cin
         d.oh, d.ow, d.cout, d.ldy = 1, tiles, cout, cout
         d.kh, d.kw, d.stride, d.pad, d.splitk = 1, 1, 1, 0, 0
-        d.groups = 25
+        d.groups = nc
         d.x_group_stride, d.dy_group_stride, d.dw_group_stride = tp * c, tp * cout, cout * cin
         need = _L.hnd_conv2d_wgrad_workspace(C.byref(d))
         if slabs is None or slabs.numel() * 4 < need:
             slabs = torch.empty((need + 3) // 4, dtype=torch.float32, device=dy.device)
         d.slabs = ptr(slabs)
-        self.gemm = WgradLaunch(d, (fwd.v, z, s, slabs), 2 * 25 * tiles * cout * cin)
+        self.gemm = WgradLaunch(d, (fwd.v, z, s, slabs), 2 * nc * tiles * cout * cin)
         self.gemm.alg_flops = 2 * n * oh * ow * cout * 4 * cin
         self.flops, self.variant = self.gemm.flops, self.gemm.variant
 
     def _run_dy(self, stream=None):
         n, oh, ow, cout, ldy, cin = self.geom
-        check(_L.hnd_wino2_dy(ptr(self.dy), ptr(self.z), n, oh, ow, cout, ldy,
+        check(_L.hnd_wino2_dy(ptr(self.dy), ptr(self.z), n, oh, ow, cout, ldy, self.tile,
                               stream if stream is not None else stream_ptr()), 'hnd_wino2_dy')
 
     def _run_out(self, stream=None):
         n, oh, ow, cout, ldy, cin = self.geom
-        check(_L.hnd_wino2_wgrad_output(ptr(self.s), ptr(self.dw), cout, cin,
+        check(_L.hnd_wino2_wgrad_output(ptr(self.s), ptr(self.dw), cout, cin, self.tile,
                                         stream if stream is not None else stream_ptr()), 'hnd_wino2_wgrad_output')
 
     def launches(self, tag):
         n, oh, ow, cout, ldy, cin = self.geom
-        tiles = n * ((oh + 3) // 4) * ((ow + 3) // 4)
-        return [(_Step(self._run_dy, 'wino2_dy', 4 * (n * oh * ow * cout + 25 * tiles * cout)), tag + '.wino_dy'),
-                (self.gemm, tag), (_Step(self._run_out, 'wino2_wgrad_output', 4 * 29 * cout * cin), tag + '.wino_out')]
+        nc = self.ncomp
+        tiles = n * ((oh + self.tile - 1) // self.tile) * ((ow + self.tile - 1) // self.tile)
+        return [(_Step(self._run_dy, 'wino2_dy', 4 * (n * oh * ow * cout + nc * tiles * cout)), tag + '.wino_dy'),
+                (self.gemm, tag),
+                (_Step(self._run_out, 'wino2_wgrad_output', 4 * (nc + 4) * cout * cin), tag + '.wino_out')]
 
     def run(self, stream=None):
         self._run_dy(stream)

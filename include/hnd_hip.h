@@ -188,25 +188,27 @@ int hnd_wino_input(const float* x, float* v, int n, int h, int w, int c, const f
 int hnd_wino_output(const float* m, float* y, int n, int h, int w, int cout, int ldc, const float* epi_scale,
                     const float* epi_shift, const float* res1, const float* mask, int relu, int tile, void* stream);
 
-/* ---- Winograd F(4x4, 2x2) for the student head's 2x2 convolutions (src/models/mimic/resnet_layer.py:43-62), forward
- * (padding 1 in the encoder, 0 in the decoder) and data gradient (the same correlation with flipped, transposed
- * weights and padding 1 - pad): 25 GEMMs in one grouped hnd_conv2d_igemm launch, 2.56x fewer multiplies than direct.
- * Geometry is given by the OUTPUT extent oh x ow = (h + 2*pad - 1) x (w + 2*pad - 1).
- * hnd_wino2_output with `stats` also emits the per-block partial (sum, sum of squares) per channel of what it stored:
- * stats[hnd_wino2_stats_blocks(...)][2][cout], the layout hnd_bn_finalize reads (ntiles = number of blocks). */
-int64_t hnd_wino2_tiles_pad(int n, int oh, int ow);
-int hnd_wino2_stats_blocks(int n, int oh, int ow, int cout);
-int hnd_wino2_weights(const float* weight, float* u, int cout, int cin, int dgrad, void* stream);
+/* ---- Winograd F(tile x tile, 2x2), tile = 4 or 6, for the student head's 2x2 convolutions
+ * (src/models/mimic/resnet_layer.py:43-62), forward (padding 1 in the encoder, 0 in the decoder) and data gradient (the
+ * same correlation with flipped, transposed weights and padding 1 - pad): (tile+1)^2 = 25 / 49 GEMMs in one grouped
+ * hnd_conv2d_igemm launch, 2.56x / 2.94x fewer multiplies than direct, transformed tensors 1.56x / 1.36x the activation
+ * (points 0, +-1, 2, inf / 0, +-1, +-2, 1/2, inf).  Geometry is given by the OUTPUT extent oh x ow = (h + 2*pad - 1) x
+ * (w + 2*pad - 1).  hnd_wino2_output with `stats` also emits the per-block partial (sum, sum of squares) per channel of
+ * what it stored: stats[hnd_wino2_stats_blocks(...)][2][cout], the layout hnd_bn_finalize reads (ntiles = blocks). */
+int64_t hnd_wino2_tiles_pad(int n, int oh, int ow, int tile);
+int hnd_wino2_stats_blocks(int n, int oh, int ow, int cout, int tile);
+int hnd_wino2_weights(const float* weight, float* u, int cout, int cin, int dgrad, int tile, void* stream);
 int hnd_wino2_input(const float* x, float* v, int n, int h, int w, int c, int pad, const float* pro_scale,
-                    const float* pro_shift, int pro_relu, void* stream);
+                    const float* pro_shift, int pro_relu, int tile, void* stream);
 int hnd_wino2_output(const float* m, float* y, int n, int oh, int ow, int cout, int ldc, const float* epi_scale,
-                     const float* epi_shift, int relu, float* stats, void* stream);
-/* Weight gradient of the same convs in the Winograd domain, F(2x2 taps, 4x4 tile) over the same points: the data
- * transform is the v [25][tiles_pad][cin] hnd_wino2_input made in the forward pass (keep it); hnd_wino2_dy makes
- * z [25][tiles_pad][cout] from dy [n][oh][ow][ldy]; 25 grouped reductions over the tiles (hnd_conv2d_wgrad with
- * kh = kw = 1, groups = 25, x = v, dy = z) give s [25][cout][cin]; hnd_wino2_wgrad_output -> dW [cout][cin][2][2]. */
-int hnd_wino2_dy(const float* dy, float* z, int n, int oh, int ow, int cout, int ldy, void* stream);
-int hnd_wino2_wgrad_output(const float* s, float* dw, int cout, int cin, void* stream);
+                     const float* epi_shift, int relu, float* stats, int tile, void* stream);
+/* Weight gradient of the same convs in the Winograd domain, F(2x2 taps, tile x tile) over the same points: the data
+ * transform is the v [(tile+1)^2][tiles_pad][cin] hnd_wino2_input made in the forward pass (keep it); hnd_wino2_dy
+ * makes z [(tile+1)^2][tiles_pad][cout] from dy [n][oh][ow][ldy]; the grouped reductions over the tiles
+ * (hnd_conv2d_wgrad with kh = kw = 1, groups = (tile+1)^2, x = v, dy = z) give s [groups][cout][cin];
+ * hnd_wino2_wgrad_output -> dW [cout][cin][2][2]. */
+int hnd_wino2_dy(const float* dy, float* z, int n, int oh, int ow, int cout, int ldy, int tile, void* stream);
+int hnd_wino2_wgrad_output(const float* s, float* dw, int cout, int cin, int tile, void* stream);
 
 /* nn.MaxPool2d(3, 2, 1) (custom/resnet.py:30,99) NHWC; idx (uint8 tap 0..8) kept for backward. */
 int hnd_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* idx, int n, int h, int w, int c, int oh, int ow,

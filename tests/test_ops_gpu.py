@@ -561,19 +561,20 @@ def test_winograd_conv3x3_dgrad_with_prologue_and_mask(ops, tile):
 
 @pytest.mark.parametrize('n,cin,h,w,cout,pad', [(2, 64, 13, 17, 64, 1), (2, 256, 21, 30, 256, 0), (1, 128, 9, 9, 256, 0),
                                                 (3, 64, 8, 11, 256, 1), (2, 256, 12, 16, 64, 1)])
-def test_winograd_conv2x2_forward_prologue_and_bn_stats(ops, n, cin, h, w, cout, pad):
-    """F(4x4,2x2) head conv: BN+ReLU on load, raw output + per-channel (sum, sum^2) partials for the next BN"""
+@pytest.mark.parametrize('tile', [4, 6])
+def test_winograd_conv2x2_forward_prologue_and_bn_stats(ops, n, cin, h, w, cout, pad, tile):
+    """F(4x4,2x2) / F(6x6,2x2) head conv: BN+ReLU on load, raw output + per-channel (sum, sum^2) partials for the next BN"""
     g = gen(60 + cin + h)
     x = torch.randn(n, cin, h, w, generator=g)
     ps, pb = torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g) * 0.3
     wt = torch.randn(cout, cin, 2, 2, generator=g) / math.sqrt(cin * 4)
     ref = F.conv2d(F.relu(x * ps[None, :, None, None] + pb[None, :, None, None]), wt, None, 1, pad)
     oh, ow = ref.shape[2], ref.shape[3]
-    ww = ops.Wino2Weights(wt.to(DEV).contiguous())
-    nv, nm = ops.Wino2Conv.scratch_elems(n, oh, ow, cin, cout)
+    ww = ops.Wino2Weights(wt.to(DEV).contiguous(), tile=tile)
+    nv, nm = ops.Wino2Conv.scratch_elems(n, oh, ow, cin, cout, tile)
     v, m = torch.empty(nv, device=DEV), torch.empty(nm, device=DEV)
     y = torch.full((n, oh, ow, cout), float('nan'), device=DEV)
-    nb = ops.Wino2Conv.stats_blocks(n, oh, ow, cout)
+    nb = ops.Wino2Conv.stats_blocks(n, oh, ow, cout, tile)
     st = torch.full((nb, 2, cout), float('nan'), device=DEV)
     ops.Wino2Conv(nhwc(x), ww, y, v, m, pad, pro_scale=ps.to(DEV), pro_shift=pb.to(DEV), pro_relu=True, stats=st).run()
     ops.sync_check()
@@ -582,8 +583,9 @@ def test_winograd_conv2x2_forward_prologue_and_bn_stats(ops, n, cin, h, w, cout,
     assert relerr(tot[0], ref.sum(dim=(0, 2, 3))) < 2e-4 and relerr(tot[1], (ref * ref).sum(dim=(0, 2, 3))) < 2e-4
 
 
+@pytest.mark.parametrize('tile', [4, 6])
 @pytest.mark.parametrize('pad', [0, 1])
-def test_winograd_conv2x2_dgrad(ops, pad):
+def test_winograd_conv2x2_dgrad(ops, pad, tile):
     g = gen(71 + pad)
     n, cin, h, w, cout = 2, 128, 14, 19, 256
     x = torch.randn(n, cin, h, w, generator=g, requires_grad=True)
@@ -591,8 +593,8 @@ def test_winograd_conv2x2_dgrad(ops, pad):
     out = F.conv2d(x, wt, None, 1, pad)
     dy = torch.randn(out.shape, generator=g)
     out.backward(dy)
-    ww = ops.Wino2Weights(wt.to(DEV).contiguous(), dgrad=True)
-    nv, nm = ops.Wino2Conv.scratch_elems(n, h, w, cout, cin)
+    ww = ops.Wino2Weights(wt.to(DEV).contiguous(), dgrad=True, tile=tile)
+    nv, nm = ops.Wino2Conv.scratch_elems(n, h, w, cout, cin, tile)
     v, m = torch.empty(nv, device=DEV), torch.empty(nm, device=DEV)
     dx = torch.full((n, h, w, cin), float('nan'), device=DEV)
     ops.Wino2Conv(nhwc(dy), ww, dx, v, m, 1 - pad).run()
@@ -601,7 +603,8 @@ def test_winograd_conv2x2_dgrad(ops, pad):
 
 
 @pytest.mark.parametrize('n,cin,h,w,cout,pad', [(2, 128, 14, 19, 256, 0), (3, 256, 9, 12, 256, 0), (2, 64, 10, 10, 128, 1)])
-def test_winograd_conv2x2_wgrad_reuses_forward_transform(ops, n, cin, h, w, cout, pad):
+@pytest.mark.parametrize('tile', [4, 6])
+def test_winograd_conv2x2_wgrad_reuses_forward_transform(ops, n, cin, h, w, cout, pad, tile):
     """dW in the Winograd domain: forward V (with the BN+ReLU prologue baked in) x transformed dy, 25 grouped
     split-K reductions, inverse transform -- against autograd"""
     g = gen(80 + cin + h)
@@ -612,14 +615,14 @@ def test_winograd_conv2x2_wgrad_reuses_forward_transform(ops, n, cin, h, w, cout
     dy = torch.randn(out.shape, generator=g)
     out.backward(dy)
     oh, ow = out.shape[2], out.shape[3]
-    ww = ops.Wino2Weights(wt.detach().to(DEV).contiguous())
-    nv, nm = ops.Wino2Conv.scratch_elems(n, oh, ow, cin, cout)
+    ww = ops.Wino2Weights(wt.detach().to(DEV).contiguous(), tile=tile)
+    nv, nm = ops.Wino2Conv.scratch_elems(n, oh, ow, cin, cout, tile)
     v, m = torch.empty(nv, device=DEV), torch.full((nm,), float('nan'), device=DEV)
     y = torch.empty(n, oh, ow, cout, device=DEV)
     fwd = ops.Wino2Conv(nhwc(x), ww, y, v, m, pad, pro_scale=ps.to(DEV), pro_shift=pb.to(DEV), pro_relu=True)
     fwd.run()
     dw = torch.full((cout, cin, 2, 2), float('nan'), device=DEV)
-    s = torch.empty(25 * cout * cin, device=DEV)
+    s = torch.empty((tile + 1) ** 2 * cout * cin, device=DEV)
     outs = []
     for _ in range(2):
         ops.Wino2Wgrad(fwd, nhwc(dy), dw, m, s).run()       # z may alias the forward's M scratch

@@ -26,31 +26,31 @@ def main():
         direct = ops.conv_forward(x, ops.pack_weights(wt), y0, 2, 1, pad, stats=st0)
         td = timed(direct.run)
         line = '%-20s direct %7.3f ms (%5.1f TF)' % (name, td, direct.flops / td / 1e9)
-        for dgrad in (False, True):
+        for tile, dgrad in ((4, False), (4, True), (6, False), (6, True)):
             if dgrad:   # data gradient of the same conv: dy [oh, ow, cout] -> dx [h, w, cin]
                 src, dst, wpad = y0, torch.empty(n, h, w, cin, device=dev), 1 - pad
-                ww = ops.Wino2Weights(wt, dgrad=True)
-                nv, nm = ops.Wino2Conv.scratch_elems(n, h, w, cout, cin)
+                ww = ops.Wino2Weights(wt, dgrad=True, tile=tile)
+                nv, nm = ops.Wino2Conv.scratch_elems(n, h, w, cout, cin, tile)
                 ls, _ = ops.conv_dgrad(y0, wt, torch.empty(n, h, w, cin, device=dev), 2, 1, pad)
                 tdir = timed(lambda: [l.run() for l in ls])
             else:
                 src, dst, wpad = x, y1, pad
-                ww = ops.Wino2Weights(wt)
-                nv, nm = ops.Wino2Conv.scratch_elems(n, oh, ow, cin, cout)
+                ww = ops.Wino2Weights(wt, tile=tile)
+                nv, nm = ops.Wino2Conv.scratch_elems(n, oh, ow, cin, cout, tile)
                 tdir = td
             v, m = torch.empty(nv, device=dev), torch.empty(nm, device=dev)
-            st = None if dgrad else torch.empty(ops.Wino2Conv.stats_blocks(n, oh, ow, cout), 2, cout, device=dev)
+            st = None if dgrad else torch.empty(ops.Wino2Conv.stats_blocks(n, oh, ow, cout, tile), 2, cout, device=dev)
             wino = ops.Wino2Conv(src, ww, dst, v, m, wpad, stats=st)
             tw, tg = timed(wino.run), timed(wino.gemm.run)
-            line += ' | %s direct %6.3f wino %6.3f ms (gemm %6.3f, %5.1f TF %s) x%.2f' % (
-                'dgrad' if dgrad else 'fwd', tdir, tw, tg, wino.gemm.flops / tg / 1e9, wino.variant.split('_')[-1],
+            line += ' | F(%d,2) %s direct %6.3f wino %6.3f ms (gemm %6.3f, %5.1f TF %s) x%.2f' % (
+                tile, 'dgrad' if dgrad else 'fwd', tdir, tw, tg, wino.gemm.flops / tg / 1e9, wino.gemm.variant,
                 tdir / tw)
             if not dgrad:
                 line += ' err %.1e' % float((y0 - y1).abs().max() / y0.abs().max())
                 # weight gradient: direct split-K wgrad vs the Winograd-domain one that reuses this V
                 dw0, dw1 = torch.empty_like(wt), torch.empty_like(wt)
                 wdir = ops.conv_wgrad(x, y0, dw0, 2, 1, pad)
-                sbuf = torch.empty(25 * cout * cin, device=dev)
+                sbuf = torch.empty((tile + 1) ** 2 * cout * cin, device=dev)
                 wwin = ops.Wino2Wgrad(wino, y0, dw1, m, sbuf)
                 t0, t1 = timed(wdir.run), timed(wwin.run)
                 line += ' | wgrad direct %6.3f wino %6.3f ms x%.2f err %.1e' % (
