@@ -144,6 +144,111 @@ __global__ void __launch_bounds__(256, 2) stem7_kernel(const hnd_conv_desc d, co
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Weight gradient of the same convolution (student conv1 is trainable: custom/resnet.py:26, autograd at
+// src/mimic_runner.py:53):  dW[co][tap][c] = sum_pixels dy[p][co] * x[2p + tap][c].  The generic split-K kernel gathered
+// one 16-byte tap per (pixel, tap) from global memory and ran at 51 TFLOP/s.  Here a workgroup walks 8 x 16 output
+// tiles: dy of the tile is transposed into LDS ([co][pixel], so an MFMA A-fragment -- output channel l16, 4
+// consecutive pixels -- is one ds_read_b128), the 21 x 37 input patch sits beside it and a B-fragment -- column
+// (tap, c) = l16, the same 4 pixels -- is four ds_read_b32 two pixels apart.  The 64 x 208 accumulator stays in
+// registers (each wave owns 3-4 of the 13 column tiles) across all tiles of the workgroup and is written ONCE as a slab
+// in the generic kernel's layout; wgrad_reduce_kernel sums the slabs in fixed order (bit-reproducible).
+constexpr int WTH = 8, WTW = 16;                     // output tile (rows x cols) = 128 pixels = 8 k groups of 16
+constexpr int WPH = 2 * WTH + 5, WPW = 2 * WTW + 5;  // input patch 21 x 37
+constexpr int DYLD = WTH * WTW + 4;                  // row stride of the transposed dy tile: 33 sixteen-byte slots
+
+__global__ void __launch_bounds__(256, 3) stem7_wgrad_kernel(const hnd_wgrad_desc d, const int tiles_x, const int tiles_y,
+                                                             const int ncols_pad) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* patch = smem;                               // [WPH][WPW][4]
+  float* dyt = smem + ((WPH * WPW * 4 + 3) & ~3);    // [64][DYLD]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l16 = lane & 15, g4 = lane >> 4;
+  const int ntiles = d.n * tiles_x * tiles_y;
+
+  // this wave's column tiles nt = wave, wave + 4, wave + 8, (wave + 12): column n = 16 nt + l16 = 4 tap + c
+  int boff[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int n = (wave + 4 * q) * 16 + l16;
+    int t = n >> 2;
+    t = t < 49 ? t : 48;                             // columns >= 196 are never read back
+    boff[q] = ((t / 7) * WPW + (t % 7)) * 4 + (n & 3) + 32 * g4;      // + 2 * (4 g4) pixels of 4 floats
+  }
+  const bool has4 = wave + 12 < 13;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[mi][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int b = tile;
+    const int tx = b % tiles_x;
+    b /= tiles_x;
+    const int ty = b % tiles_y, n = b / tiles_y;
+    const int oy0 = ty * WTH, ox0 = tx * WTW;
+    const int iy0 = 2 * oy0 - 3, ix0 = 2 * ox0 - 3;
+    __syncthreads();                                 // the previous tile's fragment reads are done
+    const float* img = d.x + (size_t)n * d.h * d.w_ * 4;
+    for (int e = tid; e < WPH * WPW; e += 256) {
+      const int py = e / WPW, px = e - py * WPW;
+      const int iy = iy0 + py, ix = ix0 + px;
+      const bool ok = (unsigned)iy < (unsigned)d.h && (unsigned)ix < (unsigned)d.w_;
+      const f32x4 v = *(const f32x4*)(img + (ok ? ((size_t)iy * d.w_ + ix) * 4 : 0));
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      *(f32x4*)(patch + e * 4) = ok ? v : z;
+    }
+    {   // dy tile, transposed: thread = (pixel group, 4 channels); 16 threads read one pixel's 256 bytes
+      const int c4 = tid & 15;
+#pragma unroll
+      for (int j = 0; j < (WTH * WTW) / 16; ++j) {
+        const int p = (tid >> 4) + 16 * j;           // pixel of the tile: row p / 16, col p % 16
+        const int oy = oy0 + p / WTW, ox = ox0 + p % WTW;
+        const bool ok = oy < d.oh && ox < d.ow;
+        const f32x4 v = *(const f32x4*)(d.dy + (ok ? (((size_t)n * d.oh + oy) * d.ow + ox) * (size_t)d.ldy + c4 * 4 : 0));
+        dyt[(c4 * 4 + 0) * DYLD + p] = ok ? v.x : 0.f;
+        dyt[(c4 * 4 + 1) * DYLD + p] = ok ? v.y : 0.f;
+        dyt[(c4 * 4 + 2) * DYLD + p] = ok ? v.z : 0.f;
+        dyt[(c4 * 4 + 3) * DYLD + p] = ok ? v.w : 0.f;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < WTH; ++r) {                  // one k group = the 16 pixels of tile row r
+      f32x4 a[4], bq[4];
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) a[mi] = *(const f32x4*)(dyt + (mi * 16 + l16) * DYLD + r * WTW + 4 * g4);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float* bp = patch + boff[q] + 2 * r * WPW * 4;
+        bq[q] = f32x4{bp[0], bp[8], bp[16], bp[24]};     // pixels 4 g4 + s: two input pixels (8 floats) apart
+      }
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_) {
+#pragma unroll
+          for (int q = 0; q < 3; ++q)
+            acc[mi][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi][s_], bq[q][s_], acc[mi][q], 0, 0, 0);
+          if (has4) acc[mi][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi][s_], bq[3][s_], acc[mi][3], 0, 0, 0);
+        }
+    }
+  }
+  // ---- one slab per workgroup: [64][ncols_pad], column = 4 tap + c (the generic kernel's layout)
+  float* slab = d.slabs + (size_t)blockIdx.x * 64 * ncols_pad;
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (q == 3 && !has4) continue;
+      const int ncol = (wave + 4 * q) * 16 + l16;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) slab[(size_t)(mi * 16 + 4 * g4 + i) * ncols_pad + ncol] = acc[mi][q][i];
+    }
+}
+
 }  // namespace
 
 namespace hnd {
@@ -177,6 +282,43 @@ int launch_stem7(const hnd_conv_desc& d, hipStream_t stream) {
   const int grid = ntiles < 2 * cus ? ntiles : 2 * cus;        // persistent: two workgroups per CU walk the tiles
   hipLaunchKernelGGL(stem7_kernel, dim3((unsigned)grid), dim3(256), lds, stream, d, tiles_x, tiles_y);
   return check_launch("hnd_conv2d_igemm(stem7)");
+}
+
+
+bool stem7_wgrad_applies(const hnd_wgrad_desc& d) {
+  const char* e = getenv("HND_STEM7");
+  if (e && atoi(e) == 0) return false;
+  return d.cin == 4 && d.kh == 7 && d.kw == 7 && d.stride == 2 && d.pad == 3 && d.cout == 64 && d.ldy % 4 == 0 &&
+         !d.pro_scale && d.groups <= 1 && d.oh == (d.h + 6 - 7) / 2 + 1 && d.ow == (d.w_ + 6 - 7) / 2 + 1 &&
+         (uintptr_t)d.dy % 16 == 0 && (uintptr_t)d.x % 16 == 0;
+}
+
+int stem7_wgrad_blocks(const hnd_wgrad_desc& d) {
+  int dev = 0, cus = 256;
+  (void)hipGetDevice(&dev);
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  const int ntiles = d.n * ((d.ow + WTW - 1) / WTW) * ((d.oh + WTH - 1) / WTH);
+  return ntiles < 3 * cus ? ntiles : 3 * cus;        // persistent: three workgroups per CU walk the tiles
+}
+
+// writes stem7_wgrad_blocks(d) slabs of [64][ncols_pad] floats into d.slabs
+int launch_stem7_wgrad(const hnd_wgrad_desc& d, int ncols_pad, hipStream_t stream) {
+  static bool attr_done[64] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const size_t lds = ((size_t)((WPH * WPW * 4 + 3) & ~3) + 64 * DYLD) * sizeof(float);
+  if (!attr_done[dev & 63]) {
+    hipError_t e = hipFuncSetAttribute((const void*)stem7_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      set_error("hipFuncSetAttribute(stem7_wgrad) failed: %s", hipGetErrorString(e));
+      return HND_ERR_LAUNCH;
+    }
+    attr_done[dev & 63] = true;
+  }
+  const int tiles_x = (d.ow + WTW - 1) / WTW, tiles_y = (d.oh + WTH - 1) / WTH;
+  hipLaunchKernelGGL(stem7_wgrad_kernel, dim3((unsigned)stem7_wgrad_blocks(d)), dim3(256), lds, stream, d, tiles_x, tiles_y,
+                     ncols_pad);
+  return check_launch("hnd_conv2d_wgrad(stem7)");
 }
 
 }  // namespace hnd

@@ -261,13 +261,24 @@ int plan(const hnd_wgrad_desc& d, WgradArgs& a, int BKW) {
 
 }  // namespace
 
+namespace hnd {
+bool stem7_wgrad_applies(const hnd_wgrad_desc& d);             // conv_stem.hip: the stem's dW from an LDS patch
+int stem7_wgrad_blocks(const hnd_wgrad_desc& d);
+int launch_stem7_wgrad(const hnd_wgrad_desc& d, int ncols_pad, hipStream_t stream);
+}  // namespace hnd
+
 extern "C" size_t hnd_conv2d_wgrad_workspace(const hnd_wgrad_desc* desc) {
   if (!desc) return 0;
   WgradArgs a;
   hnd_wgrad_desc d = *desc;
   if (d.cin <= 0 || d.cout <= 0 || d.kh <= 0 || d.kw <= 0 || d.oh <= 0 || d.ow <= 0 || d.n <= 0) return 0;
   plan(d, a, wgrad_bk());
-  return (size_t)(d.groups > 1 ? d.groups : 1) * a.d.splitk * a.co_pad * a.ncols_pad * sizeof(float);
+  size_t need = (size_t)(d.groups > 1 ? d.groups : 1) * a.d.splitk * a.co_pad * a.ncols_pad * sizeof(float);
+  if (hnd::stem7_wgrad_applies(d)) {                    // one [64][ncols_pad] slab per persistent workgroup
+    const size_t stem = (size_t)hnd::stem7_wgrad_blocks(d) * 64 * a.ncols_pad * sizeof(float);
+    if (stem > need) need = stem;
+  }
+  return need;
 }
 
 extern "C" int hnd_conv2d_wgrad(const hnd_wgrad_desc* desc, void* stream) {
@@ -289,6 +300,14 @@ extern "C" int hnd_conv2d_wgrad(const hnd_wgrad_desc* desc, void* stream) {
   const int groups = d.groups > 1 ? d.groups : 1;
   HND_REQUIRE(groups == 1 || (d.x_group_stride > 0 && d.dy_group_stride > 0 && d.dw_group_stride > 0),
               "hnd_conv2d_wgrad: group strides must be positive when groups > 1");
+  if (hnd::stem7_wgrad_applies(d)) {
+    int rc = hnd::launch_stem7_wgrad(d, a.ncols_pad, s);
+    if (rc) return rc;
+    const int total = d.cout * d.kh * d.kw * d.cin_real;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 63) / 64, 1), dim3(256), 0, s, d.slabs, d.dw,
+                       hnd::stem7_wgrad_blocks(d), 64, a.ncols_pad, d.cout, d.cin, d.cin_real, d.kh, d.kw, 0ll);
+    return hnd::check_launch("hnd_conv2d_wgrad(stem7 reduce)");
+  }
   const dim3 grid(a.rtiles * a.ctiles * a.d.splitk, groups);
   // tuning knob HND_WGRAD_BPC: cap the resident blocks per CU by padding the dynamic LDS request.  Measured in the
   // step (batch 16): 4 blocks/CU (the register / LDS limit, default) 5.95 ms, 3 -> 6.34 ms, 2 -> 5.97 ms for the

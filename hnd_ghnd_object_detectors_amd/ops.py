@@ -5,6 +5,7 @@ the hot path goes through libhnd_hip.so.  Launch objects are built once per geom
 replayed each step (no per-step ctypes struct construction).
 """
 import ctypes as C
+import os
 import math
 
 import torch
@@ -238,6 +239,9 @@ class WgradLaunch(object):
         self.alg_flops = flops
         self.ref = C.byref(desc)
         self.variant = 'wgrad_m128' if desc.cout >= 128 else 'wgrad_m64'
+        if (desc.cin == 4 and desc.kh == 7 and desc.stride == 2 and desc.cout == 64 and desc.groups <= 1
+                and os.environ.get('HND_STEM7', '1') != '0'):
+            self.variant = 'stem7_wgrad'          # csrc/conv_stem.hip: dW from an LDS-staged patch
 
     def run(self, stream=None):
         rc = _L.hnd_conv2d_wgrad(self.ref, stream if stream is not None else stream_ptr())

@@ -961,6 +961,35 @@ def test_stem_conv_from_lds_patch_is_bit_identical_and_matches_torch(ops, n, h, 
     assert relerr(nchw(outs['1']), ref) < 1e-5
 
 
+@pytest.mark.parametrize('n,h,w', [(2, 800, 1344), (1, 75, 133), (3, 64, 96)])
+def test_stem_weight_gradient_from_lds_patch(ops, n, h, w, monkeypatch):
+    """csrc/conv_stem.hip stem7_wgrad_kernel: dW of the 7x7 stride-2 stem with dy transposed into LDS and the input
+    patch beside it, accumulator resident across a workgroup's tiles, slabs summed in fixed order -- against autograd,
+    against the generic split-K kernel, and bit-reproducible."""
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(n, 3, h, w, generator=g)
+    wt = (torch.randn(64, 3, 7, 7, generator=g) * (1.0 / 147 ** 0.5)).requires_grad_(True)
+    out = F.conv2d(x, wt, stride=2, padding=3)
+    dy = torch.randn(out.shape, generator=g)
+    out.backward(dy)
+    xd, dyd = nhwc(x, 4), nhwc(dy)
+    res = {}
+    for mode in ('0', '1'):
+        monkeypatch.setenv('HND_STEM7', mode)
+        dw = torch.full((64, 3, 7, 7), float('nan'), device=DEV)
+        l = ops.conv_wgrad(xd, dyd, dw, 7, 2, 3)
+        outs = []
+        for _ in range(2):
+            l.run()
+            ops.sync_check()
+            outs.append(dw.cpu().clone())
+        assert torch.equal(outs[0], outs[1])                     # fixed-order reductions
+        res[mode] = (outs[0], l.variant)
+    assert res['0'][1] == 'wgrad_m64' and res['1'][1] == 'stem7_wgrad'
+    assert relerr(res['1'][0], wt.grad) < 2e-5, relerr(res['1'][0], wt.grad)
+    assert relerr(res['1'][0], res['0'][0]) < 2e-5
+
+
 def test_jpeg_codec_and_data_logger_follow_the_reference(tmp_path):
     """structure/transformer.py JpegCompressor / JpegDecompressor / DataLogger (reference :58-128): the 3-channel
     bottleneck is quantised by the HIP codec (byte-exact to myutils' quantize_tensor), written as a JPEG with PIL and
