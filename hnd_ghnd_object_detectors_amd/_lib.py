@@ -112,6 +112,7 @@ _SIGNATURES = {
     'hnd_nonzero_min_size': (C.c_int, [vp, C.c_int64, C.c_float, vp, vp, vp]),
     'hnd_argsort_desc_workspace': (C.c_size_t, [C.c_int64]),
     'hnd_argsort_desc_f32': (C.c_int, [vp, C.c_int64, vp, vp, vp]),
+    'hnd_mask_run_boundaries': (C.c_int, [vp, C.c_int64, C.c_int, C.c_int, C.c_float, vp, C.c_int64, vp, vp, vp]),
     'hnd_resize_mask_nearest_u8': (C.c_int, [vp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, vp, vp]),
     'hnd_upsample_bilinear_nhwc': (C.c_int, [vp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     'hnd_heatmaps_to_keypoints': (C.c_int, [vp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]),

@@ -42,6 +42,32 @@ __global__ void resize_mask_nearest_kernel(const unsigned char* __restrict__ in,
   }
 }
 
+// Run boundaries of the thresholded masks in COCO's column-major order (reference src/utils/coco_eval_util.py:101:
+// `masks > 0.5`, then pycocotools' mask.encode): position p = x*h + y of mask k is a boundary when its bit differs from
+// the bit at p-1 -- the pixel above, or for y = 0 the last pixel of the previous column.  Row-major, coalesced reads;
+// the few thousand boundaries of an image are appended through one atomic counter in any order (the host sorts the
+// keys k*h*w + p): only they cross PCIe instead of a 107 MB bit stack.
+__global__ void mask_boundaries_kernel(const float* __restrict__ probs, long long n, int h, int w, float thr,
+                                       long long* __restrict__ out, long long capacity,
+                                       unsigned long long* __restrict__ count, unsigned char* __restrict__ first) {
+  const long long hw = (long long)h * w, total = n * hw;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const long long k = e / hw, r = e - k * hw;
+    const int y = (int)(r / w), x = (int)(r - (long long)y * w);
+    const float* m = probs + k * hw;
+    const bool bit = m[r] > thr;
+    if (y == 0 && x == 0) {
+      first[k] = bit ? 1 : 0;
+      continue;
+    }
+    const bool prev = y > 0 ? (m[r - w] > thr) : (m[(long long)(h - 1) * w + (x - 1)] > thr);
+    if (bit != prev) {
+      const unsigned long long slot = atomicAdd(count, 1ull);
+      if ((long long)slot < capacity) out[slot] = k * hw + (long long)x * h + y;
+    }
+  }
+}
+
 __global__ void mask_probs_kernel(const float* __restrict__ logits, const long long* __restrict__ labels, long long k,
                                   int m, int ldc, float* __restrict__ probs) {
   const long long total = k * m * m;
@@ -228,6 +254,19 @@ int hnd_paste_masks(const float* probs, const int64_t* boxes, int64_t k, int m, 
   hipLaunchKernelGGL(paste_masks_kernel, dim3(grid_for(k * (long long)im_h * im_w)), dim3(256), 0, hnd::as_stream(stream),
                      probs, (const long long*)boxes, (long long)k, m, im_h, im_w, out);
   return hnd::check_launch("hnd_paste_masks");
+}
+
+int hnd_mask_run_boundaries(const float* probs, int64_t n, int h, int w, float threshold, int64_t* out, int64_t capacity,
+                            int64_t* count, uint8_t* first, void* stream) {
+  HND_REQUIRE(count != nullptr, "hnd_mask_run_boundaries: null counter");
+  if (hipMemsetAsync(count, 0, sizeof(int64_t), hnd::as_stream(stream)) != hipSuccess)
+    return hnd::check_launch("hnd_mask_run_boundaries(memset)");
+  if (n <= 0) return HND_OK;
+  HND_REQUIRE(probs && out && first && h > 0 && w > 0 && capacity >= 0, "hnd_mask_run_boundaries: bad arguments");
+  hipLaunchKernelGGL(mask_boundaries_kernel, dim3(grid_for(n * (long long)h * w)), dim3(256), 0, hnd::as_stream(stream),
+                     probs, (long long)n, h, w, threshold, (long long*)out, (long long)capacity,
+                     (unsigned long long*)count, first);
+  return hnd::check_launch("hnd_mask_run_boundaries");
 }
 
 int hnd_resize_mask_nearest_u8(const unsigned char* in, int64_t k, int h, int w, int oh, int ow, double scale_factor,

@@ -385,7 +385,11 @@ class CocoEvaluator(object):
         for image_id, pred in predictions.items():
             if len(pred) == 0 or len(pred['scores']) == 0:
                 continue
-            rles = mask_util.encode_batch((pred['masks'] > 0.5)[:, 0])          # on the masks' own device
+            masks = pred['masks'][:, 0]
+            if masks.is_cuda and masks.is_floating_point():     # threshold + run boundaries in one HIP launch
+                rles = mask_util.encode_probs(masks, 0.5)
+            else:
+                rles = mask_util.encode_batch(masks > 0.5)
             for rle, s, l in zip(rles, pred['scores'].tolist(), pred['labels'].tolist()):
                 out.append({'image_id': image_id, 'category_id': l, 'rle': rle, 'score': s})
         return out

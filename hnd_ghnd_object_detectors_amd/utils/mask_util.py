@@ -30,6 +30,42 @@ def encode(mask):
     return runs.astype(np.uint32)
 
 
+def encode_probs(probs, threshold=0.5):
+    """float mask probabilities [n, h, w] on the GPU -> list of uint32 run lengths of ``probs > threshold``, equal to
+    ``encode`` of each thresholded mask: one HIP launch (hnd_mask_run_boundaries) finds the run boundaries where the
+    masks live and only those few thousand keys cross PCIe; the host sorts them and takes differences."""
+    import torch
+    from .. import _lib, ops
+    n, h, w = probs.shape
+    if n == 0:
+        return []
+    p = probs.contiguous().float()
+    lib = _lib.load()
+    capacity = max(1 << 16, 64 * n * (h + w))
+    while True:
+        out = torch.empty(capacity, dtype=torch.int64, device=p.device)
+        count = torch.empty(1, dtype=torch.int64, device=p.device)
+        first = torch.empty(n, dtype=torch.uint8, device=p.device)
+        _lib.check(lib.hnd_mask_run_boundaries(p.data_ptr(), n, h, w, float(threshold), out.data_ptr(), capacity,
+                                               count.data_ptr(), first.data_ptr(), ops.stream_ptr()),
+                   'hnd_mask_run_boundaries')
+        found = int(count.item())
+        if found <= capacity:
+            break
+        capacity = found                          # (pathological masks: every pixel a boundary)
+    keys = np.sort(out[:found].cpu().numpy())
+    first = first.cpu().numpy()
+    splits = np.searchsorted(keys, np.arange(n + 1, dtype=np.int64) * (h * w))
+    res = []
+    for i in range(n):
+        pos = keys[splits[i]:splits[i + 1]] - i * (h * w)
+        runs = np.diff(np.concatenate(([0], pos, [h * w])))
+        if first[i]:
+            runs = np.concatenate(([0], runs))
+        res.append(runs.astype(np.uint32))
+    return res
+
+
 def encode_batch(bits):
     """torch bool masks [n, h, w] on any device -> list of uint32 run lengths, equal to ``encode`` of each mask.  The
     run boundaries are found where the masks live (a 100 x 800 x 1333 stack is 107 MB; its boundaries a few thousand

@@ -374,6 +374,13 @@ int hnd_mask_probs(const float* logits, const int64_t* labels, int64_t k, int m,
  * pixel, resized bilinearly (align_corners=False) to (y1-y0+1, x1-x0+1) and pasted at (y0, x0), zero elsewhere */
 int hnd_paste_masks(const float* probs, const int64_t* boxes, int64_t k, int m, int im_h, int im_w, float* out,
                     void* stream);
+/* Run boundaries of the thresholded masks for the COCO segm evaluator (reference src/utils/coco_eval_util.py:101
+ * `masks > 0.5` + pycocotools mask.encode): probs [n][h][w]; out receives, in ANY order, the keys k*h*w + p of every
+ * column-major position p = x*h + y >= 1 of mask k whose bit (probs > threshold) differs from the bit at p - 1;
+ * *count (device) = how many exist (entries beyond `capacity` are dropped: call again with a larger buffer);
+ * first[k] = bit of mask k at p = 0.  The caller sorts the keys; run lengths are their differences. */
+int hnd_mask_run_boundaries(const float* probs, int64_t n, int h, int w, float threshold, int64_t* out, int64_t capacity,
+                            int64_t* count, uint8_t* first, void* stream);
 /* Ground-truth mask resize of the transform (reference src/models/org/rcnn.py:54-57:
  * interpolate(mask[None].float(), scale_factor=s)[0].byte(), mode 'nearest'): in [k][h][w] uint8 -> out [k][oh][ow]
  * uint8 with oh = floor(h*s), ow = floor(w*s); source index min(floor(dst * (float)(1/s)), in-1) as ATen. */

@@ -574,3 +574,22 @@ def test_ordered_compaction_equals_torch_nonzero():
         b[:, 2:] = b[:, :2] + torch.rand(n, 2, generator=g) * 3
         ws, hs = b[:, 2] - b[:, 0], b[:, 3] - b[:, 1]
         assert torch.equal(D.remove_small_boxes(b.to(DEV), 1.0).cpu(), ((ws >= 1.0) & (hs >= 1.0)).nonzero().squeeze(1))
+
+
+def test_mask_run_boundaries_kernel_equals_host_encode():
+    """hnd_mask_run_boundaries + host sort == utils.mask_util.encode of every thresholded mask (COCO column-major run
+    lengths): random blobs, empty / full masks, masks starting with a set pixel, single-column images"""
+    from hnd_ghnd_object_detectors_amd.utils import mask_util as MU
+    g = torch.Generator().manual_seed(4)
+    for n, h, w in ((5, 37, 53), (3, 1, 40), (2, 40, 1), (4, 120, 97)):
+        probs = torch.rand(n, h, w, generator=g)
+        probs = torch.nn.functional.avg_pool2d(probs[None], 5, 1, 2)[0] if min(h, w) >= 5 else probs      # blobs
+        probs[0] = 0.9                                   # a full mask (starts with a set pixel: leading zero run of 0)
+        if n > 1:
+            probs[1] = 0.1                               # an empty one
+        want = [MU.encode((p > 0.5).numpy()) for p in probs]
+        got = MU.encode_probs(probs.to(DEV), 0.5)
+        assert len(got) == n
+        for a, b in zip(got, want):
+            assert a.dtype == b.dtype and a.tolist() == b.tolist()
+    assert MU.encode_probs(torch.zeros(0, 8, 8, device=DEV)) == []

@@ -58,7 +58,7 @@ def main():
         res = [{k: (v if k == 'masks' else v.cpu()) for k, v in d.items()} for d in out]
         for d in res:                       # what CocoEvaluator.prepare_for_coco_segmentation does with the masks
             if 'masks' in d:
-                d['masks'] = mask_util.encode_batch((d['masks'] > 0.5)[:, 0])
+                d['masks'] = mask_util.encode_probs(d['masks'][:, 0], 0.5)
         return res
 
     with torch.no_grad():
