@@ -5,6 +5,8 @@
 // which run as ONE launch of the implicit-GEMM kernel (conv_igemm.hip: a 1x1 "conv" over 16*tiles_pad pixels whose
 // weight matrix is selected per 128-row group).  This file holds the three HBM-bound transforms around it.
 // fp32 throughout; the transforms only add / halve, so the result differs from direct summation by ~1e-6 relative.
+#include <type_traits>
+
 #include "common.h"
 
 using hnd::f32x4;
@@ -68,6 +70,12 @@ struct WinoGeom {
 };
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// A use of loaded values in the block that dominates a run of conditionally executed stores: hipcc's waitcnt pass
+// then waits for the loads here, once, instead of in front of every store that follows.
+__device__ __forceinline__ void arrive(const f32x2& a, const f32x2& b) {
+  asm volatile("" ::"v"(a.x), "v"(a.y), "v"(b.x), "v"(b.y));
+}
 
 // V[f][t][c] = (B^T d B)[f] of the 4x4 input patch of tile t (rows 2ty-1.., cols 2tx-1..), zero outside the image.
 // Optional prologue on in-bounds elements: a = x*scale[c] + shift[c], relu.
@@ -315,6 +323,10 @@ __global__ void wino4_input_kernel(const float* __restrict__ x, float* __restric
     o3 = q12 + 8.f * q34 + m5;                               \
   } while (0)
 
+// The epilogue operands are template parameters and tiles that lie inside the map take a branch-free path: with
+// run-time `if (ptr)` operands or per-output bounds branches hipcc puts `s_waitcnt vmcnt(0)` in front of every store
+// (stores count in vmcnt on gfx9), which serialises the 16 / 36 stores of a tile.
+template <bool RES, bool MASK>
 __global__ void wino4_output_kernel(const float* __restrict__ m, float* __restrict__ y, const WinoGeom g, int cout,
                                     const WinoEpilogue ep) {
   const int c2n = cout >> 1;
@@ -329,6 +341,9 @@ __global__ void wino4_output_kernel(const float* __restrict__ m, float* __restri
     long long q = t / g.tw;
     const int ty = (int)(q % g.th), b = (int)(q / g.th);
     const float* src = m + (size_t)t * cout + c2 * 2;
+    f32x2 es = {1.f, 1.f}, eb = {0.f, 0.f};
+    if (ep.epi_scale) es = *(const f32x2*)(ep.epi_scale + c2 * 2);
+    if (ep.epi_shift) eb = *(const f32x2*)(ep.epi_shift + c2 * 2);
     f32x2 s[4][6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) {          // A^T m (down the columns)
@@ -337,29 +352,49 @@ __global__ void wino4_output_kernel(const float* __restrict__ m, float* __restri
                   m4 = *(const f32x2*)(src + (size_t)(4 * 6 + j) * fs), m5 = *(const f32x2*)(src + (size_t)(5 * 6 + j) * fs);
       HND_WINO4_AT(m0, m1, m2, m3, m4, m5, s[0][j], s[1][j], s[2][j], s[3][j]);
     }
-    f32x2 es = {1.f, 1.f}, eb = {0.f, 0.f};
-    if (ep.epi_scale) es = *(const f32x2*)(ep.epi_scale + c2 * 2);
-    if (ep.epi_shift) eb = *(const f32x2*)(ep.epi_shift + c2 * 2);
+    arrive(es, eb);
+    auto emit = [&](auto checked) {
+      constexpr bool CHK = decltype(checked)::value;
+      // interior tiles: the residual / mask rows are fetched one output row ahead of the stores that use them
+      f32x2 rn[4], kn[4];
+      auto fetch = [&](int a) {
+        const size_t row = (((size_t)b * g.h + 4 * ty + a) * g.w + 4 * tx) * g.c + c2 * 2;
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      const int oy = 4 * ty + a;
-      f32x2 o[4];
-      HND_WINO4_AT(s[a][0], s[a][1], s[a][2], s[a][3], s[a][4], s[a][5], o[0], o[1], o[2], o[3]);
-#pragma unroll
-      for (int bb = 0; bb < 4; ++bb) {
-        const int ox = 4 * tx + bb;
-        if (oy >= g.h || ox >= g.w) continue;
-        f32x2 v = o[bb] * es + eb;
-        const size_t off = (((size_t)b * g.h + oy) * g.w + ox) * g.c + c2 * 2;
-        if (ep.res1) v += *(const f32x2*)(ep.res1 + off);
-        if (ep.mask) {
-          const f32x2 k = *(const f32x2*)(ep.mask + off);
-          v.x = k.x > 0.f ? v.x : 0.f; v.y = k.y > 0.f ? v.y : 0.f;
+        for (int bb = 0; bb < 4; ++bb) {
+          if (RES) rn[bb] = *(const f32x2*)(ep.res1 + row + (size_t)bb * g.c);
+          if (MASK) kn[bb] = *(const f32x2*)(ep.mask + row + (size_t)bb * g.c);
         }
-        if (ep.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); }
-        *(f32x2*)(y + off) = v;
+      };
+      if (!CHK && (RES || MASK)) fetch(0);
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const int oy = 4 * ty + a;
+        f32x2 o[4], rc[4], kc[4];
+        HND_WINO4_AT(s[a][0], s[a][1], s[a][2], s[a][3], s[a][4], s[a][5], o[0], o[1], o[2], o[3]);
+        if (!CHK && (RES || MASK)) {
+#pragma unroll
+          for (int bb = 0; bb < 4; ++bb) { rc[bb] = rn[bb]; kc[bb] = kn[bb]; }
+          if (a + 1 < 4) fetch(a + 1);
+        }
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) {
+          const int ox = 4 * tx + bb;
+          if (CHK && (oy >= g.h || ox >= g.w)) continue;
+          f32x2 v = o[bb] * es + eb;
+          const size_t off = (((size_t)b * g.h + oy) * g.w + ox) * g.c + c2 * 2;
+          if (CHK) {
+            if (RES) rc[bb] = *(const f32x2*)(ep.res1 + off);
+            if (MASK) kc[bb] = *(const f32x2*)(ep.mask + off);
+          }
+          if (RES) v += rc[bb];
+          if (MASK) { v.x = kc[bb].x > 0.f ? v.x : 0.f; v.y = kc[bb].y > 0.f ? v.y : 0.f; }
+          if (ep.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); }
+          *(f32x2*)(y + off) = v;
+        }
       }
-    }
+    };
+    if (4 * ty + 4 <= g.h && 4 * tx + 4 <= g.w) emit(std::false_type{});
+    else emit(std::true_type{});
   }
 }
 
@@ -499,6 +534,7 @@ __global__ void __launch_bounds__(256) wino6_input_kernel(const float* __restric
     o5 = q12 + 32.f * q34 + 0.03125f * q56 + m7;                                        \
   } while (0)
 
+template <bool RES, bool MASK>
 __global__ void __launch_bounds__(256) wino6_output_kernel(const float* __restrict__ m, float* __restrict__ y,
                                                            const WinoGeom g, int cout, const WinoEpilogue ep) {
   const int c2n = cout >> 1;
@@ -513,6 +549,9 @@ __global__ void __launch_bounds__(256) wino6_output_kernel(const float* __restri
     long long q = t / g.tw;
     const int ty = (int)(q % g.th), b = (int)(q / g.th);
     const float* src = m + (size_t)t * cout + c2 * 2;
+    f32x2 es = {1.f, 1.f}, eb = {0.f, 0.f};
+    if (ep.epi_scale) es = *(const f32x2*)(ep.epi_scale + c2 * 2);
+    if (ep.epi_shift) eb = *(const f32x2*)(ep.epi_shift + c2 * 2);
     f32x2 s[6][8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {          // A^T m (down the columns)
@@ -522,30 +561,50 @@ __global__ void __launch_bounds__(256) wino6_output_kernel(const float* __restri
       HND_WINO6_AT(mm[0], mm[1], mm[2], mm[3], mm[4], mm[5], mm[6], mm[7], s[0][j], s[1][j], s[2][j], s[3][j], s[4][j],
                    s[5][j]);
     }
-    f32x2 es = {1.f, 1.f}, eb = {0.f, 0.f};
-    if (ep.epi_scale) es = *(const f32x2*)(ep.epi_scale + c2 * 2);
-    if (ep.epi_shift) eb = *(const f32x2*)(ep.epi_shift + c2 * 2);
+    arrive(es, eb);
+    auto emit = [&](auto checked) {
+      constexpr bool CHK = decltype(checked)::value;
+      // interior tiles: the residual / mask rows are fetched one output row ahead of the stores that use them
+      f32x2 rn[6], kn[6];
+      auto fetch = [&](int a) {
+        const size_t row = (((size_t)b * g.h + 6 * ty + a) * g.w + 6 * tx) * g.c + c2 * 2;
 #pragma unroll
-    for (int a = 0; a < 6; ++a) {
-      const int oy = 6 * ty + a;
-      f32x2 o[6];
-      HND_WINO6_AT(s[a][0], s[a][1], s[a][2], s[a][3], s[a][4], s[a][5], s[a][6], s[a][7], o[0], o[1], o[2], o[3], o[4],
-                   o[5]);
-#pragma unroll
-      for (int bb = 0; bb < 6; ++bb) {
-        const int ox = 6 * tx + bb;
-        if (oy >= g.h || ox >= g.w) continue;
-        f32x2 v = o[bb] * es + eb;
-        const size_t off = (((size_t)b * g.h + oy) * g.w + ox) * g.c + c2 * 2;
-        if (ep.res1) v += *(const f32x2*)(ep.res1 + off);
-        if (ep.mask) {
-          const f32x2 k = *(const f32x2*)(ep.mask + off);
-          v.x = k.x > 0.f ? v.x : 0.f; v.y = k.y > 0.f ? v.y : 0.f;
+        for (int bb = 0; bb < 6; ++bb) {
+          if (RES) rn[bb] = *(const f32x2*)(ep.res1 + row + (size_t)bb * g.c);
+          if (MASK) kn[bb] = *(const f32x2*)(ep.mask + row + (size_t)bb * g.c);
         }
-        if (ep.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); }
-        *(f32x2*)(y + off) = v;
+      };
+      if (!CHK && (RES || MASK)) fetch(0);
+#pragma unroll
+      for (int a = 0; a < 6; ++a) {
+        const int oy = 6 * ty + a;
+        f32x2 o[6], rc[6], kc[6];
+        HND_WINO6_AT(s[a][0], s[a][1], s[a][2], s[a][3], s[a][4], s[a][5], s[a][6], s[a][7], o[0], o[1], o[2], o[3],
+                     o[4], o[5]);
+        if (!CHK && (RES || MASK)) {
+#pragma unroll
+          for (int bb = 0; bb < 6; ++bb) { rc[bb] = rn[bb]; kc[bb] = kn[bb]; }
+          if (a + 1 < 6) fetch(a + 1);
+        }
+#pragma unroll
+        for (int bb = 0; bb < 6; ++bb) {
+          const int ox = 6 * tx + bb;
+          if (CHK && (oy >= g.h || ox >= g.w)) continue;
+          f32x2 v = o[bb] * es + eb;
+          const size_t off = (((size_t)b * g.h + oy) * g.w + ox) * g.c + c2 * 2;
+          if (CHK) {
+            if (RES) rc[bb] = *(const f32x2*)(ep.res1 + off);
+            if (MASK) kc[bb] = *(const f32x2*)(ep.mask + off);
+          }
+          if (RES) v += rc[bb];
+          if (MASK) { v.x = kc[bb].x > 0.f ? v.x : 0.f; v.y = kc[bb].y > 0.f ? v.y : 0.f; }
+          if (ep.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); }
+          *(f32x2*)(y + off) = v;
+        }
       }
-    }
+    };
+    if (6 * ty + 6 <= g.h && 6 * tx + 6 <= g.w) emit(std::false_type{});
+    else emit(std::true_type{});
   }
 }
 
@@ -712,22 +771,28 @@ __global__ void wino2_output_kernel(const float* __restrict__ m, float* __restri
     f32x2 es = {1.f, 1.f}, eb = {0.f, 0.f};
     if (epi_scale) es = *(const f32x2*)(epi_scale + c2 * 2);
     if (epi_shift) eb = *(const f32x2*)(epi_shift + c2 * 2);
+    arrive(es, eb);
+    auto emit = [&](auto checked) {         // see wino4_output_kernel: interior tiles store without branches
+      constexpr bool CHK = decltype(checked)::value;
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      const int oy = 4 * ty + a;
-      f32x2 o[4];
-      HND_WINO2_AT(s[a][0], s[a][1], s[a][2], s[a][3], s[a][4], o[0], o[1], o[2], o[3]);
+      for (int a = 0; a < 4; ++a) {
+        const int oy = 4 * ty + a;
+        f32x2 o[4];
+        HND_WINO2_AT(s[a][0], s[a][1], s[a][2], s[a][3], s[a][4], o[0], o[1], o[2], o[3]);
 #pragma unroll
-      for (int bb = 0; bb < 4; ++bb) {
-        const int ox = 4 * tx + bb;
-        if (oy >= g.oh || ox >= g.ow) continue;
-        f32x2 v = o[bb] * es + eb;
-        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); }
-        *(f32x2*)(y + (((size_t)b * g.oh + oy) * g.ow + ox) * ldc + c2 * 2) = v;
-        s1 += v;
-        s2 += v * v;
+        for (int bb = 0; bb < 4; ++bb) {
+          const int ox = 4 * tx + bb;
+          if (CHK && (oy >= g.oh || ox >= g.ow)) continue;
+          f32x2 v = o[bb] * es + eb;
+          if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); }
+          *(f32x2*)(y + (((size_t)b * g.oh + oy) * g.ow + ox) * ldc + c2 * 2) = v;
+          s1 += v;
+          s2 += v * v;
+        }
       }
-    }
+    };
+    if (4 * ty + 4 <= g.oh && 4 * tx + 4 <= g.ow) emit(std::false_type{});
+    else emit(std::true_type{});
   }
   if (stats) {
     // threads tid and tid + k*c2n hold the same channel pair: fold them in a fixed order
@@ -1007,22 +1072,28 @@ __global__ void __launch_bounds__(256) wino26_output_kernel(const float* __restr
     f32x2 es = {1.f, 1.f}, eb = {0.f, 0.f};
     if (epi_scale) es = *(const f32x2*)(epi_scale + c2 * 2);
     if (epi_shift) eb = *(const f32x2*)(epi_shift + c2 * 2);
+    arrive(es, eb);
+    auto emit = [&](auto checked) {         // see wino4_output_kernel: interior tiles store without branches
+      constexpr bool CHK = decltype(checked)::value;
 #pragma unroll
-    for (int a = 0; a < 6; ++a) {
-      const int oy = 6 * ty + a;
-      f32x2 o[6];
-      mat_apply(W6_AT, s[a], o);
+      for (int a = 0; a < 6; ++a) {
+        const int oy = 6 * ty + a;
+        f32x2 o[6];
+        mat_apply(W6_AT, s[a], o);
 #pragma unroll
-      for (int bb = 0; bb < 6; ++bb) {
-        const int ox = 6 * tx + bb;
-        if (oy >= g.oh || ox >= g.ow) continue;
-        f32x2 v = o[bb] * es + eb;
-        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); }
-        *(f32x2*)(y + (((size_t)b * g.oh + oy) * g.ow + ox) * ldc + c2 * 2) = v;
-        s1 += v;
-        s2 += v * v;
+        for (int bb = 0; bb < 6; ++bb) {
+          const int ox = 6 * tx + bb;
+          if (CHK && (oy >= g.oh || ox >= g.ow)) continue;
+          f32x2 v = o[bb] * es + eb;
+          if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); }
+          *(f32x2*)(y + (((size_t)b * g.oh + oy) * g.ow + ox) * ldc + c2 * 2) = v;
+          s1 += v;
+          s2 += v * v;
+        }
       }
-    }
+    };
+    if (6 * ty + 6 <= g.oh && 6 * tx + 6 <= g.ow) emit(std::false_type{});
+    else emit(std::true_type{});
   }
   if (stats) {
     red[0][threadIdx.x * 2] = s1.x; red[0][threadIdx.x * 2 + 1] = s1.y;
@@ -1168,12 +1239,20 @@ int hnd_wino_output(const float* m, float* y, int n, int h, int w, int cout, int
   if (tile == 2)
     hipLaunchKernelGGL(wino_output_kernel, dim3(grid_for(tiles * (cout / 4))), dim3(256), 0, hnd::as_stream(stream), m,
                        y, g, cout, ep);
-  else if (tile == 4)
-    hipLaunchKernelGGL(wino4_output_kernel, dim3(grid_for(tiles * (cout / 2))), dim3(256), 0, hnd::as_stream(stream), m,
-                       y, g, cout, ep);
-  else
-    hipLaunchKernelGGL(wino6_output_kernel, dim3(grid_for(tiles * (cout / 2))), dim3(256), 0, hnd::as_stream(stream), m,
-                       y, g, cout, ep);
+  else {
+    const dim3 grid(grid_for(tiles * (cout / 2))), block(256);
+    hipStream_t st = hnd::as_stream(stream);
+#define HND_WINO_OUT(K)                                                                          \
+  do {                                                                                           \
+    if (res1 && mask) hipLaunchKernelGGL((K<true, true>), grid, block, 0, st, m, y, g, cout, ep);   \
+    else if (res1) hipLaunchKernelGGL((K<true, false>), grid, block, 0, st, m, y, g, cout, ep);     \
+    else if (mask) hipLaunchKernelGGL((K<false, true>), grid, block, 0, st, m, y, g, cout, ep);     \
+    else hipLaunchKernelGGL((K<false, false>), grid, block, 0, st, m, y, g, cout, ep);              \
+  } while (0)
+    if (tile == 4) HND_WINO_OUT(wino4_output_kernel);
+    else HND_WINO_OUT(wino6_output_kernel);
+#undef HND_WINO_OUT
+  }
   return hnd::check_launch("hnd_wino_output");
 }
 
