@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('HND_LIB_PATH') or os.path.join(_HERE, 'libhnd_hip.so')     # env: kernel experiments
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 c_float_p = C.POINTER(C.c_float)
 vp = C.c_void_p
@@ -21,7 +21,8 @@ class ConvDesc(C.Structure):
                [(n, C.c_int32) for n in ('n', 'h', 'w_', 'cin', 'oh', 'ow', 'yh', 'yw', 'cout', 'ldc',
                                          'y_sh', 'y_oh', 'y_sw', 'y_ow', 'kh', 'kw',
                                          'sh', 'dh', 'bh', 'sw', 'dw', 'bw', 'kdim', 'pro_relu', 'relu',
-                                         'res1_mode', 'res1_h', 'res1_w', 'w_group_rows', 'w_group_stride')]
+                                         'res1_mode', 'res1_h', 'res1_w', 'w_group_rows', 'w_group_stride')] + \
+               [('relay_ws', vp)]
 
 
 class WgradDesc(C.Structure):
@@ -45,6 +46,7 @@ _SIGNATURES = {
     'hnd_device_arch': (C.c_char_p, []),
     'hnd_conv2d_igemm': (C.c_int, [C.POINTER(ConvDesc), vp]),
     'hnd_conv2d_igemm_tile': (C.c_int, [C.POINTER(ConvDesc)]),
+    'hnd_conv2d_igemm_workspace': (C.c_size_t, [C.POINTER(ConvDesc)]),
     'hnd_conv2d_wgrad_workspace': (C.c_size_t, [C.POINTER(WgradDesc)]),
     'hnd_conv2d_wgrad': (C.c_int, [C.POINTER(WgradDesc), vp]),
     'hnd_pack_weights': (C.c_int, [vp, vp] + [C.c_int] * 12 + [vp]),

@@ -598,6 +598,9 @@ int bres_variant(const hnd_conv_desc& d);                      // conv_bres.hip:
 int launch_bres(const hnd_conv_desc& d, hipStream_t stream);
 bool stem7_applies(const hnd_conv_desc& d);                    // conv_stem.hip: 7x7 s2 stem from an LDS patch
 int launch_stem7(const hnd_conv_desc& d, hipStream_t stream);
+int bstream_variant(const hnd_conv_desc& d);                   // conv_bstream.hip: B-streamed persistent GEMM (long K)
+int launch_bstream(const hnd_conv_desc& d, hipStream_t stream);
+size_t bstream_workspace(const hnd_conv_desc& d);
 }  // namespace hnd
 
 extern "C" int hnd_conv2d_igemm(const hnd_conv_desc* desc, void* stream) {
@@ -628,6 +631,7 @@ extern "C" int hnd_conv2d_igemm(const hnd_conv_desc* desc, void* stream) {
   }
   if (thin_n_applies(d)) return launch_thin_n(d, s);
   if (hnd::bres_variant(d)) return hnd::launch_bres(d, s);
+  if (hnd::bstream_variant(d)) return hnd::launch_bstream(d, s);
   const int bk16 = bk16_mask();
   switch (pick_tile(d)) {
     case 0: return (bk16 & 1) ? launch<128, 128, 16, false>(d, s) : launch<128, 128, 32, false>(d, s);
@@ -637,10 +641,16 @@ extern "C" int hnd_conv2d_igemm(const hnd_conv_desc* desc, void* stream) {
   }
 }
 
+extern "C" size_t hnd_conv2d_igemm_workspace(const hnd_conv_desc* desc) {
+  if (!desc || desc->cin == 4 || thin_n_applies(*desc) || hnd::bres_variant(*desc)) return 0;
+  return hnd::bstream_workspace(*desc);
+}
+
 extern "C" int hnd_conv2d_igemm_tile(const hnd_conv_desc* desc) {
   if (!desc) return -1;
   if (desc->cin == 4) return hnd::stem7_applies(*desc) ? 9 : 1;
   if (thin_n_applies(*desc)) return 4;
   if (const int v = hnd::bres_variant(*desc)) return v == 2 ? 5 : (v == 1 ? 6 : (v == 4 ? 7 : (v == 3 ? 8 : 10)));
+  if (const int v = hnd::bstream_variant(*desc)) return v == 2 ? 11 : 12;
   return pick_tile(*desc);
 }

@@ -92,21 +92,29 @@ def fbn_fold(weight, bias, mean, var, eps=0.0, cs=None, out=None):
 # --------------------------------------------------------------------------------------- conv launches
 class ConvLaunch(object):
     """One prebuilt hnd_conv2d_igemm launch (descriptor + keep-alive references)."""
-    __slots__ = ('desc', 'ref', 'keep', 'flops', 'alg_flops', 'variant')
+    __slots__ = ('desc', 'ref', 'keep', 'flops', 'alg_flops', 'variant', 'relay')
 
     def __init__(self, desc, keep, flops=0):
         self.desc, self.keep, self.flops = desc, keep, flops
         self.alg_flops = flops      # 2*MAC of the convolution this launch stands for (== flops unless Winograd)
         self.ref = C.byref(desc)
+        self.relay = None
         # which kernel instantiation hnd_conv2d_igemm dispatches to (mirrors csrc/conv_igemm.hip)
         self.refresh_variant()
 
     def refresh_variant(self):
         """call again after editing the descriptor (grouped weights): the dispatch may change"""
+        need = int(_L.hnd_conv2d_igemm_workspace(self.ref))
+        if need == 0:
+            self.relay, self.desc.relay_ws = None, None
+        elif self.relay is None or self.relay.numel() * 4 < need:
+            # work-balancing workspace of the B-streamed kernel: zero-filled once, owned by this launch object
+            self.relay = torch.zeros((need + 3) // 4, dtype=torch.float32, device=torch.device('cuda', torch.cuda.current_device()))
+            self.desc.relay_ws = self.relay.data_ptr()
         tile = _L.hnd_conv2d_igemm_tile(self.ref)
         self.variant = ('stem7_lds' if tile == 9 else 'igemm_c4_128x64') if self.desc.cin == 4 else \
             ('igemm_128x128', 'igemm_128x64', 'igemm_64x128', 'igemm_64x64', 'thin_n4', 'bres_128',
-             'bres_64', 'bres2_128', 'bres2_64', 'stem7_lds', 'bres2_32')[tile]
+             'bres_64', 'bres2_128', 'bres2_64', 'stem7_lds', 'bres2_32', 'bstream_128', 'bstream_64')[tile]
 
     def run(self, stream=None):
         rc = _L.hnd_conv2d_igemm(self.ref, stream if stream is not None else stream_ptr())
@@ -232,7 +240,7 @@ def conv_dgrad(dy, w_param, dx, k, stride=1, pad=0, accumulate=False, **kw_):
 
 
 class WgradLaunch(object):
-    __slots__ = ('desc', 'ref', 'keep', 'flops', 'alg_flops', 'variant')
+    __slots__ = ('desc', 'ref', 'keep', 'flops', 'alg_flops', 'variant', 'relay')
 
     def __init__(self, desc, keep, flops):
         self.desc, self.keep, self.flops = desc, keep, flops

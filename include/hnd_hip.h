@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define HND_ABI_VERSION 5
+#define HND_ABI_VERSION 6
 
 typedef enum hnd_status {
   HND_OK = 0,
@@ -97,15 +97,26 @@ typedef struct hnd_conv_desc {
    * w + g*w_group_stride floats; w_group_rows must be a multiple of 128.  Used by the Winograd path: the 16
    * transform components are 16 GEMMs over disjoint row groups of one launch. */
   int32_t w_group_rows, w_group_stride;
+  /* Work-balancing workspace of the B-streamed kernel (csrc/conv_bstream.hip), or NULL.  hnd_conv2d_igemm_workspace()
+   * bytes, zero-filled ONCE by the caller (the kernel leaves it zeroed), owned by this launch: two launches that may
+   * run concurrently must not share it.  With it, a workgroup whose share of the launch ends inside a tile parks the
+   * tile's accumulators here and its neighbour continues the same k chain (same bits as without). */
+  float* relay_ws;
 } hnd_conv_desc;
 
 int hnd_conv2d_igemm(const hnd_conv_desc* desc, void* stream);
+/* bytes of relay_ws this launch can use (0: none -- the field is ignored) */
+size_t hnd_conv2d_igemm_workspace(const hnd_conv_desc* desc);
 /* which block tile the launch above would use: 0 = 128x128, 1 = 128x64, 2 = 64x128, 3 = 64x64 (pixels x channels),
  * 4 = the vector-ALU kernel for cout <= 4 (one thread per pixel; bit-identical to the MFMA tiles),
  * 5 / 6 = the B-resident persistent GEMM (csrc/conv_bres.hip) with a 128- / 64-column weight slice held in LDS: 1x1
  * taps, K <= 256 / 512, no statistics; bit-identical to the tiled kernel.  HND_BRES=0 in the environment turns it off;
  * 7 / 8 = its one-wave-per-SIMD build (plain epilogues); 9 = the 7x7 stride-2 stem from an LDS-staged input patch
- * (csrc/conv_stem.hip; bit-identical to the generic 4-channel-input kernel, HND_STEM7=0 turns it off). */
+ * (csrc/conv_stem.hip; bit-identical to the generic 4-channel-input kernel, HND_STEM7=0 turns it off); 10 = the
+ * one-wave kernel with a 32-column slice (K = 1024, opt-in); 11 / 12 = the B-streamed persistent GEMM for long K
+ * (csrc/conv_bstream.hip: 128 x 128 / 256 x 64 block tile, the weight slice streams through three LDS stages, A
+ * fragments straight from global memory; K % 128 == 0, K >= 1024 or taps; bit-identical to the tiled kernel;
+ * HND_BSTREAM=0 turns it off). */
 int hnd_conv2d_igemm_tile(const hnd_conv_desc* desc);
 
 /* Weight gradient (autograd conv backward(weight), src/mimic_runner.py:53) of the trainable convs:

@@ -844,6 +844,7 @@ def test_bres_kernel_is_bit_identical_to_the_tiled_kernel(ops, case, monkeypatch
     g = torch.Generator().manual_seed(11)
     monkeypatch.setenv('HND_BRES_ALL', '1')
     monkeypatch.setenv('HND_BRES_K1024', '1')
+    monkeypatch.setenv('HND_BSTREAM', '0')
     if groups > 1:
         tiles_pad = (n * h * w + 127) // 128 * 128
         x = torch.randn(1, 1, groups * tiles_pad, cin, generator=g).to(DEV)
@@ -918,6 +919,103 @@ def test_bres_kernel_is_bit_identical_to_the_tiled_kernel(ops, case, monkeypatch
             rows = slice(gi * tiles_pad, (gi + 1) * tiles_pad)
             ref = x[0, 0, rows] @ ws[gi].view(cout, cin).t()
             assert float((outs['512'][0, 0, rows] - ref).norm() / ref.norm()) < 1e-5
+
+
+@pytest.mark.parametrize('case', [
+    # cin, h, w, cout, k, stride, pad, residual, mask, prologue, groups, batch
+    (1024, 50, 84, 256, 1, 1, 0, False, False, False, 1, 16),    # layer3 conv1: 1050 tiles, four per workgroup
+    (1024, 50, 84, 512, 1, 1, 0, True, False, False, 1, 4),      # + residual
+    (2048, 25, 42, 512, 1, 1, 0, False, True, True, 1, 16),      # dgrad-like: prologue scale + ReLU-backward mask
+    (1024, 37, 41, 192, 1, 1, 0, False, False, False, 1, 3),     # cout = 3 * 64: the 256 x 64 tile, ragged rows
+    (1024, 50, 84, 2048, 1, 2, 0, False, False, False, 1, 8),    # stride-2 1x1 (layer4 downsample)
+    (128, 100, 168, 128, 3, 2, 1, False, False, False, 1, 8),    # layer2.0.conv2: 3x3 stride 2 over taps, K = 1152
+    (256, 51, 85, 256, 3, 2, 1, False, False, True, 1, 8),       # ... with prologue: padding is a zero AFTER it
+    (512, 25, 42, 512, 3, 2, 1, True, False, False, 1, 16),      # K = 4608
+    (128, 40, 56, 256, 3, 1, 1, False, False, False, 1, 4),      # stride-1 3x3 on the direct path
+    (512, 50, 84, 256, 1, 1, 0, False, False, False, 1, 8),      # K = 512 (eligible, the picker prefers bres)
+    (256, 37, 53, 256, 1, 1, 0, False, False, False, 9, 64),     # grouped (Winograd-style) weights, K = 256
+])
+def test_bstream_kernel_is_bit_identical_to_the_tiled_kernel(ops, case, monkeypatch):
+    """The B-streamed persistent GEMM (csrc/conv_bstream.hip: the weight slice streams through three LDS stages with one
+    barrier per 64 k, A fragments straight from global memory through an asm register ring that runs across tile
+    boundaries) keeps the tiled kernel's accumulation order and shares its prologue / epilogue code: IDENTICAL BITS,
+    and both match a torch fp32 convolution."""
+    cin, h, w, cout, k, s, p, res, msk, pro, groups, n = case
+    g = torch.Generator().manual_seed(13)
+    monkeypatch.setenv('HND_BRES', '0')
+    if groups > 1:
+        tiles_pad = (n * h * w + 255) // 256 * 256
+        x = torch.randn(1, 1, groups * tiles_pad, cin, generator=g).to(DEV)
+        y = torch.empty(1, 1, groups * tiles_pad, cout, device=DEV)
+        ws = [torch.randn(cout, cin, 1, 1, generator=g).to(DEV) / cin ** 0.5 for _ in range(groups)]
+        pks = [ops.pack_weights(wt) for wt in ws]
+        pk = ops.PackedWeight.__new__(ops.PackedWeight)
+        pk.buf = torch.cat([q.buf for q in pks])
+        pk.kdim, pk.rows, pk.chan_pad, pk.chan_real = pks[0].kdim, cout, cin, cin
+    else:
+        x = torch.randn(n, h, w, cin, generator=g).to(DEV)
+        oh, ow = ops.conv_out_size(h, k, s, p), ops.conv_out_size(w, k, s, p)
+        y = torch.empty(n, oh, ow, cout, device=DEV)
+        wt = torch.randn(cout, cin, k, k, generator=g).to(DEV) / (cin * k * k) ** 0.5
+        pk = ops.pack_weights(wt)
+    sc, sh = torch.rand(cout, generator=g).to(DEV) + 0.5, torch.randn(cout, generator=g).to(DEV)
+    r = torch.randn(y.shape, generator=g).to(DEV) if res else None
+    mk = (torch.rand(y.shape, generator=g).to(DEV) - 0.3).clamp_min(0) if msk else None
+    ps = (torch.rand(cin, generator=g).to(DEV) + 0.5) if pro else None
+    pb = torch.randn(cin, generator=g).to(DEV) if pro else None
+    outs, variants = {}, {}
+    for mode in ('0', 'all'):
+        monkeypatch.setenv('HND_BSTREAM', mode)
+        if groups > 1:
+            l = ops.conv_desc(x, pk, y, kh=1, kw=1, oh=1, ow=groups * tiles_pad, sh=1, dh=1, bh=0, sw=1, dw=1, bw=0,
+                              cout=cout)
+            l.desc.w_group_rows, l.desc.w_group_stride = tiles_pad, pks[0].buf.numel()
+        else:
+            l = ops.conv_forward(x, pk, y, k, s, p, epi_scale=sc, epi_shift=sh, res1=r, mask=mk, relu=not msk,
+                                 pro_scale=ps, pro_shift=pb, pro_relu=pro)
+        l.refresh_variant()
+        y.fill_(float('nan'))
+        l.run()
+        ops.sync_check()
+        outs[mode], variants[mode] = y.clone(), l.variant
+    assert variants['0'].startswith('igemm'), variants
+    assert variants['all'] == ('bstream_128' if cout % 128 == 0 else 'bstream_64'), variants
+    assert not bool(torch.isnan(outs['all']).any())
+    assert torch.equal(outs['0'], outs['all']), float((outs['0'] - outs['all']).abs().max())
+    # the work-balancing relay (a workgroup parks a tile's accumulators, its neighbour continues the k chain) is on
+    # whenever every workgroup gets at least one tile; it must leave its flags cleared for the next launch, and the
+    # round-robin split (no workspace) must give the same bits
+    bm, bn = (128, 128) if cout % 128 == 0 else (256, 64)
+    tiles = -(-(y.numel() // y.shape[-1]) // bm) * (cout // bn)
+    assert (l.relay is not None) == (tiles >= 256), (tiles, l.relay is None)
+    if l.relay is not None:
+        assert int(l.relay[-256:].view(torch.int32).abs().sum()) == 0
+        l.run()                                     # a second launch on the same workspace
+        ops.sync_check()
+        assert torch.equal(outs['0'], y)
+        l.desc.relay_ws = None
+        y.fill_(float('nan'))
+        l.run()
+        ops.sync_check()
+        assert torch.equal(outs['0'], y)
+    if groups == 1:
+        xin = x.permute(0, 3, 1, 2)
+        if pro:
+            xin = torch.relu(xin * ps.view(1, -1, 1, 1) + pb.view(1, -1, 1, 1))
+        ref = F.conv2d(xin, wt, stride=s, padding=p) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+        if res:
+            ref = ref + r.permute(0, 3, 1, 2)
+        if msk:
+            ref = torch.where(mk.permute(0, 3, 1, 2) > 0, ref, torch.zeros_like(ref))
+        else:
+            ref = torch.relu(ref)
+        got = outs['all'].permute(0, 3, 1, 2)
+        assert float((got - ref).norm() / ref.norm()) < 1e-5
+    else:
+        for gi in (0, groups - 1):
+            rows = slice(gi * tiles_pad, (gi + 1) * tiles_pad)
+            ref = x[0, 0, rows] @ ws[gi].view(cout, cin).t()
+            assert float((outs['all'][0, 0, rows] - ref).norm() / ref.norm()) < 1e-5
 
 
 @pytest.mark.parametrize('h,w,scale', [(480, 640, 1.25), (800, 1333, 1.0), (375, 500, 2.1333333333333333),

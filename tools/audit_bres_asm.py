@@ -1,12 +1,13 @@
 #!/usr/bin/env python
-"""Audit of the inline-asm register ring of bres2_kernel (csrc/conv_bres.hip) in hipcc's assembly output.
+"""Audit of the inline-asm register rings of bres2_kernel (csrc/conv_bres.hip) and bstream_kernel
+(csrc/conv_bstream.hip) in hipcc's assembly output.
 
 hipcc does not know that a `global_load_dwordx4` inside an asm statement writes its destination LATER: between that
 statement and the `s_waitcnt vmcnt(N)` statement that names the same registers it is free to copy / spill / reuse them.
-This script walks every bres2 kernel in the .s file and fails if any instruction reads or writes a ring register
+This script walks every such kernel in the .s file and fails if any instruction reads or writes a ring register
 between its asm load and the asm wait that releases it (a second asm load into a still-pending register also fails).
 
-usage: python tools/audit_bres_asm.py [file.s]      (without a file: compiles csrc/conv_bres.hip to assembly first)
+usage: python tools/audit_bres_asm.py [file.s ...]      (without a file: compiles the two sources to assembly first)
 """
 import os
 import re
@@ -31,13 +32,13 @@ def regs_of(text):
 def audit(path):
     kernels, cur, name = {}, None, None
     for line in open(path):
-        m = re.match(r'^(_ZN\S*bres2_kernel\S*):', line)
+        m = re.match(r'^(_ZN\S*(?:bres2|bstream)_kernel\S*):', line)
         if m:
             name, cur = m.group(1), []
             kernels[name] = cur
         elif cur is not None:
             cur.append(line.rstrip('\n'))
-            if 's_endpgm' in line:
+            if line.startswith('.Lfunc_end'):     # (a kernel may hold several s_endpgm: early exits)
                 cur = None
     problems, stats = [], {}
     for name, lines in kernels.items():
@@ -110,24 +111,29 @@ def audit(path):
 
 
 def main():
-    if len(sys.argv) > 1:
-        path = sys.argv[1]
-    else:
-        path = os.path.join(tempfile.mkdtemp(), 'conv_bres.s')
-        src = os.path.join(ROOT, 'hnd_ghnd_object_detectors_amd', 'csrc', 'conv_bres.hip')
-        subprocess.check_call(['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950',
-                               '-I' + os.path.join(ROOT, 'include'), '-ffp-contract=fast', '-S', '--cuda-device-only',
-                               src, '-o', path], stderr=subprocess.DEVNULL)
-    kernels, problems, stats = audit(path)
-    for k, (l, w) in stats.items():
-        print('%s: %d asm loads, %d asm waits' % (k, l, w))
-    if not kernels:
-        print('no bres2 kernel found')
-        return 1
-    for p in problems[:40]:
-        print('PROBLEM', p)
-    print('%d problem(s)' % len(problems))
-    return 1 if problems else 0
+    paths = sys.argv[1:]
+    if not paths:
+        tmp = tempfile.mkdtemp()
+        for stem in ('conv_bres', 'conv_bstream'):
+            path = os.path.join(tmp, stem + '.s')
+            src = os.path.join(ROOT, 'hnd_ghnd_object_detectors_amd', 'csrc', stem + '.hip')
+            subprocess.check_call(['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950',
+                                   '-I' + os.path.join(ROOT, 'include'), '-ffp-contract=fast', '-S',
+                                   '--cuda-device-only', src, '-o', path], stderr=subprocess.DEVNULL)
+            paths.append(path)
+    rc = 0
+    for path in paths:
+        kernels, problems, stats = audit(path)
+        for k, (l, w) in stats.items():
+            print('%s: %d asm loads, %d asm waits' % (k, l, w))
+        if not kernels:
+            print('%s: no ring kernel found' % path)
+            rc = 1
+        for p in problems[:40]:
+            print('PROBLEM', p)
+        print('%s: %d problem(s)' % (os.path.basename(path), len(problems)))
+        rc = rc or (1 if problems else 0)
+    return rc
 
 
 if __name__ == '__main__':

@@ -1,0 +1,36 @@
+#!/usr/bin/env python
+"""Per-tile overhead of the B-streamed GEMM at constant work per workgroup: r tiles of 128 x 128 x K with r * K fixed.
+usage: python tools/probes/bstream_tilecost.py [cout]"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from hnd_ghnd_object_detectors_amd import ops  # noqa: E402
+
+cout = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+dev = 'cuda:0'
+os.environ['HND_BRES'] = '0'
+os.environ['HND_BSTREAM'] = 'all'
+for rep in range(2):
+    for K, r in ((256, 32), (512, 16), (1024, 8), (2048, 4), (4096, 2)):
+        rows = 256 * r * 128 // (cout // 128)
+        x = torch.randn(1, 128, rows // 128, K, device=dev)
+        y = torch.empty(1, 128, rows // 128, cout, device=dev)
+        pk = ops.pack_weights(torch.randn(cout, K, 1, 1, device=dev) / K ** 0.5)
+        l = ops.conv_forward(x, pk, y, 1, 1, 0, relu=True)
+        l.refresh_variant()
+        for _ in range(3):
+            l.run()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            l.run()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 20
+        print('%-12s relay=%s dbg=%s K=%d tiles/wg=%d  %.3f ms  %.1f TF' % (l.variant, l.relay is not None, os.environ.get('HND_BSTREAM_DBG', '0'), K, r, ms,
+                                                                 l.flops / ms / 1e9), flush=True)
+        del x, y

@@ -23,6 +23,9 @@ def short(name):
     m = re.search(r'bres(2?)_kernel<(\d+), (\d+), (true|false)(?:, (?:true|false))?(?:, \d+)?>', name)
     if m:           # B-resident persistent GEMM (conv_bres.hip): wave columns -> width of the resident weight slice
         return 'bres%s_%d' % (m.group(1), 64 * int(m.group(2))) + ('[prologue]' if m.group(4) == 'true' and FULLNAMES else '')
+    m = re.search(r'bstream_kernel<(\d+), (true|false), (true|false)>', name)
+    if m:           # B-streamed persistent GEMM (conv_bstream.hip)
+        return 'bstream_%d' % (64 * int(m.group(1))) + ('[prologue]' if m.group(2) == 'true' and FULLNAMES else '')
     m = re.search(r'wgrad_kernel<(\d+), (\d+)>', name)
     if m:
         return 'wgrad_m%s' % m.group(1)
