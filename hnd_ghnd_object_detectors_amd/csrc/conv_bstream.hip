@@ -459,6 +459,15 @@ int launch_w(const hnd_conv_desc& d, const BstreamArgs& a, size_t lds, int grid,
 
 namespace hnd {
 
+// tiles of the launch and the persistent grid
+static void bstream_grid(const hnd_conv_desc& d, int wn, int& mtiles, int& ntiles, int& grid) {
+  const long long M = (long long)d.n * d.oh * d.ow;
+  const int bm = 64 * (4 / wn), bn = 64 * wn;
+  mtiles = (int)((M + bm - 1) / bm);
+  ntiles = d.cout / bn;
+  grid = (cu_count_() / 8) * 8;
+}
+
 // 0 = not taken, 1 = 256 x 64 block tile (one wave column), 2 = 128 x 128 (two)
 int bstream_variant(const hnd_conv_desc& d) {
   const char* e = getenv("HND_BSTREAM");                // 0 = off; "all" = every eligible launch (A/B tool, tests)
@@ -478,17 +487,19 @@ int bstream_variant(const hnd_conv_desc& d) {
                      sizeof(float);
   if (lds > 160 * 1024) return 0;
   if (all) return wn;
-  if (d.kdim < 1024 && !taps) return 0;                 // K <= 512 without taps: the B-resident kernels
+  // Where it is taken by default (round 3, batch 16, per-launch HIP events of the step, tiled -> this kernel): the
+  // stride-2 3x3 convs over taps (1.39 -> 1.24 ms, 1.45 -> 1.24 ms), the K = 2048 1x1 convs and data gradients of layer4
+  // (0.33 -> 0.29 ms), K = 1024 with >= 512 output channels (1.19 -> 1.12 ms).  The K = 1024 -> 256 launches of layer3
+  // gain 3 % alone and nothing in the step (the teacher / FPN streams already fill the tiled kernel's partial last
+  // round, and a persistent one-wave-per-SIMD kernel shares a CU with nobody): they stay on the tiled kernel, as does
+  // K <= 512 without taps (the B-resident kernels).
+  if (!taps && (d.kdim < 1024 || (d.kdim < 2048 && d.cout < 512))) return 0;
+  // ... and only with at least one tile per workgroup (the relay's condition): a persistent kernel that leaves CUs
+  // idle loses to the tiled kernel's small blocks (validation at batch 1: 148 -> 128 img/s when it took those too)
+  int mtiles, ntiles, grid;
+  bstream_grid(d, wn, mtiles, ntiles, grid);
+  if ((long long)mtiles * ntiles < grid) return 0;
   return wn;
-}
-
-// tiles of the launch and the persistent grid
-static void bstream_grid(const hnd_conv_desc& d, int wn, int& mtiles, int& ntiles, int& grid) {
-  const long long M = (long long)d.n * d.oh * d.ow;
-  const int bm = 64 * (4 / wn), bn = 64 * wn;
-  mtiles = (int)((M + bm - 1) / bm);
-  ntiles = d.cout / bn;
-  grid = (cu_count_() / 8) * 8;
 }
 
 // the relay needs at least one whole tile of work per workgroup (see the kernel)
