@@ -226,6 +226,146 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __re
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// The two 3-channel weight gradients of the b3ch bottleneck (layer1.conv3: 2x2x64 -> 3, layer1.conv4: 2x2x3 -> 64):
+//   dW[co][ci][i][j] = sum_m dy[m][co] * a(m; i, j, ci)
+// is the outer product of a 64-channel tensor and a 4-channel one over four taps, reduced over 1.1 M pixels.  On the
+// MFMA tile above 60 of 64 rows (conv3) or 112 of 128 columns (conv4) are padding: 0.44 / 0.30 ms for 1.7 GFLOP.  Here
+// the THICK tensor (conv3: the input x, conv4: dy) streams through once -- 16 lanes x float4 per pixel, four pixels per
+// wave instruction -- the thin one (conv3: dy, conv4: x, 16 bytes per pixel) is fetched per tap from the cache, and
+// every lane keeps its 4 channels x 4 taps x 4 thin channels = 64 sums in registers: HBM-bound (275 MB).
+// Reduction order is fixed: a lane's pixels in ascending order, then pixel slots (xor 16, xor 32), waves 0..3, and the
+// per-block partials in wgrad_reduce_kernel's order -> bitwise reproducible.
+// THICK_IS_X: conv3 form (thick = x with the BN/ReLU prologue, thin = dy); else conv4 form (thick = dy, thin = x).
+struct ThinWgradArgs {
+  hnd_wgrad_desc d;
+  FastDiv div_w, div_h;       // thick pixel -> (n, y, x)
+  int th, tw;                 // thick map extent
+  int nh, nw;                 // thin map extent
+  long long P;                // thick pixels
+  int per_block;              // thick pixels per block (multiple of 64)
+};
+
+template <bool THICK_IS_X>
+__global__ void __launch_bounds__(256) thin_wgrad_kernel(const ThinWgradArgs a) {
+  __shared__ float red[4][1024];
+  const hnd_wgrad_desc& d = a.d;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c4 = lane & 15, sub = lane >> 4;          // channels 4*c4 .. 4*c4+3 of pixel slot `sub`
+  const float* __restrict__ thick = THICK_IS_X ? d.x : d.dy;
+  const float* __restrict__ thin = THICK_IS_X ? d.dy : d.x;
+  f32x4 tps = {1.f, 1.f, 1.f, 1.f}, tpb = {0.f, 0.f, 0.f, 0.f};     // prologue of the tensor x (thick or thin)
+  const bool has_pro = d.pro_scale != nullptr;
+  if (has_pro) {
+    tps = *(const f32x4*)(d.pro_scale + (THICK_IS_X ? 4 * c4 : 0));
+    if (d.pro_shift) tpb = *(const f32x4*)(d.pro_shift + (THICK_IS_X ? 4 * c4 : 0));
+  }
+  const float floor_ = d.pro_relu ? 0.f : -INFINITY;
+  auto pro = [&](f32x4 v) {
+    if (has_pro) {
+      v = v * tps + tpb;
+      v.x = fmaxf(v.x, floor_); v.y = fmaxf(v.y, floor_); v.z = fmaxf(v.z, floor_); v.w = fmaxf(v.w, floor_);
+    }
+    return v;
+  };
+  f32x4 acc[4][4];                                    // [tap][thin channel] x (4 thick channels)
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const long long p0 = (long long)blockIdx.x * a.per_block;
+  long long p1 = p0 + a.per_block;
+  if (p1 > a.P) p1 = a.P;
+  const int sgn = THICK_IS_X ? -1 : 1;                // thin pixel = thick pixel + sgn * (tap - pad)
+  // 64 pixels per block and iteration: every wave requests four 1 KB rows of the thick tensor and their 16 thin
+  // pixels before the first fma (one row per iteration ran at the memory latency: 1 TB/s)
+  constexpr int UN = 4;
+  for (long long pb = p0; pb < p1; pb += 16 * UN) {
+    f32x4 v[UN], q[UN][4];
+    unsigned okm = 0;                                 // bit 4u + t: thin pixel of tap t exists
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const long long p = pb + (u * 4 + wave) * 4 + sub;
+      const bool pok = p < p1;
+      const unsigned pp = (unsigned)(pok ? p : p0);
+      const unsigned t_ = hnd::fdiv(pp, a.div_w), px = pp - t_ * (unsigned)a.tw;
+      const unsigned n_ = hnd::fdiv(t_, a.div_h), py = t_ - n_ * (unsigned)a.th;
+      v[u] = *(const f32x4*)(thick + (size_t)pp * 64 + 4 * c4);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int ty = (int)py + sgn * ((t >> 1) - d.pad), tx = (int)px + sgn * ((t & 1) - d.pad);
+        const bool ok = pok && (unsigned)ty < (unsigned)a.nh && (unsigned)tx < (unsigned)a.nw;
+        const size_t off = ok ? ((size_t)((int)n_ * a.nh + ty) * a.nw + tx) * 4 : 0;
+        q[u][t] = *(const f32x4*)(thin + off);
+        okm |= (ok ? 1u : 0u) << (4 * u + t);
+      }
+    }
+    // (nothing above consumes a loaded value: all 20 loads are in flight before the first fma)
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const f32x4 vv = THICK_IS_X ? pro(v[u]) : v[u];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        f32x4 w = THICK_IS_X ? q[u][t] : pro(q[u][t]);
+        if (!((okm >> (4 * u + t)) & 1)) w = f32x4{0.f, 0.f, 0.f, 0.f};      // padding: a zero of the NORMALISED tensor
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[t][c] += vv * w[c];
+      }
+    }
+  }
+  // pixel slots of the wave, then the four waves, in fixed order
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float x = acc[t][c][k];
+        x += __shfl_xor(x, 16);
+        x += __shfl_xor(x, 32);
+        acc[t][c][k] = x;
+      }
+  if (sub == 0) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) red[wave][(t * 4 + c) * 64 + 4 * c4 + k] = acc[t][c][k];
+  }
+  __syncthreads();
+  // slab[block][co][col], col = tap * cin + ci (wgrad_reduce_kernel's layout): conv3 form co = thin channel (co_pad 4,
+  // 256 cols), conv4 form co = thick channel (co_pad 64, 16 cols)
+  float* slab = d.slabs + (size_t)blockIdx.x * 1024;
+  for (int e = tid; e < 1024; e += 256) {
+    const int tc = e >> 6, ch = e & 63, t = tc >> 2, c = tc & 3;
+    const float x = ((red[0][e] + red[1][e]) + red[2][e]) + red[3][e];
+    if (THICK_IS_X) slab[c * 256 + t * 64 + ch] = x;
+    else slab[ch * 16 + t * 4 + c] = x;
+  }
+}
+
+bool thin_wgrad_applies(const hnd_wgrad_desc& d, bool& thick_is_x) {
+  const char* e = getenv("HND_THIN_WGRAD");           // 0 = the MFMA kernel (read per call: in-process A/B)
+  if ((e && atoi(e) == 0) || d.kh != 2 || d.kw != 2 || d.stride != 1 || d.groups > 1 || (d.pad != 0 && d.pad != 1)) return false;
+  if (d.oh != d.h + 2 * d.pad - 1 || d.ow != d.w_ + 2 * d.pad - 1) return false;
+  if (d.cin == 64 && d.cin_real == 64 && d.cout <= 4 && d.ldy == 4) { thick_is_x = true; return true; }
+  if (d.cin == 4 && d.cout == 64 && d.ldy == 64) { thick_is_x = false; return true; }
+  return false;
+}
+
+int thin_wgrad_blocks(const hnd_wgrad_desc& d, bool thick_is_x, int& per_block) {
+  const long long P = thick_is_x ? (long long)d.n * d.h * d.w_ : (long long)d.n * d.oh * d.ow;
+  long long blocks = (P + 511) / 512;                 // >= 512 pixels per block ...
+  const char* e = getenv("HND_THIN_WGRAD_BLOCKS");
+  const long long cap = e ? atoi(e) : 512;
+  if (blocks > cap) blocks = cap;                     // ... and at most 512 partial slabs of 4 KB (measured: 1024 -> 0.156 ms, 512 -> 0.118, 256 -> 0.130)
+  if (blocks < 1) blocks = 1;
+  per_block = (int)(((P + blocks - 1) / blocks + 63) / 64 * 64);
+  return (int)((P + per_block - 1) / per_block);
+}
+
 // k-step depth of the build in use: 16 (32 KB LDS, 4 resident blocks per CU) unless HND_WGRAD_BK=32
 int wgrad_bk() {
   static const int bk = (getenv("HND_WGRAD_BK") && atoi(getenv("HND_WGRAD_BK")) == 32) ? 32 : 16;
@@ -278,6 +418,12 @@ extern "C" size_t hnd_conv2d_wgrad_workspace(const hnd_wgrad_desc* desc) {
     const size_t stem = (size_t)hnd::stem7_wgrad_blocks(d) * 64 * a.ncols_pad * sizeof(float);
     if (stem > need) need = stem;
   }
+  bool tx;
+  if (thin_wgrad_applies(d, tx)) {                      // one 4 KB partial per block
+    int per_block;
+    const size_t thin = (size_t)thin_wgrad_blocks(d, tx, per_block) * 1024 * sizeof(float);
+    if (thin > need) need = thin;
+  }
   return need;
 }
 
@@ -307,6 +453,25 @@ extern "C" int hnd_conv2d_wgrad(const hnd_wgrad_desc* desc, void* stream) {
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 63) / 64, 1), dim3(256), 0, s, d.slabs, d.dw,
                        hnd::stem7_wgrad_blocks(d), 64, a.ncols_pad, d.cout, d.cin, d.cin_real, d.kh, d.kw, 0ll);
     return hnd::check_launch("hnd_conv2d_wgrad(stem7 reduce)");
+  }
+  bool thick_is_x;
+  if (thin_wgrad_applies(d, thick_is_x)) {
+    ThinWgradArgs t;
+    t.d = d;
+    t.th = thick_is_x ? d.h : d.oh; t.tw = thick_is_x ? d.w_ : d.ow;
+    t.nh = thick_is_x ? d.oh : d.h; t.nw = thick_is_x ? d.ow : d.w_;
+    t.div_w = hnd::make_fastdiv((unsigned)t.tw);
+    t.div_h = hnd::make_fastdiv((unsigned)t.th);
+    t.P = (long long)d.n * t.th * t.tw;
+    const int blocks = thin_wgrad_blocks(d, thick_is_x, t.per_block);
+    if (thick_is_x) hipLaunchKernelGGL(thin_wgrad_kernel<true>, dim3(blocks), dim3(256), 0, s, t);
+    else hipLaunchKernelGGL(thin_wgrad_kernel<false>, dim3(blocks), dim3(256), 0, s, t);
+    int rc = hnd::check_launch("hnd_conv2d_wgrad(thin)");
+    if (rc) return rc;
+    const int total = d.cout * d.kh * d.kw * d.cin_real;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 63) / 64, 1), dim3(256), 0, s, d.slabs, d.dw, blocks,
+                       thick_is_x ? 4 : 64, thick_is_x ? 256 : 16, d.cout, d.cin, d.cin_real, d.kh, d.kw, 0ll);
+    return hnd::check_launch("hnd_conv2d_wgrad(thin reduce)");
   }
   const dim3 grid(a.rtiles * a.ctiles * a.d.splitk, groups);
   // tuning knob HND_WGRAD_BPC: cap the resident blocks per CU by padding the dynamic LDS request.  Measured in the

@@ -240,7 +240,7 @@ def conv_dgrad(dy, w_param, dx, k, stride=1, pad=0, accumulate=False, **kw_):
 
 
 class WgradLaunch(object):
-    __slots__ = ('desc', 'ref', 'keep', 'flops', 'alg_flops', 'variant', 'relay')
+    __slots__ = ('desc', 'ref', 'keep', 'flops', 'alg_flops', 'variant')
 
     def __init__(self, desc, keep, flops):
         self.desc, self.keep, self.flops = desc, keep, flops
@@ -250,6 +250,11 @@ class WgradLaunch(object):
         if (desc.cin == 4 and desc.kh == 7 and desc.stride == 2 and desc.cout == 64 and desc.groups <= 1
                 and os.environ.get('HND_STEM7', '1') != '0'):
             self.variant = 'stem7_wgrad'          # csrc/conv_stem.hip: dW from an LDS-staged patch
+        if (desc.kh == 2 and desc.kw == 2 and desc.stride == 1 and desc.groups <= 1 and desc.pad in (0, 1)
+                and os.environ.get('HND_THIN_WGRAD', '1') != '0'
+                and ((desc.cin == 64 and desc.cin_real == 64 and desc.cout <= 4 and desc.ldy == 4)
+                     or (desc.cin == 4 and desc.cout == 64 and desc.ldy == 64))):
+            self.variant = 'thin_wgrad'           # csrc/conv_wgrad.hip: the two 3-channel weight gradients (vector ALU)
 
     def run(self, stream=None):
         rc = _L.hnd_conv2d_wgrad(self.ref, stream if stream is not None else stream_ptr())

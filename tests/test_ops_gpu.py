@@ -224,6 +224,36 @@ def test_conv_wgrad(ops, case, splitk):
     assert relerr(dw.cpu(), wt.grad) < 1e-4
 
 
+@pytest.mark.parametrize('cin,cout,pad,n,h,w', [(64, 3, 1, 2, 57, 83), (64, 3, 0, 3, 40, 64), (3, 64, 0, 2, 58, 84),
+                                                (3, 64, 1, 1, 200, 336)])
+def test_thin_wgrad_matches_the_mfma_kernel_and_torch(ops, cin, cout, pad, n, h, w, monkeypatch):
+    """csrc/conv_wgrad.hip thin_wgrad_kernel: the two 3-channel weight gradients of the b3ch bottleneck on the vector ALU
+    (the 64-channel tensor streams once, 64 sums per lane).  A different summation order than the MFMA split-K kernel:
+    both must agree with torch's fp32 autograd to 1e-4 and with each other to 1e-5, and the kernel must be reproducible."""
+    g = gen(77 + cin + pad)
+    x = torch.randn(n, cin, h, w, generator=g)
+    ps, pb = torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g) * 0.3
+    wt = (torch.randn(cout, cin, 2, 2, generator=g) / math.sqrt(cin * 4)).requires_grad_(True)
+    out = F.conv2d(F.relu(x * ps[None, :, None, None] + pb[None, :, None, None]), wt, None, 1, pad)
+    dy = torch.randn(out.shape, generator=g)
+    out.backward(dy)
+    cp = ops.chan_pad_of(cin)
+    xd, dyd = nhwc(x, cp), nhwc(dy, ops.chan_pad_of(cout))
+    psd, pbd = F.pad(ps, (0, cp - cin)).to(DEV), F.pad(pb, (0, cp - cin)).to(DEV)
+    res = {}
+    for mode in ('0', '1', '1b'):
+        monkeypatch.setenv('HND_THIN_WGRAD', mode[0])
+        dw = torch.full((cout, cin, 2, 2), float('nan'), device=DEV)
+        l = ops.conv_wgrad(xd, dyd, dw, 2, 1, pad, pro_scale=psd, pro_shift=pbd, pro_relu=True)
+        l.run()
+        ops.sync_check()
+        res[mode] = (dw.cpu(), l.variant)
+    assert res['0'][1] == 'wgrad_m64' and res['1'][1] == 'thin_wgrad', (res['0'][1], res['1'][1])
+    assert torch.equal(res['1'][0], res['1b'][0])
+    assert relerr(res['1'][0], wt.grad) < 1e-4 and relerr(res['0'][0], wt.grad) < 1e-4
+    assert relerr(res['1'][0], res['0'][0]) < 1e-5
+
+
 def test_wgrad_is_deterministic(ops):
     g = gen(3)
     x = torch.randn(2, 64, 40, 50, generator=g)
