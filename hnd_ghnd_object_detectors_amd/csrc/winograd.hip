@@ -22,13 +22,6 @@ inline int grid_for(long long work_items, int threads = 256) {
   return (int)b;
 }
 
-// Workgroup b runs on XCD b % 8 (each XCD has its own L2).  The input transforms read overlapping patches -- tile
-// (ty, tx) shares two of its eight columns with (ty, tx + 1) -- so consecutive LOGICAL blocks, i.e. neighbouring tiles,
-// are given to one XCD: the shared columns are then L2 hits instead of a second trip to HBM.  Bijective for any grid.
-__device__ __forceinline__ int xcd_contiguous_block() {
-  const int nb = gridDim.x, b = blockIdx.x, q = nb >> 3, r = nb & 7, xcd = b & 7, slot = b >> 3;
-  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-}
 
 // U_f[co][ci] = (G g G^T)[f], g = w[co][ci] (forward) or w[ci][co] flipped (data gradient), written in the packed
 // GEMM-operand layout of hnd_pack_weights: [16][rows_pad][kdim], K (= input channel of the GEMM) contiguous.
@@ -484,7 +477,7 @@ __global__ void __launch_bounds__(256) wino6_input_kernel(const float* __restric
   const long long tiles = (long long)g.n * g.th * g.tw;
   const long long total = tiles * c2n;
   const size_t fs = (size_t)g.tiles_pad * g.c;
-  for (long long e = xcd_contiguous_block() * (long long)blockDim.x + threadIdx.x; e < total;
+  for (long long e = hnd::xcd_contiguous_block() * (long long)blockDim.x + threadIdx.x; e < total;
        e += (long long)gridDim.x * blockDim.x) {
     const int c2 = (int)(e % c2n);
     long long t = e / c2n;
@@ -998,7 +991,7 @@ __global__ void __launch_bounds__(256) wino26_input_kernel(const float* __restri
   const long long tiles = (long long)g.n * g.th * g.tw;
   const long long total = tiles * c2n;
   const size_t fs = (size_t)g.tiles_pad * g.c;
-  for (long long e = xcd_contiguous_block() * (long long)blockDim.x + threadIdx.x; e < total;
+  for (long long e = hnd::xcd_contiguous_block() * (long long)blockDim.x + threadIdx.x; e < total;
        e += (long long)gridDim.x * blockDim.x) {
     const int c2 = (int)(e % c2n);
     long long t = e / c2n;
