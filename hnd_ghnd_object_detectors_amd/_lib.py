@@ -50,6 +50,7 @@ _SIGNATURES = {
     'hnd_conv2d_wgrad_workspace': (C.c_size_t, [C.POINTER(WgradDesc)]),
     'hnd_conv2d_wgrad': (C.c_int, [C.POINTER(WgradDesc), vp]),
     'hnd_pack_weights': (C.c_int, [vp, vp] + [C.c_int] * 12 + [vp]),
+    'hnd_scale_packed_k': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]),
     'hnd_fbn_fold': (C.c_int, [vp] * 6 + [C.c_int, C.c_int, C.c_float, vp]),
     'hnd_transform_image': (C.c_int, [vp, C.c_int, C.c_int, vp] + [C.c_int] * 5 + [C.c_float, C.c_float,
                                                                                     c_float_p, c_float_p, vp]),

@@ -119,6 +119,18 @@ __global__ void transform_kernel(const TransformArgs a) {
   }
 }
 
+// packed[r][tap * chan_pad + c] *= scale[c]  (c < nscale): folds a per-channel scale of the GEMM's K operand into the
+// packed weights (hnd_scale_packed_k)
+__global__ void scale_packed_k_kernel(float* __restrict__ w, const float* __restrict__ scale, long long total, int kdim,
+                                      int ntaps, int chan_pad, int nscale) {
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    const int k = (int)(e % kdim);
+    const int tap = k / chan_pad, c = k - tap * chan_pad;
+    if (tap < ntaps && c < nscale) w[e] *= scale[c];
+  }
+}
+
 // ------------------------------------------------------------------------------------ max pool
 __global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, uint8_t* __restrict__ idx,
                                    int n, int h, int w, int c, int oh, int ow) {
@@ -563,6 +575,16 @@ int hnd_pack_weights(const float* src, float* dst, int cout, int cin, int kh, in
                      hnd::as_stream(stream), src, dst, cout, cin, kh, kw, transposed, chan_pad, i0, istep, ni, j0,
                      jstep, nj, rows_pad, kdim);
   return hnd::check_launch("hnd_pack_weights");
+}
+
+int hnd_scale_packed_k(float* packed, int rows_pad, int kdim, int ntaps, int chan_pad, const float* scale, int nscale,
+                       void* stream) {
+  HND_REQUIRE(packed && scale && rows_pad > 0 && kdim > 0 && ntaps > 0 && chan_pad > 0 && nscale > 0 &&
+                  nscale <= chan_pad && (long long)ntaps * chan_pad <= kdim, "hnd_scale_packed_k: bad arguments");
+  const long long total = (long long)rows_pad * kdim;
+  hipLaunchKernelGGL(scale_packed_k_kernel, dim3(grid_for(total)), dim3(256), 0, hnd::as_stream(stream), packed, scale,
+                     total, kdim, ntaps, chan_pad, nscale);
+  return hnd::check_launch("hnd_scale_packed_k");
 }
 
 int hnd_fbn_fold(const float* weight, const float* bias, const float* mean, const float* var, float* scale,

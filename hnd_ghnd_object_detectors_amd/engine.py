@@ -113,14 +113,19 @@ class WeightCache(object):
         self.packs = {}
         self.ver = None
 
-    def get(self, transposed=False, chan_pad=None, taps=None):
+    def get(self, transposed=False, chan_pad=None, taps=None, kscale=None):
         """the PackedWeight for this layout; its buffer address is stable for the life of the cache (prebuilt
-        launch descriptors point at it), refresh() re-runs the pack kernel into the same buffer."""
-        key = (transposed, chan_pad, taps)
+        launch descriptors point at it), refresh() re-runs the pack kernel into the same buffer.
+        kscale: per-channel scale folded into the K operand (ops.pack_weights); a NEW scale tensor (the FrozenBN fold
+        was refreshed) re-packs into the same buffer."""
+        key = (transposed, chan_pad, taps, kscale is not None)
         pk = self.packs.get(key)
         if pk is None:
-            pk = ops.pack_weights(self.weight.detach(), transposed, chan_pad, taps)
+            pk = ops.pack_weights(self.weight.detach(), transposed, chan_pad, taps, kscale=kscale)
             self.packs[key] = pk
+        elif kscale is not None and pk.kscale is not kscale:
+            pk.kscale = kscale
+            pk.repack()
         return pk
 
     def refresh(self, force=False):
@@ -178,6 +183,7 @@ class Wino2Cache(object):
             self.ver = ver
 
 
+FOLD_DGRAD_SCALE = os.environ.get('HND_FOLD_DGRAD_SCALE', '1') != '0'     # 0: FrozenBN scale as a launch prologue
 WINOGRAD_FROZEN = os.environ.get('HND_WINOGRAD_FROZEN', '1') != '0'   # debugging knob: frozen / FPN 3x3 convs
 WINOGRAD6_ENABLED = os.environ.get('HND_WINOGRAD6', '1') != '0'
 
@@ -470,6 +476,12 @@ class FrozenLayerEngine(object):
         flops = 0
         g = self.g_out
         nb = len(self.blocks)
+
+        def fold(scale):
+            # the FrozenBN scale between a conv and the gradient reaching it: folded into the transposed weights
+            # (one-time, the weights are frozen) instead of a prologue on every data-gradient launch
+            return {'fold_scale': scale} if FOLD_DGRAD_SCALE else {'pro_scale': scale}
+
         for i in range(nb - 1, -1, -1):
             b = self.blocks[i]
             x_in, a1, a2, out = self.acts[i]
@@ -480,7 +492,7 @@ class FrozenLayerEngine(object):
             g_a2 = self.bufs.get('g_a2_%d_%d' % (oh, b.planes), a2.shape)
             g_a1 = self.bufs.get('g_a1_%d_%d' % (h, b.planes), a1.shape)
             # conv3 (1x1): g_a2 = [a2>0] * W3^T (g * s3)
-            ls, _ = ops.conv_dgrad(g, b.w3, g_a2, 1, 1, 0, pro_scale=s3, mask=a2)
+            ls, _ = ops.conv_dgrad(g, b.w3, g_a2, 1, 1, 0, mask=a2, **fold(s3))
             self.bwd += [(l, tagp + '.conv3.dgrad') for l in ls]
             # conv2 (3x3, stride s): g_a1 = [a1>0] * dgrad(g_a2 * s2)
             if b.wino is not None:
@@ -489,7 +501,7 @@ class FrozenLayerEngine(object):
                 self.bwd += ops.WinoConv(g_a2, b.wino.get(True, tile), g_a1, v, m, pro_scale=s2,
                                          mask=a1).launches(tagp + '.conv2.dgrad')
             else:
-                ls, _ = ops.conv_dgrad(g_a2, b.w2, g_a1, 3, b.stride, 1, pro_scale=s2, mask=a1)
+                ls, _ = ops.conv_dgrad(g_a2, b.w2, g_a1, 3, b.stride, 1, mask=a1, **fold(s2))
                 self.bwd += [(l, tagp + '.conv2.dgrad') for l in ls]
             # conv1 (1x1) + identity / downsample fan-in, masked by the previous block's ReLU
             if i > 0:
@@ -498,14 +510,14 @@ class FrozenLayerEngine(object):
             else:
                 tgt, tmask, tres2 = dst, dst_mask, res2
             if b.has_ds:
-                ls, _ = ops.conv_dgrad(g_a1, b.w1, tgt, 1, 1, 0, pro_scale=s1, res2=tres2, mask=tmask)
+                ls, _ = ops.conv_dgrad(g_a1, b.w1, tgt, 1, 1, 0, res2=tres2, mask=tmask, **fold(s1))
                 self.bwd += [(l, tagp + '.conv1.dgrad') for l in ls]
-                ls, _ = ops.conv_dgrad(g, b.wd, tgt, 1, b.stride, 0, accumulate=True, pro_scale=b.fd.get()[0],
-                                       mask=tmask)
+                ls, _ = ops.conv_dgrad(g, b.wd, tgt, 1, b.stride, 0, accumulate=True, mask=tmask,
+                                       **fold(b.fd.get()[0]))
                 self.bwd += [(l, tagp + '.downsample.dgrad') for l in ls]
                 flops += 2 * n * oh * ow * b.planes * 4 * b.cin
             else:
-                ls, _ = ops.conv_dgrad(g_a1, b.w1, tgt, 1, 1, 0, pro_scale=s1, res1=g, res2=tres2, mask=tmask)
+                ls, _ = ops.conv_dgrad(g_a1, b.w1, tgt, 1, 1, 0, res1=g, res2=tres2, mask=tmask, **fold(s1))
                 self.bwd += [(l, tagp + '.conv1.dgrad') for l in ls]
             flops += 2 * n * (h * w * b.planes * b.cin + oh * ow * b.planes * b.planes * 9
                               + oh * ow * b.planes * 4 * b.planes)

@@ -48,15 +48,20 @@ def device_arch():
 # --------------------------------------------------------------------------------------- weights
 class PackedWeight(object):
     """K-contiguous GEMM operand made by hnd_pack_weights."""
-    __slots__ = ('buf', 'rows', 'kdim', 'ni', 'nj', 'chan_pad', 'chan_real', 'src', 'args')
+    __slots__ = ('buf', 'rows', 'kdim', 'ni', 'nj', 'chan_pad', 'chan_real', 'src', 'args', 'kscale')
 
     def repack(self):
         check(_L.hnd_pack_weights(self.src.data_ptr(), self.buf.data_ptr(), *self.args, stream_ptr()),
               'hnd_pack_weights')
+        if getattr(self, 'kscale', None) is not None:       # a per-channel scale of the K operand folded into the weights
+            check(_L.hnd_scale_packed_k(self.buf.data_ptr(), round_up(self.rows, 64), self.kdim, self.ni * self.nj,
+                                        self.chan_pad, self.kscale.data_ptr(), min(self.kscale.numel(), self.chan_pad),
+                                        stream_ptr()), 'hnd_scale_packed_k')
 
 
-def pack_weights(w, transposed=False, chan_pad=None, taps=None):
-    """w: torch OIHW parameter (device, contiguous).  taps = (i0, istep, ni, j0, jstep, nj) or None = all."""
+def pack_weights(w, transposed=False, chan_pad=None, taps=None, kscale=None):
+    """w: torch OIHW parameter (device, contiguous).  taps = (i0, istep, ni, j0, jstep, nj) or None = all.
+    kscale: per-channel scale of the GEMM's K operand folded into the packed weights (hnd_scale_packed_k)."""
     cout, cin, kh, kw = w.shape
     assert w.is_contiguous() and w.dtype == torch.float32
     if taps is None:
@@ -71,6 +76,7 @@ def pack_weights(w, transposed=False, chan_pad=None, taps=None):
     pw.kdim = round_up(ni * nj * chan_pad, 32)
     pw.buf = torch.empty(round_up(rows, 64) * pw.kdim, dtype=torch.float32, device=w.device)
     pw.args = (cout, cin, kh, kw, int(transposed), chan_pad, i0, istep, ni, j0, jstep, nj)
+    pw.kscale = kscale
     pw.repack()
     return pw
 
@@ -202,8 +208,10 @@ def dgrad_tap_classes(k, stride, pad):
     return out
 
 
-def conv_dgrad(dy, w_param, dx, k, stride=1, pad=0, accumulate=False, **kw_):
+def conv_dgrad(dy, w_param, dx, k, stride=1, pad=0, accumulate=False, fold_scale=None, **kw_):
     """Data gradient of nn.Conv2d(k, stride, pad): dy [N,OH,OW,Cout] -> dx [N,H,W,Cin_pad].
+    fold_scale: per-output-channel scale s of a frozen affine between the conv and dy (FrozenBatchNorm2d):
+    W^T (dy * s) is computed as (W^T diag(s)) dy with s folded into the packed operand -- no prologue on the launch.
     w_param: the OIHW weight tensor, or an object with .weight and .get(transposed, chan_pad, taps) (engine
     WeightCache) so the transposed operands are cached and refreshed with the parameter.
     Returns (launches, packed_weights).  Stride 2 is decomposed into one dense launch per output parity.
@@ -226,9 +234,9 @@ def conv_dgrad(dy, w_param, dx, k, stride=1, pad=0, accumulate=False, **kw_):
                 continue
             taps = (i0, istep, ni, j0, jstep, nj)
             if cache is not None:
-                pk = cache.get(True, dy.shape[3], taps)
+                pk = cache.get(True, dy.shape[3], taps, kscale=fold_scale)
             else:
-                pk = pack_weights(w_param, transposed=True, chan_pad=dy.shape[3], taps=taps)
+                pk = pack_weights(w_param, transposed=True, chan_pad=dy.shape[3], taps=taps, kscale=fold_scale)
             packs.append(pk)
             extra = dict(kw_)
             if accumulate:

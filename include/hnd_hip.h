@@ -154,6 +154,12 @@ int hnd_conv2d_wgrad(const hnd_wgrad_desc* desc, void* stream);
 int hnd_pack_weights(const float* src, float* dst, int cout, int cin, int kh, int kw, int transposed,
                      int chan_pad, int i0, int istep, int ni, int j0, int jstep, int nj, void* stream);
 
+/* packed[r][tap*chan_pad + c] *= scale[c] for c < nscale, all rows_pad rows and ntaps taps of an operand made by
+ * hnd_pack_weights: folds a per-channel scale of the GEMM's K operand into the weights.  Used for the data gradient
+ * through a frozen conv + FrozenBatchNorm2d: W^T (dy * s) == (W^T diag(s)) dy, so the launch needs no prologue. */
+int hnd_scale_packed_k(float* packed, int rows_pad, int kdim, int ntaps, int chan_pad, const float* scale, int nscale,
+                       void* stream);
+
 /* FrozenBatchNorm2d (torchvision 0.4.2 ops/misc.py, built at src/models/org/rcnn.py:391,394):
  *   scale = weight * rsqrt(running_var + eps),  shift = bias - running_mean*scale,
  * eps = 0 for FrozenBatchNorm2d (0.4.2 has none); eps = 1e-5 folds an eval-mode nn.BatchNorm2d.

@@ -188,6 +188,48 @@ def test_conv_dgrad_1x1_stride2_accumulate_with_mask(ops):
     assert torch.equal(got[:, :, 1::2, :], ref_odd[:, :, 1::2, :])
 
 
+@pytest.mark.parametrize('cin,cout,k,stride,pad,h,w', [(256, 512, 1, 1, 0, 19, 23), (128, 128, 3, 2, 1, 20, 28),
+                                                       (256, 512, 1, 2, 0, 18, 24)])
+def test_dgrad_with_the_frozen_bn_scale_folded_into_the_weights(ops, cin, cout, k, stride, pad, h, w):
+    """W^T (dy * s) as (W^T diag(s)) dy: the FrozenBatchNorm2d scale between a frozen conv and its output gradient is
+    folded into the packed transposed weights (hnd_scale_packed_k) instead of a prologue on the launch.  Must equal the
+    prologue form to fp32 rounding and torch's autograd to 1e-4; a new scale tensor re-packs into the same buffer."""
+    from hnd_ghnd_object_detectors_amd import engine as E
+    g = gen(41 + k + stride)
+    n = 2
+    x = torch.randn(n, cin, h, w, generator=g, requires_grad=True)
+    wt = torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k)
+    sc = torch.rand(cout, generator=g) + 0.5
+    out = F.conv2d(x, wt, None, stride, pad)
+    dy = torch.randn(out.shape, generator=g)
+    out.backward(dy * sc[None, :, None, None])
+    mk = torch.randn(n, cin, h, w, generator=g)
+    ref = torch.where(mk > 0, x.grad, torch.zeros_like(x.grad))
+    dyd, mkd, scd = nhwc(dy), nhwc(mk), sc.to(DEV)
+    got = {}
+    wc = E.WeightCache(wt.to(DEV).contiguous())
+    for mode in ('pro', 'fold'):
+        dx = torch.zeros(n, h, w, cin, device=DEV)
+        kw = {'pro_scale': scd} if mode == 'pro' else {'fold_scale': scd}
+        launches, packs = ops.conv_dgrad(dyd, wc, dx, k, stride, pad, accumulate=stride > 1, mask=mkd, **kw)
+        for l in launches:
+            assert (l.desc.pro_scale is None) == (mode == 'fold')
+            l.run()
+        ops.sync_check()
+        got[mode] = nchw(dx)
+    assert relerr(got['fold'], ref) < 1e-4 and relerr(got['pro'], ref) < 1e-4
+    assert relerr(got['fold'], got['pro']) < 1e-6
+    # a refreshed FrozenBN fold hands over a NEW scale tensor: same packed buffers, new contents
+    sc2 = (sc * 2).to(DEV)
+    dx = torch.zeros(n, h, w, cin, device=DEV)
+    launches2, packs2 = ops.conv_dgrad(dyd, wc, dx, k, stride, pad, accumulate=stride > 1, mask=mkd, fold_scale=sc2)
+    assert [q.buf.data_ptr() for q in packs2] == [q.buf.data_ptr() for q in packs]
+    for l in launches2:
+        l.run()
+    ops.sync_check()
+    assert relerr(nchw(dx), 2 * ref) < 1e-4
+
+
 WGRAD_CASES = [
     (2, 64, 13, 17, 64, 2, 1, 1),
     (2, 64, 14, 18, 256, 2, 1, 1),
