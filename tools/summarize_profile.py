@@ -25,7 +25,8 @@ def short(name):
         return 'bres%s_%d' % (m.group(1), 64 * int(m.group(2))) + ('[prologue]' if m.group(4) == 'true' and FULLNAMES else '')
     m = re.search(r'bstream_kernel<(\d+), (true|false), (true|false)>', name)
     if m:           # B-streamed persistent GEMM (conv_bstream.hip)
-        return 'bstream_%d' % (64 * int(m.group(1))) + ('[prologue]' if m.group(2) == 'true' and FULLNAMES else '')
+        return 'bstream_%d' % (64 * int(m.group(1))) + (('[prologue]' if m.group(2) == 'true' else '') +
+                                                      ('[taps]' if m.group(3) == 'true' else '') if FULLNAMES else '')
     m = re.search(r'wgrad_kernel<(\d+), (\d+)>', name)
     if m:
         return 'wgrad_m%s' % m.group(1)
