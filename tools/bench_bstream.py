@@ -30,6 +30,13 @@ SHAPES = {
     '1x1_256-1024@50+res (layer3.conv3)': (256, 50, 84, 1024, 1, 1, 0, True, False, False, 1),
     '1x1_128-512@100+res (layer2.conv3)': (128, 100, 168, 512, 1, 1, 0, True, False, False, 1),
     '1x1_512-256@100 (layer3.0.conv1)': (512, 100, 168, 256, 1, 1, 0, False, False, False, 1),
+    '1x1_512-128@100 (layer2.conv1)': (512, 100, 168, 128, 1, 1, 0, False, False, False, 1),
+    '1x1_512-2048@25+res (layer4.conv3)': (512, 25, 42, 2048, 1, 1, 0, True, False, False, 1),
+    '1x1_512-128@100 mask (l2.conv3.dgrad)': (512, 100, 168, 128, 1, 1, 0, False, True, False, 1),
+    '1x1_512-2048@25 mask (l4.conv1.dgrad)': (512, 25, 42, 2048, 1, 1, 0, False, True, False, 1),
+    '1x1_512-256@100+res (fpn.inner1)': (512, 100, 168, 256, 1, 1, 0, True, False, False, 1),
+    '1x1_256-1024@50 mask (l3.conv1.dgrad)': (256, 50, 84, 1024, 1, 1, 0, False, True, False, 1),
+    '1x1_256-512@100 mask+res (l3.0.conv1.dgrad)': (256, 100, 168, 512, 1, 1, 0, True, True, False, 1),
     'wino64_256-256@50 (layer3.conv2)': (256, 9, 14, 256, 1, 1, 0, False, False, False, 64),
     'wino64_512-512@25 (layer4.conv2)': (512, 5, 7, 512, 1, 1, 0, False, False, False, 64),
     'wino64_256-256@200 (fpn.layer0)': (256, 34, 56, 256, 1, 1, 0, False, False, False, 64),
