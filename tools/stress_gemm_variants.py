@@ -23,6 +23,40 @@ def main():
     rnd = random.Random(args.seed)
     dev = 'cuda:0'
     counts, bad = {}, 0
+    # grouped weights (the Winograd component GEMMs): rows = groups * tiles_pad, one packed matrix per group
+    for case in range(args.cases // 5):
+        cin, cout = rnd.choice([256, 384, 512]), rnd.choice([64, 128, 256, 512])
+        groups = rnd.choice([4, 9, 16, 25, 36, 49, 64])
+        tiles_pad = rnd.choice([256, 512, 1024, 2304, 4096, 30464 // 256 * 256])
+        g = torch.Generator().manual_seed(5000 + case)
+        x = torch.randn(1, 1, groups * tiles_pad, cin, generator=g).to(dev)
+        y = torch.empty(1, 1, groups * tiles_pad, cout, device=dev)
+        pks = [ops.pack_weights((torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5).to(dev)) for _ in range(groups)]
+        pk = ops.PackedWeight.__new__(ops.PackedWeight)
+        pk.buf = torch.cat([q.buf for q in pks])
+        pk.kdim, pk.rows, pk.chan_pad, pk.chan_real = pks[0].kdim, cout, cin, cin
+        outs, variants = {}, {}
+        for mode, env in (('tiled', {'HND_BRES': '0', 'HND_BSTREAM': '0'}), ('default', {}),
+                          ('bstream', {'HND_BRES': '0', 'HND_BSTREAM': 'all'})):
+            for key in ('HND_BRES', 'HND_BSTREAM', 'HND_BSTREAM_RELAY'):
+                os.environ.pop(key, None)
+            os.environ.update(env)
+            l = ops.conv_desc(x, pk, y, kh=1, kw=1, oh=1, ow=groups * tiles_pad, sh=1, dh=1, bh=0, sw=1, dw=1, bw=0,
+                              cout=cout)
+            l.desc.w_group_rows, l.desc.w_group_stride = tiles_pad, pks[0].buf.numel()
+            l.refresh_variant()
+            y.fill_(float('nan'))
+            l.run()
+            ops.sync_check()
+            outs[mode], variants[mode] = y.clone(), l.variant + ('+relay' if l.relay is not None else '')
+        ok = all(torch.equal(outs['tiled'], outs[m]) for m in outs) and not bool(torch.isnan(outs['tiled']).any())
+        for v in variants.values():
+            counts['grouped ' + v] = counts.get('grouped ' + v, 0) + 1
+        if not ok:
+            bad += 1
+            print('grouped case %d MISMATCH cin=%d cout=%d groups=%d tiles_pad=%d %s' % (case, cin, cout, groups,
+                                                                                         tiles_pad, variants), flush=True)
+        del x, y, outs
     for case in range(args.cases):
         taps = rnd.random() < 0.35
         if taps:
