@@ -224,3 +224,58 @@ def test_coco_format_loaders_without_pycocotools(tmp_path):
                'splits': {k: {'images': img_dir, 'annotations': '/nonexistent.json', 'remove_non_annotated_imgs': False,
                               'jpeg_quality': None} for k in ('train', 'val', 'test')}}
         data_util.get_coco_data_loaders(bad, 2, False)
+
+
+def _relay_segments(T, kg8, G, lb):
+    """Python mirror of the work split of csrc/conv_bstream.hip (bstream_kernel, relay mode): the units
+    [U lb / G, U (lb + 1) / G) of the linear (tile, iteration) space as (tile, it0, it1, kind) segments in the order the
+    workgroup processes them: head first, whole tiles, tail last."""
+    U = T * kg8
+    u0, u1 = U * lb // G, U * (lb + 1) // G
+    tA, tB = u0 // kg8, u1 // kg8
+    offA, offB = u0 - tA * kg8, u1 - tB * kg8
+    first_full = tA + (1 if offA > 0 else 0)
+    segs = []
+    if offB > 0:
+        segs.append((tB, 0, offB, 'head'))
+    segs += [(t, 0, kg8, 'full') for t in range(first_full, tB)]
+    if offA > 0:
+        segs.append((tA, offA, kg8, 'tail'))
+    return segs
+
+
+def test_relay_work_split_covers_every_unit_once_and_pairs_heads_with_tails():
+    """The B-streamed GEMM's relay: with at least one tile per workgroup every (tile, 128-k iteration) unit is computed
+    exactly once, a workgroup holds at most one head and one tail (of DIFFERENT tiles), the tail of workgroup w + 1
+    continues exactly where the head of w stopped, and the loads' balance is within one iteration."""
+    import random
+    rnd = random.Random(3)
+    G = 256
+    for _ in range(200):
+        kg8 = rnd.choice([2, 4, 8, 9, 16, 18, 36])
+        T = rnd.randint(G, 6 * G)
+        seen = {}
+        heads, tails, work = {}, {}, []
+        for lb in range(G):
+            segs = _relay_segments(T, kg8, G, lb)
+            kinds = [s[3] for s in segs]
+            assert kinds.count('head') <= 1 and kinds.count('tail') <= 1
+            assert kinds == sorted(kinds, key=lambda k: ('head', 'full', 'tail').index(k))
+            work.append(sum(s[2] - s[1] for s in segs))
+            for tile, it0, it1, kind in segs:
+                assert 0 <= tile < T and 0 <= it0 < it1 <= kg8
+                for it in range(it0, it1):
+                    assert (tile, it) not in seen
+                    seen[(tile, it)] = lb
+                if kind == 'head':
+                    heads[lb] = (tile, it1)
+                elif kind == 'tail':
+                    tails[lb] = (tile, it0)
+            if 'head' in kinds and 'tail' in kinds:
+                assert segs[0][0] != segs[-1][0]
+        assert len(seen) == T * kg8
+        assert max(work) - min(work) <= 1 and min(work) >= kg8
+        assert 0 not in tails and (G - 1) not in heads
+        for lb, (tile, it1) in heads.items():
+            assert tails.get(lb + 1) == (tile, it1), (lb, heads[lb], tails.get(lb + 1))
+        assert len(tails) == len(heads)
