@@ -304,7 +304,11 @@ __global__ void __launch_bounds__(256, 1) bstream_kernel(const hnd_conv_desc d, 
     if (kind == TAIL) {
       // the head of this tile: accumulators parked by workgroup lb - 1 (which computed them FIRST, see above)
       if (tid == 0) {
-        while (__hip_atomic_load(relay_f + (lb - 1), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0)
+        // (bounded: ~2 s.  The head was computed FIRST by its workgroup, so this does not spin in practice; should the
+        // flag never come -- a workspace that was not zero-filled, a neighbour that faulted -- a wrong tile that the
+        // parity checks see is better than a GPU that never returns)
+        for (int spin = 0; spin < (1 << 21) &&
+                           __hip_atomic_load(relay_f + (lb - 1), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0; ++spin)
           __builtin_amdgcn_s_sleep(8);
         __hip_atomic_store(relay_f + (lb - 1), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
       }
