@@ -421,6 +421,7 @@ def run_rank(args):
                       'algorithmic_speed_vs_direct_at_peak': round(v['alg'] / v['ms'] / 1e9 / FP32_MFMA_PEAK_TFLOPS, 4)}
                for k, v in sorted(groups.items()) if k[0] == 'head2x2' and v['ms'] > 0}
     conv_ms = sum(v['ms'] for v in per.values())
+    exec_gflop = sum(v['flop'] for v in per.values()) / 1e9          # multiplies the MFMA launches execute (x2)
     # HBM side: algorithmic bytes / in-run HIP-event time of the bandwidth-bound kernels, against the 8 TB/s spec
     # and the ~6.3 TB/s a streaming kernel reaches on this part (MI355X_MICROARCH.md)
     hbm_roofline = {k: {'launches': v['launches'], 'ms': round(v['ms'], 3), 'gbytes': round(v['bytes'] / 1e9, 3),
@@ -475,7 +476,12 @@ def run_rank(args):
                                  ('external launcher' if world > 1 else 'single process')},
         'run_cfg': run_cfg,
         'host_enqueue_ms_per_step': round(host_enqueue_ms, 3),
+        # algorithmic: direct-convolution flops the step stands for / step time -- NOT a roofline fraction (Winograd
+        # executes fewer multiplies); the executed basis follows
         'step_conv_tflops': round(gflop_img * args.batch / (ms_per_step / 1e3) / 1e3, 2),
+        'executed_gflop_per_step': round(exec_gflop, 1),
+        'executed_tflops_in_mfma_kernels': round(exec_gflop / conv_ms, 2) if conv_ms else None,
+        'executed_frac_of_mfma_peak': round(exec_gflop / conv_ms / FP32_MFMA_PEAK_TFLOPS, 4) if conv_ms else None,
         'conv_kernel_ms_per_step': round(conv_ms, 2),
         'hbm_kernel_ms_per_step': round(hbm_ms, 2),
         'hbm_roofline': hbm_roofline,
