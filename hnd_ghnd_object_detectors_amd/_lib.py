@@ -25,6 +25,12 @@ class ConvDesc(C.Structure):
                [('relay_ws', vp)]
 
 
+class ImageDesc(C.Structure):
+    """struct hnd_image_desc"""
+    _fields_ = [('src', vp)] + [(n, C.c_int32) for n in ('h', 'w', 'out_h', 'out_w', 'is_u8', 'hwc', 'flip')] + \
+               [('scale_h', C.c_float), ('scale_w', C.c_float)]
+
+
 class WgradDesc(C.Structure):
     """struct hnd_wgrad_desc"""
     _fields_ = [(n, vp) for n in ('x', 'dy', 'dw', 'slabs', 'pro_scale', 'pro_shift')] + \
@@ -56,6 +62,7 @@ _SIGNATURES = {
                                                                                     c_float_p, c_float_p, vp]),
     'hnd_transform_image_u8': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp] + [C.c_int] * 5 +
                                [C.c_float, C.c_float, c_float_p, c_float_p, vp]),
+    'hnd_transform_images': (C.c_int, [C.POINTER(ImageDesc), C.c_int, vp, C.c_int, C.c_int, c_float_p, c_float_p, vp]),
     'hnd_wino_tiles_pad': (C.c_int64, [C.c_int] * 4),
     'hnd_wino_weights': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     'hnd_wino_input': (C.c_int, [vp, vp] + [C.c_int] * 4 + [vp, vp, C.c_int, C.c_int, vp]),

@@ -75,10 +75,10 @@ struct TransformArgs {
 };
 
 template <bool U8>
-__global__ void transform_kernel(const TransformArgs a) {
+__device__ __forceinline__ void transform_body(const TransformArgs& a, int block, int nblocks) {
   const int total = a.hp * a.wp;
   const size_t plane = (size_t)a.h * a.w;
-  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < total; p += gridDim.x * blockDim.x) {
+  for (int p = block * blockDim.x + threadIdx.x; p < total; p += nblocks * blockDim.x) {
     const int y = p / a.wp, x = p - y * a.wp;
     f32x4 o = {0.f, 0.f, 0.f, 0.f};
     if (y < a.out_h && x < a.out_w) {
@@ -117,6 +117,23 @@ __global__ void transform_kernel(const TransformArgs a) {
     }
     *(f32x4*)(a.dst + (size_t)p * 4) = o;
   }
+}
+
+template <bool U8>
+__global__ void transform_kernel(const TransformArgs a) {
+  transform_body<U8>(a, blockIdx.x, gridDim.x);
+}
+
+// The whole batch in one launch (blockIdx.y = image): 16 launches of 18 us each were launch-bound (1.7 TB/s).
+constexpr int kMaxBatchImages = 32;
+struct TransformBatch {
+  TransformArgs img[kMaxBatchImages];
+  unsigned u8_mask;          // bit i: image i is a uint8 source
+};
+__global__ void transform_batch_kernel(const TransformBatch b) {
+  const TransformArgs& a = b.img[blockIdx.y];
+  if ((b.u8_mask >> blockIdx.y) & 1) transform_body<true>(a, blockIdx.x, gridDim.x);
+  else transform_body<false>(a, blockIdx.x, gridDim.x);
 }
 
 // packed[r][tap * chan_pad + c] *= scale[c]  (c < nscale): folds a per-channel scale of the GEMM's K operand into the
@@ -632,6 +649,38 @@ int hnd_transform_image_u8(const uint8_t* src, int h, int w, int hwc, int flip, 
   hipLaunchKernelGGL(transform_kernel<true>, dim3(grid_for((long long)hp * wp)), dim3(256), 0,
                      hnd::as_stream(stream), a);
   return hnd::check_launch("hnd_transform_image_u8");
+}
+
+int hnd_transform_images(const hnd_image_desc* imgs, int count, float* dst, int hp, int wp, const float mean[3],
+                         const float std[3], void* stream) {
+  HND_REQUIRE(imgs && dst && mean && std && count > 0 && hp > 0 && wp > 0, "hnd_transform_images: bad arguments");
+  for (int i0 = 0; i0 < count; i0 += kMaxBatchImages) {
+    const int nb = count - i0 < kMaxBatchImages ? count - i0 : kMaxBatchImages;
+    TransformBatch b;
+    b.u8_mask = 0;
+    for (int k = 0; k < nb; ++k) {
+      const hnd_image_desc& im = imgs[i0 + k];
+      HND_REQUIRE(im.src && im.h > 0 && im.w > 0 && im.out_h > 0 && im.out_w > 0 && im.out_h <= hp && im.out_w <= wp,
+                  "hnd_transform_images: image %d: bad geometry (out %dx%d, padded %dx%d)", i0 + k, im.out_h, im.out_w, hp,
+                  wp);
+      TransformArgs& a = b.img[k];
+      a.src = im.is_u8 ? nullptr : (const float*)im.src;
+      a.src8 = im.is_u8 ? (const uint8_t*)im.src : nullptr;
+      a.hwc = im.hwc != 0;
+      a.flip = im.flip != 0;
+      a.dst = dst + (size_t)(i0 + k) * hp * wp * 4;
+      a.h = im.h; a.w = im.w; a.out_h = im.out_h; a.out_w = im.out_w; a.hp = hp; a.wp = wp;
+      a.rh = im.scale_h; a.rw = im.scale_w;
+      for (int c = 0; c < 3; ++c) { a.mean[c] = mean[c]; a.std[c] = std[c]; a.inv_unused[c] = 0.f; }
+      if (im.is_u8) b.u8_mask |= 1u << k;
+    }
+    int bx = grid_for((long long)hp * wp);
+    if (bx > 2048) bx = 2048;
+    hipLaunchKernelGGL(transform_batch_kernel, dim3(bx, nb), dim3(256), 0, hnd::as_stream(stream), b);
+    int rc = hnd::check_launch("hnd_transform_images");
+    if (rc) return rc;
+  }
+  return HND_OK;
 }
 
 int hnd_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* idx, int n, int h, int w, int c, int oh, int ow,

@@ -289,13 +289,16 @@ class TransformEngine(object):
         key = (_SCOPE['id'],) + tuple(_image_key(im) + p for im, p in zip(images, plans))
         batch = self.bufs.get('batch', (len(images), hp, wp, 4))
         if _SCOPE['id'] is None or key != self.last_key:
-            for i, (img, (h, w, scale, oh, ow)) in enumerate(zip(images, plans)):
-                if hasattr(img, 'hwc'):         # DecodedImage
-                    ops.transform_image_u8(img.data if img.data.is_contiguous() else img.data.contiguous(), batch, i,
-                                           oh, ow, 1.0 / scale, 1.0 / scale, self.mean, self.std, img.hwc, img.flip)
-                    continue
-                src = img if (img.is_contiguous() and img.dtype == torch.float32) else img.float().contiguous()
-                ops.transform_image(src, batch, i, oh, ow, 1.0 / scale, 1.0 / scale, self.mean, self.std)
+            items, keep = [], []
+            for img, (h, w, scale, oh, ow) in zip(images, plans):
+                if hasattr(img, 'hwc'):         # DecodedImage: /255 and the pending flip are fused into the kernel
+                    src = img.data if img.data.is_contiguous() else img.data.contiguous()
+                    items.append((src, True, img.hwc, img.flip, oh, ow, 1.0 / scale, 1.0 / scale))
+                else:
+                    src = img if (img.is_contiguous() and img.dtype == torch.float32) else img.float().contiguous()
+                    items.append((src, False, False, False, oh, ow, 1.0 / scale, 1.0 / scale))
+                keep.append(src)
+            ops.transform_images(items, batch, self.mean, self.std)      # one launch for the whole batch
             self.last_key = key
         self.last_scales = [p[2] for p in plans]
         return batch, [(p[3], p[4]) for p in plans]

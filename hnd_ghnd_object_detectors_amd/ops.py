@@ -327,6 +327,27 @@ def transform_image_u8(src, dst, index, out_h, out_w, rscale_h, rscale_w, mean, 
           'hnd_transform_image_u8')
 
 
+def transform_images(items, dst, mean, std):
+    """The whole batch in one launch.  items: per image (src, is_u8, hwc, flip, out_h, out_w, rscale_h, rscale_w) with
+    src fp32 [3,H,W] or uint8 [H,W,3] / [3,H,W]; image i lands in dst[i] of dst [N,Hp,Wp,4]."""
+    from ._lib import ImageDesc
+    assert dst.shape[3] == 4 and dst.shape[0] == len(items)
+    arr = (ImageDesc * len(items))()
+    nbytes = 0
+    for d, (src, is_u8, hwc, flip, out_h, out_w, rh, rw) in zip(arr, items):
+        assert src.is_contiguous() and src.dim() == 3 and src.dtype == (torch.uint8 if is_u8 else torch.float32)
+        h, w = (src.shape[0], src.shape[1]) if (is_u8 and hwc) else (src.shape[1], src.shape[2])
+        assert src.shape[2 if (is_u8 and hwc) else 0] == 3
+        d.src, d.h, d.w, d.out_h, d.out_w = ptr(src), h, w, out_h, out_w
+        d.is_u8, d.hwc, d.flip, d.scale_h, d.scale_w = int(is_u8), int(bool(hwc)), int(bool(flip)), float(rh), float(rw)
+        nbytes += (3 if is_u8 else 12) * h * w + 16 * dst.shape[1] * dst.shape[2]
+    m = (C.c_float * 3)(*mean)
+    s = (C.c_float * 3)(*std)
+    _hbm('transform_image', nbytes, lambda: check(
+        _L.hnd_transform_images(arr, len(items), ptr(dst), dst.shape[1], dst.shape[2], m, s, stream_ptr()),
+        'hnd_transform_images'))
+
+
 # bench.py's hbm_roofline: HIP events (torch's current stream == the launch stream) around the HBM-bound launches
 # that do not go through an engine plan entry, with the bytes each of them must move
 HBM_PROFILE = {'enabled': False, 'records': []}

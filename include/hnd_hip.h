@@ -184,6 +184,17 @@ int hnd_transform_image_u8(const uint8_t* src, int h, int w, int hwc, int flip, 
                            int out_w, int hp, int wp, float scale_h, float scale_w, const float mean[3],
                            const float std[3], void* stream);
 
+/* The same transform for a whole batch in ONE launch: image i of `imgs` -> image i of dst [count][hp][wp][4].
+ * src is float [3][h][w] (is_u8 = 0) or uint8 [h][w][3] / [3][h][w] (is_u8 = 1, hwc, flip as above). */
+typedef struct hnd_image_desc {
+  const void* src;
+  int32_t h, w, out_h, out_w;
+  int32_t is_u8, hwc, flip;
+  float scale_h, scale_w;      /* source step per output pixel = 1 / resize scale */
+} hnd_image_desc;
+int hnd_transform_images(const hnd_image_desc* imgs, int count, float* dst, int hp, int wp, const float mean[3],
+                         const float std[3], void* stream);
+
 /* ---- Winograd F(tile x tile, 3x3), tile = 2, 4 or 6, for stride-1 pad-1 3x3 convolutions (torchvision Bottleneck.conv2
  * and the FPN output convs built at src/models/org/rcnn.py:391-414; forward and data gradient) ----------------------
  * y = out_transform( GEMM_f( in_transform(x), U_f ) ), f = 0..(tile+2)^2-1, with all GEMMs issued as ONE
