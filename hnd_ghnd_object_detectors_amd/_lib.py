@@ -31,6 +31,11 @@ class ImageDesc(C.Structure):
                [('scale_h', C.c_float), ('scale_w', C.c_float)]
 
 
+class BoxesDesc(C.Structure):
+    """struct hnd_boxes_desc"""
+    _fields_ = [('src', vp), ('dst', vp), ('k', C.c_int32), ('scale_w', C.c_float), ('scale_h', C.c_float)]
+
+
 class WgradDesc(C.Structure):
     """struct hnd_wgrad_desc"""
     _fields_ = [(n, vp) for n in ('x', 'dy', 'dw', 'slabs', 'pro_scale', 'pro_shift')] + \
@@ -63,6 +68,7 @@ _SIGNATURES = {
     'hnd_transform_image_u8': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp] + [C.c_int] * 5 +
                                [C.c_float, C.c_float, c_float_p, c_float_p, vp]),
     'hnd_transform_images': (C.c_int, [C.POINTER(ImageDesc), C.c_int, vp, C.c_int, C.c_int, c_float_p, c_float_p, vp]),
+    'hnd_scale_boxes': (C.c_int, [C.POINTER(BoxesDesc), C.c_int, vp]),
     'hnd_wino_tiles_pad': (C.c_int64, [C.c_int] * 4),
     'hnd_wino_weights': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     'hnd_wino_input': (C.c_int, [vp, vp] + [C.c_int] * 4 + [vp, vp, C.c_int, C.c_int, vp]),

@@ -68,10 +68,11 @@ class CustomRCNNTransform(nn.Module):
             return random.choice(self.min_size)
         return self.min_size[-1]
 
-    def resize_target(self, target, old_hw, new_hw, scale):
+    def resize_target(self, target, old_hw, new_hw, scale, boxes_done=False):
         if target is None:
             return target
-        target['boxes'] = resize_boxes(target['boxes'], old_hw, new_hw)
+        if not boxes_done:
+            target['boxes'] = resize_boxes(target['boxes'], old_hw, new_hw)
         if 'masks' in target:
             target['masks'] = resize_masks_nearest(target['masks'], scale)
         if 'keypoints' in target:
@@ -84,8 +85,22 @@ class CustomRCNNTransform(nn.Module):
         eng = E.shared_transform(self.image_mean, self.image_std, images[0].device)
         batch, image_sizes = eng.run(images, sizes, self.max_size)
         if targets is not None:
+            # the boxes of the whole batch in one HIP launch (the reference's per-image x * rw, y * rh in fp32, :50-53)
+            idx = [i for i, t in enumerate(targets) if t is not None and t['boxes'].is_cuda
+                   and t['boxes'].dtype == torch.float32 and t['boxes'].dim() == 2]
+            if idx:
+                from ... import ops
+                items = []
+                for i in idx:
+                    oh, ow = tuple(images[i].shape[-2:])
+                    nh, nw = image_sizes[i]
+                    items.append((targets[i]['boxes'], float(nw) / float(ow), float(nh) / float(oh)))
+                for i, out in zip(idx, ops.scale_boxes(items)):
+                    targets[i]['boxes'] = out
+            done = set(idx)
             for i, img in enumerate(images):
-                targets[i] = self.resize_target(targets[i], tuple(img.shape[-2:]), image_sizes[i], eng.last_scales[i])
+                targets[i] = self.resize_target(targets[i], tuple(img.shape[-2:]), image_sizes[i], eng.last_scales[i],
+                                                boxes_done=i in done)
         tensors = hipnn.attach(E.logical(batch, 3), batch)
         return hipnn.ImageList(tensors, image_sizes), targets
 

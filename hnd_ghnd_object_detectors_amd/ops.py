@@ -348,6 +348,23 @@ def transform_images(items, dst, mean, std):
         'hnd_transform_images'))
 
 
+def scale_boxes(items):
+    """items: per image (boxes [k,4] fp32 device tensor, scale_w, scale_h) -> list of rescaled [k,4] tensors, one launch
+    for the whole list (hnd_scale_boxes)."""
+    from ._lib import BoxesDesc
+    arr = (BoxesDesc * len(items))()
+    outs = []
+    for d, (bx, rw, rh) in zip(arr, items):
+        assert bx.dtype == torch.float32 and bx.dim() == 2 and bx.shape[1] == 4 and bx.is_cuda
+        src = bx if bx.is_contiguous() else bx.contiguous()
+        out = torch.empty_like(src)
+        d.src, d.dst, d.k, d.scale_w, d.scale_h = ptr(src), ptr(out), src.shape[0], float(rw), float(rh)
+        outs.append((src, out))
+    if items:
+        check(_L.hnd_scale_boxes(arr, len(items), stream_ptr()), 'hnd_scale_boxes')
+    return [o for _, o in outs]
+
+
 # bench.py's hbm_roofline: HIP events (torch's current stream == the launch stream) around the HBM-bound launches
 # that do not go through an engine plan entry, with the bytes each of them must move
 HBM_PROFILE = {'enabled': False, 'records': []}

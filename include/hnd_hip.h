@@ -195,6 +195,17 @@ typedef struct hnd_image_desc {
 int hnd_transform_images(const hnd_image_desc* imgs, int count, float* dst, int hp, int wp, const float mean[3],
                          const float std[3], void* stream);
 
+/* Ground-truth boxes of the batch rescaled with the images (src/models/org/rcnn.py:50-53 resize_boxes: x * (new_w /
+ * old_w), y * (new_h / old_h) in fp32), every image of the list in ONE launch: dst[j] = src[j] * (j odd ? scale_h :
+ * scale_w) for the 4*k floats of each image.  dst may equal src. */
+typedef struct hnd_boxes_desc {
+  const float* src;
+  float* dst;
+  int32_t k;
+  float scale_w, scale_h;
+} hnd_boxes_desc;
+int hnd_scale_boxes(const hnd_boxes_desc* items, int count, void* stream);
+
 /* ---- Winograd F(tile x tile, 3x3), tile = 2, 4 or 6, for stride-1 pad-1 3x3 convolutions (torchvision Bottleneck.conv2
  * and the FPN output convs built at src/models/org/rcnn.py:391-414; forward and data gradient) ----------------------
  * y = out_transform( GEMM_f( in_transform(x), U_f ) ), f = 0..(tile+2)^2-1, with all GEMMs issued as ONE

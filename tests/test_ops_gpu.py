@@ -1200,3 +1200,23 @@ def test_jpeg_codec_and_data_logger_follow_the_reference(tmp_path):
     assert 3 * 51 * 68 / 1024 < quant[0] < 3 * 51 * 68 / 1024 + 1.5             # uint8 payload + a small header
     log.clear()
     assert log.get_data() == ([], [], [], [])
+
+
+def test_batched_box_rescale_equals_the_reference_expression_bitwise(ops):
+    """reference src/models/org/rcnn.py:50-53 resize_boxes: stack(xmin * rw, ymin * rh, xmax * rw, ymax * rh) per image
+    (fp32 tensor times a Python float) -- hnd_scale_boxes does the whole batch in one launch and must give the same
+    bits, including an image without boxes and a non-contiguous view."""
+    from hnd_ghnd_object_detectors_amd.models.org.rcnn import resize_boxes
+    g = gen(9)
+    items, refs = [], []
+    for k, (oh, ow, nh, nw) in zip((5, 0, 33, 1, 700), ((480, 640, 800, 1066), (375, 500, 800, 1066), (640, 427, 1199, 800),
+                                                        (333, 500, 800, 1201), (500, 500, 1333, 1333))):
+        bx = (torch.rand(k, 4, generator=g) * 400).to(DEV)
+        if k == 33:
+            bx = (torch.rand(k, 8, generator=g) * 400).to(DEV)[:, ::2]          # a strided view
+        items.append((bx, float(nw) / float(ow), float(nh) / float(oh)))
+        refs.append(resize_boxes(bx, (oh, ow), (nh, nw)))
+    outs = ops.scale_boxes(items)
+    ops.sync_check()
+    for out, ref in zip(outs, refs):
+        assert out.shape == ref.shape and torch.equal(out, ref)
