@@ -36,6 +36,12 @@ class BoxesDesc(C.Structure):
     _fields_ = [('src', vp), ('dst', vp), ('k', C.c_int32), ('scale_w', C.c_float), ('scale_h', C.c_float)]
 
 
+class PackDesc(C.Structure):
+    """struct hnd_pack_desc"""
+    _fields_ = [('src', vp), ('dst', vp)] + [(n, C.c_int32) for n in ('cout', 'cin', 'kh', 'kw', 'transposed', 'chan_pad',
+                                                                      'i0', 'istep', 'ni', 'j0', 'jstep', 'nj')]
+
+
 class WgradDesc(C.Structure):
     """struct hnd_wgrad_desc"""
     _fields_ = [(n, vp) for n in ('x', 'dy', 'dw', 'slabs', 'pro_scale', 'pro_shift')] + \
@@ -62,6 +68,7 @@ _SIGNATURES = {
     'hnd_conv2d_wgrad': (C.c_int, [C.POINTER(WgradDesc), vp]),
     'hnd_pack_weights': (C.c_int, [vp, vp] + [C.c_int] * 12 + [vp]),
     'hnd_scale_packed_k': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]),
+    'hnd_pack_weights_batched': (C.c_int, [C.POINTER(PackDesc), C.c_int, vp]),
     'hnd_fbn_fold': (C.c_int, [vp] * 6 + [C.c_int, C.c_int, C.c_float, vp]),
     'hnd_transform_image': (C.c_int, [vp, C.c_int, C.c_int, vp] + [C.c_int] * 5 + [C.c_float, C.c_float,
                                                                                     c_float_p, c_float_p, vp]),

@@ -32,26 +32,38 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 }
 
 // ------------------------------------------------------------------------------------ pack / fold
-__global__ void pack_weights_kernel(const float* __restrict__ src, float* __restrict__ dst, int cout, int cin, int kh,
-                                    int kw, int transposed, int chan_pad, int i0, int istep, int ni, int j0,
-                                    int jstep, int nj, int rows_pad, int kdim) {
-  const long long total = (long long)rows_pad * kdim;
-  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
-       e += (long long)gridDim.x * blockDim.x) {
-    const int k = (int)(e % kdim);
-    const int r = hnd::chan_of_row((int)(e / kdim));        // packed row e / kdim holds this output channel
-    const int tap = k / chan_pad, c = k - tap * chan_pad;
+struct PackArgs {
+  const float* src;
+  float* dst;
+  int cout, cin, kh, kw, transposed, chan_pad, i0, istep, ni, j0, jstep, nj, rows_pad, kdim;
+};
+
+__device__ __forceinline__ void pack_weights_body(const PackArgs& a, int block, int nblocks) {
+  const long long total = (long long)a.rows_pad * a.kdim;
+  for (long long e = block * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)nblocks * blockDim.x) {
+    const int k = (int)(e % a.kdim);
+    const int r = hnd::chan_of_row((int)(e / a.kdim));      // packed row e / kdim holds this output channel
+    const int tap = k / a.chan_pad, c = k - tap * a.chan_pad;
     float v = 0.f;
-    const int rows = transposed ? cin : cout, chans = transposed ? cout : cin;
-    if (r < rows && c < chans && tap < ni * nj) {
-      const int a = tap / nj, b = tap - a * nj;
-      const int i = i0 + a * istep, j = j0 + b * jstep;
-      const int o = transposed ? c : r, ic = transposed ? r : c;
-      v = src[(((size_t)o * cin + ic) * kh + i) * kw + j];
+    const int rows = a.transposed ? a.cin : a.cout, chans = a.transposed ? a.cout : a.cin;
+    if (r < rows && c < chans && tap < a.ni * a.nj) {
+      const int ta = tap / a.nj, tb = tap - ta * a.nj;
+      const int i = a.i0 + ta * a.istep, j = a.j0 + tb * a.jstep;
+      const int o = a.transposed ? c : r, ic = a.transposed ? r : c;
+      v = a.src[(((size_t)o * a.cin + ic) * a.kh + i) * a.kw + j];
     }
-    dst[e] = v;
+    a.dst[e] = v;
   }
 }
+
+__global__ void pack_weights_kernel(const PackArgs a) { pack_weights_body(a, blockIdx.x, gridDim.x); }
+
+// several operands in one launch (blockIdx.y = operand): the trainable head re-packs ~28 small operands every step
+constexpr int kMaxBatchPacks = 32;
+struct PackBatch {
+  PackArgs op[kMaxBatchPacks];
+};
+__global__ void pack_weights_batch_kernel(const PackBatch b) { pack_weights_body(b.op[blockIdx.y], blockIdx.x, gridDim.x); }
 
 __global__ void fbn_fold_kernel(const float* w, const float* b, const float* mean, const float* var, float* scale,
                                 float* shift, int c, int cs, float eps) {
@@ -125,15 +137,17 @@ __global__ void transform_kernel(const TransformArgs a) {
 }
 
 // The whole batch in one launch (blockIdx.y = image): 16 launches of 18 us each were launch-bound (1.7 TB/s).
+// One instantiation per source type and the per-image arguments taken BY VALUE: with both types behind a run-time branch
+// (or the arguments by reference into the array) hipcc contracts the interpolation into different fma chains than in
+// the one-image kernel -- 1 ulp apart, which the few-step training goldens of the neural filter amplify past their 1e-3.
 constexpr int kMaxBatchImages = 32;
 struct TransformBatch {
   TransformArgs img[kMaxBatchImages];
-  unsigned u8_mask;          // bit i: image i is a uint8 source
 };
+template <bool U8>
 __global__ void transform_batch_kernel(const TransformBatch b) {
-  const TransformArgs& a = b.img[blockIdx.y];
-  if ((b.u8_mask >> blockIdx.y) & 1) transform_body<true>(a, blockIdx.x, gridDim.x);
-  else transform_body<false>(a, blockIdx.x, gridDim.x);
+  const TransformArgs a = b.img[blockIdx.y];
+  transform_body<U8>(a, blockIdx.x, gridDim.x);
 }
 
 // Ground-truth boxes [k][4] (x1, y1, x2, y2) of every image of the batch rescaled in one launch (blockIdx.y = image):
@@ -592,21 +606,52 @@ __global__ void roundtrip_f16_kernel(float* x, long long n) {
 // ======================================================================================== C ABI
 extern "C" {
 
+static int pack_args(const hnd_pack_desc& p, PackArgs& a, const char* who, int idx) {
+  HND_REQUIRE(p.src && p.dst, "%s: operand %d: null pointer", who, idx);
+  HND_REQUIRE(p.cout > 0 && p.cin > 0 && p.kh > 0 && p.kw > 0 && p.ni > 0 && p.nj > 0 && p.istep > 0 && p.jstep > 0,
+              "%s: operand %d: bad geometry", who, idx);
+  HND_REQUIRE(p.i0 >= 0 && p.i0 + (p.ni - 1) * p.istep < p.kh && p.j0 >= 0 && p.j0 + (p.nj - 1) * p.jstep < p.kw,
+              "%s: operand %d: tap sub-grid outside the kernel", who, idx);
+  const int chans = p.transposed ? p.cout : p.cin, rows = p.transposed ? p.cin : p.cout;
+  HND_REQUIRE(p.chan_pad >= chans, "%s: operand %d: chan_pad < channels", who, idx);
+  a.src = p.src; a.dst = p.dst;
+  a.cout = p.cout; a.cin = p.cin; a.kh = p.kh; a.kw = p.kw; a.transposed = p.transposed; a.chan_pad = p.chan_pad;
+  a.i0 = p.i0; a.istep = p.istep; a.ni = p.ni; a.j0 = p.j0; a.jstep = p.jstep; a.nj = p.nj;
+  a.rows_pad = (rows + 63) / 64 * 64;
+  a.kdim = (p.ni * p.nj * p.chan_pad + 31) / 32 * 32;
+  return HND_OK;
+}
+
 int hnd_pack_weights(const float* src, float* dst, int cout, int cin, int kh, int kw, int transposed, int chan_pad,
                      int i0, int istep, int ni, int j0, int jstep, int nj, void* stream) {
-  HND_REQUIRE(src && dst, "hnd_pack_weights: null pointer");
-  HND_REQUIRE(cout > 0 && cin > 0 && kh > 0 && kw > 0 && ni > 0 && nj > 0 && istep > 0 && jstep > 0,
-              "hnd_pack_weights: bad geometry");
-  HND_REQUIRE(i0 >= 0 && i0 + (ni - 1) * istep < kh && j0 >= 0 && j0 + (nj - 1) * jstep < kw,
-              "hnd_pack_weights: tap sub-grid outside the kernel");
-  const int chans = transposed ? cout : cin, rows = transposed ? cin : cout;
-  HND_REQUIRE(chan_pad >= chans, "hnd_pack_weights: chan_pad < channels");
-  const int rows_pad = (rows + 63) / 64 * 64;
-  const int kdim = (ni * nj * chan_pad + 31) / 32 * 32;
-  hipLaunchKernelGGL(pack_weights_kernel, dim3(grid_for((long long)rows_pad * kdim)), dim3(256), 0,
-                     hnd::as_stream(stream), src, dst, cout, cin, kh, kw, transposed, chan_pad, i0, istep, ni, j0,
-                     jstep, nj, rows_pad, kdim);
+  const hnd_pack_desc p{src, dst, cout, cin, kh, kw, transposed, chan_pad, i0, istep, ni, j0, jstep, nj};
+  PackArgs a;
+  int rc = pack_args(p, a, "hnd_pack_weights", 0);
+  if (rc) return rc;
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(grid_for((long long)a.rows_pad * a.kdim)), dim3(256), 0,
+                     hnd::as_stream(stream), a);
   return hnd::check_launch("hnd_pack_weights");
+}
+
+int hnd_pack_weights_batched(const hnd_pack_desc* ops_, int count, void* stream) {
+  HND_REQUIRE(ops_ && count > 0, "hnd_pack_weights_batched: bad arguments");
+  for (int i0 = 0; i0 < count; i0 += kMaxBatchPacks) {
+    const int nb = count - i0 < kMaxBatchPacks ? count - i0 : kMaxBatchPacks;
+    PackBatch b;
+    long long most = 0;
+    for (int k = 0; k < nb; ++k) {
+      int rc = pack_args(ops_[i0 + k], b.op[k], "hnd_pack_weights_batched", i0 + k);
+      if (rc) return rc;
+      const long long t = (long long)b.op[k].rows_pad * b.op[k].kdim;
+      if (t > most) most = t;
+    }
+    int bx = grid_for(most);
+    if (bx > 1024) bx = 1024;
+    hipLaunchKernelGGL(pack_weights_batch_kernel, dim3(bx, nb), dim3(256), 0, hnd::as_stream(stream), b);
+    int rc = hnd::check_launch("hnd_pack_weights_batched");
+    if (rc) return rc;
+  }
+  return HND_OK;
 }
 
 int hnd_scale_packed_k(float* packed, int rows_pad, int kdim, int ntaps, int chan_pad, const float* scale, int nscale,
@@ -669,30 +714,38 @@ int hnd_transform_image_u8(const uint8_t* src, int h, int w, int hwc, int flip, 
 int hnd_transform_images(const hnd_image_desc* imgs, int count, float* dst, int hp, int wp, const float mean[3],
                          const float std[3], void* stream) {
   HND_REQUIRE(imgs && dst && mean && std && count > 0 && hp > 0 && wp > 0, "hnd_transform_images: bad arguments");
-  for (int i0 = 0; i0 < count; i0 += kMaxBatchImages) {
-    const int nb = count - i0 < kMaxBatchImages ? count - i0 : kMaxBatchImages;
+  int bx = grid_for((long long)hp * wp);
+  if (bx > 2048) bx = 2048;
+  for (int u8 = 0; u8 < 2; ++u8) {                      // one launch per source type present (normally one in total)
     TransformBatch b;
-    b.u8_mask = 0;
-    for (int k = 0; k < nb; ++k) {
-      const hnd_image_desc& im = imgs[i0 + k];
+    int nb = 0;
+    auto flush = [&]() -> int {
+      if (nb == 0) return HND_OK;
+      if (u8) hipLaunchKernelGGL(transform_batch_kernel<true>, dim3(bx, nb), dim3(256), 0, hnd::as_stream(stream), b);
+      else hipLaunchKernelGGL(transform_batch_kernel<false>, dim3(bx, nb), dim3(256), 0, hnd::as_stream(stream), b);
+      nb = 0;
+      return hnd::check_launch("hnd_transform_images");
+    };
+    for (int i = 0; i < count; ++i) {
+      const hnd_image_desc& im = imgs[i];
+      if ((im.is_u8 != 0) != (u8 != 0)) continue;
       HND_REQUIRE(im.src && im.h > 0 && im.w > 0 && im.out_h > 0 && im.out_w > 0 && im.out_h <= hp && im.out_w <= wp,
-                  "hnd_transform_images: image %d: bad geometry (out %dx%d, padded %dx%d)", i0 + k, im.out_h, im.out_w, hp,
-                  wp);
-      TransformArgs& a = b.img[k];
-      a.src = im.is_u8 ? nullptr : (const float*)im.src;
-      a.src8 = im.is_u8 ? (const uint8_t*)im.src : nullptr;
+                  "hnd_transform_images: image %d: bad geometry (out %dx%d, padded %dx%d)", i, im.out_h, im.out_w, hp, wp);
+      TransformArgs& a = b.img[nb++];
+      a.src = u8 ? nullptr : (const float*)im.src;
+      a.src8 = u8 ? (const uint8_t*)im.src : nullptr;
       a.hwc = im.hwc != 0;
       a.flip = im.flip != 0;
-      a.dst = dst + (size_t)(i0 + k) * hp * wp * 4;
+      a.dst = dst + (size_t)i * hp * wp * 4;
       a.h = im.h; a.w = im.w; a.out_h = im.out_h; a.out_w = im.out_w; a.hp = hp; a.wp = wp;
       a.rh = im.scale_h; a.rw = im.scale_w;
       for (int c = 0; c < 3; ++c) { a.mean[c] = mean[c]; a.std[c] = std[c]; a.inv_unused[c] = 0.f; }
-      if (im.is_u8) b.u8_mask |= 1u << k;
+      if (nb == kMaxBatchImages) {
+        int rc = flush();
+        if (rc) return rc;
+      }
     }
-    int bx = grid_for((long long)hp * wp);
-    if (bx > 2048) bx = 2048;
-    hipLaunchKernelGGL(transform_batch_kernel, dim3(bx, nb), dim3(256), 0, hnd::as_stream(stream), b);
-    int rc = hnd::check_launch("hnd_transform_images");
+    int rc = flush();
     if (rc) return rc;
   }
   return HND_OK;

@@ -298,7 +298,14 @@ class TransformEngine(object):
                     src = img if (img.is_contiguous() and img.dtype == torch.float32) else img.float().contiguous()
                     items.append((src, False, False, False, oh, ow, 1.0 / scale, 1.0 / scale))
                 keep.append(src)
-            ops.transform_images(items, batch, self.mean, self.std)      # one launch for the whole batch
+            if os.environ.get('HND_TRANSFORM_BATCH', '1') != '0':
+                ops.transform_images(items, batch, self.mean, self.std)      # one launch for the whole batch
+            else:                                                            # (A/B: one launch per image)
+                for i, (src, is_u8, hwc, flip, oh, ow, rh, rw) in enumerate(items):
+                    if is_u8:
+                        ops.transform_image_u8(src, batch, i, oh, ow, rh, rw, self.mean, self.std, hwc, flip)
+                    else:
+                        ops.transform_image(src, batch, i, oh, ow, rh, rw, self.mean, self.std)
             self.last_key = key
         self.last_scales = [p[2] for p in plans]
         return batch, [(p[3], p[4]) for p in plans]
@@ -569,12 +576,16 @@ class HeadEngine(object):
     def forward(self, x, training, codec=None):
         if self.bufs is None:
             self.bufs = Buffers(x.device)
-        for hc in self.layers:
-            if hc.wino is not None:         # (packs are made by the plan, for the tile its geometry picks)
-                hc.wino.refresh(force=training)
-            if not hc.wino_f:
-                hc.wc.get(False, hc.cs_in)
-            hc.wc.refresh(force=training)            # forward / transposed / wgrad-side packs, whichever were made
+        ops.pack_batch_begin()              # the ~28 operand re-packs of a training step go out as one launch
+        try:
+            for hc in self.layers:
+                if hc.wino is not None:         # (packs are made by the plan, for the tile its geometry picks)
+                    hc.wino.refresh(force=training)
+                if not hc.wino_f:
+                    hc.wc.get(False, hc.cs_in)
+                hc.wc.refresh(force=training)            # forward / transposed / wgrad-side packs, whichever were made
+        finally:
+            ops.pack_batch_end()
         ptrs = tuple(t.data_ptr() for hc in self.layers
                      for t in (hc.bn.weight, hc.bn.bias, hc.bn.running_mean, hc.bn.running_var))
         key = (x.data_ptr(), tuple(x.shape), training, ptrs)

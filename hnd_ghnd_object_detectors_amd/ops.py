@@ -51,12 +51,36 @@ class PackedWeight(object):
     __slots__ = ('buf', 'rows', 'kdim', 'ni', 'nj', 'chan_pad', 'chan_real', 'src', 'args', 'kscale')
 
     def repack(self):
+        if PACK_BATCH['open'] and getattr(self, 'kscale', None) is None:
+            PACK_BATCH['items'].append(self)        # flushed as ONE launch by pack_batch_end()
+            return
         check(_L.hnd_pack_weights(self.src.data_ptr(), self.buf.data_ptr(), *self.args, stream_ptr()),
               'hnd_pack_weights')
         if getattr(self, 'kscale', None) is not None:       # a per-channel scale of the K operand folded into the weights
             check(_L.hnd_scale_packed_k(self.buf.data_ptr(), round_up(self.rows, 64), self.kdim, self.ni * self.nj,
                                         self.chan_pad, self.kscale.data_ptr(), min(self.kscale.numel(), self.chan_pad),
                                         stream_ptr()), 'hnd_scale_packed_k')
+
+
+# A caller that refreshes many small operands in a row (the trainable head after every optimizer step) brackets the loop
+# with pack_batch_begin() / pack_batch_end(): the repack() calls in between are collected into one batched launch.
+PACK_BATCH = {'open': False, 'items': []}
+
+
+def pack_batch_begin():
+    PACK_BATCH['open'], PACK_BATCH['items'] = os.environ.get('HND_PACK_BATCH', '1') != '0', []
+
+
+def pack_batch_end():
+    from ._lib import PackDesc
+    items, PACK_BATCH['open'], PACK_BATCH['items'] = PACK_BATCH['items'], False, []
+    if not items:
+        return
+    arr = (PackDesc * len(items))()
+    for d, pw in zip(arr, items):
+        d.src, d.dst = pw.src.data_ptr(), pw.buf.data_ptr()
+        (d.cout, d.cin, d.kh, d.kw, d.transposed, d.chan_pad, d.i0, d.istep, d.ni, d.j0, d.jstep, d.nj) = pw.args
+    check(_L.hnd_pack_weights_batched(arr, len(items), stream_ptr()), 'hnd_pack_weights_batched')
 
 
 def pack_weights(w, transposed=False, chan_pad=None, taps=None, kscale=None):

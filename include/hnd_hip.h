@@ -154,6 +154,15 @@ int hnd_conv2d_wgrad(const hnd_wgrad_desc* desc, void* stream);
 int hnd_pack_weights(const float* src, float* dst, int cout, int cin, int kh, int kw, int transposed,
                      int chan_pad, int i0, int istep, int ni, int j0, int jstep, int nj, void* stream);
 
+/* Several operands in one launch (same layouts as hnd_pack_weights): the trainable head re-packs its forward,
+ * transposed and tap-subset operands after every optimizer step. */
+typedef struct hnd_pack_desc {
+  const float* src;
+  float* dst;
+  int32_t cout, cin, kh, kw, transposed, chan_pad, i0, istep, ni, j0, jstep, nj;
+} hnd_pack_desc;
+int hnd_pack_weights_batched(const hnd_pack_desc* ops, int count, void* stream);
+
 /* packed[r][tap*chan_pad + c] *= scale[c] for c < nscale, all rows_pad rows and ntaps taps of an operand made by
  * hnd_pack_weights: folds a per-channel scale of the GEMM's K operand into the weights.  Used for the data gradient
  * through a frozen conv + FrozenBatchNorm2d: W^T (dy * s) == (W^T diag(s)) dy, so the launch needs no prologue. */

@@ -32,6 +32,7 @@ def test_ctypes_structs_match_header_layout():
     assert ctypes.sizeof(_lib.MsePair) == 3 * 8 + 8 + 4 + 4
     assert ctypes.sizeof(_lib.ImageDesc) == 8 + 7 * 4 + 2 * 4 + 4        # hnd_image_desc (padded to 8)
     assert ctypes.sizeof(_lib.BoxesDesc) == 2 * 8 + 4 + 2 * 4 + 4          # hnd_boxes_desc (padded to 8)
+    assert ctypes.sizeof(_lib.PackDesc) == 2 * 8 + 12 * 4                  # hnd_pack_desc
 
 
 def test_invalid_arguments_are_reported_not_thrown():
