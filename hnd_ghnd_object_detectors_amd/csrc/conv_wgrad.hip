@@ -217,7 +217,15 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __re
   const size_t stride = (size_t)co_pad * ncols_pad;
   float s = 0.f;
   if (ok)
-    for (int k = q; k < splitk; k += 4) s += slabs[off + k * stride];
+    {
+      int k = q;
+      for (; k + 12 < splitk; k += 16) {        // four loads in flight, added in the original order
+        const float a0 = slabs[off + k * stride], a1 = slabs[off + (k + 4) * stride];
+        const float a2 = slabs[off + (k + 8) * stride], a3 = slabs[off + (k + 12) * stride];
+        s += a0; s += a1; s += a2; s += a3;
+      }
+      for (; k < splitk; k += 4) s += slabs[off + k * stride];
+    }
   red[q][lane] = s;
   __syncthreads();
   if (q == 0 && ok) {

@@ -273,7 +273,20 @@ __global__ void __launch_bounds__(1024) bn_finalize_kernel(const float* __restri
   const int ch = blockIdx.x * 16 + cl;
   double s1 = 0.0, s2 = 0.0;
   if (ch < c) {
-    for (int t = wave * 4 + ts; t < ntiles; t += 64) {
+    // eight loads in flight per lane (the grid is only c / 16 blocks: the loop ran at the memory latency), added in
+    // the original order
+    int t = wave * 4 + ts;
+    for (; t + 3 * 64 < ntiles; t += 4 * 64) {
+      float a[4], b[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        a[u] = partials[((size_t)(t + u * 64) * 2 + 0) * cs + ch];
+        b[u] = partials[((size_t)(t + u * 64) * 2 + 1) * cs + ch];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { s1 += (double)a[u]; s2 += (double)b[u]; }
+    }
+    for (; t < ntiles; t += 64) {
       s1 += (double)partials[((size_t)t * 2 + 0) * cs + ch];
       s2 += (double)partials[((size_t)t * 2 + 1) * cs + ch];
     }
