@@ -256,8 +256,9 @@ __device__ __forceinline__ void ring_wait(f32x4& a0, f32x4& a1, f32x4& a2, f32x4
 }
 
 // RES: the epilogue adds `res1` (identity / downsample sum of a Bottleneck, or the nearest-upsampled FPN top-down map):
-// its 16 rows per tile are requested during the tile's LAST k group into registers of their own and consumed, like the
-// accumulators, during the next tile's first k group.
+// its 16 rows per tile are requested over the tile's k groups KG-8 .. KG-5 -- asm loads into AGPRs in the same in-order
+// stream as the ring, released by hand-counted waits -- and consumed, like the accumulators, during the next tile's
+// first k group.
 // NI = 16-column accumulator tiles per wave (4: the 64-column wave tile; 2: a 32-column one, so that a K = 1024 slice
 // of 32 columns still fits the LDS: the layer3 / layer4 1x1 convs with M of only 16 800 / 67 200 pixels).
 template <int WN, int KQ, bool PRO, bool RES, int NI = 4>
@@ -406,6 +407,11 @@ __global__ void __launch_bounds__(256, 1) bres2_kernel(const hnd_conv_desc d, co
                   pbn = *(const f32x4*)(pro + K + kn * 16 + g4 * 4);
                 }
               }
+              // the previous tile's residual rows of row group mi: requested at its k group KG-8+mi; since then the
+              // wave has issued 3 + 8 (3 - mi) + 16 + mi loads, so "at most 43 - 7 mi outstanding" means they have landed
+              if constexpr (RES && g == 0) {
+                if (s == 0) ring_wait<43 - 7 * mi, true>(resv[mi][0], resv[mi][1], resv[mi][2], resv[mi][3]);
+              }
               if (g == 0 && have_out) {              // row 4*g4 + s of row group mi of the previous tile
                 vecn v;
 #pragma unroll
@@ -416,13 +422,17 @@ __global__ void __launch_bounds__(256, 1) bres2_kernel(const hnd_conv_desc d, co
                 }
                 *(vecn*)(d.y + (size_t)(unsigned)prow[mi * 16 + 4 * g4 + s] * (unsigned)d.ldc + col0) = v;
               }
-              // this tile's residual rows, consumed one tile later: four per k group over the last four k groups (a
-              // single k group of lead -- 2048 cycles -- is less than the memory latency under load: measured slower)
-              if constexpr (RES && g >= KG - 4 && mi == 1) {
-                constexpr int q = g - (KG - 4);
-                if (full)
-                  resv[q][s] = *(const f32x4*)(d.res1 + (size_t)(unsigned)rowoff[64 + q * 16 + 4 * g4 + s] *
-                                                            (unsigned)d.ldc + col0);
+              // this tile's residual rows, consumed one tile later: four per k group over k groups KG-8 .. KG-5, as asm
+              // loads in the ring's own in-order stream.  (As compiler-visible loads hipcc waited for them with counts
+              // that ignore the asm loads in flight -- `vmcnt(3)` drained the whole ring behind them: 104 TF against
+              // the tiled kernel's 112.)  Always issued, whatever the tile: the hand-counted waits below need every
+              // wave to have the same number of loads in flight (rows beyond M read pixel 0).  They land in the
+              // accumulator half of the register file: into architectural VGPRs hipcc copied the (not yet landed)
+              // values to AGPRs on the spot.
+              if constexpr (RES && g >= KG - 8 && g < KG - 4 && mi == 1) {
+                constexpr int q = g - (KG - 8);
+                ring_load<0, true>(resv[q][s], d.res1 + (size_t)(unsigned)rowoff[64 + q * 16 + 4 * g4 + s] *
+                                                               (unsigned)d.ldc + col0);
               }
               __builtin_amdgcn_sched_barrier(0);
             }
@@ -605,10 +615,11 @@ int bres_variant(const hnd_conv_desc& d) {
     // (8 VALU per A fragment beside a single wave's MFMAs) does not, and K = 512 needs >= 48 chunks per team
     const bool spills = (d.pro_scale || d.res1) && d.kdim == 512;      // those two builds do not fit 512 registers
     if (getenv("HND_BRES_ALL") && !spills) return 2 + wn;
-    // the residual build (RES) is bit-exact but slower than the tiled kernel's three co-resident blocks wherever it was
-    // tried (256->1024 @50x84 + res: 104 vs 112 TF; 128->512 @100x168 + res: 81 vs 94): hipcc's own counted waits for the
-    // residual loads also retire the asm ring loads queued behind them.  Kept for the A/B tool and the tests only.
-    if (!d.pro_scale && !d.res1 && !spills && per_team >= (d.w_group_rows > 0 || d.kdim == 512 ? 48 : 8)) return 2 + wn;
+    // the residual build (RES): its rows travel as asm loads in the ring's own in-order stream with hand-counted
+    // waits (as compiler-visible loads they drained the ring once per tile and lost to the tiled kernel, 104 vs 112 TF).
+    // Measured (tools/bench_bres.py): 256->256 @200x336 + upsampled residual 109 -> 123 TF, 128->512 @100x168 + res
+    // 95 -> 102, 256->1024 @50x84 + res 112 -> 116.  K = 512 with a residual spills and stays on the 8-wave kernel.
+    if (!d.pro_scale && !spills && per_team >= (d.w_group_rows > 0 || d.kdim == 512 ? 48 : 8)) return 2 + wn;
   }
   if (per_team < 2ll * (8 / wn)) return 0;              // every wave row gets at least two chunks
   if (!getenv("HND_BRES_ALL")) {
