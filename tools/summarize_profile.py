@@ -20,9 +20,10 @@ def short(name):
     if m:
         base = ('igemm_c4_%sx%s' if m.group(4) == 'true' else 'igemm_%sx%s') % (m.group(1), m.group(2))
         return base + ('[bn-prologue]' if m.group(5) == 'true' and FULLNAMES else '')
-    m = re.search(r'bres(2?)_kernel<(\d+), (\d+), (true|false)(?:, (?:true|false))?(?:, \d+)?>', name)
+    m = re.search(r'bres(2?)_kernel<(\d+), (\d+), (true|false)(?:, (true|false))?(?:, \d+)?>', name)
     if m:           # B-resident persistent GEMM (conv_bres.hip): wave columns -> width of the resident weight slice
-        return 'bres%s_%d' % (m.group(1), 64 * int(m.group(2))) + ('[prologue]' if m.group(4) == 'true' and FULLNAMES else '')
+        tag = ('[prologue]' if m.group(4) == 'true' else '') + ('[res]' if m.group(5) == 'true' else '')
+        return 'bres%s_%d' % (m.group(1), 64 * int(m.group(2))) + (tag if FULLNAMES else '')
     m = re.search(r'bstream_kernel<(\d+), (true|false), (true|false)>', name)
     if m:           # B-streamed persistent GEMM (conv_bstream.hip)
         return 'bstream_%d' % (64 * int(m.group(1))) + (('[prologue]' if m.group(2) == 'true' else '') +
