@@ -55,6 +55,10 @@ def parse():
     ap.add_argument('--dist_backend', default='nccl', help="'nccl' (= RCCL); 'gloo' only to exercise the multi-rank "
                     "code path on a single-GPU box together with --share_device")
     ap.add_argument('--share_device', action='store_true', help='testing: every rank uses cuda:0')
+    ap.add_argument('--rank_timeout_s', type=int, default=1500, help='self-launched ranks (--gpus N, no RANK in the '
+                    'environment): wall-clock limit after which the launcher kills its children and exits non-zero')
+    ap.add_argument('--ref_1gpu_img_s', type=float, default=None, help='a --gpus 1 value of the same build on the same '
+                    'node: the line then carries scaling_efficiency = value / (N * this)')
     ap.add_argument('--detail', default=None, help='write the per-launch table of the profiled step to this file')
     return ap.parse_args()
 
@@ -66,12 +70,37 @@ def free_port():
         return sk.getsockname()[1]
 
 
+def visible_gpu_count():
+    """GPUs this process would see, WITHOUT loading torch or touching HIP: KFD topology nodes with SIMDs, narrowed by
+    HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES when one is set.  None when the topology cannot
+    be read (the caller then asks torch)."""
+    try:
+        top = '/sys/class/kfd/kfd/topology/nodes'
+        n = 0
+        for node in os.listdir(top):
+            props = dict(l.split() for l in open(os.path.join(top, node, 'properties')) if len(l.split()) == 2)
+            n += int(props.get('simd_count', 0)) > 0
+    except (OSError, ValueError):
+        return None
+    for var in ('ROCR_VISIBLE_DEVICES', 'HIP_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+        val = os.environ.get(var)
+        if val is not None:
+            n = min(n, len([v for v in val.split(',') if v.strip() != '']))
+    return n
+
+
 def launch_ranks(args):
-    """--gpus N without a launcher: become one.  The parent makes no HIP call (torch.cuda.device_count() does not
-    initialise the runtime on this image) and execs nothing: the ranks are plain child processes."""
+    """--gpus N without a launcher: become one.  The parent makes no HIP call (GPUs are counted from sysfs) and execs
+    nothing: the ranks are plain child processes, ALL of them watched while rank 0's output is drained -- the first
+    rank to fail starts a 60 s deadline for its siblings (they would otherwise sit in a rendezvous / collective until
+    the process-group timeout), and --rank_timeout_s bounds the whole run; on either the parent kills the CHILDREN it
+    started (by pid) and exits non-zero."""
     import subprocess
-    import torch
-    have = torch.cuda.device_count()
+    import threading
+    have = visible_gpu_count()
+    if have is None:
+        import torch            # (device_count() does not initialise HIP on this image)
+        have = torch.cuda.device_count()
     if have < args.gpus and not args.share_device:
         sys.stderr.write('bench.py: --gpus %d but this node exposes %d GPU(s); refusing to report a %d-GPU number '
                          '(--share_device puts every rank on cuda:0 for plumbing tests only)\n'
@@ -91,24 +120,36 @@ def launch_ranks(args):
             env['HND_DEFER_FPN'] = '0'
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    raw = procs[0].stdout.read().decode()      # rank 0 prints the JSON line; native libraries (gloo, RCCL
-    line = ''.join(l + '\n' for l in raw.splitlines() if l.startswith('{"metric"'))      # debug) may add their own
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    t_end = time.time() + args.rank_timeout_s
+    codes, why = [None] * len(procs), None
+    while any(c is None for c in codes):
+        for r, pr in enumerate(procs):
+            if codes[r] is None:
+                codes[r] = pr.poll()
+                if codes[r] not in (None, 0) and why is None:
+                    why = 'rank %d exited with %d' % (r, codes[r])
+                    t_end = min(t_end, time.time() + float(os.environ.get('HND_BENCH_SIBLING_GRACE_S', '60')))
+        if time.time() > t_end:
+            why = why or ('no result after --rank_timeout_s %d' % args.rank_timeout_s)
+            for r, pr in enumerate(procs):
+                if codes[r] is None:
+                    pr.kill()
+                    codes[r] = pr.wait()
+            break
+        time.sleep(0.2)
+    reader.join(timeout=10.0)
+    raw = (chunks[0] if chunks else b'').decode(errors='replace')      # rank 0 prints the JSON line; native libraries
+    line = ''.join(l + '\n' for l in raw.splitlines() if l.startswith('{"metric"'))     # (gloo, RCCL debug) may add theirs
     sys.stderr.write(''.join(l + '\n' for l in raw.splitlines() if l.strip() and not l.startswith('{"metric"')))
-    codes, deadline = [], None
-    for r, pr in enumerate(procs):
-        try:
-            codes.append(pr.wait(timeout=None if deadline is None else max(1.0, deadline - time.time())))
-        except subprocess.TimeoutExpired:      # a rank outlived a failed sibling by a minute: stop THAT pid
-            pr.kill()
-            codes.append(pr.wait())
-        if codes[-1] != 0 and deadline is None:
-            deadline = time.time() + 60.0
-    sys.stdout.write(line)
-    sys.stdout.flush()
     bad = [c for c in codes if c != 0]
     if bad:
-        sys.stderr.write('bench.py: rank exit codes %s\n' % codes)
+        sys.stderr.write('bench.py: %s; rank exit codes %s -- no line reported\n' % (why, codes))
         return bad[0] if bad[0] > 0 else 1
+    sys.stdout.write(line)
+    sys.stdout.flush()
     return 0
 
 
@@ -204,7 +245,11 @@ def run_rank(args):
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     if world != args.gpus:
         raise SystemExit('WORLD_SIZE=%d but --gpus %d: the line would be mislabelled' % (world, args.gpus))
+    if os.environ.get('HND_BENCH_FAIL_RANK') == str(rank):      # tests: a rank that dies before the rendezvous
+        raise SystemExit(3)
     affinity = gpu_cpu_affinity(0 if args.share_device else local_rank) if world > 1 else 'unbound (single rank)'
+    # dmabuf IPC (RCCL needs it on this pool), also when the ranks come from torch.distributed.run: before any HIP call
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     import torch
     import torch.distributed as dist
     if not args.share_device and torch.cuda.device_count() < world:
@@ -302,12 +347,18 @@ def run_rank(args):
     last = first
     for _ in range(args.warmup - 1):
         last = step()
+    if world > 1:
+        student_w.timing = True
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
         last = step()
     fence()
     elapsed = time.perf_counter() - t0
+    exchange_ms = None
+    if world > 1:
+        student_w.timing = False
+        exchange_ms = student_w.exchange_ms()
     rank_ms = [elapsed / args.steps * 1e3]
     if world > 1:
         t = torch.zeros(world, dtype=torch.float64, device=dev)
@@ -315,6 +366,12 @@ def run_rank(args):
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         rank_ms = [round(v / args.steps * 1e3, 3) for v in t.tolist()]
         elapsed = float(t.max().item())                          # MAX over ranks
+    exchange_ms_ranks = None
+    if world > 1:
+        t = torch.zeros(world, dtype=torch.float64, device=dev)
+        t[rank] = exchange_ms or 0.0
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        exchange_ms_ranks = [round(v, 4) for v in t.tolist()]
     rccl_ranks = dist.get_world_size() if (world > 1 and dist.get_backend() == 'nccl') else (1 if world == 1 else 0)
     exchange = 'none (1 rank)'
     if world > 1:
@@ -471,9 +528,18 @@ def run_rank(args):
         'head2x2_roofline': head2x2,
         'loss_check': loss_check,
         'ranks': {'world': world, 'rccl_ranks': rccl_ranks, 'backend': dist.get_backend() if world > 1 else None,
-                  'ms_per_step_per_rank': rank_ms, 'exchange': exchange, 'rank0_affinity': affinity,
+                  'ms_per_step_per_rank': rank_ms,
+                  'ms_per_step_spread': round((max(rank_ms) - min(rank_ms)) / max(rank_ms), 4),
+                  'exchange': exchange,
+                  # HIP events on the compute stream of every rank, timed steps only: last gradient kernel done ->
+                  # reduced arena visible to the optimizer launch (the exposed part of the all-reduce); max over ranks
+                  'exchange_ms_per_step': None if exchange_ms_ranks is None else max(exchange_ms_ranks),
+                  'exchange_ms_per_step_per_rank': exchange_ms_ranks, 'rank0_affinity': affinity,
                   'launched_by': 'bench.py' if os.environ.get('HND_BENCH_LAUNCHED') else
                                  ('external launcher' if world > 1 else 'single process')},
+        # the driver computes scaling efficiency itself from the per-N lines; this is only filled when the caller hands
+        # over a --gpus 1 figure of the same build on the same node
+        'scaling_efficiency': (round(value / (world * args.ref_1gpu_img_s), 4) if args.ref_1gpu_img_s else None),
         'run_cfg': run_cfg,
         'host_enqueue_ms_per_step': round(host_enqueue_ms, 3),
         # algorithmic: direct-convolution flops the step stands for / step time -- NOT a roofline fraction (Winograd

@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('HND_LIB_PATH') or os.path.join(_HERE, 'libhnd_hip.so')     # env: kernel experiments
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 c_float_p = C.POINTER(C.c_float)
 vp = C.c_void_p
@@ -60,6 +60,7 @@ _SIGNATURES = {
     'hnd_last_error_string': (C.c_char_p, []),
     'hnd_abi_version': (C.c_int, []),
     'hnd_sync_check': (C.c_int, [vp]),
+    'hnd_relay_timeouts': (C.c_int, [C.c_int]),
     'hnd_device_arch': (C.c_char_p, []),
     'hnd_conv2d_igemm': (C.c_int, [C.POINTER(ConvDesc), vp]),
     'hnd_conv2d_igemm_tile': (C.c_int, [C.POINTER(ConvDesc)]),

@@ -14,6 +14,8 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+int relay_timeouts(int reset);     // conv_bstream.hip
+
 int check_launch(const char* what) {
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) return HND_OK;
@@ -32,10 +34,17 @@ int hnd_abi_version(void) { return HND_ABI_VERSION; }
 int hnd_sync_check(void* stream) {
   hipError_t e = hipStreamSynchronize(hnd::as_stream(stream));
   if (e == hipSuccess) e = hipGetLastError();
+  if (e == hipSuccess && hnd::relay_timeouts(0) != 0) {
+    hnd::set_error("hnd_sync_check: a B-streamed GEMM gave up waiting for a neighbour's partial tile (relay time-out): "
+                   "its output is invalid; hnd_relay_timeouts(1) acknowledges");
+    return HND_ERR_ASYNC;
+  }
   if (e == hipSuccess) return HND_OK;
   hnd::set_error("hnd_sync_check: %s", hipGetErrorString(e));
   return HND_ERR_ASYNC;
 }
+
+int hnd_relay_timeouts(int reset) { return hnd::relay_timeouts(reset); }
 
 size_t hnd_workspace_size(int op, const void* desc, int64_t arg) {
   switch (op) {

@@ -45,8 +45,10 @@ struct BstreamArgs {
   FastDiv div_ow, div_oh;     // m -> (n, oh, ow)
   int mtiles, ntiles;         // tile grid
   int kg8;                    // iterations of 8 k groups (128 k) per tile
-  int dbg;
+  int dbg;                    // HND_BSTREAM_DBG: 1 = no epilogue (timing), 2 = heads never raise their flag (tests the timeout)
+  int spin_limit;             // polls of a relay flag before the wait gives up
   float* relay;               // stream-K relay workspace (hnd_conv2d_igemm_workspace), or null: tiles round-robin
+  int* err;                   // host-visible sticky error word (pinned, mapped): a relay wait that timed out raises it
 };
 
 template <int N, class F, int... I>
@@ -128,7 +130,27 @@ __global__ void __launch_bounds__(256, 1) bstream_kernel(const hnd_conv_desc d, 
     if (lb >= T) return;
     nfull = nseg = (T - lb + G - 1) / G;                // tiles lb, lb + G, ...
   }
-  if (nseg == 0) return;
+  // ---- relay bookkeeping behind the accumulator sets: [G] flags, launch counter, finished-workgroup ticket.
+  // A flag carries the EPOCH of the launch that raised it (counter + 1), never 0 / 1: a reader waits for exactly this
+  // launch's value and nobody resets anything, so a writer that arrives after its reader gave up (see the timeout
+  // below) cannot leave a flag that a later launch on this workspace would mistake for its own.  The counter is advanced
+  // by the last workgroup to finish; every workgroup reads it before it takes its ticket, so all G see one value.
+  float* relay_p = a.relay;                             // [G][16][256] float4 accumulator sets
+  int* relay_f = (int*)(a.relay + (size_t)G * 16384);   // [G] flags, [G] = launch counter, [G + 1] = ticket
+  int epoch = 0;                                        // (thread 0 only)
+  if (a.relay && tid == 0) epoch = __hip_atomic_load(relay_f + G, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+  auto launch_done = [&]() {
+    if (a.relay && tid == 0) {
+      if (__hip_atomic_fetch_add(relay_f + G + 1, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == G - 1) {
+        __hip_atomic_store(relay_f + G + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(relay_f + G, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  };
+  if (nseg == 0) {
+    launch_done();
+    return;
+  }
   auto seg_of = [&](int i, int& tile, int& it0, int& it1, int& kind) {
     i = i < nseg ? i : nseg - 1;
     if (!a.relay) { tile = lb + i * G; it0 = 0; it1 = kg8; kind = FULL; return; }
@@ -276,9 +298,6 @@ __global__ void __launch_bounds__(256, 1) bstream_kernel(const hnd_conv_desc d, 
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) bcur[ni] = *(const f32x4*)(Bs + frow + ni * 16 * 64 + bsw[0]);
 
-  float* relay_p = a.relay;                             // [G][16][256] float4 accumulator sets, then [G] flags
-  int* relay_f = (int*)(a.relay + (size_t)G * 16384);
-
   for (int sg = 0; sg < nseg; ++sg) {
     int tile, it0, it1, kind;
     seg_of(sg, tile, it0, it1, kind);
@@ -304,13 +323,19 @@ __global__ void __launch_bounds__(256, 1) bstream_kernel(const hnd_conv_desc d, 
     if (kind == TAIL) {
       // the head of this tile: accumulators parked by workgroup lb - 1 (which computed them FIRST, see above)
       if (tid == 0) {
-        // (bounded: ~2 s.  The head was computed FIRST by its workgroup, so this does not spin in practice; should the
-        // flag never come -- a workspace that was not zero-filled, a neighbour that faulted -- a wrong tile that the
-        // parity checks see is better than a GPU that never returns)
-        for (int spin = 0; spin < (1 << 21) &&
-                           __hip_atomic_load(relay_f + (lb - 1), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0; ++spin)
+        // Bounded (~2 s): the head was computed FIRST by its workgroup, so this does not spin in practice.  Should the
+        // flag never come (a workspace that was not zero-filled once, a neighbour that faulted or was starved) the
+        // launch must neither hang the GPU nor pass for correct: the wait gives up, raises the host-visible sticky
+        // error word -- every later hnd_conv2d_igemm / hnd_sync_check then fails with HND_ERR_LAUNCH / HND_ERR_ASYNC --
+        // and this tile's output is garbage by declaration.  Nothing is reset here (epoch flags, see above).
+        int spin = 0;
+        while (__hip_atomic_load(relay_f + (lb - 1), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+          if (++spin >= a.spin_limit) {
+            if (a.err) __hip_atomic_store(a.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            break;
+          }
           __builtin_amdgcn_s_sleep(8);
-        __hip_atomic_store(relay_f + (lb - 1), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+        }
       }
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -401,7 +426,7 @@ __global__ void __launch_bounds__(256, 1) bstream_kernel(const hnd_conv_desc d, 
         for (int ni = 0; ni < NI; ++ni) __builtin_nontemporal_store(acc[mi][ni], dst + (mi * NI + ni) * 256);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      if (tid == 0) __hip_atomic_store(relay_f + lb, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      if (tid == 0 && a.dbg != 2) __hip_atomic_store(relay_f + lb, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     } else {
       // ---- epilogue of this tile; the loads of the next segment are already in flight
       const int col0 = nt * BN + wn * 64 + l16 * 4;     // hnd::chan_of_row of the wave's packed rows
@@ -418,6 +443,7 @@ __global__ void __launch_bounds__(256, 1) bstream_kernel(const hnd_conv_desc d, 
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the stream's last (unused) prefetches land before the end
+  launch_done();
 }
 
 int cu_count_() {
@@ -430,6 +456,39 @@ int cu_count_() {
     cached.store(v, std::memory_order_relaxed);
   }
   return v;
+}
+
+// The sticky error word: one int of pinned, device-mapped host memory per process.  A kernel raises it with a
+// system-scope store, the host reads it without touching the GPU.
+std::atomic<int*> g_err_host{nullptr};
+int* g_err_dev = nullptr;
+
+int* relay_error_word() {
+  int* h = g_err_host.load(std::memory_order_acquire);
+  if (h) return h;
+  static std::atomic<bool> busy{false};
+  bool expect = false;
+  if (!busy.compare_exchange_strong(expect, true)) {
+    while (!(h = g_err_host.load(std::memory_order_acquire))) {}
+    return h;
+  }
+  int* hp = nullptr;
+  if (hipHostMalloc((void**)&hp, 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess || !hp) {
+    (void)hipGetLastError();
+    static int fallback = 0;                            // no pinned memory: timeouts stay unreported (err = null)
+    g_err_dev = nullptr;
+    g_err_host.store(&fallback, std::memory_order_release);
+    return &fallback;
+  }
+  *hp = 0;
+  void* dp = nullptr;
+  if (hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    dp = nullptr;
+  }
+  g_err_dev = (int*)dp;
+  g_err_host.store(hp, std::memory_order_release);
+  return hp;
 }
 
 template <int WN, bool PRO, bool TAPS>
@@ -515,7 +574,15 @@ size_t bstream_workspace(const hnd_conv_desc& d) {
   int mtiles, ntiles, grid;
   bstream_grid(d, wn, mtiles, ntiles, grid);
   if ((long long)mtiles * ntiles < grid) return 0;
-  return (size_t)grid * (16384 * sizeof(float) + sizeof(int));
+  return (size_t)grid * (16384 * sizeof(float) + sizeof(int)) + 16 * sizeof(int);     // sets, flags, counter + ticket
+}
+
+int relay_timeouts(int reset) {
+  int* h = g_err_host.load(std::memory_order_acquire);
+  if (!h) return 0;
+  const int v = __atomic_load_n(h, __ATOMIC_RELAXED);
+  if (reset) __atomic_store_n(h, 0, __ATOMIC_RELAXED);
+  return v;
 }
 
 int launch_bstream(const hnd_conv_desc& d, hipStream_t stream) {
@@ -527,6 +594,15 @@ int launch_bstream(const hnd_conv_desc& d, hipStream_t stream) {
   const int bn = 64 * wn;
   BstreamArgs a;
   int grid;
+  const int* errw = relay_error_word();
+  if (__atomic_load_n(errw, __ATOMIC_RELAXED) != 0) {
+    set_error("hnd_conv2d_igemm(bstream): an earlier launch gave up waiting for a neighbour's partial tile (relay "
+              "time-out): results since then are invalid; hnd_relay_timeouts(1) acknowledges");
+    return HND_ERR_LAUNCH;
+  }
+  a.err = g_err_dev;
+  a.spin_limit = 1 << 21;
+  if (const char* e = getenv("HND_BSTREAM_SPIN")) a.spin_limit = atoi(e) > 0 ? atoi(e) : a.spin_limit;
   a.div_ow = make_fastdiv((unsigned)d.ow);
   a.div_oh = make_fastdiv((unsigned)d.oh);
   bstream_grid(d, wn, a.mtiles, a.ntiles, grid);

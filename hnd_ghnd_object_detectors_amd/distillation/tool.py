@@ -10,8 +10,8 @@ forward, so the tails of one network's launches are filled by the other's); both
 batch inside a transform scope.  Both feature pyramids -- executed as written, but read by nobody when
 ``org_loss_factor`` is 0 -- are issued on a third stream so they trail into the backward pass and fill the last-round
 gaps of its dgrad launches (joined before the next forward): +0.8 % on a dedicated GPU (round 3, A/B on one box:
-101.76 -> 100.94 ms).  It collapses (50x slower) when two PROCESSES time-share one GPU, which only the 2-rank
-plumbing tests do: they, and ``bench.py --share_device``, set ``HND_DEFER_FPN=0``.
+101.76 -> 100.94 ms).  It collapses (50x slower) when two PROCESSES time-share one GPU, so it is on by default only when
+the local ranks do not outnumber the visible devices (``_defer_fpn_default``; ``HND_DEFER_FPN=0/1`` overrides).
 """
 import os
 import random
@@ -26,6 +26,30 @@ from ..myutils.pytorch import module_util
 from .loss import get_loss
 
 _SLOT = 'distillation_box'
+
+
+def _defer_fpn_default():
+    """HND_DEFER_FPN=0/1 decides when set.  Unset: on only when this process has its GPU to itself -- with more local
+    ranks than visible devices (two processes time-sharing one GPU) the third stream makes the step ~50x slower
+    (module docstring), so it stays off there and says so once."""
+    env = os.environ.get('HND_DEFER_FPN')
+    if env is not None:
+        return env != '0'
+    try:
+        local_world = int(os.environ.get('LOCAL_WORLD_SIZE') or os.environ.get('WORLD_SIZE') or 1)
+    except ValueError:
+        local_world = 1
+    devices = torch.cuda.device_count() if torch.cuda.is_available() else 1
+    if local_world > max(devices, 1):
+        if not _WARNED['defer_fpn']:
+            _WARNED['defer_fpn'] = True
+            print('DistillationBox: %d local ranks share %d GPU(s): feature pyramids stay on the main stream '
+                  '(HND_DEFER_FPN=1 forces the deferred stream)' % (local_world, devices))
+        return False
+    return True
+
+
+_WARNED = {'defer_fpn': False}
 
 
 def _stash_output(module, inputs, output):
@@ -49,8 +73,7 @@ class DistillationBox(nn.Module):
         self.overlap_teacher = os.environ.get('HND_TEACHER_STREAM', '1') != '0'
         self._side_stream = None
         # the criterion ignores the models' own outputs (org_loss_factor 0): their FPNs may trail into the backward
-        self.defer_fpn = (os.environ.get('HND_DEFER_FPN', '1') != '0' and
-                          getattr(self.criterion, 'org_loss_factor', 1) == 0)
+        self.defer_fpn = _defer_fpn_default() and getattr(self.criterion, 'org_loss_factor', 1) == 0
         self._fpn_stream = None
 
     def _run_models(self, images, targets, extra):

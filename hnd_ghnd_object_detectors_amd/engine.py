@@ -185,7 +185,7 @@ class Wino2Cache(object):
 
 FOLD_DGRAD_SCALE = os.environ.get('HND_FOLD_DGRAD_SCALE', '1') != '0'     # 0: FrozenBN scale as a launch prologue
 WINOGRAD_FROZEN = os.environ.get('HND_WINOGRAD_FROZEN', '1') != '0'   # debugging knob: frozen / FPN 3x3 convs
-WINOGRAD6_ENABLED = os.environ.get('HND_WINOGRAD6', '1') != '0'
+WINOGRAD6 = os.environ.get('HND_WINOGRAD6', '1') != '0'       # F(6x6,3x3) on maps large enough (wino_tile_for)
 
 
 def use_winograd(cin, cout, stride):
@@ -197,11 +197,10 @@ def use_winograd(cin, cout, stride):
         return 0
     # with F(6x6,3x3) available even the 64-channel convs of the teacher's layer1 gain (x1.20 at 200x336,
     # profiles/r03_bench_wino.txt; F(4x4): x1.06): their 64 component GEMMs are K = 64 deep, HBM-bound like the transforms
-    floor = (64 if WINOGRAD6_ENABLED else 128) if WINOGRAD == 4 else 256
+    floor = (64 if WINOGRAD6 else 128) if WINOGRAD == 4 else 256
     return WINOGRAD if min(cin, cout) >= floor else 0
 
 
-WINOGRAD6 = os.environ.get('HND_WINOGRAD6', '1') != '0'
 WINOGRAD6_MIN_TILES = int(os.environ.get('HND_WINOGRAD6_MIN_TILES', '32'))      # 6x6 tiles per IMAGE
 
 
@@ -407,8 +406,7 @@ class FrozenLayerEngine(object):
                 if wc is not None and not (wc is b.w2 and b.wino is not None):
                     wc.get()
                     wc.refresh()
-            if b.wino is not None:
-                b.wino.get(False)
+            if b.wino is not None:          # (its packs are made by the plans, for the tile the geometry picks)
                 b.wino.refresh()
         key = (x.data_ptr(), tuple(x.shape), keep, tuple(a[0][0].data_ptr() for a in affs))
         if key != self.plan_key:
@@ -861,8 +859,7 @@ class FpnEngine(object):
             self.bufs = Buffers(feats[0].device)
         for i, (m, wc) in enumerate(self.inner + self.layer):
             if i >= len(self.inner) and self.wino[i - len(self.inner)] is not None:
-                self.wino[i - len(self.inner)].get(False)
-                self.wino[i - len(self.inner)].refresh()
+                self.wino[i - len(self.inner)].refresh()      # (packs are made by the plan, per level geometry)
                 continue
             wc.get()
             wc.refresh()

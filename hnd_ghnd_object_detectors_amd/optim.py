@@ -99,6 +99,7 @@ class FusedAdam(torch.optim.Adam):
                     ops.adam_step_flat(p.data, g, st['exp_avg'], st['exp_avg_sq'], group['lr'], beta1, beta2,
                                        group['eps'], step, grad_scale)
                     st['step'] = torch.tensor(float(step))
+        parallel.end_step()
         return None
 
 
@@ -168,4 +169,5 @@ class FusedSGD(torch.optim.SGD):
                     g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                     ops.sgd_step_flat(p.data, g, st.get('momentum_buffer'), *hyper, first_step=first,
                                       grad_scale=grad_scale)
+        parallel.end_step()
         return None

@@ -28,8 +28,8 @@ import torch
 import torch.distributed as dist
 from torch import nn
 
-# reductions in flight, keyed by the arena they belong to: id(arena) -> (flat tensor, waiter, scale).  Each fused
-# optimizer group consumes ONLY the entry whose flat arena holds the gradients it is about to apply.
+# reductions in flight, keyed by the arena they belong to: id(arena) -> [flat tensor, waiter, scale, consumed].  Each
+# fused optimizer group consumes ONLY the entry whose flat arena holds the gradients it is about to apply.
 _PENDING = {}
 # id(parameter) of every tensor a DistributedStudent of world > 1 is responsible for: an optimizer step over one of
 # them with no exchanged gradient is an unsynchronised step and is refused
@@ -54,16 +54,18 @@ def finish_pending(grads=None, params=()):
         grads = [grads]
     scale, hit = 1.0, 0
     for key in list(_PENDING):
-        flat, waiter, s = _PENDING[key]
+        entry = _PENDING[key]
+        flat, waiter, s, consumed = entry
         inside = [_covers(flat, g) for g in grads]
         if not any(inside):
             continue
         if not all(inside):
             raise RuntimeError('finish_pending: only %d of %d gradients of this optimizer group lie in the all-reduced '
                                'arena; the group would mix averaged and local gradients' % (sum(inside), len(inside)))
-        del _PENDING[key]
-        waiter()
-        scale, hit = s, hit + 1
+        if not consumed:
+            waiter()
+            entry[3] = True      # kept until end_step(): a later param group of the same optimizer whose gradients
+        scale, hit = s, hit + 1  # lie in this arena too gets the same factor instead of "not all-reduced"
     if hit > 1:
         raise RuntimeError('finish_pending: the gradients of one optimizer group matched %d exchanged arenas' % hit)
     if not hit and any(id(p) in _GUARDED for p in params):
@@ -73,13 +75,20 @@ def finish_pending(grads=None, params=()):
     return scale
 
 
+def end_step():
+    """called by the fused optimizers when step() has visited all its param groups: exchanges consumed by this step are
+    dropped, so a second step() without a new backward is refused like any other unsynchronised step"""
+    for key in [k for k, e in _PENDING.items() if e[3]]:
+        del _PENDING[key]
+
+
 def _post(arena, flat, waiter, scale):
     """register the exchange of `arena`; a previous, never consumed one of the same arena (backward without an
     optimizer step) is completed and dropped first so entries cannot pile up"""
     old = _PENDING.pop(id(arena), None)
-    if old is not None:
+    if old is not None and not old[3]:
         old[1]()
-    _PENDING[id(arena)] = (flat, waiter, scale)
+    _PENDING[id(arena)] = [flat, waiter, scale, False]
 
 
 class _NativeComm(object):
@@ -125,6 +134,9 @@ class DistributedStudent(nn.Module):
         self.optimizer = optimizer
         self.native = None
         self.reductions = 0            # all-reduces fired so far (tests / logging)
+        # bench.py: with `timing` on, every exchange is bracketed by HIP events on the compute stream -- from "the last
+        # gradient kernel is done" to "the reduced arena is visible to the optimizer launch" = the exposed exchange time
+        self.timing, self.exchange_events = False, []
         if self.world > 1:
             for p in module.parameters():          # same start on every rank (DDP broadcasts at construction)
                 dist.broadcast(p.data, 0)
@@ -183,25 +195,42 @@ class DistributedStudent(nn.Module):
                                    'call optimizer.zero_grad() (set_to_none) before loss.backward() as '
                                    'mimic_runner.distill_model does -- gradient accumulation is not supported')
         self.reductions += 1
+        e0 = None
+        if self.timing and flat.is_cuda:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
         if self.native is not None:
-            _post(arena, flat, self.native.all_reduce_avg(flat), 1.0)
-            return
-        work = dist.all_reduce(flat, async_op=True)              # sum; 1/world is folded into the optimizer launch
-        _post(arena, flat, work.wait, 1.0 / self.world)
+            waiter, scale = self.native.all_reduce_avg(flat), 1.0
+        else:
+            work = dist.all_reduce(flat, async_op=True)          # sum; 1/world is folded into the optimizer launch
+            waiter, scale = work.wait, 1.0 / self.world
+        if e0 is not None:
+            inner = waiter
+
+            def waiter():
+                inner()
+                e1 = torch.cuda.Event(enable_timing=True)
+                e1.record()
+                self.exchange_events.append((e0, e1))
+        _post(arena, flat, waiter, scale)
+
+    def exchange_ms(self):
+        """mean exposed exchange time of the exchanges timed so far (call after a device synchronize)"""
+        ev, self.exchange_events = self.exchange_events, []
+        return sum(a.elapsed_time(b) for a, b in ev) / len(ev) if ev else None
 
     def reduce_gradients(self):
-        """explicit form of round 1's loop (between loss.backward() and optimizer.step()).  The exchange now fires
-        from inside backward, so this only covers models whose gradients did not come from a flat arena."""
+        """explicit form of round 1's loop (between loss.backward() and optimizer.step()).  The exchange fires from
+        inside backward, so there is nothing left to reduce here: this only VERIFIES that every gradient of the wrapped
+        model lies in an exchanged arena (every trainable tensor of this package's models does) and refuses otherwise
+        -- there is no per-tensor fallback that could silently mix exchanged and local gradients."""
         if self.world == 1:
             return
         for p in self.module.parameters():
-            if p.grad is None or any(_covers(f, p.grad) for f, _, _ in _PENDING.values()):
+            if p.grad is None or any(_covers(e[0], p.grad) for e in _PENDING.values()):
                 continue                     # exchanged (or being exchanged) through its arena
-            if id(p) in _GUARDED:
-                raise RuntimeError('reduce_gradients: a data-parallel parameter has a gradient outside every '
-                                   'exchanged arena; its backward bypassed the DistributedStudent hook')
-            dist.all_reduce(p.grad)
-            p.grad.mul_(1.0 / self.world)
+            raise RuntimeError('reduce_gradients: a parameter has a gradient outside every exchanged arena; its '
+                               'backward bypassed the DistributedStudent hook')
 
 
 def all_reduce_flat_(flat, world):

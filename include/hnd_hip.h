@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define HND_ABI_VERSION 6
+#define HND_ABI_VERSION 7
 
 typedef enum hnd_status {
   HND_OK = 0,
@@ -43,6 +43,10 @@ const char* hnd_last_error_string(void);
 int hnd_abi_version(void);
 /* hipStreamSynchronize + hipGetLastError; surfaces asynchronous faults. */
 int hnd_sync_check(void* stream);
+/* Non-zero once a B-streamed GEMM (hnd_conv2d_igemm with relay_ws) gave up waiting for a partial tile; from then on
+ * hnd_conv2d_igemm launches of that kernel return HND_ERR_LAUNCH and hnd_sync_check returns HND_ERR_ASYNC until the
+ * caller acknowledges with reset = 1 (the workspaces themselves need no repair: their flags carry launch epochs). */
+int hnd_relay_timeouts(int reset);
 /* name of the device the library sees ("gfx950..."), or "" */
 const char* hnd_device_arch(void);
 
@@ -98,9 +102,11 @@ typedef struct hnd_conv_desc {
    * transform components are 16 GEMMs over disjoint row groups of one launch. */
   int32_t w_group_rows, w_group_stride;
   /* Work-balancing workspace of the B-streamed kernel (csrc/conv_bstream.hip), or NULL.  hnd_conv2d_igemm_workspace()
-   * bytes, zero-filled ONCE by the caller (the kernel leaves it zeroed), owned by this launch: two launches that may
-   * run concurrently must not share it.  With it, a workgroup whose share of the launch ends inside a tile parks the
-   * tile's accumulators here and its neighbour continues the same k chain (same bits as without). */
+   * bytes, zero-filled ONCE by the caller before the first launch (the kernel keeps a launch counter in it and never
+   * needs it cleared again), owned by this launch: two launches that may run concurrently must not share it.  With it,
+   * a workgroup whose share of the launch ends inside a tile parks the tile's accumulators here and its neighbour
+   * continues the same k chain (same bits as without).  The neighbour's wait is bounded: if it gives up, the launch's
+   * output is invalid and a sticky process-wide error is raised -- see hnd_relay_timeouts. */
   float* relay_ws;
 } hnd_conv_desc;
 

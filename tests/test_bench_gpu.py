@@ -73,3 +73,43 @@ def test_bench_refuses_eight_gpus_on_a_smaller_node():
         pytest.skip('this node has 8 GPUs')
     r = _run(['--gpus', '8', '--steps', '1', '--warmup', '1'], timeout=300)
     assert r.returncode != 0 and r.stdout.strip() == b''
+
+
+@pytest.mark.gpu
+def test_bench_four_ranks_on_a_shared_device_report_the_exchange():
+    """the 4-rank line (plumbing: one GPU shared, gloo, batch 2 -- an ungated geometry) carries the
+    event-timed exchange and the per-rank spread the first real N = 8 run will be read by"""
+    r = _run(['--gpus', '4', '--share_device', '--dist_backend', 'gloo', '--batch', '2', '--steps', '2', '--warmup', '1',
+              '--no_cpu_baseline', '--ref_1gpu_img_s', '100'])
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    rk = out['ranks']
+    assert out['n_gpus'] == 4 and out['config']['global_batch'] == 8 and rk['world'] == 4
+    assert len(rk['ms_per_step_per_rank']) == 4 and len(rk['exchange_ms_per_step_per_rank']) == 4
+    assert rk['exchange_ms_per_step'] is not None and rk['exchange_ms_per_step'] > 0
+    assert 0 <= rk['ms_per_step_spread'] < 1
+    assert abs(out['scaling_efficiency'] - out['value'] / 400.0) < 1e-3
+    print('\n[bench --gpus 4, shared device, batch 2] %.1f img/s, exchange %.3f ms/step (gloo), spread %.3f'
+          % (out['value'], rk['exchange_ms_per_step'], rk['ms_per_step_spread']))
+
+
+@pytest.mark.gpu
+def test_launcher_stops_the_siblings_of_a_rank_that_died_at_start_up():
+    """rank 1 dies before the rendezvous; rank 0 would wait in it for the process-group timeout.  The
+    launcher watches every child while it drains rank 0's pipe, gives the survivors a grace period, kills them by pid
+    and exits non-zero with no line."""
+    import time
+    t0 = time.time()
+    r = _run(['--gpus', '2', '--share_device', '--dist_backend', 'gloo', '--batch', '2', '--steps', '1', '--warmup', '1',
+              '--no_cpu_baseline'], timeout=600, extra_env={'HND_BENCH_FAIL_RANK': '1', 'HND_BENCH_SIBLING_GRACE_S': '5'})
+    assert r.returncode != 0 and r.stdout.strip() == b''
+    assert b'rank 1 exited with 3' in r.stderr and time.time() - t0 < 240
+
+
+@pytest.mark.gpu
+def test_launcher_rank_timeout_kills_the_children():
+    r = _run(['--gpus', '2', '--share_device', '--dist_backend', 'gloo', '--steps', '50', '--warmup', '1',
+              '--no_cpu_baseline', '--rank_timeout_s', '8'], timeout=600)
+    assert r.returncode != 0 and r.stdout.strip() == b'' and b'no result after --rank_timeout_s 8' in r.stderr

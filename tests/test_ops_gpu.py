@@ -1061,10 +1061,12 @@ def test_bstream_kernel_is_bit_identical_to_the_tiled_kernel(ops, case, monkeypa
     tiles = -(-(y.numel() // y.shape[-1]) // bm) * (cout // bn)
     assert (l.relay is not None) == (tiles >= 256), (tiles, l.relay is None)
     if l.relay is not None:
-        assert int(l.relay[-256:].view(torch.int32).abs().sum()) == 0
+        book = l.relay.view(torch.int32)[256 * 16384:]      # [256] flags (launch epochs), launch counter, ticket
+        assert int(book[256]) == 1 and int(book[257]) == 0 and set(book[:256].tolist()) <= {0, 1}
         l.run()                                     # a second launch on the same workspace
         ops.sync_check()
         assert torch.equal(outs['0'], y)
+        assert int(book[256]) == 2 and int(book[257]) == 0 and set(book[:256].tolist()) <= {0, 2}
         l.desc.relay_ws = None
         y.fill_(float('nan'))
         l.run()
@@ -1088,6 +1090,47 @@ def test_bstream_kernel_is_bit_identical_to_the_tiled_kernel(ops, case, monkeypa
             rows = slice(gi * tiles_pad, (gi + 1) * tiles_pad)
             ref = x[0, 0, rows] @ ws[gi].view(cout, cin).t()
             assert float((outs['all'][0, 0, rows] - ref).norm() / ref.norm()) < 1e-5
+
+
+def test_bstream_relay_timeout_is_loud_and_does_not_poison_the_workspace(ops, monkeypatch):
+    """a relay wait that gives up must not pass for a correct launch, and a writer that arrives late must not
+    leave state a later launch on the same workspace would trust.  HND_BSTREAM_DBG=2 makes every head keep its flag
+    down, so every tail wait times out (HND_BSTREAM_SPIN bounds it to milliseconds): the sticky error word is raised --
+    hnd_sync_check fails, the next B-streamed launch is refused -- and, once acknowledged, the SAME workspace gives the
+    tiled kernel's bits again without being re-zeroed."""
+    from hnd_ghnd_object_detectors_amd import _lib
+    L = _lib.load()
+    g = torch.Generator().manual_seed(3)
+    n, h, w, cin, cout = 16, 50, 84, 1024, 256
+    x = torch.randn(n, h, w, cin, generator=g).to(DEV)
+    wt = torch.randn(cout, cin, 1, 1, generator=g).to(DEV) / 32.0
+    pk = ops.pack_weights(wt)
+    monkeypatch.setenv('HND_BRES', '0')
+    monkeypatch.setenv('HND_BSTREAM', '0')
+    ref = torch.empty(n, h, w, cout, device=DEV)
+    ops.conv_forward(x, pk, ref, 1, 1, 0, relu=True).run()
+    monkeypatch.setenv('HND_BSTREAM', 'all')
+    y = torch.empty_like(ref)
+    l = ops.conv_forward(x, pk, y, 1, 1, 0, relu=True)
+    assert l.variant == 'bstream_128' and l.relay is not None
+    L.hnd_relay_timeouts(1)
+    l.run()
+    ops.sync_check()
+    assert torch.equal(y, ref) and L.hnd_relay_timeouts(0) == 0
+    monkeypatch.setenv('HND_BSTREAM_DBG', '2')
+    monkeypatch.setenv('HND_BSTREAM_SPIN', '2000')
+    l.run()                                                 # every tail gives up
+    with pytest.raises(RuntimeError, match='relay time-out'):
+        ops.sync_check()
+    monkeypatch.delenv('HND_BSTREAM_DBG')
+    with pytest.raises(RuntimeError, match='relay time-out'):
+        l.run()                                             # refused at launch until acknowledged
+    assert L.hnd_relay_timeouts(1) == 1 and L.hnd_relay_timeouts(0) == 0
+    monkeypatch.delenv('HND_BSTREAM_SPIN')
+    y.fill_(float('nan'))
+    l.run()                                                 # same workspace, not re-zeroed
+    ops.sync_check()
+    assert torch.equal(y, ref)
 
 
 @pytest.mark.parametrize('h,w,scale', [(480, 640, 1.25), (800, 1333, 1.0), (375, 500, 2.1333333333333333),

@@ -51,6 +51,11 @@ def _worker(rank, world, port, q):
     body._post_backward(arena, flat)                  # what _DistillLossFn.backward calls after its last kernel
     assert len(parallel._PENDING) == 1
     scale = parallel.finish_pending(flat)             # what FusedAdam.step does before its launch
+    # a SECOND param group of the same optimizer whose gradients lie in the same arena gets the same factor
+    # (the consumed entry stays until the optimizer's step() ends) instead of "not all-reduced"
+    half = arena.total // 2 // 64 * 64
+    assert parallel.finish_pending(flat[half:], params) == scale and len(parallel._PENDING) == 1
+    parallel.end_step()                               # what FusedAdam.step does after its last group
     assert not parallel._PENDING and parallel.finish_pending(flat) == 1.0         # nothing pending: no factor
     # (1) stepping data-parallel parameters with NO exchange in flight is refused (was: silently 1.0)
     try:
@@ -65,14 +70,18 @@ def _worker(rank, world, port, q):
     parallel._post(other, oflat, lambda: None, 0.25)
     body._post_backward(arena, flat)
     assert len(parallel._PENDING) == 2
-    assert parallel.finish_pending(flat, params) == 0.5 and list(parallel._PENDING) == [id(other)]
+    assert parallel.finish_pending(flat, params) == 0.5
+    parallel.end_step()
+    assert list(parallel._PENDING) == [id(other)]
     # (3) a group whose gradients only partly lie in an exchanged arena is refused
     try:
         parallel.finish_pending([oflat[:4], torch.zeros(4)])
         partial_refused = False
     except RuntimeError:
         partial_refused = True
-    assert parallel.finish_pending(oflat) == 0.25 and not parallel._PENDING
+    assert parallel.finish_pending(oflat) == 0.25
+    parallel.end_step()
+    assert not parallel._PENDING
     # (4) backward twice without a step: the older exchange of the same arena is completed and dropped, not piled up
     flat.fill_(float(rank + 1))
     body._post_backward(arena, flat)
@@ -81,6 +90,7 @@ def _worker(rank, world, port, q):
     body._post_backward(arena, flat2)
     assert len(parallel._PENDING) == 1 and float(flat.min()) == 3.0
     assert parallel.finish_pending(flat2, params) == 0.5 and float(flat2.max()) == 3.0
+    parallel.end_step()
     wrapped.close()
     assert parallel.finish_pending(flat, params) == 1.0          # guard released with the wrapper
     wrapped._guarded = [id(q_) for q_ in params]
