@@ -103,8 +103,7 @@ def distill_loss(terms):
                              % (tname, tuple(t_buf.shape), tuple(s_buf.shape)))
         grad = None
         if trainable:
-            layer = body[lname]
-            eng = layer.engine() if hasattr(layer, 'engine') else layer.head_engine()
+            eng = body.layer_engine(lname)          # its own engine, or the SharedTrunk's (engine.SharedTrunk)
             if lname == top:
                 grad = eng.grad_out_buffer()            # masked by the producing ReLU in the same pass
             else:

@@ -5,7 +5,10 @@ that stashes their output in ``module.__dict__['distillation_box']`` (:19-20, :2
 runs the teacher without targets, then the student with targets (Keypoint R-CNN: both with the same randomly
 drawn ``fixed_sizes``, :45-48), collects ``{loss_name: ((teacher_path, out), (student_path, out))}`` (:53-58) and
 returns ``criterion(output_dict, org_loss_dict)``.
-MI355X specifics: the frozen teacher forward is issued on a second HIP stream (it is independent of the student
+MI355X specifics: layers 2-4 and the feature pyramid of BOTH networks run as one pass over the concatenated batch
+whenever their (frozen) weights are bit-equal -- they are in every hnd / ghnd config, the student being initialised from
+the teacher -- see ``engine.SharedTrunk``: the teacher's hooks then stash views that are filled by the student's call, which
+is all the criterion needs.  The frozen teacher front (stem + layer1) is issued on a second HIP stream (it is independent of the student
 forward, so the tails of one network's launches are filled by the other's); both models share one transformed
 batch inside a transform scope.  Both feature pyramids -- executed as written, but read by nobody when
 ``org_loss_factor`` is 0 -- are issued on a third stream so they trail into the backward pass and fill the last-round
@@ -75,8 +78,33 @@ class DistillationBox(nn.Module):
         # the criterion ignores the models' own outputs (org_loss_factor 0): their FPNs may trail into the backward
         self.defer_fpn = _defer_fpn_default() and getattr(self.criterion, 'org_loss_factor', 1) == 0
         self._fpn_stream = None
+        self._trunk = None          # engine.SharedTrunk, built lazily when both backbones qualify
+
+    def _shared_trunk(self):
+        """the SharedTrunk of this pair when layers 2-4 + FPN of teacher and student are frozen and bit-equal (every
+        hnd / ghnd config: the student is initialised from the teacher, src/models/org/rcnn.py:444-450), else None --
+        then each network runs its own pass as before.  HND_MERGE_TRUNK=0 turns it off (A/B)."""
+        if not E.MERGE_TRUNK:
+            return None
+        teacher, student = unwrap(self.teacher_model), unwrap(self.student_model)
+        t_bb, s_bb = getattr(teacher, 'backbone', None), getattr(student, 'backbone', None)
+        if teacher.training or t_bb is None or s_bb is None or not E.SharedTrunk.structure_ok(t_bb, s_bb):
+            return None
+        if self._trunk is None or self._trunk.backbones != (t_bb, s_bb):
+            self._trunk = E.SharedTrunk(t_bb, s_bb)
+        return self._trunk if self._trunk.weights_equal() else None
 
     def _run_models(self, images, targets, extra):
+        trunk = self._shared_trunk() if images[0].is_cuda else None
+        if trunk is not None:
+            trunk.begin()
+        E.MERGE['trunk'] = trunk
+        try:
+            return self._run_models_inner(images, targets, extra)
+        finally:
+            E.MERGE['trunk'] = None
+
+    def _run_models_inner(self, images, targets, extra):
         teacher = unwrap(self.teacher_model)
         overlap = self.overlap_teacher and images[0].is_cuda and not E.PROFILE['enabled']
         if not overlap:

@@ -387,6 +387,18 @@ class FrozenLayerEngine(object):
         self.plan_key = None
         self.bwd_key = None
         self.flops_fwd = self.flops_bwd = 0
+        # out_provider(shape) -> NHWC tensor: where the layer's output goes instead of a buffer of its own (SharedTrunk:
+        # layer1 of teacher / student write straight into their half of the concatenated batch)
+        self.out_provider = None
+        # bslice = (lo, hi): backward runs over images lo..hi of the forward batch only (SharedTrunk: the student half)
+        self.bslice = None
+
+    def _b(self, t):
+        return t if self.bslice is None else t[self.bslice[0]:self.bslice[1]]
+
+    def bwd_out(self):
+        """the layer output the backward pass sees (ReLU mask of the gradient that enters the NEXT layer's dgrad)"""
+        return self._b(self.out)
 
     def _check_frozen(self):
         for b in self.blocks:
@@ -396,8 +408,15 @@ class FrozenLayerEngine(object):
                         '%s has trainable parameters: the HIP path implements the reference distillation '
                         'configs, which freeze layer2-4/FPN (yaml student_model.frozen_modules)' % self.name)
 
-    def forward(self, x, keep):
-        """x: NHWC input. keep=True retains every activation for backward (student), else buffers ping-pong."""
+    def out_shape(self, x):
+        n, h, w, _ = x.shape
+        for b in self.blocks:
+            h, w = ops.conv_out_size(h, 3, b.stride, 1), ops.conv_out_size(w, 3, b.stride, 1)
+        return (n, h, w, self.blocks[-1].planes * 4)
+
+    def prepare(self, x, keep):
+        """refresh the operands and (re)build the launch plan for this input without launching anything; afterwards
+        ``self.out`` is the buffer the next forward() will fill"""
         if self.bufs is None:
             self.bufs = Buffers(x.device)
         affs = [(b.f1.get(), b.f2.get(), b.f3.get(), b.fd.get() if b.has_ds else None) for b in self.blocks]
@@ -408,11 +427,18 @@ class FrozenLayerEngine(object):
                     wc.refresh()
             if b.wino is not None:          # (its packs are made by the plans, for the tile the geometry picks)
                 b.wino.refresh()
-        key = (x.data_ptr(), tuple(x.shape), keep, tuple(a[0][0].data_ptr() for a in affs))
+        self._out_buf = self.out_provider(self.out_shape(x)) if self.out_provider is not None else None
+        key = (x.data_ptr(), tuple(x.shape), keep, tuple(a[0][0].data_ptr() for a in affs),
+               None if self._out_buf is None else self._out_buf.data_ptr())
         if key != self.plan_key:
             self._build_forward(x, keep, affs)
             self.plan_key = key
             self.bwd_key = None
+        return self.out
+
+    def forward(self, x, keep):
+        """x: NHWC input. keep=True retains every activation for backward (student), else buffers ping-pong."""
+        self.prepare(x, keep)
         for l, tag in self.fwd:
             _run(l, tag)
         return self.out
@@ -430,6 +456,9 @@ class FrozenLayerEngine(object):
             a1 = self.bufs.get('a1_' + sfx, (n, h, w, b.planes))
             a2 = self.bufs.get('a2_' + sfx, (n, oh, ow, b.planes))
             out = self.bufs.get('out_' + sfx, (n, oh, ow, b.planes * 4))
+            if i == len(self.blocks) - 1 and self._out_buf is not None:
+                assert tuple(self._out_buf.shape) == tuple(out.shape), (self._out_buf.shape, out.shape)
+                out = self._out_buf
             self.fwd.append((ops.conv_forward(cur, b.w1.get(), a1, 1, 1, 0, epi_scale=a1f[0], epi_shift=a1f[1],
                                               relu=True), tagp + '.conv1'))
             if b.wino is not None:      # stride-1 3x3, >= 256 channels: Winograd F(2x2,3x3)
@@ -465,14 +494,15 @@ class FrozenLayerEngine(object):
 
     # ---- backward: self.g_out holds the gradient w.r.t. this layer's output, already masked by out > 0
     def grad_out_buffer(self):
-        self.g_out = self.bufs.get('g_out', self.out.shape)
+        self.g_out = self.bufs.get('g_out', self.bwd_out().shape)
         return self.g_out
 
     def backward(self, dst, dst_mask, res2):
         """Propagate self.g_out to `dst` (grad w.r.t. this layer's input):
         dst = [dst_mask > 0] * (dgrad + res2).  res2 (the loss gradient of the previous layer) may be None."""
         self._check_frozen()
-        key = (dst.data_ptr(), dst_mask.data_ptr(), None if res2 is None else res2.data_ptr(), self.g_out.data_ptr())
+        key = (dst.data_ptr(), dst_mask.data_ptr(), None if res2 is None else res2.data_ptr(), self.g_out.data_ptr(),
+               self.bslice)
         if key != self.bwd_key:
             self._build_backward(dst, dst_mask, res2)
             self.bwd_key = key
@@ -492,7 +522,7 @@ class FrozenLayerEngine(object):
 
         for i in range(nb - 1, -1, -1):
             b = self.blocks[i]
-            x_in, a1, a2, out = self.acts[i]
+            x_in, a1, a2, out = (self._b(t) for t in self.acts[i])
             s1, s2, s3 = b.f1.get()[0], b.f2.get()[0], b.f3.get()[0]
             tagp = '%s.%d' % (self.name, i)
             n, h, w, _ = x_in.shape
@@ -570,6 +600,16 @@ class HeadEngine(object):
         self.bwd_key = None
         self.flops_fwd = self.flops_bwd = 0
         self.encoder_len = 4          # convs 0..3 form the encoder, 4..7 the decoder (resnet_layer.py:42-65)
+        self.out_provider = None      # see FrozenLayerEngine.out_provider
+
+    def out_shape(self, x):
+        n, h, w, _ = x.shape
+        for hc in self.layers:
+            h, w = ops.conv_out_size(h, 2, 1, hc.pad), ops.conv_out_size(w, 2, 1, hc.pad)
+        return (n, h, w, self.layers[-1].cs_out)
+
+    def bwd_out(self):
+        return self.out
 
     def forward(self, x, training, codec=None):
         if self.bufs is None:
@@ -586,7 +626,8 @@ class HeadEngine(object):
             ops.pack_batch_end()
         ptrs = tuple(t.data_ptr() for hc in self.layers
                      for t in (hc.bn.weight, hc.bn.bias, hc.bn.running_mean, hc.bn.running_var))
-        key = (x.data_ptr(), tuple(x.shape), training, ptrs)
+        self._out_buf = self.out_provider(self.out_shape(x)) if self.out_provider is not None else None
+        key = (x.data_ptr(), tuple(x.shape), training, ptrs, None if self._out_buf is None else self._out_buf.data_ptr())
         if key != self.plan_key:
             self._build_forward(x, training)
             self.plan_key = key
@@ -662,7 +703,8 @@ class HeadEngine(object):
             self.count.append(m)
             cur, cur_scale, cur_shift, cur_relu = y, sc, sh, hc.relu
             h, w = oh, ow
-        self.out = b.get('out', (n, h, w, self.layers[-1].cs_out))
+        self.out = b.get('out', (n, h, w, self.layers[-1].cs_out)) if self._out_buf is None else self._out_buf
+        assert tuple(self.out.shape) == (n, h, w, self.layers[-1].cs_out)
         self.flops_fwd = flops
 
     def _wino_scratch(self, n, oh, ow, cin, cout, tile=4):
@@ -853,8 +895,8 @@ class FpnEngine(object):
         self.plan_key = None
         self.flops_fwd = 0
 
-    def forward(self, feats):
-        """feats: list of NHWC layer outputs (fine -> coarse).  Returns list of NHWC pyramid maps + 'pool'."""
+    def prepare(self, feats):
+        """refresh the operands and (re)build the plan for these inputs without launching; returns the output list"""
         if self.bufs is None:
             self.bufs = Buffers(feats[0].device)
         for i, (m, wc) in enumerate(self.inner + self.layer):
@@ -902,10 +944,156 @@ class FpnEngine(object):
             self.pool = self.bufs.get('pool', (n, (h + 1) // 2, (w + 1) // 2, c))
             self.flops_fwd = flops
             self.plan_key = key
+        return self.results + [self.pool]
+
+    def forward(self, feats):
+        """feats: list of NHWC layer outputs (fine -> coarse).  Returns list of NHWC pyramid maps + 'pool'."""
+        outs = self.prepare(feats)
         for l, tag in self.fwd:
             _run(l, tag)
         ops.subsample2(self.results[-1], self.pool)
-        return self.results + [self.pool]
+        return outs
+
+
+# =========================================================================================== shared trunk
+# Set by DistillationBox around its teacher + student calls: the SharedTrunk both backbones then run layers 2-4 (+ the
+# feature pyramid) through, or None.
+MERGE = {'trunk': None}
+MERGE_TRUNK = os.environ.get('HND_MERGE_TRUNK', '1') != '0'
+
+
+class SharedTrunk(object):
+    """Layers 2-4 and the feature pyramid of teacher AND student as ONE pass over the concatenated batch.
+
+    The student's layer2-4 / FPN are copies of the teacher's (reference src/models/org/rcnn.py:444-450 loads the
+    teacher's COCO weights into the student with strict=False; yaml ``frozen_modules`` keeps them frozen), so the two
+    networks used to launch every one of those convs twice with the same operand at half the GEMM height.  Here
+    layer1 of the teacher and layer1 (the bottleneck head) of the student write straight into the two halves of one
+    ``[2N, H, W, 256]`` buffer (``out_provider``) and one FrozenLayerEngine per layer / one FpnEngine runs over all 2N
+    images: half the launches, twice the rows per launch -- which is what lets the persistent GEMM kernels take the
+    layer3 / layer4 launches that were too short for them at N images.  No image-to-image coupling exists in these
+    layers (FrozenBatchNorm), the Winograd tile depends on the map size only and every GEMM variant is bit-identical on
+    the same descriptor, so both halves hold exactly the bits the separate passes produced (tests).
+
+    Protocol inside one DistillationBox.forward (``MERGE['trunk']`` set): the TEACHER is called first.  Its stem and
+    layer1 are launched (on the teacher stream); its layer2-4 / FPN module calls only build the plans and return VIEWS
+    of the teacher half of the trunk's output buffers -- forward hooks fire and stash them, their contents arrive with
+    the student's call.  The STUDENT's stem and head are launched on the main stream; at its layer2 call the main
+    stream waits for the teacher stream and the merged layer is launched, and so on; the student's module calls return
+    the student half.  The backward plan runs over the student half only (``bslice``).
+
+    Used only while both weight sets are bit-equal (checked on the device whenever a tensor's version or address
+    changed) and frozen; otherwise DistillationBox falls back to two separate passes."""
+    LAYERS = ('layer2', 'layer3', 'layer4')
+
+    def __init__(self, t_backbone, s_backbone):
+        self.backbones = (t_backbone, s_backbone)
+        self.bodies = (t_backbone.body, s_backbone.body)
+        s_body, s_fpn = s_backbone.body, s_backbone.fpn
+        self.engines = OrderedDict((name, FrozenLayerEngine(list(s_body[name]), name)) for name in self.LAYERS)
+        self.fpn_engine = FpnEngine(list(s_fpn.inner_blocks), list(s_fpn.layer_blocks))
+        self.bufs = None
+        self.x1 = None                  # [2N, H, W, 256]: layer1 outputs, teacher half first
+        self.n = None
+        self.t_stream = None
+        self.seen = [False, False]      # which role has delivered its layer1 output in the current scope
+        self._equal_key, self._equal = None, False
+
+    # ---- eligibility
+    @staticmethod
+    def structure_ok(t_backbone, s_backbone):
+        from . import hipnn
+        try:
+            tb, sb = t_backbone.body, s_backbone.body
+            for name in SharedTrunk.LAYERS:
+                if not (isinstance(tb[name], hipnn.ResLayer) and isinstance(sb[name], hipnn.ResLayer)
+                        and len(tb[name]) == len(sb[name])):
+                    return False
+                if any(p.requires_grad for m in (tb[name], sb[name]) for p in m.parameters()):
+                    return False
+            if not (isinstance(tb['layer1'], hipnn.ResLayer) and hasattr(sb['layer1'], 'head_engine')
+                    and not getattr(sb['layer1'], 'uses_ext_encoder', False)):
+                return False
+            if any(p.requires_grad for m in (t_backbone.fpn, s_backbone.fpn) for p in m.parameters()):
+                return False
+            return t_backbone.run_fpn == s_backbone.run_fpn
+        except (KeyError, AttributeError, TypeError):
+            return False
+
+    def _tensor_pairs(self):
+        (tb, sb), (tf, sf) = self.bodies, (self.backbones[0].fpn, self.backbones[1].fpn)
+        pairs = []
+        for tm, sm in [(tb[n], sb[n]) for n in self.LAYERS] + [(tf, sf)]:
+            t_sd, s_sd = tm.state_dict(keep_vars=True), sm.state_dict(keep_vars=True)
+            if list(t_sd) != list(s_sd):
+                return None
+            pairs += [(t_sd[k], s_sd[k]) for k in t_sd]
+        return pairs
+
+    def weights_equal(self):
+        """every tensor of layer2-4 and the FPN bit-equal between the two networks (re-checked on the device only when
+        a version counter or an address moved: load_state_dict, .to(), a hand edit)"""
+        pairs = self._tensor_pairs()
+        if pairs is None:
+            return False
+        key = tuple((a.data_ptr(), a._version, b.data_ptr(), b._version) for a, b in pairs)
+        if key != self._equal_key:
+            self._equal = all(a.shape == b.shape and a.dtype == b.dtype and torch.equal(a, b) for a, b in pairs)
+            self._equal_key = key
+        return self._equal
+
+    # ---- one step
+    def begin(self):
+        self.seen = [False, False]
+
+    def role_of(self, body):
+        return 0 if body is self.bodies[0] else (1 if body is self.bodies[1] else None)
+
+    def slot_provider(self, role):
+        def provide(shape):
+            n = int(shape[0])
+            full = (2 * n,) + tuple(int(v) for v in shape[1:])
+            if self.bufs is None:
+                self.bufs = Buffers(torch.device('cuda', torch.cuda.current_device()))
+            if role == 1 and self.x1 is not None and tuple(self.x1.shape) != full:
+                raise RuntimeError('SharedTrunk: teacher and student layer1 outputs differ in shape (%s vs %s)'
+                                   % (tuple(self.x1.shape), full))
+            self.x1 = self.bufs.get('x1', full)
+            self.n = n
+            return self.x1[role * n:(role + 1) * n]
+        return provide
+
+    def delivered(self, role):
+        """layer1 of `role` has been enqueued into its half of x1 (on the current stream)"""
+        if role == 0:
+            self.t_stream = torch.cuda.current_stream()
+        elif not self.seen[0]:
+            raise RuntimeError('SharedTrunk: the student reached the shared layers before the teacher delivered layer1 '
+                               '(DistillationBox calls the teacher first)')
+        self.seen[role] = True
+
+    def _half(self, t, role):
+        return t[role * self.n:(role + 1) * self.n]
+
+    def layer_forward(self, name, role):
+        eng = self.engines[name]
+        idx = self.LAYERS.index(name)
+        x = self.x1 if idx == 0 else self.engines[self.LAYERS[idx - 1]].out
+        keep = self.bodies[1].needs_backward()
+        eng.bslice = (self.n, 2 * self.n)
+        if role == 0:
+            return self._half(eng.prepare(x, keep), 0)         # a view; filled by the student's call
+        if idx == 0:
+            cur = torch.cuda.current_stream()
+            if self.t_stream is not None and self.t_stream != cur:
+                cur.wait_stream(self.t_stream)
+        return self._half(eng.forward(x, keep), 1)
+
+    def fpn_forward(self, role):
+        feats = [self.x1] + [self.engines[n].out for n in self.LAYERS]
+        if role == 0:
+            return [self._half(t, 0) for t in self.fpn_engine.prepare(feats)]
+        return [self._half(t, 1) for t in self.fpn_engine.forward(feats)]
 
 
 # =========================================================================================== neural filter

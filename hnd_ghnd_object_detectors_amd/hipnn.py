@@ -143,7 +143,15 @@ class ResLayer(nn.Sequential):
         return self._engine
 
     def forward(self, x):
+        merged = getattr(self, '_merged', None)
+        if merged is not None and E.MERGE['trunk'] is merged[0]:
+            # (trunk, role): this call is one half of a SharedTrunk pass (engine.SharedTrunk)
+            trunk, role = merged
+            out = trunk.layer_forward(self._name, role)
+            self._used_engine = trunk.engines[self._name]
+            return attach(E.logical(out), out)
         eng = self.engine()
+        self._used_engine = eng
         out = eng.forward(to_nhwc(x), self._keep)
         return attach(E.logical(out), out)
 
@@ -183,21 +191,42 @@ class IntermediateLayerGetter(nn.ModuleDict):
         if x4.shape[3] != 4:
             raise RuntimeError('the stem expects the 3-channel image batch stored as NHWC4')
         keep = self.needs_backward()
+        trunk = E.MERGE['trunk']
+        role = trunk.role_of(self) if trunk is not None else None
         x0 = self.stem().forward(x4, keep)
         cur = attach(E.logical(x0), x0)
         out = OrderedDict()
+        self._fwd_engines = {}
         for name, module in self.items():
             if name in ('conv1', 'bn1', 'relu', 'maxpool'):
                 continue
             if isinstance(module, ResLayer):
                 module._keep = keep
+                module._merged = (trunk, role) if (role is not None and name in trunk.LAYERS) else None
+            if name == 'layer1':
+                # SharedTrunk pass: layer1 writes straight into this network's half of the concatenated batch
+                l1 = module.engine() if isinstance(module, ResLayer) else \
+                    (module.head_engine() if hasattr(module, 'head_engine') else None)
+                if l1 is not None:
+                    l1.out_provider = trunk.slot_provider(role) if role is not None else None
             cur = module(cur)
+            if name == 'layer1' and role is not None:
+                trunk.delivered(role)
             if isinstance(cur, torch.Tensor):
                 cur._hnd_src = (self, name)
+            if isinstance(module, ResLayer):
+                self._fwd_engines[name] = module._used_engine
+            elif hasattr(module, 'head_engine'):
+                self._fwd_engines[name] = module.head_engine()
             if name in self.return_layers:
                 out[self.return_layers[name]] = cur
         self._last_keep = keep
         return out
+
+    def layer_engine(self, name):
+        """the engine that ran layer `name` in the LAST forward (its own, or the SharedTrunk's): what the loss and the
+        backward plan must talk to"""
+        return self._fwd_engines[name]
 
     # ------------------------------------------------------------------ manual backward (student)
     def trainable_plan(self):
@@ -212,12 +241,10 @@ class IntermediateLayerGetter(nn.ModuleDict):
         order = ['layer4', 'layer3', 'layer2', 'layer1']
         start = order.index(top)
         for name in order[start:-1]:
-            layer = self[name]
             prev_name = order[order.index(name) + 1]
-            prev = self[prev_name]
-            prev_eng = prev.engine() if isinstance(prev, ResLayer) else prev.head_engine()
+            prev_eng = self.layer_engine(prev_name)
             dst = prev_eng.grad_out_buffer()
-            layer.engine().backward(dst, prev_eng.out, loss_grads.get(prev_name))
+            self.layer_engine(name).backward(dst, prev_eng.bwd_out(), loss_grads.get(prev_name))
         l1 = self['layer1']
         conv1_w = self['conv1'].weight
         dw1 = grad_dst.get(conv1_w)
@@ -250,9 +277,16 @@ class FeaturePyramidNetwork(nn.Module):
 
     def forward(self, x):
         names, feats = list(x.keys()), [to_nhwc(v) for v in x.values()]
-        if self._engine is None:
-            self._engine = E.FpnEngine(list(self.inner_blocks), list(self.layer_blocks))
-        outs = self._engine.forward(feats)
+        trunk = E.MERGE['trunk']
+        role = None
+        if trunk is not None:
+            role = 0 if self is trunk.backbones[0].fpn else (1 if self is trunk.backbones[1].fpn else None)
+        if role is not None:            # one half of a SharedTrunk pass: the pyramid of both networks in one plan
+            outs = trunk.fpn_forward(role)
+        else:
+            if self._engine is None:
+                self._engine = E.FpnEngine(list(self.inner_blocks), list(self.layer_blocks))
+            outs = self._engine.forward(feats)
         if self.extra_blocks is None:
             outs = outs[:-1]
         else:

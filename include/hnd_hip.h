@@ -400,9 +400,9 @@ int hnd_rpn_decode(const float* head, int n, int h, int w, int ldc, int num_anch
                    float* objectness, float* proposals, void* stream);
 /* clip_boxes_to_image: x to [0, width], y to [0, height], in place; boxes [n][4] */
 int hnd_clip_boxes(float* boxes, int64_t n, float height, float width, void* stream);
-/* torchvision.ops.nms.  boxes [n][4]; order [n] = indices in descending-score order (the host sorts);
- * keep [n] (bytes) = 1 for boxes that survive greedy suppression at IoU > iou_threshold, indexed like boxes;
- * workspace: hnd_nms_workspace(n) bytes.  n <= 65536. */
+/* torchvision.ops.nms.  boxes [n][4]; order [n] = indices in descending-score order (hnd_argsort_desc_f32 makes it on
+ * the device); keep [n] (bytes) = 1 for boxes that survive greedy suppression at IoU > iou_threshold, indexed like
+ * boxes; workspace: hnd_nms_workspace(n) bytes.  n <= 131072. */
 size_t hnd_nms_workspace(int64_t n);
 int hnd_nms(const float* boxes, const int64_t* order, int64_t n, float iou_threshold, void* workspace,
             uint8_t* keep, void* stream);

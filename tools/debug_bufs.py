@@ -22,8 +22,8 @@ for step in range(2):
     loss.backward()
     torch.cuda.synchronize()
     body = student.backbone.body
-    engines = {'stem': body.stem(), 'layer1': body.layer1.head_engine(), 'layer2': body.layer2.engine(),
-               'layer3': body.layer3.engine(), 'layer4': body.layer4.engine()}
+    engines = {'stem': body.stem(), 'layer1': body.layer1.head_engine(), 'layer2': body.layer_engine('layer2'),
+               'layer3': body.layer_engine('layer3'), 'layer4': body.layer_engine('layer4')}
     for en, e in engines.items():
         for bn, t in sorted(e.bufs.t.items()):
             if t.is_floating_point():

@@ -48,11 +48,23 @@ def short(name):
     return name.split('(')[0][:48]
 
 
+def steps_label(json_name, default):
+    """what the profiled bench.py process executed: its W warm-up (the first of them is the gated step) + K timed steps,
+    then 3 enqueue-probe steps and 1 single-stream event-profiled step -- the call counts below cover ALL of them"""
+    try:
+        d = json.loads(open(os.path.join(out, json_name)).read().strip().splitlines()[-1])
+        w, k = int(d['warmup']), int(d['steps'])
+        return '%d steps in the process: %d warm-up + %d timed + 3 enqueue-probe + 1 event-profiled' % (w + k + 4, w, k)
+    except Exception:      # noqa
+        return default
+
+
 print('# rocprofv3 summary %s (bench.py GHND Faster R-CNN b3ch, batch 16, 1 x MI355X)\n' % tag)
 stats = glob.glob(os.path.join(out, 'trace', '*kernel_stats.csv'))
 if stats:
     rows = list(csv.DictReader(open(stats[0])))
-    print('## kernel-trace --stats (6 timed + 2 warm-up steps, teacher/student stream overlap off)\n')
+    print('## kernel-trace --stats (%s; teacher/student stream overlap off)\n'
+          % steps_label('bench_trace.json', '12 steps in the process: 2 warm-up + 6 timed + 3 enqueue-probe + 1 event-profiled'))
     print('| kernel | calls | total ms | avg us | % |')
     print('|---|---|---|---|---|')
     for r in rows[:24]:
@@ -70,8 +82,10 @@ for label, sub, col in (('FETCH_SIZE', 'pmc_fetch', 'FETCH_SIZE'), ('WRITE_SIZE'
             a = agg[short(r['Kernel_Name'])]
             a[0] += float(r['Counter_Value'])
             a[1] += 1
-    print('\n## %s per kernel (one warm-up + one timed step; counter unit KiB; on gfx950 FETCH_SIZE counts half '
-          'the bytes of wide coalesced reads -> double it, MI355X_MICROARCH.md HBM section)\n' % label)
+    print('\n## %s per kernel (%s; counter unit KiB; on gfx950 FETCH_SIZE counts half '
+          'the bytes of wide coalesced reads -> double it, MI355X_MICROARCH.md HBM section)\n'
+          % (label, steps_label('bench_fetch.json' if label == 'FETCH_SIZE' else 'bench_write.json',
+                                '6 steps in the process: 1 warm-up + 1 timed + 3 enqueue-probe + 1 event-profiled')))
     traffic.setdefault(label, agg)
     print('| kernel | dispatches | sum KiB | avg MiB / dispatch |')
     print('|---|---|---|---|')
@@ -88,7 +102,8 @@ for f in ('bench_trace.json',):
 
 if 'FETCH_SIZE' in traffic and 'WRITE_SIZE' in traffic:
     tj = {'source': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `bench.py --steps 1 '
-                    '--warmup 1`, summed over both steps; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts '
+                    '--warmup 1`, summed over all 6 steps that process runs (1 warm-up + 1 timed + 3 enqueue-probe + 1 '
+                    'event-profiled) and divided by the dispatch count; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts '
                     '64 B per 128-B request)', 'unit': 'bytes per launch', 'kernels': {}}
     for k, (fv, fn) in traffic['FETCH_SIZE'].items():
         if k in traffic['WRITE_SIZE'] and ('igemm' in k or 'wgrad' in k or 'bres' in k):
