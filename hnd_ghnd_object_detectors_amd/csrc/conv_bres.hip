@@ -619,7 +619,8 @@ int bres_variant(const hnd_conv_desc& d) {
     // waits (as compiler-visible loads they drained the ring once per tile and lost to the tiled kernel, 104 vs 112 TF).
     // Measured (tools/bench_bres.py): 256->256 @200x336 + upsampled residual 109 -> 123 TF, 128->512 @100x168 + res
     // 95 -> 102, 256->1024 @50x84 + res 112 -> 116.  K = 512 with a residual spills and stays on the 8-wave kernel.
-    if (!d.pro_scale && !spills && per_team >= (d.w_group_rows > 0 || d.kdim == 512 ? 48 : 8)) return 2 + wn;
+    static const int wino_min = getenv("HND_BRES2_WINO_MIN") ? atoi(getenv("HND_BRES2_WINO_MIN")) : 48;
+    if (!d.pro_scale && !spills && per_team >= (d.w_group_rows > 0 ? wino_min : (d.kdim == 512 ? 48 : 8))) return 2 + wn;
   }
   if (per_team < 2ll * (8 / wn)) return 0;              // every wave row gets at least two chunks
   if (!getenv("HND_BRES_ALL")) {

@@ -72,7 +72,7 @@ class _DistillLossFn(torch.autograd.Function):
         go = grad_output.detach().reshape(()).float().contiguous()
         for buf in st['grad_bufs']:
             ops.scale_by_device_scalar(buf, go)
-        body.hnd_backward(st['top'], st['loss_grads'], grad_dst)
+        body.hnd_backward(st['top'], st['loss_grads'], grad_dst, st['top_block'], st['block_grads'])
         del views
         hook = getattr(body, '_post_backward', None)
         if hook is not None:        # parallel.DistributedStudent: the stem's wgrad (last kernel) is enqueued -> exchange
@@ -82,35 +82,71 @@ class _DistillLossFn(torch.autograd.Function):
 
 
 _ORDER = ('layer1', 'layer2', 'layer3', 'layer4')
+_SUPPORTED = ('backbone.body.layerN; backbone.body.layerN.K (a Bottleneck of layer2-4); backbone.body.layer1.decoder '
+              '(= the layer1 output)')
+
+
+def _student_position(src, body):
+    """where a student-side tensor enters the backward plan: (layer name, block index or None = the layer output)"""
+    if src is None or src[0] is not body or src[1] not in _ORDER:
+        raise NotImplementedError('HIP distillation loss: the student tensor of a term must come from one of: %s -- the '
+                                  'hand-written backward plan starts there' % _SUPPORTED)
+    lname, sub = src[1], src[2] if len(src) > 2 else None
+    if sub is None or sub == 'decoder':
+        return lname, None
+    if sub == 'encoder':
+        raise NotImplementedError('a loss term on backbone.body.layer1.encoder (the bottleneck tensor itself) has no '
+                                  'backward plan on the HIP path; supported student-side paths: %s' % _SUPPORTED)
+    nblocks = len(body[lname])
+    if not (isinstance(sub, int) and 0 <= sub < nblocks):
+        raise NotImplementedError('unexpected source %r of a student tensor' % (src[1:],))
+    return lname, (None if sub == nblocks - 1 else sub)
 
 
 def distill_loss(terms):
-    """terms: list of (name, teacher_out, student_out, factor).  Returns a 0-dim float32 loss tensor."""
+    """terms: list of (name, teacher_out, student_out, factor).  Returns a 0-dim float32 loss tensor.
+    Teacher tensors may be ANY tensor produced by the HIP path; student tensors are located in the backward plan by
+    their ``_hnd_src`` tag (see _student_position)."""
     srcs = [getattr(s, '_hnd_src', None) for _, _, s, _ in terms]
     body = srcs[0][0] if srcs[0] is not None else None
+    if isinstance(body, str):           # ('fpn', ...): a pyramid map on the student side
+        raise NotImplementedError('a loss term on the student\'s feature pyramid would need the backward of the (frozen) '
+                                  'FPN, which is not built; supported student-side paths: %s' % _SUPPORTED)
     trainable = body is not None and getattr(body, '_last_keep', False)
-    if any(src is None or src[0] is not body or src[1] not in _ORDER for src in srcs):
-        raise NotImplementedError('HIP distillation loss expects student tensors produced by backbone.body.layer1-4 '
-                                  '(the ts_modules of every hnd/ghnd config)')
+    pos = [_student_position(src, body) for src in srcs]
     dev = terms[0][2].device
-    names = [src[1] for src in srcs]
-    top = max(names, key=_ORDER.index)
-    pairs, loss_grads, grad_bufs = [], {}, []
-    for (tname, t_out, s_out, factor), lname in zip(terms, names):
+
+    def rank(p):
+        nb = len(body[p[0]]) if p[0] != 'layer1' else 1
+        return (_ORDER.index(p[0]), nb - 1 if p[1] is None else p[1])
+    top = max(pos, key=rank)
+    pairs, loss_grads, block_grads, grad_bufs = [], {}, {}, []
+    for (tname, t_out, s_out, factor), p in zip(terms, pos):
         t_buf, s_buf = to_nhwc(t_out), to_nhwc(s_out)
         if tuple(t_buf.shape) != tuple(s_buf.shape):
             raise ValueError('teacher/student shapes differ for term %s: %s vs %s'
                              % (tname, tuple(t_buf.shape), tuple(s_buf.shape)))
         grad = None
         if trainable:
+            lname, blk = p
             eng = body.layer_engine(lname)          # its own engine, or the SharedTrunk's (engine.SharedTrunk)
-            if lname == top:
-                grad = eng.grad_out_buffer()            # masked by the producing ReLU in the same pass
-            else:
+            if p == top:
+                # masked by the producing ReLU in the same pass
+                grad = eng.grad_out_buffer(blk) if blk is not None else eng.grad_out_buffer()
+            elif blk is None:
                 grad = eng.bufs.get('loss_grad', s_buf.shape)
+                if lname in loss_grads:
+                    raise NotImplementedError('two loss terms on the output of %s' % lname)
                 loss_grads[lname] = grad
+            else:
+                grad = eng.bufs.get('loss_grad_blk%d' % blk, s_buf.shape)
+                if blk in block_grads.setdefault(lname, {}):
+                    raise NotImplementedError('two loss terms on the output of %s.%d' % (lname, blk))
+                block_grads[lname][blk] = grad
             grad_bufs.append(grad)
-        pairs.append((t_buf, s_buf, grad, float(factor), lname == top))
+        pairs.append((t_buf, s_buf, grad, float(factor), p == top))
+    if len([p for p in pos if p == top]) > 1:
+        raise NotImplementedError('two loss terms on the same (top) student tensor')
     key = tuple((p[0].data_ptr(), p[1].data_ptr(), None if p[2] is None else p[2].data_ptr(), p[3], p[4])
                 for p in pairs)
     cache = getattr(body, '_mse_cache', None)
@@ -128,7 +164,8 @@ def distill_loss(terms):
     if arena is None or [id(p) for p in arena.params] != [id(p) for p in params]:
         arena = GradArena(params)
         body._grad_arena = arena
-    state = {'body': body, 'arena': arena, 'top': top, 'loss_grads': loss_grads, 'grad_bufs': grad_bufs}
+    state = {'body': body, 'arena': arena, 'top': top[0], 'top_block': top[1], 'loss_grads': loss_grads,
+             'block_grads': block_grads, 'grad_bufs': grad_bufs}
     loss = _DistillLossFn.apply(loss_value, state, *params)
     loss.per_term = per_term
     return loss

@@ -90,7 +90,7 @@ class DistillationBox(nn.Module):
         t_bb, s_bb = getattr(teacher, 'backbone', None), getattr(student, 'backbone', None)
         if teacher.training or t_bb is None or s_bb is None or not E.SharedTrunk.structure_ok(t_bb, s_bb):
             return None
-        if self._trunk is None or self._trunk.backbones != (t_bb, s_bb):
+        if self._trunk is None or self._trunk.backbones != (t_bb, s_bb) or self._trunk.LAYERS[0] != E.MERGE_FROM:
             self._trunk = E.SharedTrunk(t_bb, s_bb)
         return self._trunk if self._trunk.weights_equal() else None
 
@@ -143,5 +143,12 @@ class DistillationBox(nn.Module):
         for teacher_path, student_path in self.target_module_pairs:
             t = module_util.get_module(unwrap(self.teacher_model), teacher_path).__dict__[_SLOT]
             s = module_util.get_module(unwrap(self.student_model), student_path).__dict__[_SLOT]
+            for slot in (t, s):
+                if 'output' not in slot:
+                    raise NotImplementedError(
+                        'the forward hook on `%s` never fired: that module executes fused inside its parent on the HIP '
+                        'path and has no tensor of its own.  Hookable: backbone.body.layerN, backbone.body.layerN.K (a '
+                        'Bottleneck), backbone.body.layer1.encoder / .decoder, backbone.fpn.layer_blocks.K'
+                        % slot['path_from_root'])
             output_dict[t['loss_name']] = ((t['path_from_root'], t['output']), (s['path_from_root'], s['output']))
         return self.criterion(output_dict, org_loss_dict)

@@ -493,27 +493,41 @@ class FrozenLayerEngine(object):
         return self.bufs.get('wino_v', (self._wino_need[0],)), self.bufs.get('wino_m', (self._wino_need[1],))
 
     # ---- backward: self.g_out holds the gradient w.r.t. this layer's output, already masked by out > 0
-    def grad_out_buffer(self):
-        self.g_out = self.bufs.get('g_out', self.bwd_out().shape)
+    def block_out(self, i):
+        """output of Bottleneck i as the backward pass sees it (forward hooks on ``layerN.i``)"""
+        return self._b(self.acts[i][3])
+
+    def grad_out_buffer(self, top_block=None):
+        """where the (ReLU-masked) gradient w.r.t. the layer output -- or, with top_block, w.r.t. the output of that
+        inner Bottleneck, when the highest loss term sits there -- is written before backward()"""
+        if top_block is None or top_block == len(self.blocks) - 1:
+            self.g_out = self.bufs.get('g_out', self.bwd_out().shape)
+        else:
+            self.g_out = self.bufs.get('g_out_blk%d' % top_block, self.block_out(top_block).shape)
         return self.g_out
 
-    def backward(self, dst, dst_mask, res2):
+    def backward(self, dst, dst_mask, res2, top_block=None, block_grads=None):
         """Propagate self.g_out to `dst` (grad w.r.t. this layer's input):
-        dst = [dst_mask > 0] * (dgrad + res2).  res2 (the loss gradient of the previous layer) may be None."""
+        dst = [dst_mask > 0] * (dgrad + res2).  res2 (the loss gradient of the previous layer) may be None.
+        top_block: the gradient enters at the output of that Bottleneck (later blocks carry no loss: skipped);
+        block_grads: {i: unmasked loss gradient w.r.t. the output of Bottleneck i}, added where the gradient of that
+        output is formed (and masked by its ReLU there)."""
         self._check_frozen()
+        block_grads = block_grads or {}
         key = (dst.data_ptr(), dst_mask.data_ptr(), None if res2 is None else res2.data_ptr(), self.g_out.data_ptr(),
-               self.bslice)
+               self.bslice, top_block, tuple(sorted((i, t.data_ptr()) for i, t in block_grads.items())))
         if key != self.bwd_key:
-            self._build_backward(dst, dst_mask, res2)
+            self._build_backward(dst, dst_mask, res2, top_block, block_grads)
             self.bwd_key = key
         for l, tag in self.bwd:
             _run(l, tag)
 
-    def _build_backward(self, dst, dst_mask, res2):
+    def _build_backward(self, dst, dst_mask, res2, top_block=None, block_grads=None):
         self.bwd = []
         flops = 0
         g = self.g_out
-        nb = len(self.blocks)
+        nb = len(self.blocks) if top_block is None else top_block + 1
+        block_grads = block_grads or {}
 
         def fold(scale):
             # the FrozenBN scale between a conv and the gradient reaching it: folded into the transposed weights
@@ -544,7 +558,7 @@ class FrozenLayerEngine(object):
             # conv1 (1x1) + identity / downsample fan-in, masked by the previous block's ReLU
             if i > 0:
                 g_prev = self.bufs.get('g_blk_%d' % ((i - 1) & 1), x_in.shape)
-                tgt, tmask, tres2 = g_prev, x_in, None
+                tgt, tmask, tres2 = g_prev, x_in, block_grads.get(i - 1)      # a loss term on block i-1's output
             else:
                 tgt, tmask, tres2 = dst, dst_mask, res2
             if b.has_ds:
@@ -960,6 +974,9 @@ class FpnEngine(object):
 # feature pyramid) through, or None.
 MERGE = {'trunk': None}
 MERGE_TRUNK = os.environ.get('HND_MERGE_TRUNK', '1') != '0'
+# first layer of the shared pass: earlier layers run per network (teacher || student on two streams, which is where the
+# HBM-bound high-resolution kernels find an MFMA-bound partner), later ones over the concatenated batch
+MERGE_FROM = os.environ.get('HND_MERGE_FROM', 'layer3')
 
 
 class SharedTrunk(object):
@@ -969,8 +986,9 @@ class SharedTrunk(object):
     teacher's COCO weights into the student with strict=False; yaml ``frozen_modules`` keeps them frozen), so the two
     networks used to launch every one of those convs twice with the same operand at half the GEMM height.  Here
     layer1 of the teacher and layer1 (the bottleneck head) of the student write straight into the two halves of one
-    ``[2N, H, W, 256]`` buffer (``out_provider``) and one FrozenLayerEngine per layer / one FpnEngine runs over all 2N
-    images: half the launches, twice the rows per launch -- which is what lets the persistent GEMM kernels take the
+    ``[2N, H, W, 256]`` buffer (``out_provider``) -- and so do their layer2 passes when the shared pass starts at layer3
+    (``HND_MERGE_FROM``, the default: see MERGE_FROM) -- and one FrozenLayerEngine per shared layer / one FpnEngine runs
+    over all 2N images: half the launches, twice the rows per launch -- which is what lets the persistent GEMM kernels take the
     layer3 / layer4 launches that were too short for them at N images.  No image-to-image coupling exists in these
     layers (FrozenBatchNorm), the Winograd tile depends on the map size only and every GEMM variant is bit-identical on
     the same descriptor, so both halves hold exactly the bits the separate passes produced (tests).
@@ -984,16 +1002,21 @@ class SharedTrunk(object):
 
     Used only while both weight sets are bit-equal (checked on the device whenever a tensor's version or address
     changed) and frozen; otherwise DistillationBox falls back to two separate passes."""
-    LAYERS = ('layer2', 'layer3', 'layer4')
+    ALL = ('layer1', 'layer2', 'layer3', 'layer4')
 
-    def __init__(self, t_backbone, s_backbone):
+    def __init__(self, t_backbone, s_backbone, first=None):
+        first = first or MERGE_FROM
+        if first not in self.ALL[1:]:
+            raise ValueError('HND_MERGE_FROM must be one of layer2 / layer3 / layer4, got %r' % (first,))
+        self.LAYERS = self.ALL[self.ALL.index(first):]          # the layers of the shared pass
+        self.FRONT = self.ALL[:self.ALL.index(first)]           # per-network layers that write into shared buffers
         self.backbones = (t_backbone, s_backbone)
         self.bodies = (t_backbone.body, s_backbone.body)
         s_body, s_fpn = s_backbone.body, s_backbone.fpn
         self.engines = OrderedDict((name, FrozenLayerEngine(list(s_body[name]), name)) for name in self.LAYERS)
         self.fpn_engine = FpnEngine(list(s_fpn.inner_blocks), list(s_fpn.layer_blocks))
         self.bufs = None
-        self.x1 = None                  # [2N, H, W, 256]: layer1 outputs, teacher half first
+        self.front = {}                 # front layer -> [2N, H, W, C]: its outputs, teacher half first
         self.n = None
         self.t_stream = None
         self.seen = [False, False]      # which role has delivered its layer1 output in the current scope
@@ -1005,7 +1028,7 @@ class SharedTrunk(object):
         from . import hipnn
         try:
             tb, sb = t_backbone.body, s_backbone.body
-            for name in SharedTrunk.LAYERS:
+            for name in SharedTrunk.ALL[1:]:
                 if not (isinstance(tb[name], hipnn.ResLayer) and isinstance(sb[name], hipnn.ResLayer)
                         and len(tb[name]) == len(sb[name])):
                     return False
@@ -1023,7 +1046,7 @@ class SharedTrunk(object):
     def _tensor_pairs(self):
         (tb, sb), (tf, sf) = self.bodies, (self.backbones[0].fpn, self.backbones[1].fpn)
         pairs = []
-        for tm, sm in [(tb[n], sb[n]) for n in self.LAYERS] + [(tf, sf)]:
+        for tm, sm in [(tb[n], sb[n]) for n in self.ALL[1:]] + [(tf, sf)]:
             t_sd, s_sd = tm.state_dict(keep_vars=True), sm.state_dict(keep_vars=True)
             if list(t_sd) != list(s_sd):
                 return None
@@ -1049,37 +1072,41 @@ class SharedTrunk(object):
     def role_of(self, body):
         return 0 if body is self.bodies[0] else (1 if body is self.bodies[1] else None)
 
-    def slot_provider(self, role):
+    def slot_provider(self, role, name):
+        """out_provider of front layer `name` of network `role`: its half of the shared [2N, ...] buffer"""
         def provide(shape):
             n = int(shape[0])
             full = (2 * n,) + tuple(int(v) for v in shape[1:])
             if self.bufs is None:
                 self.bufs = Buffers(torch.device('cuda', torch.cuda.current_device()))
-            if role == 1 and self.x1 is not None and tuple(self.x1.shape) != full:
-                raise RuntimeError('SharedTrunk: teacher and student layer1 outputs differ in shape (%s vs %s)'
-                                   % (tuple(self.x1.shape), full))
-            self.x1 = self.bufs.get('x1', full)
+            cur = self.front.get(name)
+            if role == 1 and cur is not None and tuple(cur.shape) != full:
+                raise RuntimeError('SharedTrunk: teacher and student %s outputs differ in shape (%s vs %s)'
+                                   % (name, tuple(cur.shape), full))
+            self.front[name] = self.bufs.get('front_' + name, full)
             self.n = n
-            return self.x1[role * n:(role + 1) * n]
+            return self.front[name][role * n:(role + 1) * n]
         return provide
 
     def delivered(self, role):
-        """layer1 of `role` has been enqueued into its half of x1 (on the current stream)"""
+        """the front layers of `role` have been enqueued into their halves of the shared buffers (current stream)"""
         if role == 0:
             self.t_stream = torch.cuda.current_stream()
         elif not self.seen[0]:
-            raise RuntimeError('SharedTrunk: the student reached the shared layers before the teacher delivered layer1 '
-                               '(DistillationBox calls the teacher first)')
+            raise RuntimeError('SharedTrunk: the student reached the shared layers before the teacher delivered its '
+                               'front layers (DistillationBox calls the teacher first)')
         self.seen[role] = True
 
     def _half(self, t, role):
         return t[role * self.n:(role + 1) * self.n]
 
-    def layer_forward(self, name, role):
+    def layer_forward(self, name, role, force_keep=False):
         eng = self.engines[name]
         idx = self.LAYERS.index(name)
-        x = self.x1 if idx == 0 else self.engines[self.LAYERS[idx - 1]].out
-        keep = self.bodies[1].needs_backward()
+        x = self.front[self.FRONT[-1]] if idx == 0 else self.engines[self.LAYERS[idx - 1]].out
+        # the same answer in both roles (the teacher's views must survive until the student's launch): keep every block's
+        # output when the student trains or when a Bottleneck of either network carries a forward hook
+        keep = self.bodies[1].needs_backward() or any(bool(b[name].hooked_blocks()) for b in self.bodies)
         eng.bslice = (self.n, 2 * self.n)
         if role == 0:
             return self._half(eng.prepare(x, keep), 0)         # a view; filled by the student's call
@@ -1090,7 +1117,7 @@ class SharedTrunk(object):
         return self._half(eng.forward(x, keep), 1)
 
     def fpn_forward(self, role):
-        feats = [self.x1] + [self.engines[n].out for n in self.LAYERS]
+        feats = [self.front[n] for n in self.FRONT] + [self.engines[n].out for n in self.LAYERS]
         if role == 0:
             return [self._half(t, 0) for t in self.fpn_engine.prepare(feats)]
         return [self._half(t, 1) for t in self.fpn_engine.forward(feats)]

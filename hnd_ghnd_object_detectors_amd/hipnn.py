@@ -70,6 +70,20 @@ def attach(t, buf, src=None):
     return t
 
 
+def fire_forward_hooks(module, inp, out):
+    """Forward hooks of a module that executes FUSED inside its parent's engine (a Bottleneck of a ResLayer, the
+    encoder / decoder of the bottleneck head, an FPN output conv): the parent calls this with the engine-produced input
+    and output so that ``register_forward_hook`` on ANY of those dotted paths sees its tensors, as it would in the
+    reference (src/distillation/tool.py:22-35).  A hook that returns a replacement output cannot be honoured."""
+    hooks = getattr(module, '_forward_hooks', None)
+    if not hooks:
+        return
+    for hook in list(hooks.values()):
+        if hook(module, (inp,), out) is not None:
+            raise RuntimeError('a forward hook on %s returned a new output: modules that execute fused inside their '
+                               'parent cannot have their output replaced' % type(module).__name__)
+
+
 def to_nhwc(x, pad_to=None):
     """logical NCHW tensor -> NHWC buffer.  Tensors produced by this package carry their buffer; foreign
     tensors are re-laid out once with torch copies (plumbing, off the distillation hot path)."""
@@ -142,17 +156,33 @@ class ResLayer(nn.Sequential):
             self._engine = E.FrozenLayerEngine(list(self), self._name)
         return self._engine
 
+    def hooked_blocks(self):
+        return [i for i, blk in enumerate(self) if blk._forward_hooks]
+
+    def _fire_block_hooks(self, eng, half=lambda t: t):
+        """forward hooks registered on the Bottleneck blocks (``backbone.body.layer2.1`` ...): their outputs are the
+        engine's per-block buffers (kept: see forward)"""
+        for i in self.hooked_blocks():
+            x_in, _, _, out = (half(t) for t in eng.acts[i])
+            fire_forward_hooks(self[i], attach(E.logical(x_in), x_in),
+                               attach(E.logical(out), out, (self.__dict__.get('_body'), self._name, i)))
+
     def forward(self, x):
         merged = getattr(self, '_merged', None)
+        hooked = bool(self.hooked_blocks())                 # a hooked block's output must survive the layer: keep all
         if merged is not None and E.MERGE['trunk'] is merged[0]:
             # (trunk, role): this call is one half of a SharedTrunk pass (engine.SharedTrunk)
             trunk, role = merged
-            out = trunk.layer_forward(self._name, role)
+            out = trunk.layer_forward(self._name, role, force_keep=hooked)
             self._used_engine = trunk.engines[self._name]
+            if hooked:
+                self._fire_block_hooks(self._used_engine, lambda t: trunk._half(t, role))
             return attach(E.logical(out), out)
         eng = self.engine()
         self._used_engine = eng
-        out = eng.forward(to_nhwc(x), self._keep)
+        out = eng.forward(to_nhwc(x), self._keep or hooked)
+        if hooked:
+            self._fire_block_hooks(eng)
         return attach(E.logical(out), out)
 
 
@@ -200,20 +230,20 @@ class IntermediateLayerGetter(nn.ModuleDict):
         for name, module in self.items():
             if name in ('conv1', 'bn1', 'relu', 'maxpool'):
                 continue
+            module.__dict__['_body'] = self          # (not a submodule registration: the parent for _hnd_src tags)
             if isinstance(module, ResLayer):
                 module._keep = keep
                 module._merged = (trunk, role) if (role is not None and name in trunk.LAYERS) else None
-            if name == 'layer1':
-                # SharedTrunk pass: layer1 writes straight into this network's half of the concatenated batch
-                l1 = module.engine() if isinstance(module, ResLayer) else \
-                    (module.head_engine() if hasattr(module, 'head_engine') else None)
-                if l1 is not None:
-                    l1.out_provider = trunk.slot_provider(role) if role is not None else None
+            own = module.engine() if (isinstance(module, ResLayer) and module._merged is None) else \
+                (module.head_engine() if hasattr(module, 'head_engine') else None)
+            if own is not None:
+                # SharedTrunk pass: the layers in front of it write straight into this network's half of shared buffers
+                own.out_provider = trunk.slot_provider(role, name) if (role is not None and name in trunk.FRONT) else None
             cur = module(cur)
-            if name == 'layer1' and role is not None:
+            if role is not None and name == trunk.FRONT[-1]:
                 trunk.delivered(role)
             if isinstance(cur, torch.Tensor):
-                cur._hnd_src = (self, name)
+                cur._hnd_src = (self, name, None)
             if isinstance(module, ResLayer):
                 self._fwd_engines[name] = module._used_engine
             elif hasattr(module, 'head_engine'):
@@ -233,18 +263,23 @@ class IntermediateLayerGetter(nn.ModuleDict):
         """(parameters that receive gradients, in state-dict order)."""
         return [p for _, p in self.named_parameters() if p.requires_grad]
 
-    def hnd_backward(self, top, loss_grads, grad_dst):
+    def hnd_backward(self, top, loss_grads, grad_dst, top_block=None, block_grads=None):
         """Run the hand-written backward.
         top: name of the highest layer that carries a loss term (its engine's g_out already holds the masked
-        loss gradient).  loss_grads: {layer name: unmasked loss-gradient buffer} for lower layers with a term.
+        loss gradient); top_block: the block of that layer the gradient enters at (None = the layer output).
+        loss_grads: {layer name: unmasked loss-gradient buffer} for lower layers with a term on their output.
+        block_grads: {layer name: {block index: unmasked loss-gradient buffer}} for terms on inner Bottleneck outputs.
         grad_dst: {parameter: destination tensor} for every trainable parameter."""
         order = ['layer4', 'layer3', 'layer2', 'layer1']
         start = order.index(top)
+        block_grads = block_grads or {}
         for name in order[start:-1]:
             prev_name = order[order.index(name) + 1]
             prev_eng = self.layer_engine(prev_name)
             dst = prev_eng.grad_out_buffer()
-            self.layer_engine(name).backward(dst, prev_eng.bwd_out(), loss_grads.get(prev_name))
+            self.layer_engine(name).backward(dst, prev_eng.bwd_out(), loss_grads.get(prev_name),
+                                             top_block=top_block if name == top else None,
+                                             block_grads=block_grads.get(name))
         l1 = self['layer1']
         conv1_w = self['conv1'].weight
         dw1 = grad_dst.get(conv1_w)
@@ -281,12 +316,26 @@ class FeaturePyramidNetwork(nn.Module):
         role = None
         if trunk is not None:
             role = 0 if self is trunk.backbones[0].fpn else (1 if self is trunk.backbones[1].fpn else None)
+        half = (lambda t: t)
         if role is not None:            # one half of a SharedTrunk pass: the pyramid of both networks in one plan
             outs = trunk.fpn_forward(role)
+            eng, half = trunk.fpn_engine, (lambda t: trunk._half(t, role))
         else:
             if self._engine is None:
                 self._engine = E.FpnEngine(list(self.inner_blocks), list(self.layer_blocks))
             outs = self._engine.forward(feats)
+            eng = self._engine
+        for i, m in enumerate(self.layer_blocks):           # hooks on backbone.fpn.layer_blocks.K: the pyramid maps
+            if m._forward_hooks:
+                fire_forward_hooks(m, None, attach(E.logical(outs[i]), outs[i], ('fpn', 'layer_blocks', i)))
+        for i, m in enumerate(self.inner_blocks):
+            if m._forward_hooks:
+                if i != len(self.inner_blocks) - 1:
+                    raise NotImplementedError('backbone.fpn.inner_blocks.%d executes fused with the top-down add: its '
+                                              'bare lateral output does not exist on the HIP path (the top level, '
+                                              'inner_blocks.%d, does)' % (i, len(self.inner_blocks) - 1))
+                t = half(eng.bufs.t['inner%d' % i])
+                fire_forward_hooks(m, None, attach(E.logical(t), t, ('fpn', 'inner_blocks', i)))
         if self.extra_blocks is None:
             outs = outs[:-1]
         else:

@@ -66,8 +66,21 @@ class BottleneckBase4Ext(nn.Module):
                     self.bottleneck_transformer(None, target=None)
                 return None, ext_z
         use_codec = self.use_bottleneck_transformer and not self.training and self.bottleneck_transformer is not None
-        out = self.head_engine().forward(to_nhwc(x), self.training,
-                                         codec=self.bottleneck_transformer if use_codec else None)   # base.py:54-57
+        eng = self.head_engine()
+        out = eng.forward(to_nhwc(x), self.training,
+                          codec=self.bottleneck_transformer if use_codec else None)   # base.py:54-57
+        body = self.__dict__.get('_body')
+        z = None
+        if self.encoder._forward_hooks or self.decoder._forward_hooks:
+            # hooks on ``...layer1.encoder`` / ``...layer1.decoder`` (src/distillation/tool.py:22-35 takes any path): the
+            # encoder's output is the bottleneck tensor z (raw output of its last conv; the BatchNorm that follows is
+            # decoder.0), the decoder's output is the layer's
+            from ...hipnn import fire_forward_hooks
+            zi = eng.encoder_len - 1
+            zbuf = eng.y[zi]
+            z = attach(E.logical(zbuf, eng.layers[zi].cout), zbuf, (body, 'layer1', 'encoder'))
+            fire_forward_hooks(self.encoder, x, z)
+            fire_forward_hooks(self.decoder, z, attach(E.logical(out), out, (body, 'layer1', 'decoder')))
         out = attach(E.logical(out), out)
         return (out, ext_z) if self.uses_ext_encoder else out
 

@@ -281,9 +281,13 @@ def bottleneck_block(x, sd, p, stride):
     return F.relu(y + x)
 
 
-def resnet_layer(x, sd, li):
+def resnet_layer(x, sd, li, hooked=None):
+    """hooked: dict that also receives every Bottleneck's output under 'layer<li>.<i>' (forward hooks on inner blocks:
+    src/distillation/tool.py:22-35 accepts any dotted module path)"""
     for i in range(RESNET50_BLOCKS[li - 1]):
         x = bottleneck_block(x, sd, '%slayer%d.%d.' % (B, li, i), 2 if (i == 0 and li > 1) else 1)
+        if hooked is not None:
+            hooked['layer%d.%d' % (li, i)] = x
     return x
 
 
@@ -346,11 +350,12 @@ def backbone_forward(x, sd, student, training=True, update_buffers=True, with_fp
         intermediates['stem'] = x
     if student:
         x = student_layer1(x, sd, training, update_buffers, intermediates, codec_bits)
+        hooked['layer1.decoder'] = x            # the decoder's output IS the layer's (base.py:50-58)
     else:
-        x = resnet_layer(x, sd, 1)
+        x = resnet_layer(x, sd, 1, hooked)
     hooked['layer1'] = x
     for li in (2, 3, 4):
-        x = resnet_layer(x, sd, li)
+        x = resnet_layer(x, sd, li, hooked)
         hooked['layer%d' % li] = x
     feats = fpn([hooked['layer%d' % i] for i in (1, 2, 3, 4)], sd) if with_fpn else None
     return hooked, feats
@@ -360,7 +365,10 @@ def mimic_loss(t_hooked, s_hooked, terms):
     """loss.py:27-33: sum_k factor_k * MSELoss(reduction='sum')(teacher_k, student_k)."""
     per_term = OrderedDict()
     for name, factor in terms.items():
-        per_term[name] = F.mse_loss(t_hooked[name], s_hooked[name], reduction='sum') * factor
+        # a term is `factor` (both tensors hooked under the term's own name) or (teacher key, student key, factor) with
+        # keys relative to backbone.body: 'layer2', 'layer2.1' (a Bottleneck), 'layer1.decoder'
+        t_key, s_key, factor = (name, name, factor) if not isinstance(factor, (tuple, list)) else factor
+        per_term[name] = F.mse_loss(t_hooked[t_key], s_hooked[s_key], reduction='sum') * factor
     return sum(per_term.values()), per_term
 
 

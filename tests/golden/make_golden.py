@@ -54,6 +54,15 @@ CASES = OrderedDict((
                                 num_classes=2)),
     ('tiny_ghnd_faster_b6', dict(yaml='ghnd/faster_rcnn-backbone_resnet50-b6ch.yaml', model='faster_rcnn',
                                  sizes=[(64, 96)], min_size=64, max_size=128, steps=1, seed=15, bch=6)),
+    # round 4: forward hooks on NON-STANDARD module paths (src/distillation/tool.py:22-35 takes any dotted path): the
+    # student's decoder (an alias of its layer1 output), an inner Bottleneck of layer2, layer3 as usual, and the FIRST
+    # Bottleneck of layer4 as the highest term (the backward starts in the middle of a layer)
+    ('tiny_ghnd_custom_hooks', dict(yaml='ghnd/faster_rcnn-backbone_resnet50-b3ch.yaml', model='faster_rcnn',
+                                    sizes=[(60, 90), (56, 100)], min_size=64, max_size=128, steps=2, seed=31,
+                                    terms=[['layer1', 'backbone.body.layer1', 'backbone.body.layer1.decoder', 1.0],
+                                           ['l2b1', 'backbone.body.layer2.1', 'backbone.body.layer2.1', 0.5],
+                                           ['layer3', 'backbone.body.layer3', 'backbone.body.layer3', 1.0],
+                                           ['l4b0', 'backbone.body.layer4.0', 'backbone.body.layer4.0', 2.0]])),
     ('full_ghnd_faster', dict(yaml='ghnd/faster_rcnn-backbone_resnet50-b3ch.yaml', model='faster_rcnn',
                               sizes=[(800, 1333)], min_size=800, max_size=1333, steps=1, seed=16, full=True)),
     # full-size pins of every BASELINE.json config (round 2).  b4 is the reference's own train batch_size
@@ -142,7 +151,14 @@ def run_case(name, case):
     assert updatable == O.trainable_keys(s_sd), (updatable, O.trainable_keys(s_sd))
 
     crit = config['train']['criterion']
-    terms = OrderedDict((k, v['factor']) for k, v in crit['terms'].items())
+    if 'terms' in case:             # non-standard ts_modules: same criterion type / params as the yaml's own terms
+        proto = next(iter(crit['terms'].values()))['criterion']
+        crit['terms'] = OrderedDict((name, {'ts_modules': [tp, sp], 'criterion': proto, 'factor': f})
+                                    for name, tp, sp, f in case['terms'])
+        strip = len('backbone.body.')
+        terms = OrderedDict((name, (tp[strip:], sp[strip:], f)) for name, tp, sp, f in case['terms'])
+    else:
+        terms = OrderedDict((k, v['factor']) for k, v in crit['terms'].items())
     box = DistillationBox(teacher, student, crit)
     opt_cfg = config['train']['optimizer']
     optimizer = func_util.get_optimizer(student, opt_cfg['type'], opt_cfg['params'])
@@ -190,6 +206,7 @@ def run_case(name, case):
         for k, f in terms.items():
             path = crit['terms'][k]['ts_modules']
             t_out, s_out = hooked(teacher, path[0]), hooked(student, path[1])
+            f = f[2] if isinstance(f, tuple) else f
             out[pre + 'term/' + k] = np.float64((torch.nn.functional.mse_loss(t_out, s_out, reduction='sum') * f).item())
             if step == 0:
                 put(out, pre + 'teacher/' + k, t_out)
@@ -205,7 +222,7 @@ def run_case(name, case):
             put(out, 'transform', teacher_x)
             worst = max(worst, float((teacher_x - o_x).abs().max()))
             feats = student.backbone.fpn(OrderedDict((i, hooked(student, 'backbone.body.layer%d' % (i + 1)))
-                                                     for i in range(4))) if len(terms) == 4 else None
+                                                     for i in range(4))) if (len(terms) == 4 and 'terms' not in case) else None
             if feats is not None:
                 for k, v in feats.items():
                     put(out, 'student_fpn/%s' % k, v, full_limit=30000)

@@ -617,9 +617,99 @@ def test_full_size_dense_parity_every_element(case):
                                              abs(loss.item() - float(l64)) / abs(float(l64)), worst_g))
 
 
-def _one_step_bits(meta, images, targets, merged, monkeypatch, fixed_seed=None):
+@pytest.mark.parametrize('first', [False, 'layer2', 'layer3'])
+def test_custom_hook_paths_match_reference_golden(first, monkeypatch):
+    """VERDICT r3 item 7 / reference src/distillation/tool.py:22-35: ``ts_modules`` may name ANY dotted module path.  The
+    fixture was produced by the reference's own DistillationBox with teacher ``layer1`` <-> student ``layer1.decoder``,
+    an inner Bottleneck of layer2 on both sides, layer3 as usual, and the FIRST Bottleneck of layer4 as the highest term
+    (so the backward starts in the middle of a layer and layer4.1 / layer4.2 carry no gradient).  Hooks on modules that
+    execute fused inside their parent fire with the engine's tensors; two Adam steps against the reference, gradients
+    against the fp64 oracle -- with the shared trunk off, from layer2 and from layer3."""
     from hnd_ghnd_object_detectors_amd import engine as E
-    monkeypatch.setattr(E, 'MERGE_TRUNK', merged)
+    from hnd_ghnd_object_detectors_amd.distillation.tool import DistillationBox
+    from hnd_ghnd_object_detectors_amd.myutils.pytorch import func_util
+    from hnd_ghnd_object_detectors_amd.utils import main_util
+    monkeypatch.setattr(E, 'MERGE_TRUNK', bool(first))
+    monkeypatch.setattr(E, 'MERGE_FROM', first or 'layer3')
+    z, meta = G.load('tiny_ghnd_custom_hooks')
+    cfg = MU.config_for(meta)
+    crit = cfg['train']['criterion']
+    proto = next(iter(crit['terms'].values()))['criterion']
+    crit['terms'] = OrderedDict((name, {'ts_modules': [tp, sp], 'criterion': proto, 'factor': f})
+                                for name, tp, sp, f in meta['terms'])
+    strip = len('backbone.body.')
+    terms = OrderedDict((name, (tp[strip:], sp[strip:], f)) for name, tp, sp, f in meta['terms'])
+    t_sd, s_sd = MU.oracle_states(meta['seed'], meta['model'])
+    teacher, student = MU.build_pair(cfg, t_sd, s_sd, DEV)
+    box = DistillationBox(teacher, student, crit)
+    opt = func_util.get_optimizer(student, 'Adam', {'lr': 1e-3})
+    warm = main_util.warmup_lr_scheduler(opt, 4, 1e-3)
+    images, targets = G.case_inputs(meta)
+    kw = dict(terms=terms, min_size=(meta['min_size'],), max_size=meta['max_size'])
+    orc64, orc32 = O.DistillOracle(t_sd, s_sd, dtype=torch.float64, **kw), O.DistillOracle(t_sd, s_sd, **kw)
+    worst = {'feat': 0.0, 'loss': 0.0, 'grad': 0.0}
+    for step in range(meta['steps']):
+        ims, tgs = _to_dev(images, targets)
+        _sync_oracle(orc64, student)
+        _sync_oracle(orc32, student)
+        _, _, g64, _ = orc64.step(images)
+        _, _, g32, _ = orc32.step(images)
+        loss = box(ims, tgs)
+        ref_loss = float(z['step%d/loss' % step])
+        worst['loss'] = max(worst['loss'], abs(loss.item() - ref_loss) / abs(ref_loss))
+        for i, (name, tp, sp, f) in enumerate(meta['terms']):
+            ref_t = float(z['step%d/term/%s' % (step, name)])
+            worst['loss'] = max(worst['loss'], abs(float(loss.per_term[i]) - ref_t) / abs(ref_t))
+            if step == 0:
+                worst['feat'] = max(worst['feat'], G.compare(z, 'step0/teacher/' + name, _hooked(teacher, tp), FEAT_TOL),
+                                    G.compare(z, 'step0/student/' + name, _hooked(student, sp), FEAT_TOL))
+        opt.zero_grad()
+        loss.backward()
+        for n, p in student.named_parameters():
+            if p.requires_grad and not n.endswith(G.ZERO_GRAD_SUFFIXES):
+                worst['grad'] = max(worst['grad'], _grad_check(n, p.grad, g32[n], g64[n]))
+        opt.step()
+        warm.step()
+    assert worst['loss'] < LOSS_TOL, worst
+    body = student.backbone.body
+    shared = [n for n in ('layer2', 'layer3', 'layer4') if body.layer_engine(n) is not body[n]._engine]
+    assert shared == (['layer2', 'layer3', 'layer4'][int(first[-1]) - 2:] if first else [])
+    sd = student.state_dict()
+    ptol = 2e-2 if worst['grad'] > 1e-4 else 2e-3          # (a ReLU flip: see test_distill_steps_match_reference_golden)
+    worst['param'] = max(G.compare(z, 'after/param/' + n, sd[n], ptol, atol=1e-6)
+                         for n in O.trainable_keys(s_sd) if not n.endswith(G.ZERO_GRAD_SUFFIXES))
+    from tests.conftest import record_achieved
+    record_achieved('[custom hook paths (layer1.decoder, layer2.1, layer3, layer4.0), trunk %s] maps %.1e, loss / terms %.1e, '
+                    'gradients vs fp64 %.2e, parameters after 2 Adam steps %.1e'
+                    % (first or 'off', worst['feat'], worst['loss'], worst['grad'], worst['param']))
+
+
+def test_unsupported_hook_paths_are_refused_with_the_list_of_supported_ones():
+    """a student-side term on the bottleneck tensor or on a pyramid map has no backward plan: refused loudly, never
+    silently ignored; a hook on a parameter holder that never runs on its own names the problem"""
+    from hnd_ghnd_object_detectors_amd.distillation.tool import DistillationBox
+    z, meta = G.load('tiny_ghnd_custom_hooks')
+    images, targets = G.case_inputs(meta)
+    for tp, sp, msg in (('backbone.body.layer1', 'backbone.fpn.layer_blocks.0', 'feature pyramid'),
+                        ('backbone.fpn.layer_blocks.1', 'backbone.body.layer1.encoder', 'layer1.encoder'),
+                        ('backbone.body.layer1', 'backbone.body.layer1.decoder.3', 'fused')):
+        cfg = MU.config_for(meta)
+        crit = cfg['train']['criterion']
+        proto = next(iter(crit['terms'].values()))['criterion']
+        crit['terms'] = OrderedDict([('t', {'ts_modules': [tp, sp], 'criterion': proto, 'factor': 1.0})])
+        t_sd, s_sd = MU.oracle_states(meta['seed'], meta['model'])
+        teacher, student = MU.build_pair(cfg, t_sd, s_sd, DEV)
+        box = DistillationBox(teacher, student, crit)
+        ims, tgs = _to_dev(images, targets)
+        with pytest.raises((NotImplementedError, ValueError), match=msg):
+            box(ims, tgs)
+
+
+def _one_step_bits(meta, images, targets, merged, monkeypatch, fixed_seed=None):
+    """merged: False (two separate passes) or the first layer of the shared pass"""
+    from hnd_ghnd_object_detectors_amd import engine as E
+    monkeypatch.setattr(E, 'MERGE_TRUNK', bool(merged))
+    monkeypatch.setattr(E, 'MERGE_FROM', merged or 'layer3')
     cfg, t_sd, s_sd, teacher, student, box, opt, warm = _setup(meta)
     ims, tgs = _to_dev(images, [dict(t) for t in targets])
     if fixed_seed is not None:
@@ -628,7 +718,7 @@ def _one_step_bits(meta, images, targets, merged, monkeypatch, fixed_seed=None):
     opt.zero_grad()
     loss.backward()
     body = student.backbone.body
-    used = body.layer_engine('layer2') is not body['layer2']._engine
+    used = [n for n in ('layer2', 'layer3', 'layer4') if body.layer_engine(n) is not body[n]._engine]
     maps = OrderedDict()
     for who, model in (('teacher', teacher), ('student', student)):
         for k in MU.terms_of(cfg):
@@ -639,8 +729,11 @@ def _one_step_bits(meta, images, targets, merged, monkeypatch, fixed_seed=None):
     return used, loss.item(), loss.per_term.cpu().clone(), maps, grads, teacher, student
 
 
-@pytest.mark.parametrize('case', ['tiny_ghnd_faster', 'tiny_ghnd_keypoint', 'full_ghnd_faster_b4', 'full_hnd_faster_b2'])
-def test_shared_trunk_halves_equal_the_separate_passes_bit_for_bit(case, monkeypatch):
+@pytest.mark.parametrize('case,first', [('tiny_ghnd_faster', 'layer2'), ('tiny_ghnd_faster', 'layer3'),
+                                        ('tiny_ghnd_keypoint', 'layer4'), ('tiny_ghnd_keypoint', 'layer3'),
+                                        ('full_ghnd_faster_b4', 'layer3'), ('full_ghnd_faster_b4', 'layer2'),
+                                        ('full_hnd_faster_b2', 'layer3')])
+def test_shared_trunk_halves_equal_the_separate_passes_bit_for_bit(case, first, monkeypatch):
     """layers 2-4 + FPN of teacher and student as ONE pass over the concatenated batch
     (engine.SharedTrunk) must give, in the teacher half, exactly the teacher's separate pass and, in the student half,
     exactly the student's -- every hooked map, the loss and its terms, and every gradient (the backward plan runs over
@@ -650,13 +743,14 @@ def test_shared_trunk_halves_equal_the_separate_passes_bit_for_bit(case, monkeyp
         meta = dict(meta, sizes=meta['sizes'][:2])
     images, targets = G.case_inputs(meta)
     seed = 100 if meta['model'] == 'keypoint_rcnn' else None
-    runs = {m: _one_step_bits(meta, images, targets, m, monkeypatch, seed) for m in (False, True)}
-    assert runs[True][0] and not runs[False][0], 'the merged run must use the shared engines, the other its own'
-    assert runs[True][1] == runs[False][1] and torch.equal(runs[True][2], runs[False][2])
+    runs = {m: _one_step_bits(meta, images, targets, m, monkeypatch, seed) for m in (False, first)}
+    shared = ['layer2', 'layer3', 'layer4'][int(first[-1]) - 2:]
+    assert runs[first][0] == shared and runs[False][0] == [], 'the merged run uses the shared engines from `first` on'
+    assert runs[first][1] == runs[False][1] and torch.equal(runs[first][2], runs[False][2])
     for k in runs[False][3]:
-        assert torch.equal(runs[True][3][k], runs[False][3][k]), k
+        assert torch.equal(runs[first][3][k], runs[False][3][k]), k
     for n in runs[False][4]:
-        assert torch.equal(runs[True][4][n], runs[False][4][n]), n
+        assert torch.equal(runs[first][4][n], runs[False][4][n]), n
 
 
 def test_shared_trunk_is_dropped_when_the_frozen_weights_differ(monkeypatch):

@@ -7,13 +7,17 @@ import torch
 from oracle import hnd_oracle as O
 from tests import golden_util as G
 
-TINY = ['tiny_ghnd_faster', 'tiny_hnd_faster', 'tiny_ghnd_mask', 'tiny_ghnd_keypoint', 'tiny_ghnd_faster_b6']
+TINY = ['tiny_ghnd_faster', 'tiny_hnd_faster', 'tiny_ghnd_mask', 'tiny_ghnd_keypoint', 'tiny_ghnd_faster_b6',
+        'tiny_ghnd_custom_hooks']
 
 
 def _oracle_for(meta, z):
     t_sd = O.init_teacher_state(meta['seed'], meta['model'], num_classes=meta.get('num_classes', 91))
     s_sd = O.init_student_state(t_sd, meta['seed'] + 1000, bch=meta.get('bch', 3))
     terms = O.HND_TERMS if meta['yaml'].startswith('hnd/') else O.GHND_TERMS
+    if 'terms' in meta:             # non-standard hook paths: (teacher key, student key, factor) relative to backbone.body
+        strip = len('backbone.body.')
+        terms = OrderedDict((name, (tp[strip:], sp[strip:], f)) for name, tp, sp, f in meta['terms'])
     ms = meta['min_size'] if isinstance(meta['min_size'], list) else [meta['min_size']]
     return O.DistillOracle(t_sd, s_sd, terms=terms, min_size=tuple(ms), max_size=meta['max_size'],
                            warmup_iters=4, warmup_factor=1e-3), terms
@@ -30,10 +34,11 @@ def test_oracle_matches_reference_fixture(name):
         if step == 0:
             _, _, t_h, s_h, _, s_f, x = orc.forward(images, fs, update_buffers=False)
             G.compare(z, 'transform', x, 1e-6)
-            for k in terms:
-                G.compare(z, 'step0/teacher/' + k, t_h[k], 1e-6)
-                G.compare(z, 'step0/student/' + k, s_h[k], 1e-6)
-            if len(terms) == 4:
+            for k, v in terms.items():
+                tk, sk = (v[0], v[1]) if isinstance(v, tuple) else (k, k)
+                G.compare(z, 'step0/teacher/' + k, t_h[tk], 1e-6)
+                G.compare(z, 'step0/student/' + k, s_h[sk], 1e-6)
+            if len(terms) == 4 and 'terms' not in meta:
                 for k, v in s_f.items():
                     G.compare(z, 'student_fpn/%s' % k, v, 1e-6)
         loss, per_term, grads, lr = orc.step(images, fs)
