@@ -67,6 +67,7 @@ _SIGNATURES = {
     'hnd_conv2d_igemm_workspace': (C.c_size_t, [C.POINTER(ConvDesc)]),
     'hnd_conv2d_wgrad_workspace': (C.c_size_t, [C.POINTER(WgradDesc)]),
     'hnd_conv2d_wgrad': (C.c_int, [C.POINTER(WgradDesc), vp]),
+    'hnd_conv2d_wgrad_variant': (C.c_int, [C.POINTER(WgradDesc)]),
     'hnd_pack_weights': (C.c_int, [vp, vp] + [C.c_int] * 12 + [vp]),
     'hnd_scale_packed_k': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]),
     'hnd_pack_weights_batched': (C.c_int, [C.POINTER(PackDesc), C.c_int, vp]),

@@ -413,6 +413,9 @@ namespace hnd {
 bool stem7_wgrad_applies(const hnd_wgrad_desc& d);             // conv_stem.hip: the stem's dW from an LDS patch
 int stem7_wgrad_blocks(const hnd_wgrad_desc& d);
 int launch_stem7_wgrad(const hnd_wgrad_desc& d, int ncols_pad, hipStream_t stream);
+bool wgrad_ring_applies(const hnd_wgrad_desc& d);              // conv_wgrad_ring.hip: operands straight from global
+size_t wgrad_ring_workspace(const hnd_wgrad_desc& d);
+int launch_wgrad_ring(const hnd_wgrad_desc& d, int& splits, int& co_pad, int& ncols_pad, hipStream_t stream);
 }  // namespace hnd
 
 extern "C" size_t hnd_conv2d_wgrad_workspace(const hnd_wgrad_desc* desc) {
@@ -426,6 +429,10 @@ extern "C" size_t hnd_conv2d_wgrad_workspace(const hnd_wgrad_desc* desc) {
     const size_t stem = (size_t)hnd::stem7_wgrad_blocks(d) * 64 * a.ncols_pad * sizeof(float);
     if (stem > need) need = stem;
   }
+  if (hnd::wgrad_ring_applies(d)) {                     // one [cout][cols] slab per workgroup of the ring kernel
+    const size_t ring = hnd::wgrad_ring_workspace(d);
+    if (ring > need) need = ring;
+  }
   bool tx;
   if (thin_wgrad_applies(d, tx)) {                      // one 4 KB partial per block
     int per_block;
@@ -433,6 +440,16 @@ extern "C" size_t hnd_conv2d_wgrad_workspace(const hnd_wgrad_desc* desc) {
     if (thin > need) need = thin;
   }
   return need;
+}
+
+extern "C" int hnd_conv2d_wgrad_variant(const hnd_wgrad_desc* desc) {
+  if (!desc) return -1;
+  const hnd_wgrad_desc& d = *desc;
+  bool tx;
+  if (hnd::stem7_wgrad_applies(d)) return 1;
+  if (thin_wgrad_applies(d, tx)) return 2;
+  if (hnd::wgrad_ring_applies(d)) return 3;
+  return 0;
 }
 
 extern "C" int hnd_conv2d_wgrad(const hnd_wgrad_desc* desc, void* stream) {
@@ -480,6 +497,15 @@ extern "C" int hnd_conv2d_wgrad(const hnd_wgrad_desc* desc, void* stream) {
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 63) / 64, 1), dim3(256), 0, s, d.slabs, d.dw, blocks,
                        thick_is_x ? 4 : 64, thick_is_x ? 256 : 16, d.cout, d.cin, d.cin_real, d.kh, d.kw, 0ll);
     return hnd::check_launch("hnd_conv2d_wgrad(thin reduce)");
+  }
+  if (hnd::wgrad_ring_applies(d)) {
+    int splits = 0, co_pad = 0, ncols_pad = 0;
+    int rc = hnd::launch_wgrad_ring(d, splits, co_pad, ncols_pad, s);
+    if (rc) return rc;
+    const int total = d.cout * d.kh * d.kw * d.cin_real;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 63) / 64, groups), dim3(256), 0, s, d.slabs, d.dw, splits,
+                       co_pad, ncols_pad, d.cout, d.cin, d.cin_real, d.kh, d.kw, (long long)d.dw_group_stride);
+    return hnd::check_launch("hnd_conv2d_wgrad(ring reduce)");
   }
   const dim3 grid(a.rtiles * a.ctiles * a.d.splitk, groups);
   // tuning knob HND_WGRAD_BPC: cap the resident blocks per CU by padding the dynamic LDS request.  Measured in the

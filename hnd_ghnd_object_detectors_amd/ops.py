@@ -278,15 +278,9 @@ class WgradLaunch(object):
         self.desc, self.keep, self.flops = desc, keep, flops
         self.alg_flops = flops
         self.ref = C.byref(desc)
-        self.variant = 'wgrad_m128' if desc.cout >= 128 else 'wgrad_m64'
-        if (desc.cin == 4 and desc.kh == 7 and desc.stride == 2 and desc.cout == 64 and desc.groups <= 1
-                and os.environ.get('HND_STEM7', '1') != '0'):
-            self.variant = 'stem7_wgrad'          # csrc/conv_stem.hip: dW from an LDS-staged patch
-        if (desc.kh == 2 and desc.kw == 2 and desc.stride == 1 and desc.groups <= 1 and desc.pad in (0, 1)
-                and os.environ.get('HND_THIN_WGRAD', '1') != '0'
-                and ((desc.cin == 64 and desc.cin_real == 64 and desc.cout <= 4 and desc.ldy == 4)
-                     or (desc.cin == 4 and desc.cout == 64 and desc.ldy == 64))):
-            self.variant = 'thin_wgrad'           # csrc/conv_wgrad.hip: the two 3-channel weight gradients (vector ALU)
+        # which kernel hnd_conv2d_wgrad dispatches to (asked of the library: csrc/conv_wgrad.hip)
+        self.variant = {1: 'stem7_wgrad', 2: 'thin_wgrad', 3: 'wgrad_ring'}.get(
+            int(_L.hnd_conv2d_wgrad_variant(self.ref)), 'wgrad_m128' if desc.cout >= 128 else 'wgrad_m64')
 
     def run(self, stream=None):
         rc = _L.hnd_conv2d_wgrad(self.ref, stream if stream is not None else stream_ptr())

@@ -151,6 +151,12 @@ typedef struct hnd_wgrad_desc {
 
 size_t hnd_conv2d_wgrad_workspace(const hnd_wgrad_desc* desc);
 int hnd_conv2d_wgrad(const hnd_wgrad_desc* desc, void* stream);
+/* which kernel the launch above would use: 0 = the LDS-staged split-K kernel (csrc/conv_wgrad.hip), 1 = the 7x7 stem from
+ * an LDS patch (csrc/conv_stem.hip), 2 = the vector-ALU kernel of the two 3-channel gradients, 3 = the ring kernel
+ * (csrc/conv_wgrad_ring.hip: cout % 128 == 0, cin % 64 == 0; both operands straight from global memory through a
+ * counted register ring, accumulators resident; HND_WGRAD_RING=0 turns it off).  All sum their split-K slabs in a fixed
+ * order: each is bitwise reproducible; different kernels differ in rounding. */
+int hnd_conv2d_wgrad_variant(const hnd_wgrad_desc* desc);
 
 /* Re-layout torch OIHW weights [cout][cin][kh][kw] into the K-contiguous GEMM operand of
  * hnd_conv2d_igemm.  transposed=0: rows=cout, K=(tap, cin_pad) (forward);  transposed=1: rows=cin,

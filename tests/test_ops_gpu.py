@@ -296,6 +296,64 @@ def test_thin_wgrad_matches_the_mfma_kernel_and_torch(ops, cin, cout, pad, n, h,
     assert relerr(res['1'][0], res['0'][0]) < 1e-5
 
 
+@pytest.mark.parametrize('case', [
+    # n, cin, h, w, cout, k, pad, groups      (groups > 1: the grouped Winograd-domain form, 1x1 over `h * w` tiles)
+    (2, 64, 37, 53, 256, 2, 1, 1),            # head conv1: 256 x 256 tile, four taps of 64 channels, BN+ReLU prologue
+    (3, 64, 40, 41, 128, 2, 0, 1),            # conv5: 128 x 256 tile
+    (2, 128, 23, 31, 256, 2, 0, 1),           # 256 x 512 columns: two column tiles, halves inside one tap
+    (1, 256, 1, 3001, 256, 1, 0, 7),          # conv7 in the Winograd domain: grouped, K = tiles, ragged against 32
+    (1, 128, 1, 1777, 256, 1, 0, 5),          # conv6 in the Winograd domain: 256 x 128 tile
+    (2, 64, 9, 9, 128, 2, 1, 1),              # fewer pixels than workgroups
+])
+def test_wgrad_ring_matches_the_staged_kernel_and_torch(ops, case, monkeypatch):
+    """csrc/conv_wgrad_ring.hip: both operands straight from global memory through a counted register
+    ring, accumulators resident.  A different summation order than the LDS-staged split-K kernel: both must agree with
+    torch's fp32 autograd to 1e-4 and with each other to 2e-5, and the ring kernel must be bitwise reproducible."""
+    n, cin, h, w, cout, k, pad, groups = case
+    g = gen(500 + sum(case))
+    res = {}
+    if groups == 1:
+        x = torch.randn(n, cin, h, w, generator=g)
+        ps, pb = torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g) * 0.3
+        wt = (torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k)).requires_grad_(True)
+        out = F.conv2d(F.relu(x * ps[None, :, None, None] + pb[None, :, None, None]), wt, None, 1, pad)
+        dy = torch.randn(out.shape, generator=g)
+        out.backward(dy)
+        ref = wt.grad
+        xd, dyd, psd, pbd = nhwc(x), nhwc(dy), ps.to(DEV), pb.to(DEV)
+        for mode in ('0', '1', '1b'):
+            monkeypatch.setenv('HND_WGRAD_RING', mode[0])
+            dw = torch.full((cout, cin, k, k), float('nan'), device=DEV)
+            l = ops.conv_wgrad(xd, dyd, dw, k, 1, pad, pro_scale=psd, pro_shift=pbd, pro_relu=True)
+            l.run()
+            ops.sync_check()
+            res[mode] = (dw.cpu(), l.variant)
+    else:
+        tiles = w
+        xs = torch.randn(groups, tiles, cin, generator=g)
+        dys = torch.randn(groups, tiles, cout, generator=g)
+        ref = torch.einsum('gtc,gtd->gdc', xs, dys)            # [groups, cout, cin]
+        xd, dyd = xs.to(DEV).contiguous(), dys.to(DEV).contiguous()
+        for mode in ('0', '1', '1b'):
+            monkeypatch.setenv('HND_WGRAD_RING', mode[0])
+            dw = torch.full((groups, cout, cin), float('nan'), device=DEV)
+            d = ops.WgradDesc()
+            d.x, d.dy, d.dw = xd.data_ptr(), dyd.data_ptr(), dw.data_ptr()
+            d.n, d.h, d.w_, d.cin, d.cin_real, d.oh, d.ow, d.cout, d.ldy = 1, 1, tiles, cin, cin, 1, tiles, cout, cout
+            d.kh, d.kw, d.stride, d.pad, d.splitk, d.groups = 1, 1, 1, 0, 0, groups
+            d.x_group_stride, d.dy_group_stride, d.dw_group_stride = tiles * cin, tiles * cout, cout * cin
+            slabs = torch.empty((ops.wgrad_workspace_of(d) + 3) // 4, device=DEV)
+            d.slabs = slabs.data_ptr()
+            l = ops.WgradLaunch(d, (xd, dyd, dw, slabs), 2 * groups * tiles * cout * cin)
+            l.run()
+            ops.sync_check()
+            res[mode] = (dw.cpu(), l.variant)
+    assert res['0'][1].startswith('wgrad_m') and res['1'][1] == 'wgrad_ring', (res['0'][1], res['1'][1])
+    assert torch.equal(res['1'][0], res['1b'][0])
+    assert relerr(res['1'][0], ref) < 1e-4 and relerr(res['0'][0], ref) < 1e-4, (relerr(res['1'][0], ref),)
+    assert relerr(res['1'][0], res['0'][0]) < 2e-5
+
+
 def test_wgrad_is_deterministic(ops):
     g = gen(3)
     x = torch.randn(2, 64, 40, 50, generator=g)

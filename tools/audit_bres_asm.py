@@ -1,11 +1,12 @@
 #!/usr/bin/env python
-"""Audit of the inline-asm register rings of bres2_kernel (csrc/conv_bres.hip) and bstream_kernel
-(csrc/conv_bstream.hip) in hipcc's assembly output.
+"""Audit of the inline-asm register rings of bres2_kernel (csrc/conv_bres.hip), bstream_kernel
+(csrc/conv_bstream.hip) and wgrad_ring_kernel (csrc/conv_wgrad_ring.hip) in hipcc's assembly output.
 
 hipcc does not know that a `global_load_dwordx4` inside an asm statement writes its destination LATER: between that
 statement and the `s_waitcnt vmcnt(N)` statement that names the same registers it is free to copy / spill / reuse them.
-This script walks every such kernel in the .s file and fails if any instruction reads or writes a ring register
-between its asm load and the asm wait that releases it (a second asm load into a still-pending register also fails).
+This script walks the control-flow graph of every such kernel in the .s file (every path, loop back edges included, each
+basic block once per distinct set of loads in flight) and fails if any instruction reads or writes a ring register
+between its asm load and the wait that releases it (a second asm load into a still-pending register also fails).
 
 usage: python tools/audit_bres_asm.py [file.s ...]      (without a file: compiles the two sources to assembly first)
 """
@@ -32,7 +33,7 @@ def regs_of(text):
 def audit(path):
     kernels, cur, name = {}, None, None
     for line in open(path):
-        m = re.match(r'^(_ZN\S*(?:bres2|bstream)_kernel\S*):', line)
+        m = re.match(r'^(_ZN\S*(?:bres2|bstream|wgrad_ring)_kernel\S*):', line)
         if m:
             name, cur = m.group(1), []
             kernels[name] = cur
@@ -42,70 +43,82 @@ def audit(path):
                 cur = None
     problems, stats = [], {}
     for name, lines in kernels.items():
-        pending = {}            # register -> line number of the asm load that targets it
-        order = []              # asm loads still in flight, oldest first: (line, destination registers)
-        in_asm, loads, waits = False, 0, 0
+        # ---- basic blocks: a label starts one, a branch / s_endpgm ends one
+        label_at = {}
+        for i, l in enumerate(lines):
+            m = re.match(r'^(\.LBB\S+):', l)
+            if m:
+                label_at[m.group(1)] = i
+        starts = sorted(set([0] + list(label_at.values())))
+        loads, waits = 0, 0
+        seen, found = set(), set()
 
-        def release(keep):
-            """memory operations retire in issue order: after `vmcnt(keep)` all but the `keep` youngest have landed
-            (the compiler's own loads / stores in between only make the real state more complete than this model)"""
-            while len(order) > keep:
-                _, dst = order.pop(0)
-                for r in dst:
-                    pending.pop(r, None)
-
-        labels = {l.split(':')[0].strip(): i for i, l in enumerate(lines) if re.match(r'^\.LBB\S+:', l)}
-        replayed = set()
-
-        def scan(lo, hi, top):
-            nonlocal in_asm, loads, waits
-            for idx in range(lo, hi):
+        def step_block(lo, state):
+            """simulate lines from `lo` to the end of its block; returns [(next line index, state)]"""
+            nonlocal loads, waits
+            pending, order = dict(state[0]), list(state[1])
+            in_asm = False
+            idx = lo
+            while idx < len(lines):
                 raw, no = lines[idx], idx + 1
+                if idx != lo and idx in starts_set:         # fell into the next block
+                    return [(idx, (pending, order))]
                 text = raw.split(';')[0].strip() if not raw.strip().startswith(';') else ''
                 if '#ASMSTART' in raw:
                     in_asm = True
-                    continue
-                if '#ASMEND' in raw:
+                elif '#ASMEND' in raw:
                     in_asm = False
-                    continue
-                if not text or text.endswith(':') or text.startswith('.'):
-                    continue
-                m = re.match(r's_waitcnt.*vmcnt\((\d+)\)', text)
-                if m:                                   # asm or compiler wait: same hardware counter
-                    waits += in_asm and top
-                    release(int(m.group(1)))
-                    continue
-                if in_asm and text.startswith('global_load_dwordx4'):
-                    dst = regs_of(text.split(',')[0])
-                    clash = dst & set(pending)
-                    if clash:
-                        problems.append('%s:%d asm load into still-pending %s' % (name[-40:], no, sorted(clash)[:4]))
-                    srcs = regs_of(','.join(text.split(',')[1:]))
-                    if srcs & set(pending):
-                        problems.append('%s:%d asm load address uses a pending register' % (name[-40:], no))
-                    for r in dst:
-                        pending[r] = no
-                    order.append((no, dst))
-                    loads += top
-                    continue
-                if in_asm:
-                    continue
-                touched = regs_of(text) & set(pending)
-                if touched:     # a compiler instruction reads / writes a register whose asm load may still be in flight
-                    problems.append('%s:%d `%s` touches %s (asm load at line %d)'
-                                    % (name[-40:], no, text[:60], sorted(touched)[:4], pending[sorted(touched)[0]]))
-                b = re.match(r's_cbranch_\w+\s+(\.LBB\S+)|s_branch\s+(\.LBB\S+)', text)
-                if b and top:
-                    tgt = labels.get(b.group(1) or b.group(2))
-                    if tgt is not None and tgt < idx and (tgt, idx) not in replayed:
-                        # loop back edge: walk the body once more with what is in flight at the bottom of the loop
-                        replayed.add((tgt, idx))
-                        saved = (dict(pending), list(order))
-                        scan(tgt, idx, False)
-                        pending.clear(); pending.update(saved[0])
-                        order[:] = saved[1]
+                elif text and not text.endswith(':') and not text.startswith('.'):
+                    m = re.match(r's_waitcnt.*vmcnt\((\d+)\)', text)
+                    if m:                                   # asm or compiler wait: same hardware counter; memory
+                        keep = int(m.group(1))              # operations retire in issue order
+                        while len(order) > keep:
+                            _, dst = order.pop(0)
+                            for r in dst:
+                                pending.pop(r, None)
+                    elif in_asm and text.startswith('global_load_dwordx4'):
+                        dst = regs_of(text.split(',')[0])
+                        clash = dst & set(pending)
+                        if clash:
+                            found.add('%s:%d asm load into still-pending %s' % (name[-40:], no, sorted(clash)[:4]))
+                        if regs_of(','.join(text.split(',')[1:])) & set(pending):
+                            found.add('%s:%d asm load address uses a pending register' % (name[-40:], no))
+                        for r in dst:
+                            pending[r] = no
+                        order.append((no, frozenset(dst)))
+                    elif not in_asm:
+                        touched = regs_of(text) & set(pending)
+                        if touched:     # a compiler instruction reads / writes a register whose asm load may be in flight
+                            found.add('%s:%d `%s` touches %s (asm load at line %d)'
+                                      % (name[-40:], no, text[:60], sorted(touched)[:4], pending[sorted(touched)[0]]))
+                        if text.startswith('s_endpgm'):
+                            return []
+                        b = re.match(r's_branch\s+(\.LBB\S+)', text)
+                        if b:
+                            return [(label_at[b.group(1)], (pending, order))] if b.group(1) in label_at else []
+                        b = re.match(r's_cbranch_\w+\s+(\.LBB\S+)', text)
+                        if b and b.group(1) in label_at:
+                            return [(label_at[b.group(1)], (dict(pending), list(order))), (idx + 1, (pending, order))]
+                idx += 1
+            return []
 
-        scan(0, len(lines), True)
+        starts_set = set(starts)
+        for l in lines:                                     # counts for the report
+            t = l.split(';')[0].strip()
+            loads += t.startswith('global_load_dwordx4') and 1 or 0
+        work = [(0, ({}, []))]
+        while work:
+            lo, state = work.pop()
+            key = (lo, tuple(sorted(state[0].items())), tuple(state[1]))
+            if key in seen:
+                continue
+            seen.add(key)
+            if len(seen) > 20000:
+                found.add('%s: state space of the walk exploded' % name[-40:])
+                break
+            work.extend(step_block(lo, state))
+        problems.extend(sorted(found))
+        waits = sum(1 for l in lines if re.match(r'\s*s_waitcnt vmcnt\(\d+\)\s*$', l))
         stats[name] = (loads, waits)
     return kernels, problems, stats
 
@@ -114,7 +127,7 @@ def main():
     paths = sys.argv[1:]
     if not paths:
         tmp = tempfile.mkdtemp()
-        for stem in ('conv_bres', 'conv_bstream'):
+        for stem in ('conv_bres', 'conv_bstream', 'conv_wgrad_ring'):
             path = os.path.join(tmp, stem + '.s')
             src = os.path.join(ROOT, 'hnd_ghnd_object_detectors_amd', 'csrc', stem + '.hip')
             subprocess.check_call(['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950',
@@ -125,7 +138,7 @@ def main():
     for path in paths:
         kernels, problems, stats = audit(path)
         for k, (l, w) in stats.items():
-            print('%s: %d asm loads, %d asm waits' % (k, l, w))
+            print('%s: %d 16-byte loads, %d bare vmcnt waits' % (k, l, w))
         if not kernels:
             print('%s: no ring kernel found' % path)
             rc = 1

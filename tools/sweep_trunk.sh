@@ -24,3 +24,9 @@ run l2_k8_w32        HND_MERGE_FROM=layer2 HND_BSTREAM_K1024_TILES=8 HND_BRES2_W
 run l4_k4            HND_MERGE_FROM=layer4 HND_BSTREAM_K1024_TILES=4
 run sep_k4           HND_MERGE_TRUNK=0 HND_BSTREAM_K1024_TILES=4
 run sep_b            HND_MERGE_TRUNK=0
+if [ "${2:-}" = "more" ]; then
+run l3_nodefer       HND_MERGE_FROM=layer3 HND_BSTREAM_K1024_TILES=4 HND_BRES2_WINO_MIN=32 HND_DEFER_FPN=0
+run l3_noteacher     HND_MERGE_FROM=layer3 HND_BSTREAM_K1024_TILES=4 HND_BRES2_WINO_MIN=32 HND_TEACHER_STREAM=0
+run sep_single       HND_MERGE_TRUNK=0 HND_TEACHER_STREAM=0 HND_DEFER_FPN=0
+run l2_single        HND_MERGE_FROM=layer2 HND_BSTREAM_K1024_TILES=4 HND_BRES2_WINO_MIN=32 HND_TEACHER_STREAM=0 HND_DEFER_FPN=0
+fi
