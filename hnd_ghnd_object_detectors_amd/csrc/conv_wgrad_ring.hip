@@ -78,8 +78,12 @@ __device__ __forceinline__ void rwait(f32x4& a0, f32x4& a1, f32x4& a2, f32x4& a3
 
 // AH / BH: 64-channel halves of a wave's tile along cout / along the columns.  TAPS: columns are (tap, ci) of a conv with
 // kh * kw > 1 or padding, each 64-column half inside ONE tap (cin % 64 == 0); else a 1x1 problem (x pixel = dy pixel).
-template <int AH, int BH, bool TAPS>
-__global__ void __launch_bounds__(256, 1) wgrad_ring_kernel(const WringArgs a) {
+// WPS: workgroups per CU = waves per SIMD.  The 1x1 problems run one wave per SIMD on 128-row wave tiles (all the vector
+// work of a k-step is two address computations); the tap problems run TWO waves per SIMD on 64-row wave tiles, so that
+// one wave's address arithmetic, prologue and padding selects (~100 vector instructions per k-step) issue while the
+// other wave's MFMAs own the matrix pipe -- interleaving them by hand inside one wave cost more registers than it hid.
+template <int AH, int BH, bool TAPS, int WPS>
+__global__ void __launch_bounds__(256, WPS) wgrad_ring_kernel(const WringArgs a) {
   constexpr int RING = 8, NL = AH + BH, VM = NL * (RING - 1);
   const hnd_wgrad_desc& d = a.d;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -121,39 +125,68 @@ __global__ void __launch_bounds__(256, 1) wgrad_ring_kernel(const WringArgs a) {
   }
   const float relu_floor = (TAPS && d.pro_scale && d.pro_relu) ? 0.f : -INFINITY;
 
-  // the lane's load addresses for k-step ks (pixel m = 4 ks + g4): A = dy row, B = one x row per column half
-  auto addr = [&](int ks, const float*& pa, const float* (&pbv)[BH], unsigned& okb) {
-    const int m = 4 * ks + g4;
-    const bool mok = m < m_end;
-    const int mm = mok ? m : 0;
-    pa = mok ? dyg + (size_t)mm * (size_t)d.ldy + (size_t)(co0 + 4 * l16) : zero;
+  // ---- the lane's load addresses, k-step after k-step (pixel m = 4 ks + g4: A = dy row m, B = one x row per column half).
+  // The k-steps are requested strictly in order, so the pixel's coordinates are carried along instead of divided out:
+  // (oh_, ow_) and px0 = (n H + oh_ s) W + ow_ s, the input pixel of tap (0, 0) without padding.
+  int m_run = 4 * (blk0 * 8) + g4;
+  int ow_run = 0, oh_run = 0, px_run = 0;
+  if (TAPS) {
+    const unsigned mm = (unsigned)(m_run < M ? m_run : 0);
+    const unsigned t = hnd::fdiv(mm, a.div_ow), n_ = hnd::fdiv(t, a.div_oh);
+    ow_run = (int)(mm - t * (unsigned)d.ow);
+    oh_run = (int)(t - n_ * (unsigned)d.oh);
+    px_run = ((int)n_ * d.h + oh_run * d.stride) * d.w_ + ow_run * d.stride;
+  }
+  const int row_wrap = d.stride * d.w_ - d.ow * d.stride;            // px0 correction when ow_ wraps into the next row
+  const int img_wrap = d.h * d.w_ - d.oh * d.stride * d.w_;          // ... and when oh_ wraps into the next image
+  int tap_off[BH], tap_dh[BH], tap_dw[BH];
+#pragma unroll
+  for (int h = 0; h < BH; ++h) {
+    tap_dh[h] = tap_i[h] - d.pad;
+    tap_dw[h] = tap_j[h] - d.pad;
+    tap_off[h] = tap_dh[h] * d.w_ + tap_dw[h];
+  }
+  const unsigned dy_row = (unsigned)d.ldy * 4u, x_row = (unsigned)d.cin * 4u;      // bytes per pixel
+  const char* dy_base = (const char*)(dyg + co0 + 4 * l16);
+  auto addr = [&](const float*& pa, const float* (&pbv)[BH], unsigned& okb) __attribute__((always_inline)) {
+    const bool mok = m_run < m_end;
+    pa = mok ? (const float*)(dy_base + (size_t)((unsigned)m_run * (unsigned long long)dy_row)) : zero;
     okb = 0;
     if (!TAPS) {
-      pbv[0] = mok ? xg + (size_t)mm * (size_t)d.cin + (size_t)(col0 + 4 * l16) : zero;
+      pbv[0] = mok ? (const float*)((const char*)(xg + col0 + 4 * l16) + (size_t)((unsigned)m_run * (unsigned long long)x_row))
+                   : zero;
       okb = mok ? 3u : 0u;
     } else {
-      const unsigned t = hnd::fdiv((unsigned)mm, a.div_ow), ow_ = (unsigned)mm - t * (unsigned)d.ow;
-      const unsigned n_ = hnd::fdiv(t, a.div_oh), oh_ = t - n_ * (unsigned)d.oh;
 #pragma unroll
       for (int h = 0; h < BH; ++h) {
-        const int ih = (int)oh_ * d.stride - d.pad + tap_i[h], iw = (int)ow_ * d.stride - d.pad + tap_j[h];
+        const int ih = oh_run * d.stride + tap_dh[h], iw = ow_run * d.stride + tap_dw[h];
         const bool ok = mok && (unsigned)ih < (unsigned)d.h && (unsigned)iw < (unsigned)d.w_;
-        const float* src = xg + ((size_t)((int)n_ * d.h + ih) * (size_t)d.w_ + (size_t)iw) * (size_t)d.cin +
-                           (size_t)(ci0[h] + 4 * l16);
+        const unsigned px = (unsigned)(px_run + tap_off[h]);
+        const float* src = (const float*)((const char*)(xg + ci0[h] + 4 * l16) + (size_t)(px * (unsigned long long)x_row));
         pbv[h] = ok ? src : zero;
         okb |= (ok ? 1u : 0u) << h;
       }
+      ow_run += 4;                                           // one k-step = 4 pixels on (ow >= 4: at most one row wrap)
+      px_run += 4 * d.stride;
+      const bool wrap = ow_run >= d.ow;
+      ow_run -= wrap ? d.ow : 0;
+      oh_run += wrap ? 1 : 0;
+      px_run += wrap ? row_wrap : 0;
+      const bool wrap2 = oh_run >= d.oh;
+      oh_run -= wrap2 ? d.oh : 0;
+      px_run += wrap2 ? img_wrap : 0;
     }
+    m_run += 4;
   };
 
   f32x4 ra[RING][AH], rb[RING][BH];
   unsigned okr[RING];
-  auto issue = [&](auto U, int ks) __attribute__((always_inline)) {
+  auto issue = [&](auto U) __attribute__((always_inline)) {       // the next k-step, into ring slot u
     constexpr int u = decltype(U)::value;
     const float* pa;
     const float* pbv[BH];
     unsigned okb;
-    addr(ks, pa, pbv, okb);
+    addr(pa, pbv, okb);
     okr[u] = okb;
     rload<0>(ra[u][0], pa);
     if constexpr (AH == 2) rload<256>(ra[u][1], pa);
@@ -171,10 +204,8 @@ __global__ void __launch_bounds__(256, 1) wgrad_ring_kernel(const WringArgs a) {
     for (int j = 0; j < 4 * BH; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   if (nblk > 0) {
-    const int ks0 = blk0 * 8;
-    wfor<RING>([&](auto U) __attribute__((always_inline)) { issue(U, ks0 + decltype(U)::value); });
-    for (int b = 0; b < nblk; ++b) {
-      const int ksn = ks0 + (b + 1) * 8;                     // the k-steps requested during this block
+    wfor<RING>([&](auto U) __attribute__((always_inline)) { issue(U); });
+    for (int b = 0; b < nblk * (8 / RING); ++b) {            // a block = 8 k-steps = 8 / RING turns of the ring
       wfor<RING>([&](auto U) __attribute__((always_inline)) {
         constexpr int u = decltype(U)::value;
         if constexpr (NL == 2) rwait<VM>(ra[u][0], rb[u][0]);
@@ -207,7 +238,7 @@ __global__ void __launch_bounds__(256, 1) wgrad_ring_kernel(const WringArgs a) {
                     __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[hb][q], acc[4 * ha + r][4 * hb + q], 0, 0, 0);
           }
         __builtin_amdgcn_sched_barrier(0);
-        issue(U, ksn + u);                                   // beyond this workgroup's range: the page of zeros
+        issue(U);                                            // beyond this workgroup's range: the page of zeros
         __builtin_amdgcn_sched_barrier(0);
       });
     }
@@ -246,10 +277,25 @@ int cu_count_wr() {
   return v;
 }
 
+// The tap form (direct 2x2 convs; ~100 vector instructions of address arithmetic, prologue and padding selects per
+// k-step).  Measured at batch 16 (tools/bench_wgrad.py, staged kernel -> one wave per SIMD on the large tile / two waves
+// per SIMD on 64 x 64 wave tiles): 64 -> 256 (conv1) 1.455 -> 1.361 / 1.384 ms, 64 -> 128 (conv5) 0.800 -> 0.807 /
+// 0.752 ms.  So: 256 output channels take the large tile, 128 the small one with two waves per SIMD.
+bool taps_small(const hnd_wgrad_desc& d) { return d.cout % 256 != 0; }
+
 template <int AH, int BH>
 int launch_ab(const WringArgs& a, bool taps, dim3 grid, hipStream_t s) {
-  if (taps) hipLaunchKernelGGL((wgrad_ring_kernel<AH, BH, true>), grid, dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((wgrad_ring_kernel<AH, BH, false>), grid, dim3(256), 0, s, a);
+  if (taps) {
+    if constexpr (AH == 1 && BH == 1) {
+      if (taps_small(a.d)) {
+        hipLaunchKernelGGL((wgrad_ring_kernel<1, 1, true, 2>), grid, dim3(256), 0, s, a);
+        return hnd::check_launch("hnd_conv2d_wgrad(ring, taps x2)");
+      }
+    }
+    hipLaunchKernelGGL((wgrad_ring_kernel<AH, BH, true, 1>), grid, dim3(256), 0, s, a);
+    return hnd::check_launch("hnd_conv2d_wgrad(ring, taps)");
+  }
+  hipLaunchKernelGGL((wgrad_ring_kernel<AH, BH, false, 1>), grid, dim3(256), 0, s, a);
   return hnd::check_launch("hnd_conv2d_wgrad(ring)");
 }
 
@@ -267,6 +313,7 @@ bool wgrad_ring_applies(const hnd_wgrad_desc& d) {
   const bool taps = d.kh * d.kw > 1 || d.pad != 0 || d.stride != 1;
   if (!taps && (d.oh != d.h || d.ow != d.w_)) return false;
   if (!taps && d.pro_scale) return false;               // (the prologue lives on the tap path)
+  if (taps && d.ow < 4) return false;                   // (a k-step of 4 pixels wraps at most one row)
   // 32-bit pixel arithmetic: element offsets are formed in size_t, pixel indices in int
   if ((long long)d.n * d.oh * d.ow >= (1ll << 31) - 64 || (long long)d.n * d.h * d.w_ >= (1ll << 31)) return false;
   return true;
@@ -276,8 +323,10 @@ static void wring_plan(const hnd_wgrad_desc& d, WringArgs& a, int& ah, int& bh) 
   a.d = d;
   a.M = d.n * d.oh * d.ow;
   const int ncols = d.kh * d.kw * d.cin;
-  ah = d.cout % 256 == 0 ? 2 : 1;
-  bh = ncols % 256 == 0 ? 2 : 1;
+  const bool taps = d.kh * d.kw > 1 || d.pad != 0 || d.stride != 1;
+  const bool small = taps && taps_small(d);                 // 64 x 64 wave tiles, two waves per SIMD
+  ah = (d.cout % 256 == 0 && !small) ? 2 : 1;
+  bh = (ncols % 256 == 0 && !small) ? 2 : 1;
   a.rtiles = d.cout / (128 * ah);
   a.ctiles = ncols / (128 * bh);
   a.co_pad = d.cout;
@@ -287,7 +336,8 @@ static void wring_plan(const hnd_wgrad_desc& d, WringArgs& a, int& ah, int& bh) 
   a.total_blocks = (a.M + 31) / 32;
   const int groups = d.groups > 1 ? d.groups : 1;
   const int tiles = a.rtiles * a.ctiles * groups;
-  int splits = d.splitk > 0 ? d.splitk : cu_count_wr() / tiles;   // one workgroup per CU, as many CUs as divide evenly
+  // one workgroup per CU (two for the tap form), as many as divide evenly
+  int splits = d.splitk > 0 ? d.splitk : (cu_count_wr() * (small ? 2 : 1)) / tiles;
   if (splits < 1) splits = 1;
   if (splits > a.total_blocks) splits = a.total_blocks;
   if (splits > 512) splits = 512;

@@ -38,9 +38,9 @@ def main():
     for name, (cin, h, w, cout, k, s, p, pro, groups) in SHAPES.items():
         if only and not any(name.startswith(o) for o in only):
             continue
-        torch.manual_seed(0)
         line, outs = '%-34s' % name, {}
         for mode in ('0', '1'):
+            torch.manual_seed(0)
             os.environ['HND_WGRAD_RING'] = mode
             if groups == 1:
                 n = args.batch
