@@ -259,8 +259,8 @@ __device__ __forceinline__ void ring_wait(f32x4& a0, f32x4& a1, f32x4& a2, f32x4
 // its 16 rows per tile are requested over the tile's k groups KG-8 .. KG-5 -- asm loads into AGPRs in the same in-order
 // stream as the ring, released by hand-counted waits -- and consumed, like the accumulators, during the next tile's
 // first k group.
-// NI = 16-column accumulator tiles per wave (4: the 64-column wave tile; 2: a 32-column one, so that a K = 1024 slice
-// of 32 columns still fits the LDS: the layer3 / layer4 1x1 convs with M of only 16 800 / 67 200 pixels).
+// NI = 16-column accumulator tiles per wave (4: the 64-column wave tile).  (A 32-column build for K = 1024 slices was
+// measured in round 3 -- 110 vs 106 TF alone, nothing in the step -- and removed in round 4.)
 template <int WN, int KQ, bool PRO, bool RES, int NI = 4>
 __global__ void __launch_bounds__(256, 1) bres2_kernel(const hnd_conv_desc d, const BresArgs a) {
   constexpr int WM = 4 / WN, WTN = 16 * NI, BN = WTN * WN, MI = 4, RING = 8;
@@ -544,24 +544,6 @@ int launch_bres2_t(const hnd_conv_desc& d, const BresArgs& a, size_t lds, int gr
   return hnd::check_launch("hnd_conv2d_igemm(bres2)");
 }
 
-int launch_bres2_k1024(const hnd_conv_desc& d, const BresArgs& a, size_t lds, int grid, hipStream_t stream) {
-  static std::atomic<unsigned long long> attr_set{0};
-  auto kern = bres2_kernel<1, 16, false, false, 2>;
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  const unsigned long long bit = 1ull << (dev & 63);
-  if (!(attr_set.load(std::memory_order_relaxed) & bit)) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) {
-      hnd::set_error("hipFuncSetAttribute(bres2<K=1024>) failed: %s", hipGetErrorString(e));
-      return HND_ERR_LAUNCH;
-    }
-    attr_set.fetch_or(bit, std::memory_order_relaxed);
-  }
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, d, a);
-  return hnd::check_launch("hnd_conv2d_igemm(bres2 K=1024)");
-}
-
 template <int WN, int KQ>
 int launch_bres2_p(const hnd_conv_desc& d, const BresArgs& a, size_t lds, int grid, hipStream_t stream) {
   if (d.res1) return launch_bres2_t<WN, KQ, false, true>(d, a, lds, grid, stream);      // (never with a prologue)
@@ -574,28 +556,12 @@ int launch_bres2_p(const hnd_conv_desc& d, const BresArgs& a, size_t lds, int gr
 namespace hnd {
 
 // 0 = not taken; 1 / 2 = the 8-wave kernel with a 64- / 128-column weight slice (K <= 512 / 256); 3 / 4 = the
-// one-wave-per-SIMD kernel (bres2) with a 64- / 128-column slice, for epilogues without residual / mask operands
+// one-wave-per-SIMD kernel (bres2) with a 64- / 128-column slice, for epilogues without a mask operand
 int bres_variant(const hnd_conv_desc& d) {
   const int kmax = bres_kmax();
   if (kmax <= 0 || d.kh != 1 || d.kw != 1 || d.bh != 0 || d.bw != 0 || d.stats != nullptr) return 0;
   if (d.cin != d.kdim) return 0;
   if (d.w_group_rows % 64 != 0) return 0;
-  if (d.kdim == 1024) {
-    // 5 = the one-wave kernel with a 32-column slice (32 x 1024 floats = 128 KB) for the K = 1024 1x1 convs of layer3 /
-    // layer4.  Measured and NOT adopted (round 3): 110 vs 106 TF (1024->256 @50x84) and 121 vs 117 (1024->512) in
-    // isolation, nothing in the step (101.1 vs 100.8 ms): with NI = 2 a wave issues one 16-byte A load per 8 MFMAs and
-    // every A row is fetched by Cout / 32 workgroups.  Opt-in: HND_BRES_K1024=1 (the tests and tools/bench_bres.py).
-    const char* e = getenv("HND_BRES_K1024");
-    const char* e2 = getenv("HND_BRES2");
-    if (!(e && atoi(e) != 0) || (e2 && atoi(e2) == 0) ||
-        kmax < 512 || d.res1 || d.res2 || d.mask || d.pro_scale || d.w_group_rows != 0) return 0;
-    const int per_xcd = cu_count() / 8, nsl = d.cout / 32;
-    if (d.cout % 32 != 0 || per_xcd < 1 || nsl > per_xcd || per_xcd % nsl != 0) return 0;
-    if ((long long)(d.oh - 1) * d.sh >= d.h || (long long)(d.ow - 1) * d.sw >= d.w_) return 0;
-    const long long M = (long long)d.n * d.oh * d.ow;
-    const long long per_team = ((M + 63) / 64) / (8ll * (per_xcd / nsl));
-    return per_team >= 8 ? 5 : 0;
-  }
   if (d.kdim > kmax) return 0;
   const int wn = (d.kdim <= 256 && d.cout % 128 == 0) ? 2 : 1;
   // instantiated depths: 64 / 128 / 256 with the 128-column slice, 256 / 512 with the 64-column slice
@@ -610,20 +576,20 @@ int bres_variant(const hnd_conv_desc& d) {
   const long long per_team = nchunks / nteams;
   const bool plain = !d.res2 && !d.mask && !(d.res1 && d.pro_scale);      // the one-wave kernel: optional res1 only
   const char* v2 = getenv("HND_BRES2");                   // 0 = never the one-wave kernel (A/B)
+  const bool all = getenv("HND_BRES_ALL") != nullptr;     // every eligible launch, not only where it was measured to win
   if (plain && d.kdim >= 128 && !(v2 && atoi(v2) == 0) && per_team >= 2ll * (4 / wn)) {
     // measured (profiles/r03_bres_vs_tiled.txt): the one-wave kernel wins on long runs of chunks; its prologue form
     // (8 VALU per A fragment beside a single wave's MFMAs) does not, and K = 512 needs >= 48 chunks per team
     const bool spills = (d.pro_scale || d.res1) && d.kdim == 512;      // those two builds do not fit 512 registers
-    if (getenv("HND_BRES_ALL") && !spills) return 2 + wn;
+    if (all && !spills) return 2 + wn;
     // the residual build (RES): its rows travel as asm loads in the ring's own in-order stream with hand-counted
     // waits (as compiler-visible loads they drained the ring once per tile and lost to the tiled kernel, 104 vs 112 TF).
     // Measured (tools/bench_bres.py): 256->256 @200x336 + upsampled residual 109 -> 123 TF, 128->512 @100x168 + res
     // 95 -> 102, 256->1024 @50x84 + res 112 -> 116.  K = 512 with a residual spills and stays on the 8-wave kernel.
-    static const int wino_min = getenv("HND_BRES2_WINO_MIN") ? atoi(getenv("HND_BRES2_WINO_MIN")) : 48;
-    if (!d.pro_scale && !spills && per_team >= (d.w_group_rows > 0 ? wino_min : (d.kdim == 512 ? 48 : 8))) return 2 + wn;
+    if (!d.pro_scale && !spills && per_team >= (d.w_group_rows > 0 || d.kdim == 512 ? 48 : 8)) return 2 + wn;
   }
   if (per_team < 2ll * (8 / wn)) return 0;              // every wave row gets at least two chunks
-  if (!getenv("HND_BRES_ALL")) {
+  if (!all) {
     // where the free-running waves beat the tiled kernel (profiles/r03_bres_vs_tiled.txt, both with the specialised
     // epilogue): long runs of chunks per weight slice.  A Winograd launch whose components are short reloads its
     // slice every few chunks; an epilogue with residual / mask loads drains the wave's prefetch ring (one wave cannot
@@ -641,18 +607,6 @@ int launch_bres(const hnd_conv_desc& d, hipStream_t stream) {
     set_error("launch_bres: descriptor not eligible");
     return HND_ERR_INVALID;
   }
-  if (var == 5) {
-    const long long M5 = (long long)d.n * d.oh * d.ow;
-    BresArgs a5;
-    a5.div_ow = make_fastdiv((unsigned)d.ow);
-    a5.div_oh = make_fastdiv((unsigned)d.oh);
-    a5.nsl = d.cout / 32;
-    a5.nchunks = (int)((M5 + 63) / 64);
-    a5.cpg = 0;
-    a5.dbg = 0;
-    const size_t lds5 = ((size_t)32 * d.kdim + 8 * 256) * sizeof(float);
-    return launch_bres2_k1024(d, a5, lds5, (cu_count() / 8) * 8, stream);
-  }
   const bool v2 = var > 2;
   const int wn = v2 ? var - 2 : var;
   const long long M = (long long)d.n * d.oh * d.ow;
@@ -662,7 +616,7 @@ int launch_bres(const hnd_conv_desc& d, hipStream_t stream) {
   a.nsl = d.cout / (64 * wn);
   a.nchunks = (int)((M + 63) / 64);
   a.cpg = d.w_group_rows / 64;
-  a.dbg = getenv("HND_BRES_DBG") ? atoi(getenv("HND_BRES_DBG")) : 0;
+  a.dbg = 0;
   const bool pro = d.pro_scale != nullptr;
   const size_t lds = ((size_t)64 * wn * d.kdim + (pro ? 2 * (size_t)d.kdim : 0) + 8 * 256) * sizeof(float);
   const int grid = (cu_count() / 8) * 8;

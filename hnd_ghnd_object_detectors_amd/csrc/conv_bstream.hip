@@ -556,18 +556,14 @@ int bstream_variant(const hnd_conv_desc& d) {
   // gain 3 % alone and nothing in the step (the teacher / FPN streams already fill the tiled kernel's partial last
   // round, and a persistent one-wave-per-SIMD kernel shares a CU with nobody): they stay on the tiled kernel, as does
   // K <= 512 without taps (the B-resident kernels).
-  if (!taps && d.kdim < 1024) return 0;
+  if (!taps && (d.kdim < 1024 || (d.kdim < 2048 && d.cout < 512))) return 0;
+  // (K = 1024 -> 256 with >= 4 tiles per workgroup was tried again in round 4, with and without the shared trunk: 95.2 vs
+  // 94.5-95.3 ms, nothing)
   // ... and only with at least one tile per workgroup (the relay's condition): a persistent kernel that leaves CUs
   // idle loses to the tiled kernel's small blocks (validation at batch 1: 148 -> 128 img/s when it took those too)
   int mtiles, ntiles, grid;
   bstream_grid(d, wn, mtiles, ntiles, grid);
   if ((long long)mtiles * ntiles < grid) return 0;
-  if (!taps && d.kdim < 2048 && d.cout < 512) {
-    // K = 1024 -> 256 (layer3 conv1 / conv3 data gradients, fpn.inner2): a tile is only 4 iterations long, so the
-    // ~2 us tile switch weighs 6 %; taken when a workgroup walks at least `k1024_tiles` tiles
-    static const int k1024_tiles = getenv("HND_BSTREAM_K1024_TILES") ? atoi(getenv("HND_BSTREAM_K1024_TILES")) : 1 << 30;
-    if ((long long)mtiles * ntiles < (long long)k1024_tiles * grid) return 0;
-  }
   return wn;
 }
 
@@ -575,8 +571,6 @@ int bstream_variant(const hnd_conv_desc& d) {
 size_t bstream_workspace(const hnd_conv_desc& d) {
   const int wn = bstream_variant(d);
   if (wn == 0) return 0;
-  const char* e = getenv("HND_BSTREAM_RELAY");          // 0 = tiles round-robin (A/B)
-  if (e && atoi(e) == 0) return 0;
   int mtiles, ntiles, grid;
   bstream_grid(d, wn, mtiles, ntiles, grid);
   if ((long long)mtiles * ntiles < grid) return 0;

@@ -500,22 +500,11 @@ int launch_thin_n(const hnd_conv_desc& d, hipStream_t stream) {
   return hnd::check_launch("hnd_conv2d_igemm(thin)");
 }
 
-// tuning knob: cap the resident blocks per CU below what registers / LDS allow by padding the dynamic LDS request
-// (160 KB per CU).  The matrix pipe serves two waves per SIMD at 99 % and three at 95 % (16x16x4), four at 79 %.
-int bpc_cap() {
-  static const int v = getenv("HND_IGEMM_BPC") ? atoi(getenv("HND_IGEMM_BPC")) : 0;
-  return v;
-}
-
 template <int BM, int BN, int BK, bool CIN4, bool PRO>
 int launch_pro(const hnd_conv_desc& d, hipStream_t stream) {
   static std::atomic<unsigned long long> attr_set{0};    // per device: the attribute lives on the device's function
   auto kern = igemm_kernel<BM, BN, BK, CIN4, PRO>;
-  size_t lds = lds_bytes<BM, BN, BK, PRO>();
-  if (bpc_cap() > 0) {
-    const size_t pad = (size_t)(160 * 1024) / (size_t)bpc_cap() - 1024;
-    if (pad > lds) lds = pad;
-  }
+  const size_t lds = lds_bytes<BM, BN, BK, PRO>();
   int dev = 0;
   (void)hipGetDevice(&dev);
   const unsigned long long bit = 1ull << (dev & 63);
@@ -543,12 +532,8 @@ int launch(const hnd_conv_desc& d, hipStream_t stream) {
   return d.pro_scale ? launch_pro<BM, BN, BK, CIN4, true>(d, stream) : launch_pro<BM, BN, BK, CIN4, false>(d, stream);
 }
 
-// bit t set: tile t runs its 16-deep k-step build (smaller LDS footprint -> more resident blocks per CU)
-int bk16_mask() {
-  static const int m = getenv("HND_IGEMM_BK16") ? atoi(getenv("HND_IGEMM_BK16")) : 7;
-  return m;
-}
-
+// (k-step depth per tile: 16 for 128x128 / 128x64 / 64x128 -- smaller LDS footprint, 3-4 resident blocks per CU -- and 32
+// for 64x64; measured in rounds 1-2)
 int pick_tile(const hnd_conv_desc& d) {
   if (const char* f = getenv("HND_IGEMM_TILE")) {       // testing / tuning override: 0..3
     const int t = atoi(f);
@@ -567,14 +552,11 @@ int pick_tile(const hnd_conv_desc& d) {
   // (a block alone on a CU does not run bpc times faster: 0.57 of a round at bpc 2, 0.34 at bpc 4 -- fitted to
   // the 512->512 @25x42 and 256->256 @50x84 3x3 convs, which the model then predicts within 3 %).
   struct Cand { int id, bm, bn, bpc; double eff, lone; };
-  const int b16 = bk16_mask();
   // (a re-fit of `eff` on the isolated-launch sweep of tools/bench_conv.py --tiles for the 16x16x4 kernel -- 1.00 /
   // 0.945 / 0.977 / 0.913 -- picked differently and made the step 1.5 % slower: inside the step the launches run with
   // the previous layer's output in L2 / MALL, so the round-1 constants, fitted in the step, stay)
-  const Cand cands[4] = {{0, 128, 128, (b16 & 1) ? 3 : 2, (b16 & 1) ? 1.00 : 0.97, (b16 & 1) ? 0.45 : 0.57},
-                         {1, 128, 64, (b16 & 2) ? 4 : 2, (b16 & 2) ? 0.90 : 0.88, (b16 & 2) ? 0.34 : 0.57},
-                         {2, 64, 128, (b16 & 4) ? 4 : 2, (b16 & 4) ? 0.91 : 0.895, (b16 & 4) ? 0.34 : 0.57},
-                         {3, 64, 64, (b16 & 8) ? 5 : 4, (b16 & 8) ? 0.86 : 0.885, (b16 & 8) ? 0.30 : 0.34}};
+  const Cand cands[4] = {{0, 128, 128, 3, 1.00, 0.45}, {1, 128, 64, 4, 0.90, 0.34}, {2, 64, 128, 4, 0.91, 0.34},
+                         {3, 64, 64, 4, 0.885, 0.34}};
   int best = n128 ? 0 : 1;
   double best_t = 1e300;
   for (const Cand& c : cands) {
@@ -632,12 +614,11 @@ extern "C" int hnd_conv2d_igemm(const hnd_conv_desc* desc, void* stream) {
   if (thin_n_applies(d)) return launch_thin_n(d, s);
   if (hnd::bres_variant(d)) return hnd::launch_bres(d, s);
   if (hnd::bstream_variant(d)) return hnd::launch_bstream(d, s);
-  const int bk16 = bk16_mask();
   switch (pick_tile(d)) {
-    case 0: return (bk16 & 1) ? launch<128, 128, 16, false>(d, s) : launch<128, 128, 32, false>(d, s);
-    case 1: return (bk16 & 2) ? launch<128, 64, 16, false>(d, s) : launch<128, 64, 32, false>(d, s);
-    case 2: return (bk16 & 4) ? launch<64, 128, 16, false>(d, s) : launch<64, 128, 32, false>(d, s);
-    default: return (bk16 & 8) ? launch<64, 64, 16, false>(d, s) : launch<64, 64, 32, false>(d, s);
+    case 0: return launch<128, 128, 16, false>(d, s);
+    case 1: return launch<128, 64, 16, false>(d, s);
+    case 2: return launch<64, 128, 16, false>(d, s);
+    default: return launch<64, 64, 32, false>(d, s);
   }
 }
 
@@ -650,7 +631,7 @@ extern "C" int hnd_conv2d_igemm_tile(const hnd_conv_desc* desc) {
   if (!desc) return -1;
   if (desc->cin == 4) return hnd::stem7_applies(*desc) ? 9 : 1;
   if (thin_n_applies(*desc)) return 4;
-  if (const int v = hnd::bres_variant(*desc)) return v == 2 ? 5 : (v == 1 ? 6 : (v == 4 ? 7 : (v == 3 ? 8 : 10)));
+  if (const int v = hnd::bres_variant(*desc)) return v == 2 ? 5 : (v == 1 ? 6 : (v == 4 ? 7 : 8));
   if (const int v = hnd::bstream_variant(*desc)) return v == 2 ? 11 : 12;
   return pick_tile(*desc);
 }

@@ -253,9 +253,13 @@ __global__ void __launch_bounds__(256, 3) stem7_wgrad_kernel(const hnd_wgrad_des
 
 namespace hnd {
 
-bool stem7_applies(const hnd_conv_desc& d) {
+static bool stem7_on() {                // HND_STEM7=0: the generic kernels (A/B, bit-identity tests)
   const char* e = getenv("HND_STEM7");
-  if (e && atoi(e) == 0) return false;
+  return !(e && atoi(e) == 0);
+}
+
+bool stem7_applies(const hnd_conv_desc& d) {
+  if (!stem7_on()) return false;
   return d.cin == 4 && d.kh == 7 && d.kw == 7 && d.sh == 2 && d.sw == 2 && d.dh == 1 && d.dw == 1 && d.bh == -3 &&
          d.bw == -3 && d.cout == 64 && d.ldc % 4 == 0 && d.kdim >= 4 * KG * 4 && !d.pro_scale && !d.res1 && !d.res2 &&
          !d.mask && !d.stats && d.w_group_rows == 0 && d.y_sh == 1 && d.y_sw == 1 && d.y_oh == 0 && d.y_ow == 0 &&
@@ -286,8 +290,7 @@ int launch_stem7(const hnd_conv_desc& d, hipStream_t stream) {
 
 
 bool stem7_wgrad_applies(const hnd_wgrad_desc& d) {
-  const char* e = getenv("HND_STEM7");
-  if (e && atoi(e) == 0) return false;
+  if (!stem7_on()) return false;
   return d.cin == 4 && d.kh == 7 && d.kw == 7 && d.stride == 2 && d.pad == 3 && d.cout == 64 && d.ldy % 4 == 0 &&
          !d.pro_scale && d.groups <= 1 && d.oh == (d.h + 6 - 7) / 2 + 1 && d.ow == (d.w_ + 6 - 7) / 2 + 1 &&
          (uintptr_t)d.dy % 16 == 0 && (uintptr_t)d.x % 16 == 0;

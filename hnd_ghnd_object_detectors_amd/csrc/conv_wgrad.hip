@@ -366,19 +366,15 @@ bool thin_wgrad_applies(const hnd_wgrad_desc& d, bool& thick_is_x) {
 int thin_wgrad_blocks(const hnd_wgrad_desc& d, bool thick_is_x, int& per_block) {
   const long long P = thick_is_x ? (long long)d.n * d.h * d.w_ : (long long)d.n * d.oh * d.ow;
   long long blocks = (P + 511) / 512;                 // >= 512 pixels per block ...
-  const char* e = getenv("HND_THIN_WGRAD_BLOCKS");
-  const long long cap = e ? atoi(e) : 512;
+  const long long cap = 512;
   if (blocks > cap) blocks = cap;                     // ... and at most 512 partial slabs of 4 KB (measured: 1024 -> 0.156 ms, 512 -> 0.118, 256 -> 0.130)
   if (blocks < 1) blocks = 1;
   per_block = (int)(((P + blocks - 1) / blocks + 63) / 64 * 64);
   return (int)((P + per_block - 1) / per_block);
 }
 
-// k-step depth of the build in use: 16 (32 KB LDS, 4 resident blocks per CU) unless HND_WGRAD_BK=32
-int wgrad_bk() {
-  static const int bk = (getenv("HND_WGRAD_BK") && atoi(getenv("HND_WGRAD_BK")) == 32) ? 32 : 16;
-  return bk;
-}
+// k-step depth: 16 (32 KB LDS, 4 resident blocks per CU; 32 and caps of 2 / 3 blocks per CU measured neutral in rounds 1-2)
+constexpr int wgrad_bk() { return 16; }
 
 int plan(const hnd_wgrad_desc& d, WgradArgs& a, int BKW) {
   a.d = d;
@@ -508,23 +504,9 @@ extern "C" int hnd_conv2d_wgrad(const hnd_wgrad_desc* desc, void* stream) {
     return hnd::check_launch("hnd_conv2d_wgrad(ring reduce)");
   }
   const dim3 grid(a.rtiles * a.ctiles * a.d.splitk, groups);
-  // tuning knob HND_WGRAD_BPC: cap the resident blocks per CU by padding the dynamic LDS request.  Measured in the
-  // step (batch 16): 4 blocks/CU (the register / LDS limit, default) 5.95 ms, 3 -> 6.34 ms, 2 -> 5.97 ms for the
-  // cout >= 128 launches -- this kernel is not bound by matrix-pipe contention, so the uncapped occupancy stays
-  static const int bpc = getenv("HND_WGRAD_BPC") ? atoi(getenv("HND_WGRAD_BPC")) : 0;
-  const size_t floor_lds = bpc > 0 ? (size_t)(160 * 1024) / (size_t)bpc - 2048 : 0;
-  auto lds_of = [&](size_t need) { return need > floor_lds || floor_lds > 65536 ? need : floor_lds; };
-  if (bk == 16) {
-    if (bmw == 128)
-      hipLaunchKernelGGL((wgrad_kernel<128, 16>), grid, dim3(256), lds_of(wgrad_lds_bytes<128, 16>()), s, a);
-    else
-      hipLaunchKernelGGL((wgrad_kernel<64, 16>), grid, dim3(256), lds_of(wgrad_lds_bytes<64, 16>()), s, a);
-  } else {
-    if (bmw == 128)
-      hipLaunchKernelGGL((wgrad_kernel<128, 32>), grid, dim3(256), lds_of(wgrad_lds_bytes<128, 32>()), s, a);
-    else
-      hipLaunchKernelGGL((wgrad_kernel<64, 32>), grid, dim3(256), lds_of(wgrad_lds_bytes<64, 32>()), s, a);
-  }
+  constexpr size_t lds128 = wgrad_lds_bytes<128, 16>(), lds64 = wgrad_lds_bytes<64, 16>();
+  if (bmw == 128) hipLaunchKernelGGL((wgrad_kernel<128, 16>), grid, dim3(256), lds128, s, a);
+  else hipLaunchKernelGGL((wgrad_kernel<64, 16>), grid, dim3(256), lds64, s, a);
   int rc = hnd::check_launch("hnd_conv2d_wgrad");
   if (rc) return rc;
   const int total = d.cout * d.kh * d.kw * d.cin_real;

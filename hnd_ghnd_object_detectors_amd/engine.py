@@ -184,7 +184,6 @@ class Wino2Cache(object):
 
 
 FOLD_DGRAD_SCALE = os.environ.get('HND_FOLD_DGRAD_SCALE', '1') != '0'     # 0: FrozenBN scale as a launch prologue
-WINOGRAD_FROZEN = os.environ.get('HND_WINOGRAD_FROZEN', '1') != '0'   # debugging knob: frozen / FPN 3x3 convs
 WINOGRAD6 = os.environ.get('HND_WINOGRAD6', '1') != '0'       # F(6x6,3x3) on maps large enough (wino_tile_for)
 
 
@@ -193,7 +192,7 @@ def use_winograd(cin, cout, stride):
     at MFMA rate and the inflated transformed tensors stay cheap next to them (tools/bench_wino.py, batch 16):
     F(4x4,3x3) x2.2-2.8 over the direct kernel for 256/512 channels and x1.7 for 128; F(2x2,3x3) x1.3-2.0 for
     256/512 and x1.0 for 128."""
-    if WINOGRAD not in (2, 4) or not WINOGRAD_FROZEN or stride != 1 or cin % 32 != 0 or cout % 4 != 0:
+    if WINOGRAD not in (2, 4) or stride != 1 or cin % 32 != 0 or cout % 4 != 0:
         return 0
     # with F(6x6,3x3) available even the 64-channel convs of the teacher's layer1 gain (x1.20 at 200x336,
     # profiles/r03_bench_wino.txt; F(4x4): x1.06): their 64 component GEMMs are K = 64 deep, HBM-bound like the transforms
@@ -201,7 +200,7 @@ def use_winograd(cin, cout, stride):
     return WINOGRAD if min(cin, cout) >= floor else 0
 
 
-WINOGRAD6_MIN_TILES = int(os.environ.get('HND_WINOGRAD6_MIN_TILES', '32'))      # 6x6 tiles per IMAGE
+WINOGRAD6_MIN_TILES = 32      # 6x6 tiles per IMAGE below which F(4x4,.) stays (border waste of the 6x6 tiling)
 
 
 def wino_tile_for(tile, n, h, w):
@@ -297,14 +296,7 @@ class TransformEngine(object):
                     src = img if (img.is_contiguous() and img.dtype == torch.float32) else img.float().contiguous()
                     items.append((src, False, False, False, oh, ow, 1.0 / scale, 1.0 / scale))
                 keep.append(src)
-            if os.environ.get('HND_TRANSFORM_BATCH', '1') != '0':
-                ops.transform_images(items, batch, self.mean, self.std)      # one launch for the whole batch
-            else:                                                            # (A/B: one launch per image)
-                for i, (src, is_u8, hwc, flip, oh, ow, rh, rw) in enumerate(items):
-                    if is_u8:
-                        ops.transform_image_u8(src, batch, i, oh, ow, rh, rw, self.mean, self.std, hwc, flip)
-                    else:
-                        ops.transform_image(src, batch, i, oh, ow, rh, rw, self.mean, self.std)
+            ops.transform_images(items, batch, self.mean, self.std)          # one launch for the whole batch
             self.last_key = key
         self.last_scales = [p[2] for p in plans]
         return batch, [(p[3], p[4]) for p in plans]
@@ -973,7 +965,11 @@ class FpnEngine(object):
 # Set by DistillationBox around its teacher + student calls: the SharedTrunk both backbones then run layers 2-4 (+ the
 # feature pyramid) through, or None.
 MERGE = {'trunk': None}
-MERGE_TRUNK = os.environ.get('HND_MERGE_TRUNK', '1') != '0'
+# Off by default -- measured, round 4 (profiles/r04_trunk_sweep.txt, same box, batch 16): the shared pass takes 1.0-1.5 ms
+# of kernel time off the step (437 -> ~350 launches, layer3 / layer4 on the persistent kernels) but the two networks no
+# longer run as two independent chains on two streams, and that overlap is worth ~3 ms: 94.5-95.3 ms with separate passes,
+# 96.0-97.1 ms merged (from layer2, layer3 or layer4 alike).  HND_MERGE_TRUNK=1 turns it on; results are bit-identical.
+MERGE_TRUNK = os.environ.get('HND_MERGE_TRUNK', '0') != '0'
 # first layer of the shared pass: earlier layers run per network (teacher || student on two streams, which is where the
 # HBM-bound high-resolution kernels find an MFMA-bound partner), later ones over the concatenated batch
 MERGE_FROM = os.environ.get('HND_MERGE_FROM', 'layer3')

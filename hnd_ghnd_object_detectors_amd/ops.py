@@ -68,7 +68,7 @@ PACK_BATCH = {'open': False, 'items': []}
 
 
 def pack_batch_begin():
-    PACK_BATCH['open'], PACK_BATCH['items'] = os.environ.get('HND_PACK_BATCH', '1') != '0', []
+    PACK_BATCH['open'], PACK_BATCH['items'] = True, []
 
 
 def pack_batch_end():
@@ -144,7 +144,7 @@ class ConvLaunch(object):
         tile = _L.hnd_conv2d_igemm_tile(self.ref)
         self.variant = ('stem7_lds' if tile == 9 else 'igemm_c4_128x64') if self.desc.cin == 4 else \
             ('igemm_128x128', 'igemm_128x64', 'igemm_64x128', 'igemm_64x64', 'thin_n4', 'bres_128',
-             'bres_64', 'bres2_128', 'bres2_64', 'stem7_lds', 'bres2_32', 'bstream_128', 'bstream_64')[tile]
+             'bres_64', 'bres2_128', 'bres2_64', 'stem7_lds', 'unused', 'bstream_128', 'bstream_64')[tile]
 
     def run(self, stream=None):
         rc = _L.hnd_conv2d_igemm(self.ref, stream if stream is not None else stream_ptr())

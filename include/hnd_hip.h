@@ -118,8 +118,8 @@ size_t hnd_conv2d_igemm_workspace(const hnd_conv_desc* desc);
  * 5 / 6 = the B-resident persistent GEMM (csrc/conv_bres.hip) with a 128- / 64-column weight slice held in LDS: 1x1
  * taps, K <= 256 / 512, no statistics; bit-identical to the tiled kernel.  HND_BRES=0 in the environment turns it off;
  * 7 / 8 = its one-wave-per-SIMD build (plain epilogues); 9 = the 7x7 stride-2 stem from an LDS-staged input patch
- * (csrc/conv_stem.hip; bit-identical to the generic 4-channel-input kernel, HND_STEM7=0 turns it off); 10 = the
- * one-wave kernel with a 32-column slice (K = 1024, opt-in); 11 / 12 = the B-streamed persistent GEMM for long K
+ * (csrc/conv_stem.hip; bit-identical to the generic 4-channel-input kernel, HND_STEM7=0 turns it off); 10 = unused
+ * (a K = 1024 build of the one-wave kernel, removed in round 4); 11 / 12 = the B-streamed persistent GEMM for long K
  * (csrc/conv_bstream.hip: 128 x 128 / 256 x 64 block tile, the weight slice streams through three LDS stages, A
  * fragments straight from global memory; K % 128 == 0, K >= 1024 or taps; bit-identical to the tiled kernel;
  * HND_BSTREAM=0 turns it off). */

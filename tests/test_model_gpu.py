@@ -757,6 +757,8 @@ def test_shared_trunk_is_dropped_when_the_frozen_weights_differ(monkeypatch):
     """the merged pass needs bit-equal frozen weights; a student whose layer3 was edited (a checkpoint that did not come
     from this teacher) runs its own pass -- and the pyramids of the merged pass equal the separate ones"""
     from hnd_ghnd_object_detectors_amd import engine as E
+    monkeypatch.setattr(E, 'MERGE_TRUNK', True)             # (opt-in: HND_MERGE_TRUNK=1)
+    monkeypatch.setattr(E, 'MERGE_FROM', 'layer3')
     z, meta = G.load('tiny_ghnd_faster')
     images, targets = G.case_inputs(meta)
     cfg, t_sd, s_sd, teacher, student, box, opt, warm = _setup(meta)

@@ -32,5 +32,4 @@ for name, cin, cout, pad in (('conv3.wgrad 64->3', 64, 3, 1), ('conv4.wgrad 3->6
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 20
         gb = (x.numel() + dy.numel()) * 4 / 1e9
-        print('%-20s %-11s blocks<=%s  %.3f ms  %.2f TB/s' % (name, l.variant, os.environ.get('HND_THIN_WGRAD_BLOCKS', '1024'),
-                                                            ms, gb / ms), flush=True)
+        print('%-20s %-11s  %.3f ms  %.2f TB/s' % (name, l.variant, ms, gb / ms), flush=True)

@@ -38,7 +38,7 @@ def main():
         outs, variants = {}, {}
         for mode, env in (('tiled', {'HND_BRES': '0', 'HND_BSTREAM': '0'}), ('default', {}),
                           ('bstream', {'HND_BRES': '0', 'HND_BSTREAM': 'all'})):
-            for key in ('HND_BRES', 'HND_BSTREAM', 'HND_BSTREAM_RELAY'):
+            for key in ('HND_BRES', 'HND_BSTREAM'):
                 os.environ.pop(key, None)
             os.environ.update(env)
             l = ops.conv_desc(x, pk, y, kh=1, kw=1, oh=1, ow=groups * tiles_pad, sh=1, dh=1, bh=0, sw=1, dw=1, bw=0,
@@ -89,12 +89,14 @@ def main():
         outs, variants = {}, {}
         for mode, env in (('tiled', {'HND_BRES': '0', 'HND_BSTREAM': '0'}), ('default', {}),
                           ('bstream', {'HND_BRES': '0', 'HND_BSTREAM': 'all'}),
-                          ('bstream_rr', {'HND_BRES': '0', 'HND_BSTREAM': 'all', 'HND_BSTREAM_RELAY': '0'})):
-            for key in ('HND_BRES', 'HND_BSTREAM', 'HND_BSTREAM_RELAY'):
+                          ('bstream_rr', {'HND_BRES': '0', 'HND_BSTREAM': 'all'})):      # round-robin tiles: no workspace
+            for key in ('HND_BRES', 'HND_BSTREAM'):
                 os.environ.pop(key, None)
             os.environ.update(env)
             l = ops.conv_forward(x, pk, y, k, s, p, epi_scale=sc, epi_shift=sh, res1=r, mask=mk, relu=not msk,
                                  pro_scale=ps, pro_shift=pb, pro_relu=pro_relu)
+            if mode == 'bstream_rr':                    # drop the work-balancing workspace: tiles go round-robin
+                l.desc.relay_ws, l.relay = None, None
             reps = 2 if mode == 'bstream' else 1
             for _ in range(reps):
                 y.fill_(float('nan'))
@@ -114,7 +116,7 @@ def main():
         elif case % 20 == 0:
             print('case %d ok  M=%d N=%d K=%d  %s' % (case, n * oh * ow, cout, k * k * cin, variants), flush=True)
         del x, y, r, mk, outs
-    for key in ('HND_BRES', 'HND_BSTREAM', 'HND_BSTREAM_RELAY'):
+    for key in ('HND_BRES', 'HND_BSTREAM'):
         os.environ.pop(key, None)
     print('variants exercised:', counts)
     print('%d mismatch(es) in %d cases' % (bad, args.cases))
