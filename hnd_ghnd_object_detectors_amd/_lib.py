@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('HND_LIB_PATH') or os.path.join(_HERE, 'libhnd_hip.so')     # env: kernel experiments
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 c_float_p = C.POINTER(C.c_float)
 vp = C.c_void_p
@@ -22,7 +22,7 @@ class ConvDesc(C.Structure):
                                          'y_sh', 'y_oh', 'y_sw', 'y_ow', 'kh', 'kw',
                                          'sh', 'dh', 'bh', 'sw', 'dw', 'bw', 'kdim', 'pro_relu', 'relu',
                                          'res1_mode', 'res1_h', 'res1_w', 'w_group_rows', 'w_group_stride')] + \
-               [('relay_ws', vp)]
+               [('relay_ws', vp), ('mask_bits', vp), ('mask_out', vp)]
 
 
 class ImageDesc(C.Structure):
@@ -93,7 +93,7 @@ _SIGNATURES = {
     'hnd_maxpool3x3s2_bwd_relu_scale': (C.c_int, [vp] * 5 + [C.c_int] * 6 + [vp]),
     'hnd_bn_finalize': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int64, vp, vp, vp, vp, vp,
                                   C.c_float, C.c_float, vp, vp, vp, vp, vp]),
-    'hnd_affine_relu': (C.c_int, [vp, vp, vp, vp, C.c_int64, C.c_int, C.c_int, vp]),
+    'hnd_affine_relu': (C.c_int, [vp, vp, vp, vp, C.c_int64, C.c_int, C.c_int, vp, vp]),
     'hnd_bn_bwd_ntiles': (C.c_int, [C.c_int64]),
     'hnd_bn_bwd_reduce': (C.c_int, [vp] * 6 + [C.c_int, C.c_int64, C.c_int, vp, vp]),
     'hnd_bn_bwd_finalize': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int64, vp, vp, vp, vp, vp, vp, vp]),

@@ -420,7 +420,11 @@ __global__ void __launch_bounds__(256, 1) bres2_kernel(const hnd_conv_desc d, co
                   if (RES) x += resv[mi][s][ni];
                   v[ni] = d.relu ? fmaxf(x, 0.f) : x;
                 }
-                *(vecn*)(d.y + (size_t)(unsigned)prow[mi * 16 + 4 * g4 + s] * (unsigned)d.ldc + col0) = v;
+                const size_t yo = (size_t)(unsigned)prow[mi * 16 + 4 * g4 + s] * (unsigned)d.ldc + col0;
+                *(vecn*)(d.y + yo) = v;
+                if (NI == 4 && d.mask_out)          // ReLU-mask nibble of the stored values (hnd_conv_desc.mask_out)
+                  d.mask_out[yo >> 2] = (uint8_t)((v[0] > 0.f ? 1 : 0) | (v[1] > 0.f ? 2 : 0) | (v[2] > 0.f ? 4 : 0) |
+                                                  (v[3] > 0.f ? 8 : 0));
               }
               // this tile's residual rows, consumed one tile later: four per k group over k groups KG-8 .. KG-5, as asm
               // loads in the ring's own in-order stream.  (As compiler-visible loads hipcc waited for them with counts
@@ -475,7 +479,11 @@ __global__ void __launch_bounds__(256, 1) bres2_kernel(const hnd_conv_desc d, co
               if (RES) x += resv[mi][s][ni];
               v[ni] = d.relu ? fmaxf(x, 0.f) : x;
             }
-            *(vecn*)(d.y + (size_t)(unsigned)prow[mi * 16 + 4 * g4 + s] * (unsigned)d.ldc + col0) = v;
+            const size_t yo = (size_t)(unsigned)prow[mi * 16 + 4 * g4 + s] * (unsigned)d.ldc + col0;
+            *(vecn*)(d.y + yo) = v;
+            if (NI == 4 && d.mask_out)
+              d.mask_out[yo >> 2] = (uint8_t)((v[0] > 0.f ? 1 : 0) | (v[1] > 0.f ? 2 : 0) | (v[2] > 0.f ? 4 : 0) |
+                                              (v[3] > 0.f ? 8 : 0));
           }
       }
     }
@@ -574,7 +582,7 @@ int bres_variant(const hnd_conv_desc& d) {
   const long long M = (long long)d.n * d.oh * d.ow;
   const long long nchunks = (M + 63) / 64, nteams = 8ll * (per_xcd / nsl);
   const long long per_team = nchunks / nteams;
-  const bool plain = !d.res2 && !d.mask && !(d.res1 && d.pro_scale);      // the one-wave kernel: optional res1 only
+  const bool plain = !d.res2 && !d.mask && !d.mask_bits && !(d.res1 && d.pro_scale);  // one-wave kernel: optional res1 only
   const char* v2 = getenv("HND_BRES2");                   // 0 = never the one-wave kernel (A/B)
   const bool all = getenv("HND_BRES_ALL") != nullptr;     // every eligible launch, not only where it was measured to win
   if (plain && d.kdim >= 128 && !(v2 && atoi(v2) == 0) && per_team >= 2ll * (4 / wn)) {
@@ -595,7 +603,7 @@ int bres_variant(const hnd_conv_desc& d) {
     // slice every few chunks; an epilogue with residual / mask loads drains the wave's prefetch ring (one wave cannot
     // hold both in 256 registers), which only the K = 512 launches amortise.
     if (d.w_group_rows > 0 && per_team < 64) return 0;
-    if ((d.res1 || d.res2 || d.mask) && d.kdim < 512) return 0;
+    if ((d.res1 || d.res2 || d.mask || d.mask_bits) && d.kdim < 512) return 0;
     if (d.kdim == 128 && d.cout >= 512) return 0;
   }
   return wn;

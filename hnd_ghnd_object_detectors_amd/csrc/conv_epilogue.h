@@ -27,17 +27,22 @@ __device__ __forceinline__ float sq_acc(float s2, float x) {
 // the memory pipe per 16-row group, i.e. twelve per tile, which stalled every store burst and every prefetch in flight
 // (round 3: the Winograd component GEMMs, which have no optional operand at all, went 115 -> 140 TFLOP/s with the
 // epilogue compiled out; profiles/r03_bres_ablation.txt).  The callers switch ONCE per tile (epilogue_tile).
-template <int NI, bool R1, bool R2, bool MK>
+// MK: 0 = no mask operand, 1 = fp32 mask tensor (d.mask), 2 = mask nibbles (d.mask_bits: one byte per pixel and group of
+// four channels -- a lane's NI = 4 consecutive channels are exactly one byte).  d.mask_out (the nibbles of the STORED
+// values; NI = 4 builds only -- the launcher keeps such launches on 128-column tiles) is a run-time branch around a
+// store: no load sits behind it, so it does not cost the drains described above.
+template <int NI, bool R1, bool R2, int MK>
 __device__ __forceinline__ void epilogue_rows_full(const hnd_conv_desc& d, const f32x4 (&acc)[NI], const int* rowoff,
                                                    const int* resoff, int rbase, int col0, const float (&es)[NI],
                                                    const float (&eb)[NI], float (&s1)[NI], float (&s2)[NI]) {
   typedef float vec __attribute__((ext_vector_type(NI)));
   unsigned off[4];
   vec r1v[4], r2v[4], mkv[4];
+  unsigned mkb[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     off[i] = (unsigned)rowoff[rbase + i] * (unsigned)d.ldc + (unsigned)col0;
-    r1v[i] = 0.f; r2v[i] = 0.f; mkv[i] = 1.f;
+    r1v[i] = 0.f; r2v[i] = 0.f; mkv[i] = 1.f; mkb[i] = 0xfu;
   }
   if (R1) {
     if (d.res1_mode == 1) {
@@ -53,9 +58,13 @@ __device__ __forceinline__ void epilogue_rows_full(const hnd_conv_desc& d, const
 #pragma unroll
     for (int i = 0; i < 4; ++i) r2v[i] = *(const vec*)(d.res2 + off[i]);
   }
-  if (MK) {
+  if (MK == 1) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) mkv[i] = *(const vec*)(d.mask + off[i]);
+  }
+  if (MK == 2) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) mkb[i] = d.mask_bits[off[i] >> 2];
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -65,13 +74,20 @@ __device__ __forceinline__ void epilogue_rows_full(const hnd_conv_desc& d, const
       float x = acc[ni][i] * es[ni] + eb[ni];
       if (R1) x += r1v[i][ni];
       if (R2) x += r2v[i][ni];
-      if (MK) x = mkv[i][ni] > 0.f ? x : 0.f;
+      if (MK == 1) x = mkv[i][ni] > 0.f ? x : 0.f;
+      if (MK == 2) x = ((mkb[i] >> ((off[i] & 3u) + ni)) & 1u) ? x : 0.f;      // (NI = 2: half a nibble per lane)
       x = d.relu ? fmaxf(x, 0.f) : x;
       v[ni] = x;
       s1[ni] += x;
       s2[ni] += x * x;
     }
     *(vec*)(d.y + off[i]) = v;
+    if (NI == 4 && d.mask_out) {
+      unsigned nib = 0;
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) nib |= (v[ni] > 0.f ? 1u : 0u) << ni;
+      d.mask_out[off[i] >> 2] = (uint8_t)nib;
+    }
   }
   asm volatile("" ::: "memory");
 }
@@ -93,16 +109,26 @@ __device__ __forceinline__ void epilogue_rows_checked(const hnd_conv_desc& d, co
       if (d.res1) x += d.res1_mode == 1 ? d.res1[(size_t)resoff[rbase + i] * d.ldc + col] : d.res1[o];
       if (d.res2) x += d.res2[o];
       if (d.mask) x = d.mask[o] > 0.f ? x : 0.f;
+      if (d.mask_bits) x = ((d.mask_bits[o >> 2] >> (o & 3)) & 1u) ? x : 0.f;
       x = d.relu ? fmaxf(x, 0.f) : x;
       d.y[o] = x;
       s1[ni] += x;
       s2[ni] = sq_acc(s2[ni], x);
     }
+    // mask nibbles on the checked path (tile edges): a byte is four channels of ONE lane (col0 is a multiple of 4 here:
+    // NI == 4 and the launcher requires ldc % 4 == 0 with mask_out), written whole when its first channel is in range
+    if (NI == 4 && d.mask_out && po >= 0 && col0 < d.cout) {
+      unsigned nib = 0;
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+        if (col0 + ni < d.cout) nib |= (d.y[(size_t)po * d.ldc + col0 + ni] > 0.f ? 1u : 0u) << ni;
+      d.mask_out[((size_t)po * d.ldc + col0) >> 2] = (uint8_t)nib;
+    }
   }
 }
 
 // The wave's MI row groups (rows rbase0 + 16*mi + 0..3 of the tables), dispatched once on the operand set.
-template <int MI, int NI, bool R1, bool R2, bool MK>
+template <int MI, int NI, bool R1, bool R2, int MK>
 __device__ __forceinline__ void epilogue_tile_full(const hnd_conv_desc& d, const f32x4 (&acc)[MI][NI], const int* rowoff,
                                                    const int* resoff, int rbase0, int col0, const float (&es)[NI],
                                                    const float (&eb)[NI], float (&s1)[NI], float (&s2)[NI]) {
@@ -121,17 +147,21 @@ __device__ __forceinline__ void epilogue_tile(const hnd_conv_desc& d, const f32x
       epilogue_rows_checked<NI>(d, acc[mi], rowoff, resoff, rbase0 + 16 * mi, col0, es, eb, s1, s2);
     return;
   }
-  const int sel = (d.res1 ? 1 : 0) | (d.res2 ? 2 : 0) | (d.mask ? 4 : 0);
+  const int sel = (d.res1 ? 1 : 0) | (d.res2 ? 2 : 0) | (d.mask ? 4 : (d.mask_bits ? 8 : 0));
 #define HND_EPI(R1, R2, MK) epilogue_tile_full<MI, NI, R1, R2, MK>(d, acc, rowoff, resoff, rbase0, col0, es, eb, s1, s2)
   switch (sel) {
-    case 0: HND_EPI(false, false, false); break;
-    case 1: HND_EPI(true, false, false); break;
-    case 2: HND_EPI(false, true, false); break;
-    case 3: HND_EPI(true, true, false); break;
-    case 4: HND_EPI(false, false, true); break;
-    case 5: HND_EPI(true, false, true); break;
-    case 6: HND_EPI(false, true, true); break;
-    default: HND_EPI(true, true, true); break;
+    case 0: HND_EPI(false, false, 0); break;
+    case 1: HND_EPI(true, false, 0); break;
+    case 2: HND_EPI(false, true, 0); break;
+    case 3: HND_EPI(true, true, 0); break;
+    case 4: HND_EPI(false, false, 1); break;
+    case 5: HND_EPI(true, false, 1); break;
+    case 6: HND_EPI(false, true, 1); break;
+    case 7: HND_EPI(true, true, 1); break;
+    case 8: HND_EPI(false, false, 2); break;
+    case 9: HND_EPI(true, false, 2); break;
+    case 10: HND_EPI(false, true, 2); break;
+    default: HND_EPI(true, true, 2); break;
   }
 #undef HND_EPI
 }

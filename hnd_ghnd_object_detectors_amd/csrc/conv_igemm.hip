@@ -487,7 +487,8 @@ __global__ void __launch_bounds__(128, 4) thin_n_kernel(const hnd_conv_desc d) {
 
 bool thin_n_applies(const hnd_conv_desc& d) {
   static const int on = getenv("HND_THIN_N") ? atoi(getenv("HND_THIN_N")) : 1;
-  return on && d.cin != 4 && d.cin % 64 == 0 && d.cout <= 4 && d.res1_mode == 0 && d.w_group_rows == 0 &&
+  return on && !d.mask_bits && !d.mask_out && d.cin != 4 && d.cin % 64 == 0 && d.cout <= 4 && d.res1_mode == 0 &&
+         d.w_group_rows == 0 &&
          d.kdim == d.kh * d.kw * d.cin && d.kdim <= 4096;
 }
 
@@ -540,6 +541,7 @@ int pick_tile(const hnd_conv_desc& d) {
     if (t >= 0 && t <= 3) {
       if ((t == 0 || t == 2) && d.cout % 128 != 0) return t + 1;
       if (d.stats && (t == 2 || t == 3)) return t - 2;
+      if (d.mask_out && (t == 1 || t == 3)) return t - 1;     // mask nibbles are written by the 128-column tiles
       return t;
     }
   }
@@ -562,6 +564,7 @@ int pick_tile(const hnd_conv_desc& d) {
   for (const Cand& c : cands) {
     if (c.bn == 128 && !n128) continue;
     if (d.stats && c.bm != 128) continue;          // BN statistics partials are per 128-pixel tile
+    if (d.mask_out && c.bn != 128) continue;       // a lane must own whole mask nibbles (4 consecutive channels)
     const long long blocks = ((M + c.bm - 1) / c.bm) * ((d.cout + c.bn - 1) / c.bn);
     const long long slots = 256ll * c.bpc;
     const long long full = blocks / slots, rem = blocks % slots;
@@ -605,6 +608,11 @@ extern "C" int hnd_conv2d_igemm(const hnd_conv_desc* desc, void* stream) {
   HND_REQUIRE(d.res1_mode == 0 || (d.res1_h > 0 && d.res1_w > 0), "hnd_conv2d_igemm: res1 upsample needs dims");
   HND_REQUIRE(d.pro_scale == nullptr || d.pro_shift != nullptr, "hnd_conv2d_igemm: pro_shift is required with pro_scale");
   HND_REQUIRE((long long)d.n * d.yh * d.yw * d.ldc < (1ll << 32) - 1, "hnd_conv2d_igemm: output exceeds 2^32 elements");
+  HND_REQUIRE(!(d.mask && d.mask_bits), "hnd_conv2d_igemm: give mask or mask_bits, not both");
+  HND_REQUIRE(!(d.mask_bits || d.mask_out) || (d.ldc % 4 == 0 && d.cin != 4),
+              "hnd_conv2d_igemm: mask nibbles need ldc %% 4 == 0 (ldc=%d) and a cin %% 32 == 0 launch", d.ldc);
+  HND_REQUIRE(!d.mask_out || d.cout % 128 == 0,
+              "hnd_conv2d_igemm: mask_out needs cout %% 128 == 0 (a lane must own whole nibbles), cout=%d", d.cout);
   HND_REQUIRE((long long)d.n * d.h * d.w_ * d.cin < (1ll << 32) - 1, "hnd_conv2d_igemm: input exceeds 2^32 elements");
   hipStream_t s = hnd::as_stream(stream);
   if (d.cin == 4) {

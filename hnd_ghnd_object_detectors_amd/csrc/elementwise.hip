@@ -323,7 +323,7 @@ __global__ void __launch_bounds__(1024) bn_finalize_kernel(const float* __restri
 
 __global__ void affine_relu_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                    const float* __restrict__ shift, float* __restrict__ y, long long n4, int cs4,
-                                   int relu) {
+                                   int relu, uint8_t* __restrict__ mask_out) {
   for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < n4; e += (long long)gridDim.x * blockDim.x) {
     const int c4 = (int)(e % cs4);
     const f32x4 v = *(const f32x4*)(x + e * 4);
@@ -331,6 +331,8 @@ __global__ void affine_relu_kernel(const float* __restrict__ x, const float* __r
     f32x4 r = v * s + b;
     if (relu) { r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f); }
     *(f32x4*)(y + e * 4) = r;
+    if (mask_out)       // ReLU-mask nibble of these four channels (hnd_conv_desc.mask_out's layout)
+      mask_out[e] = (uint8_t)((r.x > 0.f ? 1 : 0) | (r.y > 0.f ? 2 : 0) | (r.z > 0.f ? 4 : 0) | (r.w > 0.f ? 8 : 0));
   }
 }
 
@@ -818,11 +820,11 @@ int hnd_bn_finalize(const float* partials, int ntiles, int c, int cs, int64_t co
 }
 
 int hnd_affine_relu(const float* x, const float* scale, const float* shift, float* y, int64_t npix, int cs, int relu,
-                    void* stream) {
+                    uint8_t* mask_out, void* stream) {
   HND_REQUIRE(x && scale && shift && y && npix > 0 && cs > 0 && cs % 4 == 0, "hnd_affine_relu: bad arguments");
   const long long n4 = (long long)npix * (cs / 4);
   hipLaunchKernelGGL(affine_relu_kernel, dim3(grid_for(n4)), dim3(256), 0, hnd::as_stream(stream), x, scale, shift, y,
-                     n4, cs / 4, relu);
+                     n4, cs / 4, relu, mask_out);
   return hnd::check_launch("hnd_affine_relu");
 }
 

@@ -459,26 +459,6 @@ __global__ void wino6_weights_kernel(const float* __restrict__ w, float* __restr
   }
 }
 
-// Order in which the input transforms walk the tiles of an image: bands of `band` tile rows, column by column inside a
-// band -- so the tile below (which shares 2 of a patch's 8 rows) is the NEXT one instead of a whole tile row (2.75 MB of
-// input at 200 x 336 x 256) later, and the tile to the right follows within `band` tiles: the halo of the 8 x 8 (7 x 7)
-// patches is an L1 / L2 hit instead of a second trip to HBM (FETCH 1.48x the activation in row-major order).  Only the
-// processing order changes, not where a tile's components are stored.  band = 0: row-major.
-__device__ __forceinline__ void banded_tile(long long s, int th, int tw, int band, int& b, int& ty, int& tx) {
-  const int per_img = th * tw;
-  b = (int)(s / per_img);
-  const int r = (int)(s - (long long)b * per_img);
-  if (band <= 0) {
-    ty = r / tw;
-    tx = r - ty * tw;
-    return;
-  }
-  const int bi = r / (band * tw), rr = r - bi * band * tw;
-  const int rows = min(band, th - bi * band);
-  tx = rr / rows;
-  ty = bi * band + (rr - tx * rows);
-}
-
 #define HND_WINO6_BT(d0, d1, d2, d3, d4, d5, d6, d7, o0, o1, o2, o3, o4, o5, o6, o7) \
   do {                                                                               \
     const f32x2 e26_ = d2 + d6 - 4.25f * d4, o15_ = d1 + d5 - 4.25f * d3;            \
@@ -492,7 +472,7 @@ __device__ __forceinline__ void banded_tile(long long s, int th, int tw, int ban
 // 8x8 input patch of tile t (rows 6ty-1.., cols 6tx-1..), two channels per thread: 128 VGPRs of patch
 __global__ void __launch_bounds__(256) wino6_input_kernel(const float* __restrict__ x, float* __restrict__ v,
                                                           const WinoGeom g, const float* __restrict__ pro_scale,
-                                                          const float* __restrict__ pro_shift, int pro_relu, int band) {
+                                                          const float* __restrict__ pro_shift, int pro_relu) {
   const int c2n = g.c >> 1;
   const long long tiles = (long long)g.n * g.th * g.tw;
   const long long total = tiles * c2n;
@@ -500,9 +480,10 @@ __global__ void __launch_bounds__(256) wino6_input_kernel(const float* __restric
   for (long long e = hnd::xcd_contiguous_block() * (long long)blockDim.x + threadIdx.x; e < total;
        e += (long long)gridDim.x * blockDim.x) {
     const int c2 = (int)(e % c2n);
-    int b, ty, tx;
-    banded_tile(e / c2n, g.th, g.tw, band, b, ty, tx);
-    const long long t = ((long long)b * g.th + ty) * g.tw + tx;
+    long long t = e / c2n;
+    const int tx = (int)(t % g.tw);
+    long long q = t / g.tw;
+    const int ty = (int)(q % g.th), b = (int)(q / g.th);
     f32x2 ps = {1.f, 1.f}, pb = {0.f, 0.f};
     if (pro_scale) {
       ps = *(const f32x2*)(pro_scale + c2 * 2);
@@ -1005,7 +986,7 @@ __global__ void wino26_weights_kernel(const float* __restrict__ w, float* __rest
 
 __global__ void __launch_bounds__(256) wino26_input_kernel(const float* __restrict__ x, float* __restrict__ v,
                                                            const Wino2Geom g, const float* __restrict__ pro_scale,
-                                                           const float* __restrict__ pro_shift, int pro_relu, int band) {
+                                                           const float* __restrict__ pro_shift, int pro_relu) {
   const int c2n = g.c >> 1;
   const long long tiles = (long long)g.n * g.th * g.tw;
   const long long total = tiles * c2n;
@@ -1013,9 +994,10 @@ __global__ void __launch_bounds__(256) wino26_input_kernel(const float* __restri
   for (long long e = hnd::xcd_contiguous_block() * (long long)blockDim.x + threadIdx.x; e < total;
        e += (long long)gridDim.x * blockDim.x) {
     const int c2 = (int)(e % c2n);
-    int b, ty, tx;
-    banded_tile(e / c2n, g.th, g.tw, band, b, ty, tx);
-    const long long t = ((long long)b * g.th + ty) * g.tw + tx;
+    long long t = e / c2n;
+    const int tx = (int)(t % g.tw);
+    long long q = t / g.tw;
+    const int ty = (int)(q % g.th), b = (int)(q / g.th);
     f32x2 ps = {1.f, 1.f}, pb = {0.f, 0.f};
     if (pro_scale) {
       ps = *(const f32x2*)(pro_scale + c2 * 2);
@@ -1229,11 +1211,6 @@ int hnd_wino_weights(const float* weight, float* u, int cout, int cin, int dgrad
   return hnd::check_launch("hnd_wino_weights");
 }
 
-static int wino_band() {            // tile rows per band of the input transforms' walk (banded_tile); 0 = row-major
-  static const int v = getenv("HND_WINO_BAND") ? atoi(getenv("HND_WINO_BAND")) : 4;
-  return v;
-}
-
 int hnd_wino_input(const float* x, float* v, int n, int h, int w, int c, const float* pro_scale,
                    const float* pro_shift, int pro_relu, int tile, void* stream) {
   HND_REQUIRE(x && v && n > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0 && (tile == 2 || tile == 4 || tile == 6),
@@ -1249,7 +1226,7 @@ int hnd_wino_input(const float* x, float* v, int n, int h, int w, int c, const f
                        g, pro_scale, pro_shift, pro_relu);
   else
     hipLaunchKernelGGL(wino6_input_kernel, dim3(grid_for(tiles * (c / 2))), dim3(256), 0, hnd::as_stream(stream), x, v,
-                       g, pro_scale, pro_shift, pro_relu, wino_band());
+                       g, pro_scale, pro_shift, pro_relu);
   return hnd::check_launch("hnd_wino_input");
 }
 
@@ -1324,7 +1301,7 @@ int hnd_wino2_input(const float* x, float* v, int n, int h, int w, int c, int pa
                        g, pro_scale, pro_shift, pro_relu);
   else
     hipLaunchKernelGGL(wino26_input_kernel, dim3(grid_for(tiles * (c / 2))), dim3(256), 0, hnd::as_stream(stream), x, v,
-                       g, pro_scale, pro_shift, pro_relu, wino_band());
+                       g, pro_scale, pro_shift, pro_relu);
   return hnd::check_launch("hnd_wino2_input");
 }
 

@@ -184,6 +184,10 @@ class Wino2Cache(object):
 
 
 FOLD_DGRAD_SCALE = os.environ.get('HND_FOLD_DGRAD_SCALE', '1') != '0'     # 0: FrozenBN scale as a launch prologue
+# ReLU masks of the Bottleneck outputs as nibbles (one byte per pixel and 4 channels, written by the forward epilogue that
+# stores the output) instead of re-reading the fp32 activation in the conv1 data gradients -- HBM-bound launches (out +
+# residual + mask at K = 128): 1/16 of the mask's bytes.  Same decisions (x > 0), same bits.  0: fp32 masks (A/B, tests)
+MASK_BITS = os.environ.get('HND_MASK_BITS', '1') != '0'
 WINOGRAD6 = os.environ.get('HND_WINOGRAD6', '1') != '0'       # F(6x6,3x3) on maps large enough (wino_tile_for)
 
 
@@ -392,6 +396,11 @@ class FrozenLayerEngine(object):
         """the layer output the backward pass sees (ReLU mask of the gradient that enters the NEXT layer's dgrad)"""
         return self._b(self.out)
 
+    def bwd_out_bits(self):
+        """... and its ReLU mask as nibbles (None when the forward did not produce them)"""
+        bits = self.out_bits[-1] if getattr(self, 'out_bits', None) else None
+        return None if bits is None else self._b(bits)
+
     def _check_frozen(self):
         for b in self.blocks:
             for p in b.mod.parameters():
@@ -436,7 +445,7 @@ class FrozenLayerEngine(object):
         return self.out
 
     def _build_forward(self, x, keep, affs):
-        self.fwd, self.acts = [], []
+        self.fwd, self.acts, self.out_bits = [], [], []
         n = x.shape[0]
         cur = x
         flops = 0
@@ -469,8 +478,12 @@ class FrozenLayerEngine(object):
                 flops += 2 * n * oh * ow * b.planes * 4 * b.cin
             else:
                 ident = cur
+            # (keep = the student: the backward of the NEXT block / layer applies [out > 0] -- as nibbles, see MASK_BITS)
+            bits = self.bufs.get('bits_' + sfx, tuple(out.shape[:3]) + (out.shape[3] // 4,), torch.uint8) \
+                if (keep and MASK_BITS and out.shape[3] % 128 == 0) else None
             self.fwd.append((ops.conv_forward(a2, b.w3.get(), out, 1, 1, 0, epi_scale=a3f[0], epi_shift=a3f[1],
-                                              res1=ident, relu=True), tagp + '.conv3'))
+                                              res1=ident, relu=True, mask_out=bits), tagp + '.conv3'))
+            self.out_bits.append(bits)
             flops += 2 * n * (h * w * b.planes * b.cin + oh * ow * b.planes * b.planes * 9
                               + oh * ow * b.planes * 4 * b.planes)
             self.acts.append((cur, a1, a2, out))
@@ -498,7 +511,7 @@ class FrozenLayerEngine(object):
             self.g_out = self.bufs.get('g_out_blk%d' % top_block, self.block_out(top_block).shape)
         return self.g_out
 
-    def backward(self, dst, dst_mask, res2, top_block=None, block_grads=None):
+    def backward(self, dst, dst_mask, res2, top_block=None, block_grads=None, dst_mask_bits=None):
         """Propagate self.g_out to `dst` (grad w.r.t. this layer's input):
         dst = [dst_mask > 0] * (dgrad + res2).  res2 (the loss gradient of the previous layer) may be None.
         top_block: the gradient enters at the output of that Bottleneck (later blocks carry no loss: skipped);
@@ -507,14 +520,15 @@ class FrozenLayerEngine(object):
         self._check_frozen()
         block_grads = block_grads or {}
         key = (dst.data_ptr(), dst_mask.data_ptr(), None if res2 is None else res2.data_ptr(), self.g_out.data_ptr(),
-               self.bslice, top_block, tuple(sorted((i, t.data_ptr()) for i, t in block_grads.items())))
+               self.bslice, top_block, tuple(sorted((i, t.data_ptr()) for i, t in block_grads.items())),
+               None if dst_mask_bits is None else dst_mask_bits.data_ptr())
         if key != self.bwd_key:
-            self._build_backward(dst, dst_mask, res2, top_block, block_grads)
+            self._build_backward(dst, dst_mask, res2, top_block, block_grads, dst_mask_bits)
             self.bwd_key = key
         for l, tag in self.bwd:
             _run(l, tag)
 
-    def _build_backward(self, dst, dst_mask, res2, top_block=None, block_grads=None):
+    def _build_backward(self, dst, dst_mask, res2, top_block=None, block_grads=None, dst_mask_bits=None):
         self.bwd = []
         flops = 0
         g = self.g_out
@@ -551,17 +565,21 @@ class FrozenLayerEngine(object):
             if i > 0:
                 g_prev = self.bufs.get('g_blk_%d' % ((i - 1) & 1), x_in.shape)
                 tgt, tmask, tres2 = g_prev, x_in, block_grads.get(i - 1)      # a loss term on block i-1's output
+                tbits = self.out_bits[i - 1]
+                tbits = None if tbits is None else self._b(tbits)
             else:
-                tgt, tmask, tres2 = dst, dst_mask, res2
+                tgt, tmask, tres2, tbits = dst, dst_mask, res2, dst_mask_bits
+            # [x_in > 0] as nibbles where the forward wrote them (1/16 of the bytes), else the fp32 activation itself
+            mk = {'mask_bits': tbits} if tbits is not None else {'mask': tmask}
             if b.has_ds:
-                ls, _ = ops.conv_dgrad(g_a1, b.w1, tgt, 1, 1, 0, res2=tres2, mask=tmask, **fold(s1))
+                ls, _ = ops.conv_dgrad(g_a1, b.w1, tgt, 1, 1, 0, res2=tres2, **mk, **fold(s1))
                 self.bwd += [(l, tagp + '.conv1.dgrad') for l in ls]
-                ls, _ = ops.conv_dgrad(g, b.wd, tgt, 1, b.stride, 0, accumulate=True, mask=tmask,
+                ls, _ = ops.conv_dgrad(g, b.wd, tgt, 1, b.stride, 0, accumulate=True, **mk,
                                        **fold(b.fd.get()[0]))
                 self.bwd += [(l, tagp + '.downsample.dgrad') for l in ls]
                 flops += 2 * n * oh * ow * b.planes * 4 * b.cin
             else:
-                ls, _ = ops.conv_dgrad(g_a1, b.w1, tgt, 1, 1, 0, res1=g, res2=tres2, mask=tmask, **fold(s1))
+                ls, _ = ops.conv_dgrad(g_a1, b.w1, tgt, 1, 1, 0, res1=g, res2=tres2, **mk, **fold(s1))
                 self.bwd += [(l, tagp + '.conv1.dgrad') for l in ls]
             flops += 2 * n * (h * w * b.planes * b.cin + oh * ow * b.planes * b.planes * 9
                               + oh * ow * b.planes * 4 * b.planes)
@@ -617,6 +635,9 @@ class HeadEngine(object):
     def bwd_out(self):
         return self.out
 
+    def bwd_out_bits(self):
+        return getattr(self, 'out_bits', None)
+
     def forward(self, x, training, codec=None):
         if self.bufs is None:
             self.bufs = Buffers(x.device)
@@ -664,7 +685,8 @@ class HeadEngine(object):
                 ops.bn_finalize(self.stats[i], self.ntiles[i], hc.cout, hc.cs_out, m, bn.weight.detach(),
                                 bn.bias.detach(), bn.running_mean, bn.running_var, bn.num_batches_tracked,
                                 BN_MOMENTUM, BN_EPS, self.scale[i], self.shift[i], self.mean[i], self.rstd[i])
-        ops.affine_relu(self.y[-1], self.scale[-1], self.shift[-1], self.out, self.layers[-1].relu)
+        ops.affine_relu(self.y[-1], self.scale[-1], self.shift[-1], self.out, self.layers[-1].relu,
+                        mask_out=self.out_bits)
         return self.out
 
     def _build_forward(self, x, training):
@@ -711,6 +733,9 @@ class HeadEngine(object):
             h, w = oh, ow
         self.out = b.get('out', (n, h, w, self.layers[-1].cs_out)) if self._out_buf is None else self._out_buf
         assert tuple(self.out.shape) == (n, h, w, self.layers[-1].cs_out)
+        # ReLU mask of the layer output as nibbles, for the data gradient that enters this layer (MASK_BITS)
+        self.out_bits = b.get('out_bits', (n, h, w, self.layers[-1].cs_out // 4), torch.uint8) \
+            if (training and MASK_BITS and self.layers[-1].relu and self.layers[-1].cs_out % 4 == 0) else None
         self.flops_fwd = flops
 
     def _wino_scratch(self, n, oh, ow, cin, cout, tile=4):

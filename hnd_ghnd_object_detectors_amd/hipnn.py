@@ -279,7 +279,8 @@ class IntermediateLayerGetter(nn.ModuleDict):
             dst = prev_eng.grad_out_buffer()
             self.layer_engine(name).backward(dst, prev_eng.bwd_out(), loss_grads.get(prev_name),
                                              top_block=top_block if name == top else None,
-                                             block_grads=block_grads.get(name))
+                                             block_grads=block_grads.get(name),
+                                             dst_mask_bits=prev_eng.bwd_out_bits())
         l1 = self['layer1']
         conv1_w = self['conv1'].weight
         dw1 = grad_dst.get(conv1_w)

@@ -159,8 +159,9 @@ def _nhwc(t):
 
 def conv_desc(x, pw, y, *, kh, kw, oh, ow, sh, dh, bh, sw, dw, bw, cout, y_sh=1, y_oh=0, y_sw=1, y_ow=0,
               pro_scale=None, pro_shift=None, pro_relu=False, epi_scale=None, epi_shift=None, res1=None,
-              res1_up=False, res2=None, mask=None, relu=False, stats=None):
-    """Generic descriptor (see include/hnd_hip.h).  x, y, res*, mask are NHWC tensors."""
+              res1_up=False, res2=None, mask=None, relu=False, stats=None, mask_bits=None, mask_out=None):
+    """Generic descriptor (see include/hnd_hip.h).  x, y, res*, mask are NHWC tensors; mask_bits / mask_out are uint8
+    ReLU-mask nibble tensors of y's geometry with a quarter of its channels (mask_nibbles_like)."""
     n, h, w, cin = _nhwc(x)
     ny, yh, yw, ldc = _nhwc(y)
     assert ny == n and pw.kdim >= kh * kw * cin and pw.chan_pad == cin, (pw.kdim, kh, kw, cin, pw.chan_pad)
@@ -185,9 +186,14 @@ def conv_desc(x, pw, y, *, kh, kw, oh, ow, sh, dh, bh, sw, dw, bw, cout, y_sh=1,
         assert tuple(res1.shape) == tuple(y.shape)
     for t in (res2, mask):
         assert t is None or tuple(t.shape) == tuple(y.shape)
+    for t in (mask_bits, mask_out):
+        assert t is None or (t.dtype == torch.uint8 and t.is_contiguous() and ldc % 4 == 0
+                             and tuple(t.shape) == (ny, yh, yw, ldc // 4)), (None if t is None else t.shape, y.shape)
+    assert mask is None or mask_bits is None
+    d.mask_bits, d.mask_out = ptr(mask_bits), ptr(mask_out)
     if stats is not None:
         assert stats.numel() >= stats_tiles(n * oh * ow) * 2 * cout
-    keep = (x, pw, y, pro_scale, pro_shift, epi_scale, epi_shift, res1, res2, mask, stats)
+    keep = (x, pw, y, pro_scale, pro_shift, epi_scale, epi_shift, res1, res2, mask, stats, mask_bits, mask_out)
     return ConvLaunch(d, keep, flops=2 * n * oh * ow * min(cout, pw.rows) * kh * kw * min(cin, pw.chan_real))
 
 
@@ -421,11 +427,18 @@ def bn_finalize(partials, ntiles, c, cs, count, gamma, beta, running_mean, runni
                              ptr(save_rstd), stream_ptr()), 'hnd_bn_finalize')
 
 
-def affine_relu(x, scale, shift, y, relu):
+def mask_nibbles_like(y):
+    """uint8 buffer for the ReLU-mask nibbles of NHWC tensor y: one byte per pixel and group of four channels"""
+    assert y.shape[-1] % 4 == 0
+    return torch.empty(tuple(y.shape[:-1]) + (y.shape[-1] // 4,), dtype=torch.uint8, device=y.device)
+
+
+def affine_relu(x, scale, shift, y, relu, mask_out=None):
     cs = x.shape[-1]
-    _hbm('affine_relu', 8 * x.numel(), lambda: check(
-        _L.hnd_affine_relu(ptr(x), ptr(scale), ptr(shift), ptr(y), x.numel() // cs, cs, int(relu), stream_ptr()),
-        'hnd_affine_relu'))
+    assert mask_out is None or (mask_out.dtype == torch.uint8 and mask_out.numel() * 4 == y.numel())
+    _hbm('affine_relu', 8 * x.numel() + (0 if mask_out is None else mask_out.numel()), lambda: check(
+        _L.hnd_affine_relu(ptr(x), ptr(scale), ptr(shift), ptr(y), x.numel() // cs, cs, int(relu), ptr(mask_out),
+                           stream_ptr()), 'hnd_affine_relu'))
 
 
 def bn_bwd_ntiles(npix):

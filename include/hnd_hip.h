@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define HND_ABI_VERSION 7
+#define HND_ABI_VERSION 8
 
 typedef enum hnd_status {
   HND_OK = 0,
@@ -108,6 +108,14 @@ typedef struct hnd_conv_desc {
    * continues the same k chain (same bits as without).  The neighbour's wait is bounded: if it gives up, the launch's
    * output is invalid and a sticky process-wide error is raised -- see hnd_relay_timeouts. */
   float* relay_ws;
+  /* ReLU masks as NIBBLES (ABI 8): one byte per (pixel, group of 4 channels) of a tensor of the output's geometry, bit k
+   * of byte (pixel * ldc + c) / 4 = [value of channel (c & ~3) + k > 0].  The backward pass of a FROZEN layer needs only
+   * the sign of its activations, and the data gradients that apply them are HBM-bound (out + residual + mask at K = 128):
+   * 1/16 of the fp32 mask's bytes.  ldc % 4 == 0 required.
+   *   mask_bits: consumed like `mask` (v = bit ? v : 0); give one or the other, not both.
+   *   mask_out:  produced from the STORED value (after ReLU), next to y. */
+  const uint8_t* mask_bits;
+  uint8_t* mask_out;
 } hnd_conv_desc;
 
 int hnd_conv2d_igemm(const hnd_conv_desc* desc, void* stream);
@@ -290,8 +298,9 @@ int hnd_bn_finalize(const float* partials, int ntiles, int c, int cs, int64_t co
                     float momentum, float eps, float* scale, float* shift, float* save_mean, float* save_rstd,
                     void* stream);
 /* y = x*scale[ch] + shift[ch] (+ReLU), NHWC with channel stride cs (multiple of 4). */
+/* mask_out (or NULL): the ReLU-mask nibbles of y, see hnd_conv_desc.mask_out */
 int hnd_affine_relu(const float* x, const float* scale, const float* shift, float* y, int64_t npix, int cs,
-                    int relu, void* stream);
+                    int relu, uint8_t* mask_out, void* stream);
 
 /* BatchNorm backward, pass 1: with d = g * [ (x*scale+shift) > 0 ] (mask only when relu),
  * partial sums over pixels of  d  and  d * xhat  (xhat = (x-mean)*rstd) per channel. */

@@ -753,6 +753,36 @@ def test_shared_trunk_halves_equal_the_separate_passes_bit_for_bit(case, first, 
         assert torch.equal(runs[first][4][n], runs[False][4][n]), n
 
 
+@pytest.mark.parametrize('case', ['tiny_ghnd_faster', 'full_ghnd_faster_b4'])
+def test_mask_nibbles_change_no_bit_of_the_step(case, monkeypatch):
+    """engine.MASK_BITS: the conv1 data gradients of the frozen Bottlenecks read [x > 0] as nibbles written by the forward
+    epilogue instead of the fp32 activation -- the same decisions, so loss, terms and EVERY gradient are bit-identical to
+    the fp32-mask step."""
+    from hnd_ghnd_object_detectors_amd import engine as E
+    z, meta = G.load(case)
+    if case.startswith('full'):
+        meta = dict(meta, sizes=meta['sizes'][:2])
+    images, targets = G.case_inputs(meta)
+    runs = {}
+    for bits in (False, True):
+        monkeypatch.setattr(E, 'MASK_BITS', bits)
+        cfg, t_sd, s_sd, teacher, student, box, opt, warm = _setup(meta)
+        ims, tgs = _to_dev(images, [dict(t) for t in targets])
+        loss = box(ims, tgs)
+        opt.zero_grad()
+        loss.backward()
+        eng = student.backbone.body.layer_engine('layer3')
+        used = [l.desc.mask_bits is not None for l, tag in eng.bwd if tag.endswith('conv1.dgrad')]
+        assert all(used) == bits and any(used) == bits, used
+        runs[bits] = (loss.item(), loss.per_term.cpu().clone(),
+                      OrderedDict((n, p.grad.clone()) for n, p in student.named_parameters() if p.requires_grad))
+        if box.defer_fpn and box._fpn_stream is not None:
+            torch.cuda.current_stream().wait_stream(box._fpn_stream)
+    assert runs[True][0] == runs[False][0] and torch.equal(runs[True][1], runs[False][1])
+    for n in runs[False][2]:
+        assert torch.equal(runs[True][2][n], runs[False][2][n]), n
+
+
 def test_shared_trunk_is_dropped_when_the_frozen_weights_differ(monkeypatch):
     """the merged pass needs bit-equal frozen weights; a student whose layer3 was edited (a checkpoint that did not come
     from this teacher) runs its own pass -- and the pyramids of the merged pass equal the separate ones"""

@@ -1143,6 +1143,66 @@ def test_bstream_kernel_is_bit_identical_to_the_tiled_kernel(ops, case, monkeypa
             assert float((outs['all'][0, 0, rows] - ref).norm() / ref.norm()) < 1e-5
 
 
+@pytest.mark.parametrize('case', [
+    # cin, h, w, cout, residual, n, forced kernel (HND_BRES / HND_BSTREAM / HND_IGEMM_TILE)
+    (128, 50, 84, 512, True, 4, {}),                                  # layer2 conv3: bres2 + residual (own store path)
+    (256, 37, 41, 1024, True, 3, {}),                                 # ragged rows: the checked path writes nibbles too
+    (512, 25, 42, 2048, True, 4, {}),                                 # K = 512: the 8-wave kernel (shared epilogue)
+    (128, 33, 47, 256, False, 2, {'HND_BRES': '0'}),                  # tiled kernel, picker restricted to 128 columns
+    (128, 33, 47, 256, True, 2, {'HND_BRES': '0', 'HND_IGEMM_TILE': '3'}),      # 64 x 64 asked for -> 64 x 128
+    (1024, 25, 42, 512, True, 8, {'HND_BRES': '0', 'HND_BSTREAM': 'all'}),      # B-streamed kernel
+])
+def test_relu_mask_nibbles_written_by_the_forward_and_applied_by_the_data_gradient(ops, case, monkeypatch):
+    """hnd_conv_desc.mask_out / mask_bits (ABI 8): the forward epilogue writes [y > 0] as one byte per pixel and four
+    channels next to y; a launch that takes those nibbles as its mask gives EXACTLY the bits of the same launch masked by
+    the fp32 tensor y -- on every kernel behind hnd_conv2d_igemm, including 64-column tiles (half a nibble per lane)."""
+    cin, h, w, cout, res, n, env = case
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(n, h, w, cin, generator=g).to(DEV)
+    wt = torch.randn(cout, cin, 1, 1, generator=g).to(DEV) / cin ** 0.5
+    pk = ops.pack_weights(wt)
+    r = torch.randn(n, h, w, cout, generator=g).to(DEV) if res else None
+    y = torch.empty(n, h, w, cout, device=DEV)
+    bits = ops.mask_nibbles_like(y)
+    bits.fill_(0xAA)
+    l = ops.conv_forward(x, pk, y, 1, 1, 0, res1=r, relu=True, mask_out=bits)
+    l.run()
+    ops.sync_check()
+    want = (y > 0).view(n, h, w, cout // 4, 4).to(torch.uint8)
+    want = want[..., 0] | (want[..., 1] << 1) | (want[..., 2] << 2) | (want[..., 3] << 3)
+    assert torch.equal(bits, want), (l.variant, int((bits != want).sum()))
+    assert 0.2 < float((y > 0).float().mean()) < 0.8
+    # consumer: a data-gradient-like launch masked by y (fp32) vs by its nibbles, on the default and on the tiled kernels
+    for env2 in ({}, {'HND_BRES': '0', 'HND_BSTREAM': '0'}, {'HND_BRES': '0', 'HND_BSTREAM': '0', 'HND_IGEMM_TILE': '3'}):
+        for k in ('HND_BRES', 'HND_BSTREAM', 'HND_IGEMM_TILE'):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env2.items():
+            monkeypatch.setenv(k, v)
+        outs = []
+        for kw in ({'mask': y}, {'mask_bits': bits}):
+            z = torch.full_like(y, float('nan'))
+            l2 = ops.conv_forward(x, pk, z, 1, 1, 0, res1=r, **kw)
+            l2.run()
+            ops.sync_check()
+            outs.append((z.clone(), l2.variant))
+        assert torch.equal(outs[0][0], outs[1][0]), (outs[0][1], outs[1][1])
+        assert not bool(torch.isnan(outs[1][0]).any())
+
+
+def test_affine_relu_writes_mask_nibbles(ops):
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(3, 17, 23, 256, generator=g).to(DEV)
+    sc, sh = (torch.rand(256, generator=g) + 0.5).to(DEV), torch.randn(256, generator=g).to(DEV)
+    y, bits = torch.empty_like(x), ops.mask_nibbles_like(x)
+    ops.affine_relu(x, sc, sh, y, True, mask_out=bits)
+    ops.sync_check()
+    want = (y > 0).view(3, 17, 23, 64, 4).to(torch.uint8)
+    assert torch.equal(bits, want[..., 0] | (want[..., 1] << 1) | (want[..., 2] << 2) | (want[..., 3] << 3))
+    assert torch.allclose(y, torch.relu(x * sc + sh), rtol=1e-6, atol=1e-6)      # (the kernel's scale-shift is one fma)
+
+
 def test_bstream_relay_timeout_is_loud_and_does_not_poison_the_workspace(ops, monkeypatch):
     """a relay wait that gives up must not pass for a correct launch, and a writer that arrives late must not
     leave state a later launch on the same workspace would trust.  HND_BSTREAM_DBG=2 makes every head keep its flag
