@@ -162,7 +162,8 @@ int hnd_conv2d_wgrad(const hnd_wgrad_desc* desc, void* stream);
 /* which kernel the launch above would use: 0 = the LDS-staged split-K kernel (csrc/conv_wgrad.hip), 1 = the 7x7 stem from
  * an LDS patch (csrc/conv_stem.hip), 2 = the vector-ALU kernel of the two 3-channel gradients, 3 = the ring kernel
  * (csrc/conv_wgrad_ring.hip: cout % 128 == 0, cin % 64 == 0; both operands straight from global memory through a
- * counted register ring, accumulators resident; HND_WGRAD_RING=0 turns it off).  All sum their split-K slabs in a fixed
+ * counted register ring, accumulators resident; by default the 1x1 / grouped Winograd-domain form only;
+ * HND_WGRAD_RING=0 turns it off, =2 also takes the tap form).  All sum their split-K slabs in a fixed
  * order: each is bitwise reproducible; different kernels differ in rounding. */
 int hnd_conv2d_wgrad_variant(const hnd_wgrad_desc* desc);
 

@@ -113,3 +113,28 @@ def test_launcher_rank_timeout_kills_the_children():
     r = _run(['--gpus', '2', '--share_device', '--dist_backend', 'gloo', '--steps', '50', '--warmup', '1',
               '--no_cpu_baseline', '--rank_timeout_s', '8'], timeout=600)
     assert r.returncode != 0 and r.stdout.strip() == b'' and b'no result after --rank_timeout_s 8' in r.stderr
+
+
+@pytest.mark.gpu
+def test_bench_under_torch_distributed_run_as_the_driver_launches_it():
+    """the driver's own form for N > 1: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py --gpus N ...` -- ranks come from the launcher's environment (two of them sharing
+    the one GPU of this box over gloo); the line must say so and every rank must be gated"""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in LAUNCH_ENV}
+    env['HND_DEFER_FPN'] = '0'          # two processes time-share one GPU here (bench.py's own launcher sets this itself)
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                        '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.join(ROOT, 'bench.py'),
+                        '--gpus', '2', '--share_device', '--dist_backend', 'gloo', '--steps', '2', '--warmup', '1',
+                        '--no_cpu_baseline'], env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       timeout=1500)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['ranks']['launched_by'] == 'external launcher'
+    assert out['loss_check']['ranks_gated'] == 2 and out['loss_check']['worst_rel_err_all_ranks'] < 1e-3
+    assert out['ranks']['exchange_ms_per_step'] is not None

@@ -28,6 +28,10 @@ def short(name):
     if m:           # B-streamed persistent GEMM (conv_bstream.hip)
         return 'bstream_%d' % (64 * int(m.group(1))) + (('[prologue]' if m.group(2) == 'true' else '') +
                                                       ('[taps]' if m.group(3) == 'true' else '') if FULLNAMES else '')
+    m = re.search(r'wgrad_ring_kernel<(\d+), (\d+), (true|false), (\d+)>', name)
+    if m:           # ring weight gradient (conv_wgrad_ring.hip): wave tile 64 AH x 64 BH, taps, waves per SIMD
+        return 'wgrad_ring' + ('[%dx%d%s]' % (64 * int(m.group(1)), 64 * int(m.group(2)), ', taps' if m.group(3) == 'true' else '')
+                               if FULLNAMES else '')
     m = re.search(r'wgrad_kernel<(\d+), (\d+)>', name)
     if m:
         return 'wgrad_m%s' % m.group(1)
