@@ -46,6 +46,33 @@ struct BresArgs {
   int dbg;                    // tuning experiments (HND_BRES_DBG): 1 = no epilogue, 2 = A always from chunk 0
 };
 
+// The workgroup's [BN x K] weight slice -> LDS (chunk c of row r at position c ^ (r & 15)).  Up to 16 loads per thread are
+// in flight before the first LDS write: written as one load + one write per iteration hipcc waits `vmcnt(0)` in every
+// iteration -- 32 (16) dependent round trips to L2, ~25 (13) us per slice at the head of EVERY launch and at every
+// Winograd component boundary, 4-8 % of a 0.3-0.6 ms launch (round 4).
+template <int BN, int K, int NT>
+__device__ __forceinline__ void slice_to_lds(float* Bs, const float* wsrc, int tid) {
+  constexpr int cpr = K >> 2;                         // 16-byte chunks per row (a power of two)
+  constexpr int PER = BN * cpr / NT;                  // chunks per thread
+  constexpr int UMAX = NT == 256 ? 16 : 8;            // (the 8-wave kernel has 256 registers per lane: smaller batches)
+  constexpr int UB = PER < UMAX ? PER : UMAX;
+  static_assert(BN * cpr % NT == 0 && PER % UB == 0, "slice does not divide among the threads");
+#pragma unroll 1
+  for (int b0 = 0; b0 < PER; b0 += UB) {
+    f32x4 t[UB];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int e = tid + (b0 + u) * NT, r = e / cpr, ck = e - r * cpr;
+      t[u] = *(const f32x4*)(wsrc + (size_t)r * K + (ck << 2));
+    }
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int e = tid + (b0 + u) * NT, r = e / cpr, ck = e - r * cpr;
+      *(f32x4*)(Bs + r * K + ((ck ^ (r & 15)) << 2)) = t[u];
+    }
+  }
+}
+
 // WN = wave columns (BN = 64 * WN); the 8 / WN wave rows take 64-row chunks round-robin.  K = 64 * KQ is a template
 // parameter and the k loop is fully unrolled: with a loop back edge inside the chunk hipcc drains every load in
 // flight (`s_waitcnt vmcnt(0)`) at the loop header, which empties the register ring every four k groups.
@@ -113,14 +140,7 @@ __global__ void __launch_bounds__(512, 1) bres_kernel(const hnd_conv_desc d, con
     const int grp = a.cpg > 0 ? c / a.cpg : 0;
     const int seg_hi = a.cpg > 0 ? min(c_hi, (grp + 1) * a.cpg) : c_hi;
     __syncthreads();                                  // every wave is done with the previous slice
-    {
-      const float* wsrc = d.w + (size_t)grp * (size_t)d.w_group_stride + (size_t)n0 * K;
-      const int cpr = K >> 2;                         // 16-byte chunks per row
-      for (int e = tid; e < BN * cpr; e += 512) {
-        const int r = e / cpr, ck = e - r * cpr;
-        *(f32x4*)(Bs + r * K + ((ck ^ (r & 15)) << 2)) = *(const f32x4*)(wsrc + (size_t)r * K + (ck << 2));
-      }
-    }
+    slice_to_lds<BN, K, 512>(Bs, d.w + (size_t)grp * (size_t)d.w_group_stride + (size_t)n0 * K, tid);
     __syncthreads();
 
     int cc = c + wm;
@@ -332,14 +352,7 @@ __global__ void __launch_bounds__(256, 1) bres2_kernel(const hnd_conv_desc d, co
     const int grp = a.cpg > 0 ? c / a.cpg : 0;
     const int seg_hi = a.cpg > 0 ? min(c_hi, (grp + 1) * a.cpg) : c_hi;
     __syncthreads();
-    {
-      const float* wsrc = d.w + (size_t)grp * (size_t)d.w_group_stride + (size_t)n0 * K;
-      constexpr int cpr = K >> 2;
-      for (int e = tid; e < BN * cpr; e += 256) {
-        const int r = e / cpr, ck = e - r * cpr;
-        *(f32x4*)(Bs + r * K + ((ck ^ (r & 15)) << 2)) = *(const f32x4*)(wsrc + (size_t)r * K + (ck << 2));
-      }
-    }
+    slice_to_lds<BN, K, 256>(Bs, d.w + (size_t)grp * (size_t)d.w_group_stride + (size_t)n0 * K, tid);
     __syncthreads();
 
     int cc = c + wm;
