@@ -1157,6 +1157,100 @@ __global__ void __launch_bounds__(256) wino26_dy_kernel(const float* __restrict_
   }
 }
 
+// BatchNorm backward "apply" fused into BOTH consumers of its result (round 4).  For the two deep decoder convs (conv6,
+// conv7) the gradient w.r.t. the raw conv output, dy = k1 * d + k2 * x + k3 with d = [bn(x) > 0] * g, is read by exactly two
+// kernels: the input transform of the conv's data gradient (V = B^T dy B over 7x7 patches) and the dy transform of its
+// Winograd-domain weight gradient (Z = G' dy G'^T over the 6x6 tile inside that patch).  Materialising dy costs a pass
+// of 12 B per element (hnd_bn_bwd_apply) plus 4 B per element in each transform; this kernel reads g and x once per patch
+// and writes V and Z: 12 B per element less on the two largest tensors of the head.
+// The two transforms tile different extents (data gradient: the conv INPUT, oh + 2 pad - 1; weight gradient: dy itself),
+// so the launch walks the larger grid and each output exists only inside its own.
+struct BnBwdTransformGeom {
+  int n, oh, ow, c, pad;            // dy / g / x: [n][oh][ow][c]; pad = padding of the data-gradient correlation
+  int th, tw;                       // tiles walked
+  int th_d, tw_d, tiles_pad_d;      // data gradient (V)
+  int th_w, tw_w, tiles_pad_w;      // weight gradient (Z)
+};
+
+__global__ void __launch_bounds__(256) wino26_bnbwd_transforms_kernel(
+    const float* __restrict__ g, const float* __restrict__ x, const float* __restrict__ scale,
+    const float* __restrict__ shift, const float* __restrict__ k123, int relu, float* __restrict__ v,
+    float* __restrict__ z, const BnBwdTransformGeom q) {
+  const int c2n = q.c >> 1;
+  const long long total = (long long)q.n * q.th * q.tw * c2n;
+  const size_t fs_d = (size_t)q.tiles_pad_d * q.c, fs_w = (size_t)q.tiles_pad_w * q.c;
+  for (long long e = hnd::xcd_contiguous_block() * (long long)blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    const int c2 = (int)(e % c2n);
+    long long t = e / c2n;
+    const int tx = (int)(t % q.tw);
+    t /= q.tw;
+    const int ty = (int)(t % q.th), b = (int)(t / q.th);
+    const f32x2 sc = *(const f32x2*)(scale + c2 * 2), sh = *(const f32x2*)(shift + c2 * 2);
+    const f32x2 k1 = *(const f32x2*)(k123 + c2 * 2), k2 = *(const f32x2*)(k123 + q.c + c2 * 2),
+                k3 = *(const f32x2*)(k123 + 2 * q.c + c2 * 2);
+    f32x2 d[7][7];                          // d[j][i]: column j of the dy patch
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      const int iy = 6 * ty - q.pad + i;
+#pragma unroll
+      for (int j = 0; j < 7; ++j) {
+        const int ix = 6 * tx - q.pad + j;
+        const bool ok = (unsigned)iy < (unsigned)q.oh && (unsigned)ix < (unsigned)q.ow;
+        const size_t off = ok ? (((size_t)b * q.oh + iy) * q.ow + ix) * q.c + c2 * 2 : 0;
+        f32x2 dd = *(const f32x2*)(g + off);
+        const f32x2 xv = *(const f32x2*)(x + off);
+        if (relu) {
+          const f32x2 out = xv * sc + sh;
+          dd.x = out.x > 0.f ? dd.x : 0.f;
+          dd.y = out.y > 0.f ? dd.y : 0.f;
+        }
+        const f32x2 val = k1 * dd + k2 * xv + k3;
+        const f32x2 zz = {0.f, 0.f};
+        d[j][i] = ok ? val : zz;
+      }
+    }
+    if (ty < q.th_w && tx < q.tw_w) {       // Z = G' dy G'^T of the 6x6 tile: patch rows / columns pad .. pad + 5
+      f32x2 r[7][6];
+#pragma unroll
+      for (int bb = 0; bb < 6; ++bb) {
+        f32x2 col[6], o[7];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) col[a] = q.pad ? d[bb + 1][a + 1] : d[bb][a];
+        mat_apply(W6_G2, col, o);
+#pragma unroll
+        for (int i = 0; i < 7; ++i) r[i][bb] = o[i];
+      }
+      float* dst = z + ((size_t)((size_t)b * q.th_w + ty) * q.tw_w + tx) * q.c + c2 * 2;
+#pragma unroll
+      for (int i = 0; i < 7; ++i) {
+        f32x2 o[7];
+        mat_apply(W6_G2, r[i], o);
+#pragma unroll
+        for (int j = 0; j < 7; ++j) *(f32x2*)(dst + (size_t)(i * 7 + j) * fs_w) = o[j];
+      }
+    }
+    if (ty < q.th_d && tx < q.tw_d) {       // V = B^T dy B of the 7x7 patch
+      f32x2 r[7][7];
+#pragma unroll
+      for (int j = 0; j < 7; ++j) {
+        f32x2 o[7];
+        mat_apply(W6_BT, d[j], o);
+#pragma unroll
+        for (int i = 0; i < 7; ++i) r[i][j] = o[i];
+      }
+      float* dst = v + ((size_t)((size_t)b * q.th_d + ty) * q.tw_d + tx) * q.c + c2 * 2;
+#pragma unroll
+      for (int i = 0; i < 7; ++i) {
+        f32x2 o[7];
+        mat_apply(W6_BT, r[i], o);
+#pragma unroll
+        for (int j = 0; j < 7; ++j) *(f32x2*)(dst + (size_t)(i * 7 + j) * fs_d) = o[j];
+      }
+    }
+  }
+}
+
 // dW[co][ci][i][j] = (A'^T S A')[i][j],  S_f[co][ci] at s[f*cout*cin + co*cin + ci], f = 0..48
 __global__ void wino26_wgrad_out_kernel(const float* __restrict__ s, float* __restrict__ dw, int cout, int cin) {
   const long long total = (long long)cout * cin;
@@ -1338,6 +1432,25 @@ int hnd_wino2_dy(const float* dy, float* z, int n, int oh, int ow, int cout, int
     hipLaunchKernelGGL(wino26_dy_kernel, dim3(grid_for(tiles * (cout / 2))), dim3(256), 0, hnd::as_stream(stream), dy,
                        z, g, cout, ldy);
   return hnd::check_launch("hnd_wino2_dy");
+}
+
+int hnd_wino26_bnbwd_transforms(const float* g, const float* x, const float* scale, const float* shift,
+                                const float* k123, int relu, int n, int oh, int ow, int c, int pad, float* v, float* z,
+                                void* stream) {
+  HND_REQUIRE(g && x && scale && shift && k123 && v && z && n > 0 && oh > 0 && ow > 0 && c > 0 && c % 2 == 0 &&
+                  (pad == 0 || pad == 1) && oh + 2 * pad - 1 > 0 && ow + 2 * pad - 1 > 0,
+              "hnd_wino26_bnbwd_transforms: bad arguments");
+  const int ih = oh + 2 * pad - 1, iw = ow + 2 * pad - 1;      // extent of the data gradient's output (the conv input)
+  BnBwdTransformGeom q;
+  q.n = n; q.oh = oh; q.ow = ow; q.c = c; q.pad = pad;
+  q.th_d = (ih + 5) / 6; q.tw_d = (iw + 5) / 6; q.tiles_pad_d = (int)hnd_wino2_tiles_pad(n, ih, iw, 6);
+  q.th_w = (oh + 5) / 6; q.tw_w = (ow + 5) / 6; q.tiles_pad_w = (int)hnd_wino2_tiles_pad(n, oh, ow, 6);
+  q.th = q.th_d > q.th_w ? q.th_d : q.th_w;
+  q.tw = q.tw_d > q.tw_w ? q.tw_d : q.tw_w;
+  const long long tiles = (long long)n * q.th * q.tw;
+  hipLaunchKernelGGL(wino26_bnbwd_transforms_kernel, dim3(grid_for(tiles * (c / 2))), dim3(256), 0,
+                     hnd::as_stream(stream), g, x, scale, shift, k123, relu, v, z, q);
+  return hnd::check_launch("hnd_wino26_bnbwd_transforms");
 }
 
 int hnd_wino2_wgrad_output(const float* s, float* dw, int cout, int cin, int tile, void* stream) {

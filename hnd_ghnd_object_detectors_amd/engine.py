@@ -188,6 +188,8 @@ FOLD_DGRAD_SCALE = os.environ.get('HND_FOLD_DGRAD_SCALE', '1') != '0'     # 0: F
 # stores the output) instead of re-reading the fp32 activation in the conv1 data gradients -- HBM-bound launches (out +
 # residual + mask at K = 128): 1/16 of the mask's bytes.  Same decisions (x > 0), same bits.  0: fp32 masks (A/B, tests)
 MASK_BITS = os.environ.get('HND_MASK_BITS', '1') != '0'
+# BatchNorm backward "apply" of the two deep decoder convs fused into the two transforms that consume dy (ops.wino26_bnbwd_step)
+FUSE_BNBWD = os.environ.get('HND_FUSE_BNBWD', '1') != '0'
 WINOGRAD6 = os.environ.get('HND_WINOGRAD6', '1') != '0'       # F(6x6,3x3) on maps large enough (wino_tile_for)
 
 
@@ -838,7 +840,10 @@ class HeadEngine(object):
                               st['part'])
             ops.bn_bwd_finalize(st['part'], st['ntiles'], hc.cout, hc.cs_out, self.count[i], hc.bn.weight.detach(),
                                 self.mean[i], self.rstd[i], st['dgamma'], st['dbeta'], st['k123'])
-            ops.bn_bwd_apply(g, self.y[i], self.scale[i], self.shift[i], st['k123'], hc.relu, g)   # in place -> dy
+            if st['fused'] is not None:      # dy is never materialised: g, x -> V (data gradient) and Z (weight gradient)
+                _run(st['fused'], 'layer1.conv%d.bnbwd_transforms' % i)
+            else:
+                ops.bn_bwd_apply(g, self.y[i], self.scale[i], self.shift[i], st['k123'], hc.relu, g)   # in place -> dy
             for l, tag in st['wgrad']:
                 _run(l, tag)
             for l, tag in st['dgrad']:
@@ -877,14 +882,14 @@ class HeadEngine(object):
             pro = (None, None, False) if i == 0 else (self.scale[i - 1], self.shift[i - 1], self.layers[i - 1].relu)
             dw = grad_dst.get(hc.conv.weight, None)
             st['wgrad'] = []
+            wg_obj = dg_obj = None
             if dw is not None and i in self.wino_fwd and hc.cs_out == hc.cout and hc.cs_in == hc.cin:
                 # Winograd-domain weight gradient: forward V x transformed dy, 25 grouped split-K reductions
                 fw = self.wino_fwd[i]
                 _, zbuf = self._wino_scratch(fw.geom[0], fw.geom[4], fw.geom[5], hc.cs_in, hc.cs_out, fw.tile)
                 sbuf = b.get('wino_s%d' % i, (fw.ww.ncomp * hc.cout * hc.cin,))
-                st['wgrad'] = ops.Wino2Wgrad(fw, gbuf[i], dw, zbuf, sbuf,
-                                             b.get('wino_slabs', (self._wino_slab_elems(fw, hc),))
-                                             ).launches('layer1.conv%d.wgrad' % i)
+                wg_obj = ops.Wino2Wgrad(fw, gbuf[i], dw, zbuf, sbuf, b.get('wino_slabs', (self._wino_slab_elems(fw, hc),)))
+                st['wgrad'] = wg_obj.launches('layer1.conv%d.wgrad' % i)
                 flops += 2 * npix * hc.cout * 4 * hc.cin
             elif dw is not None:
                 st['wgrad'] = [(ops.conv_wgrad(src, gbuf[i], dw, 2, 1, hc.pad, pro_scale=pro[0], pro_shift=pro[1],
@@ -896,14 +901,20 @@ class HeadEngine(object):
                 nd, hd, wd, _ = tgt.shape
                 t2 = wino2_tile_for(hd, wd)
                 v, mm = self._wino_scratch(nd, hd, wd, hc.cs_out, hc.cs_in, t2)
-                st['dgrad'] = ops.Wino2Conv(gbuf[i], hc.wino.get(True, t2), tgt, v, mm,
-                                            1 - hc.pad).launches('layer1.conv%d.dgrad' % i)
+                dg_obj = ops.Wino2Conv(gbuf[i], hc.wino.get(True, t2), tgt, v, mm, 1 - hc.pad)
+                st['dgrad'] = dg_obj.launches('layer1.conv%d.dgrad' % i)
                 flops += 2 * npix * hc.cout * 4 * hc.cin
             elif tgt is not None:
                 pk = hc.wc.get(True, hc.cs_out)
                 ls, _ = _dgrad_with_pack(gbuf[i], hc, tgt, pk)
                 st['dgrad'] = [(l, 'layer1.conv%d.dgrad' % i) for l in ls]
                 flops += 2 * npix * hc.cout * 4 * hc.cin
+            # both consumers of dy are F(6x6,2x2) transforms: fuse the BN-backward apply into them (conv6, conv7 at full size)
+            st['fused'] = None
+            if FUSE_BNBWD and wg_obj is not None and dg_obj is not None and wg_obj.tile == 6 and dg_obj.tile == 6:
+                st['fused'] = ops.wino26_bnbwd_step(gbuf[i], self.y[i], self.scale[i], self.shift[i], st['k123'], hc.relu,
+                                                    dg_obj, wg_obj)
+                st['wgrad'], st['dgrad'] = st['wgrad'][1:], st['dgrad'][1:]       # (their own transforms are dropped)
             self.bsteps[i] = st
         self.flops_bwd = flops
 

@@ -778,9 +778,31 @@ class Wino2Wgrad(object):
         self._run_out(stream)
 
 
+def wino26_bnbwd_step(g, x, scale, shift, k123, relu, dgrad_conv, wgrad):
+    """BatchNorm backward "apply" fused into the two transforms that consume its result (hnd_wino26_bnbwd_transforms):
+    writes dgrad_conv.v (the input transform of the Wino2Conv data gradient) and wgrad.z (the dy transform of the
+    Wino2Wgrad) from g and the raw conv output x, without materialising dy.  Both must be F(6x6,2x2) over the same dy."""
+    assert isinstance(dgrad_conv, Wino2Conv) and isinstance(wgrad, Wino2Wgrad) and dgrad_conv.tile == 6 and wgrad.tile == 6
+    n, oh, ow, c = _nhwc(g)
+    assert tuple(x.shape) == tuple(g.shape) and tuple(dgrad_conv.geom[:4]) == (n, oh, ow, c)
+    assert wgrad.geom[:3] == (n, oh, ow) and wgrad.geom[3] == c and wgrad.geom[4] == c
+    pad = dgrad_conv.pad
+    tiles_d = n * ((oh + 2 * pad - 1 + 5) // 6) * ((ow + 2 * pad - 1 + 5) // 6)
+    tiles_w = n * ((oh + 5) // 6) * ((ow + 5) // 6)
+
+    def fn(stream=None):
+        check(_L.hnd_wino26_bnbwd_transforms(ptr(g), ptr(x), ptr(scale), ptr(shift), ptr(k123), int(relu), n, oh, ow, c,
+                                             pad, ptr(dgrad_conv.v), ptr(wgrad.z),
+                                             stream if stream is not None else stream_ptr()),
+              'hnd_wino26_bnbwd_transforms')
+    step = _Step(fn, 'wino2_bnbwd_fused', 4 * (2 * n * oh * ow * c + 49 * (tiles_d + tiles_w) * c))
+    step.keep = (g, x, scale, shift, k123, dgrad_conv, wgrad)
+    return step
+
+
 class _Step(object):
     """a plan entry without MFMA work: HBM-bound; `hbm_bytes` = the bytes it must move (bench.py's hbm_roofline)"""
-    __slots__ = ('fn', 'flops', 'alg_flops', 'variant', 'kernel', 'hbm_bytes')
+    __slots__ = ('fn', 'flops', 'alg_flops', 'variant', 'kernel', 'hbm_bytes', 'keep')
 
     def __init__(self, fn, kernel='transform', hbm_bytes=0):
         self.fn, self.flops, self.alg_flops, self.variant = fn, 0, 0, 'transform'

@@ -277,6 +277,16 @@ int hnd_wino2_output(const float* m, float* y, int n, int oh, int ow, int cout, 
  * (hnd_conv2d_wgrad with kh = kw = 1, groups = (tile+1)^2, x = v, dy = z) give s [groups][cout][cin];
  * hnd_wino2_wgrad_output -> dW [cout][cin][2][2]. */
 int hnd_wino2_dy(const float* dy, float* z, int n, int oh, int ow, int cout, int ldy, int tile, void* stream);
+/* BatchNorm backward "apply" fused into both consumers of its result (F(6x6,2x2) only): with d = g * [x*scale+shift > 0]
+ * (mask only when relu) and dy = k1*d + k2*x + k3 (k123 from hnd_bn_bwd_finalize), writes
+ *   v = the input transform of the conv's DATA gradient over dy with padding `pad` (what hnd_wino2_input(dy, pad) gives),
+ *   z = the dy transform of its Winograd-domain WEIGHT gradient (what hnd_wino2_dy(dy) gives),
+ * without materialising dy: g, x [n][oh][ow][c] are read once per patch instead of hnd_bn_bwd_apply (12 B per element)
+ * plus one read of dy per transform.  v / z extents: hnd_wino2_tiles_pad(n, oh + 2 pad - 1, ow + 2 pad - 1, 6) resp.
+ * hnd_wino2_tiles_pad(n, oh, ow, 6) tiles x 49 components x c. */
+int hnd_wino26_bnbwd_transforms(const float* g, const float* x, const float* scale, const float* shift,
+                                const float* k123, int relu, int n, int oh, int ow, int c, int pad, float* v, float* z,
+                                void* stream);
 int hnd_wino2_wgrad_output(const float* s, float* dw, int cout, int cin, int tile, void* stream);
 
 /* nn.MaxPool2d(3, 2, 1) (custom/resnet.py:30,99) NHWC; idx (uint8 tap 0..8) kept for backward. */

@@ -783,6 +783,40 @@ def test_mask_nibbles_change_no_bit_of_the_step(case, monkeypatch):
         assert torch.equal(runs[True][2][n], runs[False][2][n]), n
 
 
+def test_fused_bn_backward_transforms_give_the_unfused_gradients(monkeypatch):
+    """engine.FUSE_BNBWD (conv6 / conv7 of the head at full size: the BatchNorm backward apply inside the data-gradient
+    input transform and the weight-gradient dy transform): same loss, every gradient within 1e-5 relative L2 of the
+    unfused plan (a different rounding of k1 d + k2 x + k3 at most), and the fused plan must actually be in use"""
+    from hnd_ghnd_object_detectors_amd import engine as E
+    z, meta = G.load('full_ghnd_faster_b4')
+    meta = dict(meta, sizes=meta['sizes'][:2])
+    images, targets = G.case_inputs(meta)
+    runs = {}
+    for fuse in (False, True):
+        monkeypatch.setattr(E, 'FUSE_BNBWD', fuse)
+        cfg, t_sd, s_sd, teacher, student, box, opt, warm = _setup(meta)
+        ims, tgs = _to_dev(images, [dict(t) for t in targets])
+        loss = box(ims, tgs)
+        opt.zero_grad()
+        loss.backward()
+        head = student.backbone.body.layer1.head_engine()
+        assert [i for i, st in enumerate(head.bsteps) if st['fused'] is not None] == ([6, 7] if fuse else [])
+        runs[fuse] = (loss.item(), OrderedDict((n, p.grad.clone()) for n, p in student.named_parameters()
+                                               if p.requires_grad))
+        if box.defer_fpn and box._fpn_stream is not None:
+            torch.cuda.current_stream().wait_stream(box._fpn_stream)
+    assert runs[True][0] == runs[False][0]
+    worst = 0.0
+    for n in runs[False][1]:
+        if n.endswith(G.ZERO_GRAD_SUFFIXES):
+            continue
+        a, b = runs[True][1][n].double(), runs[False][1][n].double()
+        worst = max(worst, float((a - b).norm() / b.norm()))
+    assert worst < 1e-5, worst
+    from tests.conftest import record_achieved
+    record_achieved('[fused BN-backward transforms vs the unfused plan, 3x800x1333 b2] worst gradient rel-L2 %.1e' % worst)
+
+
 def test_shared_trunk_is_dropped_when_the_frozen_weights_differ(monkeypatch):
     """the merged pass needs bit-equal frozen weights; a student whose layer3 was edited (a checkpoint that did not come
     from this teacher) runs its own pass -- and the pyramids of the merged pass equal the separate ones"""

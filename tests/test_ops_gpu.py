@@ -762,6 +762,39 @@ def test_winograd_conv2x2_wgrad_reuses_forward_transform(ops, n, cin, h, w, cout
     assert torch.equal(outs[0], outs[1])                     # fixed-order reductions: bit-reproducible
 
 
+@pytest.mark.parametrize('n,oh,ow,c,pad,relu', [(2, 37, 50, 128, 1, True), (1, 44, 31, 256, 1, False),
+                                                (2, 30, 43, 64, 0, True), (1, 7, 13, 64, 0, True)])
+def test_bn_backward_apply_fused_into_both_winograd_transforms(ops, n, oh, ow, c, pad, relu):
+    """hnd_wino26_bnbwd_transforms: dy = k1 * [bn(x) > 0] g + k2 x + k3 is never written; the kernel must give the V of
+    hnd_wino2_input(dy, pad) and the Z of hnd_wino2_dy(dy) computed from the materialised dy of hnd_bn_bwd_apply -- for
+    both paddings (the two transforms tile different extents: with pad 0 the data gradient's grid can be the SMALLER one)"""
+    from hnd_ghnd_object_detectors_amd import _lib
+    L = _lib.load()
+    g_ = gen(60 + oh + c)
+    g = torch.randn(n, oh, ow, c, generator=g_).to(DEV)
+    x = torch.randn(n, oh, ow, c, generator=g_).to(DEV)
+    sc, sh = (torch.rand(c, generator=g_) + 0.5).to(DEV), (torch.randn(c, generator=g_) * 0.5).to(DEV)
+    k123 = (torch.randn(3, c, generator=g_) * 0.5).to(DEV).contiguous()
+    dy = torch.empty_like(g)
+    ops.bn_bwd_apply(g, x, sc, sh, k123, relu, dy)
+    ih, iw = oh + 2 * pad - 1, ow + 2 * pad - 1
+    tp_d, tp_w = int(L.hnd_wino2_tiles_pad(n, ih, iw, 6)), int(L.hnd_wino2_tiles_pad(n, oh, ow, 6))
+    v_ref = torch.full((49 * tp_d * c,), float('nan'), device=DEV)
+    z_ref = torch.full((49 * tp_w * c,), float('nan'), device=DEV)
+    s = ops.stream_ptr()
+    _lib.check(L.hnd_wino2_input(dy.data_ptr(), v_ref.data_ptr(), n, oh, ow, c, pad, None, None, 0, 6, s))
+    _lib.check(L.hnd_wino2_dy(dy.data_ptr(), z_ref.data_ptr(), n, oh, ow, c, c, 6, s))
+    v, z = torch.full_like(v_ref, float('nan')), torch.full_like(z_ref, float('nan'))
+    _lib.check(L.hnd_wino26_bnbwd_transforms(g.data_ptr(), x.data_ptr(), sc.data_ptr(), sh.data_ptr(), k123.data_ptr(),
+                                             int(relu), n, oh, ow, c, pad, v.data_ptr(), z.data_ptr(), s))
+    ops.sync_check()
+    for got, ref, tp, tiles in ((v, v_ref, tp_d, n * ((ih + 5) // 6) * ((iw + 5) // 6)),
+                                (z, z_ref, tp_w, n * ((oh + 5) // 6) * ((ow + 5) // 6))):
+        got, ref = got.view(49, tp, c)[:, :tiles], ref.view(49, tp, c)[:, :tiles]
+        assert not bool(torch.isnan(got).any()) and not bool(torch.isnan(ref).any())
+        assert relerr(got.cpu(), ref.cpu()) < 2e-6, relerr(got.cpu(), ref.cpu())
+
+
 def test_subsample_and_fill(ops):
     x = torch.randn(2, 256, 7, 9, generator=gen(14))
     y = torch.empty(2, 4, 5, 256, device=DEV)
