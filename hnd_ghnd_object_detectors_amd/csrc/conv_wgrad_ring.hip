@@ -82,12 +82,14 @@ __device__ __forceinline__ void rwait(f32x4& a0, f32x4& a1, f32x4& a2, f32x4& a3
 // work of a k-step is two address computations); the tap problems run TWO waves per SIMD on 64-row wave tiles, so that
 // one wave's address arithmetic, prologue and padding selects (~100 vector instructions per k-step) issue while the
 // other wave's MFMAs own the matrix pipe -- interleaving them by hand inside one wave cost more registers than it hid.
-template <int AH, int BH, bool TAPS, int WPS>
+// WC: wave columns of the workgroup -- 2: 2 x 2 waves, a 128 AH x 128 BH tile of dW; 1: 4 x 1 waves, 256 AH x 64 BH (the
+// Winograd-domain weight gradient of a conv with 64 input channels: 64 columns per component).
+template <int AH, int BH, bool TAPS, int WPS, int WC = 2>
 __global__ void __launch_bounds__(256, WPS) wgrad_ring_kernel(const WringArgs a) {
   constexpr int RING = 8, NL = AH + BH, VM = NL * (RING - 1);
   const hnd_wgrad_desc& d = a.d;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
+  const int wr = WC == 2 ? wave >> 1 : wave, wc = WC == 2 ? wave & 1 : 0;
   const int l16 = lane & 15, g4 = lane >> 4;
   const int grp = blockIdx.y;
   const float* __restrict__ xg = d.x + (size_t)grp * (size_t)d.x_group_stride;
@@ -97,8 +99,8 @@ __global__ void __launch_bounds__(256, WPS) wgrad_ring_kernel(const WringArgs a)
   const int split = bid / tiles;
   bid -= split * tiles;
   const int rt = bid / a.ctiles, ct = bid - rt * a.ctiles;
-  const int co0 = rt * (128 * AH) + wr * (64 * AH);          // this wave's first output channel ...
-  const int col0 = ct * (128 * BH) + wc * (64 * BH);         // ... and first column
+  const int co0 = rt * (64 * AH * (4 / WC)) + wr * (64 * AH);    // this wave's first output channel ...
+  const int col0 = ct * (64 * BH * WC) + wc * (64 * BH);         // ... and first column
   const int blk0 = split * a.blocks_per_split;
   int nblk = a.total_blocks - blk0;
   if (nblk > a.blocks_per_split) nblk = a.blocks_per_split;
@@ -299,6 +301,12 @@ int launch_ab(const WringArgs& a, bool taps, dim3 grid, hipStream_t s) {
   return hnd::check_launch("hnd_conv2d_wgrad(ring)");
 }
 
+// 64 columns (cin = 64, 1x1 / grouped): four waves stacked along cout, two workgroups per CU (148 registers per lane)
+int launch_narrow(const WringArgs& a, dim3 grid, hipStream_t s) {
+  hipLaunchKernelGGL((wgrad_ring_kernel<1, 1, false, 2, 1>), grid, dim3(256), 0, s, a);
+  return hnd::check_launch("hnd_conv2d_wgrad(ring, 64 columns)");
+}
+
 }  // namespace
 
 namespace hnd {
@@ -315,8 +323,9 @@ bool wgrad_ring_applies(const hnd_wgrad_desc& d) {
   if (mode == 0) return false;
   if (mode != 2 && (d.kh * d.kw > 1 || d.pad != 0 || d.stride != 1)) return false;
   if (d.cout % 128 != 0 || d.cin % 64 != 0 || d.cin_real != d.cin || d.ldy % 4 != 0 || d.ldy < d.cout) return false;
-  if ((d.kh * d.kw * d.cin) % 128 != 0) return false;
   const bool taps = d.kh * d.kw > 1 || d.pad != 0 || d.stride != 1;
+  const bool narrow = !taps && d.cin == 64 && d.cout % 256 == 0;      // 64 columns: the 4 x 1 wave arrangement
+  if ((d.kh * d.kw * d.cin) % 128 != 0 && !narrow) return false;
   if (!taps && (d.oh != d.h || d.ow != d.w_)) return false;
   if (!taps && d.pro_scale) return false;               // (the prologue lives on the tap path)
   if (taps && d.ow < 4) return false;                   // (a k-step of 4 pixels wraps at most one row)
@@ -325,16 +334,21 @@ bool wgrad_ring_applies(const hnd_wgrad_desc& d) {
   return true;
 }
 
+static bool wring_narrow(const hnd_wgrad_desc& d) {
+  return d.kh * d.kw == 1 && d.pad == 0 && d.stride == 1 && d.cin == 64 && d.cout % 256 == 0;
+}
+
 static void wring_plan(const hnd_wgrad_desc& d, WringArgs& a, int& ah, int& bh) {
   a.d = d;
   a.M = d.n * d.oh * d.ow;
   const int ncols = d.kh * d.kw * d.cin;
   const bool taps = d.kh * d.kw > 1 || d.pad != 0 || d.stride != 1;
-  const bool small = taps && taps_small(d);                 // 64 x 64 wave tiles, two waves per SIMD
+  const bool narrow = wring_narrow(d);
+  const bool small = (taps && taps_small(d)) || narrow;     // 64 x 64 wave tiles, two waves per SIMD
   ah = (d.cout % 256 == 0 && !small) ? 2 : 1;
   bh = (ncols % 256 == 0 && !small) ? 2 : 1;
-  a.rtiles = d.cout / (128 * ah);
-  a.ctiles = ncols / (128 * bh);
+  a.rtiles = narrow ? d.cout / 256 : d.cout / (128 * ah);
+  a.ctiles = narrow ? 1 : ncols / (128 * bh);
   a.co_pad = d.cout;
   a.ncols_pad = ncols;
   a.div_ow = make_fastdiv((unsigned)d.ow);
@@ -368,6 +382,7 @@ int launch_wgrad_ring(const hnd_wgrad_desc& d, int& splits, int& co_pad, int& nc
   ncols_pad = a.ncols_pad;
   const bool taps = d.kh * d.kw > 1 || d.pad != 0 || d.stride != 1;
   const dim3 grid(a.rtiles * a.ctiles * a.splits, d.groups > 1 ? d.groups : 1);
+  if (wring_narrow(d)) return launch_narrow(a, grid, s);
   if (ah == 2) return bh == 2 ? launch_ab<2, 2>(a, taps, grid, s) : launch_ab<2, 1>(a, taps, grid, s);
   return bh == 2 ? launch_ab<1, 2>(a, taps, grid, s) : launch_ab<1, 1>(a, taps, grid, s);
 }

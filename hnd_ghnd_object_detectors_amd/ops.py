@@ -722,13 +722,51 @@ class Wino2Conv(object):
         self._run_output(stream)
 
 
+class Wino2InputTransform(object):
+    """V = B^T d B of a 2x2 conv's input alone (no GEMM, no output): what Wino2Wgrad needs from the forward pass of a conv
+    whose FORWARD is not on the Winograd path (the head's 64 -> 256 conv: its component GEMMs would be 64 deep and
+    HBM-bound, but its weight gradient in the Winograd domain executes 2.9x fewer multiplies than the direct one).  Has the
+    attributes of Wino2Conv that Wino2Wgrad reads."""
+
+    def __init__(self, x, v, pad, cout, tile=6, pro_scale=None, pro_shift=None, pro_relu=False):
+        from types import SimpleNamespace
+        n, h, w, c = _nhwc(x)
+        oh, ow = h + 2 * pad - 1, w + 2 * pad - 1
+        assert pad in (0, 1) and tile in (4, 6) and c % 32 == 0
+        self.x, self.pad, self.tile = x, pad, tile
+        self.geom = (n, h, w, c, oh, ow)
+        self.tiles_pad = int(_L.hnd_wino2_tiles_pad(n, oh, ow, tile))
+        self.ww = SimpleNamespace(ncomp=(tile + 1) ** 2, dgrad=False, tile=tile)
+        need = self.ww.ncomp * self.tiles_pad * c
+        assert v.numel() >= need
+        if pro_scale is not None and pro_shift is None:
+            pro_shift = _zeros(c, x.device)
+        self.pro = (pro_scale, pro_shift, int(pro_relu))
+        self.v = v[:need].view(1, 1, self.ww.ncomp * self.tiles_pad, c)
+
+    @staticmethod
+    def scratch_elems(n, oh, ow, cin, tile=6):
+        return (tile + 1) ** 2 * int(_L.hnd_wino2_tiles_pad(n, oh, ow, tile)) * cin
+
+    def _run_input(self, stream=None):
+        n, h, w, c, oh, ow = self.geom
+        check(_L.hnd_wino2_input(ptr(self.x), ptr(self.v), n, h, w, c, self.pad, ptr(self.pro[0]), ptr(self.pro[1]),
+                                 self.pro[2], self.tile, stream if stream is not None else stream_ptr()),
+              'hnd_wino2_input')
+
+    def step(self, tag):
+        n, h, w, c, oh, ow = self.geom
+        tiles = n * ((oh + self.tile - 1) // self.tile) * ((ow + self.tile - 1) // self.tile)
+        return (_Step(self._run_input, 'wino2_input', 4 * (n * h * w * c + self.ww.ncomp * tiles * c)), tag + '.wino_in')
+
+
 class Wino2Wgrad(object):
     """dW of a 2x2 head conv in the Winograd domain (F(2x2 taps, 4x4 tile)): reuses the forward pass's transformed
     input `fwd.v`, transforms dy (z), reduces the 25 component products over the tiles in ONE grouped split-K
     wgrad launch and inverse-transforms into dw [cout, cin, 2, 2]."""
 
     def __init__(self, fwd, dy, dw, z, s, slabs=None):
-        assert isinstance(fwd, Wino2Conv) and not fwd.ww.dgrad
+        assert isinstance(fwd, (Wino2Conv, Wino2InputTransform)) and not fwd.ww.dgrad
         n, h, w, c, oh, ow = fwd.geom
         cout, cin = dw.shape[0], dw.shape[1]
         assert tuple(dw.shape) == (cout, cin, 2, 2) and dw.is_contiguous() and cin == c and cout % 2 == 0

@@ -784,9 +784,9 @@ def test_mask_nibbles_change_no_bit_of_the_step(case, monkeypatch):
 
 
 def test_fused_bn_backward_transforms_give_the_unfused_gradients(monkeypatch):
-    """engine.FUSE_BNBWD (conv6 / conv7 of the head at full size: the BatchNorm backward apply inside the data-gradient
-    input transform and the weight-gradient dy transform): same loss, every gradient within 1e-5 relative L2 of the
-    unfused plan (a different rounding of k1 d + k2 x + k3 at most), and the fused plan must actually be in use"""
+    """engine.FUSE_BNBWD (conv1 / conv6 / conv7 of the head at full size: the BatchNorm backward apply inside the
+    data-gradient input transform and the weight-gradient dy transform): same loss, every gradient within 1e-5 relative
+    L2 of the unfused plan (a different rounding of k1 d + k2 x + k3 at most), and the fused plan must actually be in use"""
     from hnd_ghnd_object_detectors_amd import engine as E
     z, meta = G.load('full_ghnd_faster_b4')
     meta = dict(meta, sizes=meta['sizes'][:2])
@@ -800,7 +800,7 @@ def test_fused_bn_backward_transforms_give_the_unfused_gradients(monkeypatch):
         opt.zero_grad()
         loss.backward()
         head = student.backbone.body.layer1.head_engine()
-        assert [i for i, st in enumerate(head.bsteps) if st['fused'] is not None] == ([6, 7] if fuse else [])
+        assert [i for i, st in enumerate(head.bsteps) if st['fused'] is not None] == ([1, 6, 7] if fuse else [])
         runs[fuse] = (loss.item(), OrderedDict((n, p.grad.clone()) for n, p in student.named_parameters()
                                                if p.requires_grad))
         if box.defer_fpn and box._fpn_stream is not None:

@@ -795,6 +795,37 @@ def test_bn_backward_apply_fused_into_both_winograd_transforms(ops, n, oh, ow, c
         assert relerr(got.cpu(), ref.cpu()) < 2e-6, relerr(got.cpu(), ref.cpu())
 
 
+@pytest.mark.parametrize('n,cin,h,w,cout,pad', [(2, 64, 37, 50, 256, 1), (1, 64, 44, 31, 256, 0)])
+def test_winograd_wgrad_on_an_input_transform_of_its_own(ops, n, cin, h, w, cout, pad, monkeypatch):
+    """ops.Wino2InputTransform + Wino2Wgrad: the Winograd-domain weight gradient of a conv whose FORWARD is direct (the
+    head's 64 -> 256 conv) -- V made on its own from the conv input with the BN prologue, 49 grouped reductions with 64
+    columns each on the ring kernel's 4 x 1 wave arrangement -- against autograd and against the staged kernel"""
+    g = gen(90 + h)
+    x = torch.randn(n, cin, h, w, generator=g)
+    ps, pb = torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g) * 0.3
+    wt = (torch.randn(cout, cin, 2, 2, generator=g) / math.sqrt(cin * 4)).requires_grad_(True)
+    out = F.conv2d(x * ps[None, :, None, None] + pb[None, :, None, None], wt, None, 1, pad)
+    dy = torch.randn(out.shape, generator=g)
+    out.backward(dy)
+    oh, ow = out.shape[2], out.shape[3]
+    res = {}
+    for mode in ('0', '1'):
+        monkeypatch.setenv('HND_WGRAD_RING', mode)
+        v = torch.empty(ops.Wino2InputTransform.scratch_elems(n, oh, ow, cin, 6), device=DEV)
+        own = ops.Wino2InputTransform(nhwc(x), v, pad, cout, 6, pro_scale=ps.to(DEV), pro_shift=pb.to(DEV))
+        z = torch.empty(49 * own.tiles_pad * cout, device=DEV)
+        sbuf = torch.empty(49 * cout * cin, device=DEV)
+        dw = torch.full((cout, cin, 2, 2), float('nan'), device=DEV)
+        wg = ops.Wino2Wgrad(own, nhwc(dy), dw, z, sbuf)
+        own._run_input()
+        wg.run()
+        ops.sync_check()
+        res[mode] = (dw.cpu().clone(), wg.gemm.variant)
+    assert res['0'][1] == 'wgrad_m128' and res['1'][1] == 'wgrad_ring', (res['0'][1], res['1'][1])
+    assert relerr(res['1'][0], wt.grad) < 2e-4 and relerr(res['0'][0], wt.grad) < 2e-4, relerr(res['1'][0], wt.grad)
+    assert relerr(res['1'][0], res['0'][0]) < 2e-5
+
+
 def test_subsample_and_fill(ops):
     x = torch.randn(2, 256, 7, 9, generator=gen(14))
     y = torch.empty(2, 4, 5, 256, device=DEV)
