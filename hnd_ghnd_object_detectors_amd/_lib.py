@@ -88,6 +88,7 @@ _SIGNATURES = {
     'hnd_wino2_input': (C.c_int, [vp, vp] + [C.c_int] * 5 + [vp, vp, C.c_int, C.c_int, vp]),
     'hnd_wino2_output': (C.c_int, [vp, vp] + [C.c_int] * 5 + [vp, vp, C.c_int, vp, C.c_int, vp]),
     'hnd_wino2_dy': (C.c_int, [vp, vp] + [C.c_int] * 6 + [vp]),
+    'hnd_wino26_output_bnbwd_stats': (C.c_int, [vp, vp] + [C.c_int] * 5 + [vp] * 5 + [C.c_int, vp, vp]),
     'hnd_wino26_bnbwd_transforms': (C.c_int, [vp] * 5 + [C.c_int] * 6 + [vp, vp, vp]),
     'hnd_wino2_wgrad_output': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     'hnd_maxpool3x3s2_fwd': (C.c_int, [vp, vp, vp] + [C.c_int] * 6 + [vp]),

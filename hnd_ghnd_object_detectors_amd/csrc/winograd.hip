@@ -1041,16 +1041,37 @@ __global__ void __launch_bounds__(256) wino26_input_kernel(const float* __restri
   }
 }
 
+// BatchNorm BACKWARD statistics of the tensor this launch produces (BWD): when the output is the gradient g w.r.t. the output
+// of a train-mode BatchNorm(+ReLU) -- the data gradient of the NEXT head conv -- the per-channel sums of
+// d = g [bn(x) > 0] and d * xhat that hnd_bn_bwd_reduce would make in a pass of its own (reading g and x: 8 B per element)
+// are taken here from the values in registers and one read of x (4 B per element); same [blocks][2][cout] partials,
+// consumed by hnd_bn_bwd_finalize.
+struct BnBwdStatsArgs {
+  const float* x;                 // raw conv output the BatchNorm normalises, geometry of y
+  const float* scale;             // gamma * rstd, beta - mean * gamma * rstd (the forward's folded affine: ReLU mask)
+  const float* shift;
+  const float* mean;
+  const float* rstd;
+  int relu;
+};
+
+template <bool BWD>
 __global__ void __launch_bounds__(256) wino26_output_kernel(const float* __restrict__ m, float* __restrict__ y,
                                                             const Wino2Geom g, int cout, int ldc,
                                                             const float* __restrict__ epi_scale,
                                                             const float* __restrict__ epi_shift, int relu,
-                                                            float* __restrict__ stats) {
+                                                            float* __restrict__ stats, const BnBwdStatsArgs bw) {
   __shared__ float red[2][512];
   const int c2n = cout >> 1;
   const long long tiles = (long long)g.n * g.th * g.tw;
   const long long total = tiles * c2n;
   const size_t fs = (size_t)g.tiles_pad * cout;
+  f32x2 bsc = {1.f, 1.f}, bsh = {0.f, 0.f}, bmu = {0.f, 0.f}, brs = {1.f, 1.f};
+  if (BWD) {        // (a thread's channel pair is the same in every iteration: 256 % (cout / 2) == 0)
+    const int c2b = (int)((blockIdx.x * (long long)blockDim.x + threadIdx.x) % c2n);
+    bsc = *(const f32x2*)(bw.scale + c2b * 2); bsh = *(const f32x2*)(bw.shift + c2b * 2);
+    bmu = *(const f32x2*)(bw.mean + c2b * 2); brs = *(const f32x2*)(bw.rstd + c2b * 2);
+  }
   f32x2 s1 = {0.f, 0.f}, s2 = {0.f, 0.f};
   for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
        e += (long long)gridDim.x * blockDim.x) {
@@ -1087,9 +1108,22 @@ __global__ void __launch_bounds__(256) wino26_output_kernel(const float* __restr
           if (CHK && (oy >= g.oh || ox >= g.ow)) continue;
           f32x2 v = o[bb] * es + eb;
           if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); }
-          *(f32x2*)(y + (((size_t)b * g.oh + oy) * g.ow + ox) * ldc + c2 * 2) = v;
-          s1 += v;
-          s2 += v * v;
+          const size_t yo = (((size_t)b * g.oh + oy) * g.ow + ox) * ldc + c2 * 2;
+          *(f32x2*)(y + yo) = v;
+          if (BWD) {
+            const f32x2 xv = *(const f32x2*)(bw.x + yo);
+            f32x2 dd = v;
+            if (bw.relu) {
+              const f32x2 out = xv * bsc + bsh;
+              dd.x = out.x > 0.f ? dd.x : 0.f;
+              dd.y = out.y > 0.f ? dd.y : 0.f;
+            }
+            s1 += dd;
+            s2 += dd * ((xv - bmu) * brs);
+          } else {
+            s1 += v;
+            s2 += v * v;
+          }
         }
       }
     };
@@ -1411,9 +1445,23 @@ int hnd_wino2_output(const float* m, float* y, int n, int oh, int ow, int cout, 
     hipLaunchKernelGGL(wino2_output_kernel, dim3(blocks), dim3(256), 0, hnd::as_stream(stream), m, y, g, cout, ldc,
                        epi_scale, epi_shift, relu, stats);
   else
-    hipLaunchKernelGGL(wino26_output_kernel, dim3(blocks), dim3(256), 0, hnd::as_stream(stream), m, y, g, cout, ldc,
-                       epi_scale, epi_shift, relu, stats);
+    hipLaunchKernelGGL(wino26_output_kernel<false>, dim3(blocks), dim3(256), 0, hnd::as_stream(stream), m, y, g, cout,
+                       ldc, epi_scale, epi_shift, relu, stats, BnBwdStatsArgs{});
   return hnd::check_launch("hnd_wino2_output");
+}
+
+int hnd_wino26_output_bnbwd_stats(const float* m, float* y, int n, int oh, int ow, int cout, int ldc, const float* x,
+                                  const float* scale, const float* shift, const float* mean, const float* rstd,
+                                  int relu_of_bn, float* partials, void* stream) {
+  HND_REQUIRE(m && y && x && scale && shift && mean && rstd && partials && n > 0 && oh > 0 && ow > 0 && cout > 0 &&
+                  cout % 2 == 0 && ldc >= cout && ldc % 2 == 0 && 512 % cout == 0,
+              "hnd_wino26_output_bnbwd_stats: bad arguments (cout=%d must divide 512)", cout);
+  Wino2Geom g{n, 0, 0, 0, oh, ow, (oh + 5) / 6, (ow + 5) / 6, (int)hnd_wino2_tiles_pad(n, oh, ow, 6), 0};
+  const int blocks = hnd_wino2_stats_blocks(n, oh, ow, cout, 6);
+  hipLaunchKernelGGL(wino26_output_kernel<true>, dim3(blocks), dim3(256), 0, hnd::as_stream(stream), m, y, g, cout, ldc,
+                     (const float*)nullptr, (const float*)nullptr, 0, partials,
+                     BnBwdStatsArgs{x, scale, shift, mean, rstd, relu_of_bn});
+  return hnd::check_launch("hnd_wino26_output_bnbwd_stats");
 }
 
 /* Winograd-domain weight gradient of a 2x2 head conv: z = G' dy G'^T per tile of dy [n][oh][ow][ldy] ->

@@ -191,6 +191,8 @@ MASK_BITS = os.environ.get('HND_MASK_BITS', '1') != '0'
 # BatchNorm backward "apply" of the two deep decoder convs fused into the two transforms that consume dy (ops.wino26_bnbwd_step)
 FUSE_BNBWD = os.environ.get('HND_FUSE_BNBWD', '1') != '0'
 WINO_WGRAD_OWN_V = os.environ.get('HND_WINO_WGRAD_OWN_V', '1') != '0'
+# BatchNorm backward "reduce" of a head layer folded into the output transform of the data gradient that produces its g
+FOLD_BNBWD_REDUCE = os.environ.get('HND_FOLD_BNBWD_REDUCE', '1') != '0'
 WINOGRAD6 = os.environ.get('HND_WINOGRAD6', '1') != '0'       # F(6x6,3x3) on maps large enough (wino_tile_for)
 
 
@@ -842,9 +844,13 @@ class HeadEngine(object):
         for i in range(len(self.layers) - 1, -1, -1):
             hc, st = self.layers[i], self.bsteps[i]
             g = st['g']
-            ops.bn_bwd_reduce(g, self.y[i], self.scale[i], self.shift[i], self.mean[i], self.rstd[i], hc.relu,
-                              st['part'])
-            ops.bn_bwd_finalize(st['part'], st['ntiles'], hc.cout, hc.cs_out, self.count[i], hc.bn.weight.detach(),
+            if st['folded'] is None:
+                ops.bn_bwd_reduce(g, self.y[i], self.scale[i], self.shift[i], self.mean[i], self.rstd[i], hc.relu,
+                                  st['part'])
+                part, ntiles = st['part'], st['ntiles']
+            else:                   # the sums came with g, out of the output transform of conv i+1's data gradient
+                part, ntiles = st['folded']
+            ops.bn_bwd_finalize(part, ntiles, hc.cout, hc.cs_out, self.count[i], hc.bn.weight.detach(),
                                 self.mean[i], self.rstd[i], st['dgamma'], st['dbeta'], st['k123'])
             if st['fused'] is not None:      # dy is never materialised: g, x -> V (data gradient) and Z (weight gradient)
                 _run(st['fused'], 'layer1.conv%d.bnbwd_transforms' % i)
@@ -872,7 +878,7 @@ class HeadEngine(object):
             slab_bytes = max(slab_bytes, ops.wgrad_workspace_bytes(n, h, w, hc.cs_in, oh, ow, hc.cout, 2, 1, hc.pad))
         slabs = b.get('slabs', ((slab_bytes + 3) // 4,))
         for i, hc in enumerate(self.layers):
-            st = {}
+            st = {'folded': None}
             npix = self.count[i]
             st['g'] = gbuf[i]
             st['ntiles'] = ops.bn_bwd_ntiles(npix)
@@ -920,7 +926,17 @@ class HeadEngine(object):
                 nd, hd, wd, _ = tgt.shape
                 t2 = wino2_tile_for(hd, wd)
                 v, mm = self._wino_scratch(nd, hd, wd, hc.cs_out, hc.cs_in, t2)
-                dg_obj = ops.Wino2Conv(gbuf[i], hc.wino.get(True, t2), tgt, v, mm, 1 - hc.pad)
+                bwd_stats = None
+                prev = self.layers[i - 1] if i > 0 else None
+                if (FOLD_BNBWD_REDUCE and prev is not None and t2 == 6 and prev.cs_out == prev.cout
+                        and 512 % prev.cs_out == 0 and tgt.shape[3] == prev.cs_out):
+                    # tgt = g of layer i-1: its BatchNorm-backward sums come out of this launch's output transform
+                    nblk = ops.Wino2Conv.stats_blocks(nd, hd, wd, prev.cs_out, 6)
+                    part = b.get('bpart_folded%d' % (i - 1), (nblk, 2, prev.cs_out))
+                    bwd_stats = (self.y[i - 1], self.scale[i - 1], self.shift[i - 1], self.mean[i - 1],
+                                 self.rstd[i - 1], prev.relu, part)
+                    self.bsteps[i - 1]['folded'] = (part, nblk)
+                dg_obj = ops.Wino2Conv(gbuf[i], hc.wino.get(True, t2), tgt, v, mm, 1 - hc.pad, bwd_stats=bwd_stats)
                 st['dgrad'] = dg_obj.launches('layer1.conv%d.dgrad' % i)
                 flops += 2 * npix * hc.cout * 4 * hc.cin
             elif tgt is not None:

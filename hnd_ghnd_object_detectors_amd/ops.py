@@ -653,7 +653,10 @@ class Wino2Conv(object):
     prologue on load; optional per-block BN statistics of the stored output (stats: [stats_blocks][2][cout])."""
 
     def __init__(self, x, ww, y, v, m, pad, pro_scale=None, pro_shift=None, pro_relu=False, epi_scale=None,
-                 epi_shift=None, relu=False, stats=None):
+                 epi_shift=None, relu=False, stats=None, bwd_stats=None):
+        """bwd_stats = (x_raw, scale, shift, mean, rstd, relu, partials): this launch is the DATA gradient that produces
+        the gradient w.r.t. the output of a train-mode BatchNorm(+ReLU) over x_raw; its output transform then also makes
+        the BatchNorm-backward partial sums (hnd_wino26_output_bnbwd_stats; F(6x6,2x2), plain epilogue only)."""
         n, h, w, c = _nhwc(x)
         oh, ow = h + 2 * pad - 1, w + 2 * pad - 1
         assert tuple(y.shape[:3]) == (n, oh, ow) and c == ww.depth and pad in (0, 1)
@@ -672,6 +675,11 @@ class Wino2Conv(object):
         self.stats = stats
         if stats is not None:
             assert stats.numel() >= self.stats_blocks(n, oh, ow, self.cout, self.tile) * 2 * self.cout
+        self.bwd_stats = bwd_stats
+        if bwd_stats is not None:
+            assert self.tile == 6 and stats is None and epi_scale is None and epi_shift is None and not relu
+            assert 512 % self.cout == 0 and tuple(bwd_stats[0].shape) == tuple(y.shape) and y.shape[3] == self.cout
+            assert bwd_stats[6].numel() >= self.stats_blocks(n, oh, ow, self.cout, 6) * 2 * self.cout
         self.v = v[:need_v].view(1, 1, nc * self.tiles_pad, c)
         self.m = m[:need_m].view(1, 1, nc * self.tiles_pad, self.cout)
         pw = PackedWeight.__new__(PackedWeight)
@@ -703,6 +711,13 @@ class Wino2Conv(object):
 
     def _run_output(self, stream=None):
         n, h, w, c, oh, ow = self.geom
+        if self.bwd_stats is not None:
+            xr, sc, sh, mu, rs, relu, part = self.bwd_stats
+            check(_L.hnd_wino26_output_bnbwd_stats(ptr(self.m), ptr(self.y), n, oh, ow, self.cout, self.y.shape[3],
+                                                   ptr(xr), ptr(sc), ptr(sh), ptr(mu), ptr(rs), int(relu), ptr(part),
+                                                   stream if stream is not None else stream_ptr()),
+                  'hnd_wino26_output_bnbwd_stats')
+            return
         check(_L.hnd_wino2_output(ptr(self.m), ptr(self.y), n, oh, ow, self.cout, self.y.shape[3], ptr(self.epi[0]),
                                   ptr(self.epi[1]), self.epi[2], ptr(self.stats), self.tile,
                                   stream if stream is not None else stream_ptr()), 'hnd_wino2_output')
@@ -712,7 +727,7 @@ class Wino2Conv(object):
         nc = self.ww.ncomp
         tiles = n * ((oh + self.tile - 1) // self.tile) * ((ow + self.tile - 1) // self.tile)
         b_in = 4 * (n * h * w * c + nc * tiles * c)
-        b_out = 4 * (nc * tiles * self.cout + n * oh * ow * self.cout)
+        b_out = 4 * (nc * tiles * self.cout + (2 if self.bwd_stats is not None else 1) * n * oh * ow * self.cout)
         return [(_Step(self._run_input, 'wino2_input', b_in), tag + '.wino_in'), (self.gemm, tag),
                 (_Step(self._run_output, 'wino2_output', b_out), tag + '.wino_out')]
 

@@ -277,6 +277,14 @@ int hnd_wino2_output(const float* m, float* y, int n, int oh, int ow, int cout, 
  * (hnd_conv2d_wgrad with kh = kw = 1, groups = (tile+1)^2, x = v, dy = z) give s [groups][cout][cin];
  * hnd_wino2_wgrad_output -> dW [cout][cin][2][2]. */
 int hnd_wino2_dy(const float* dy, float* z, int n, int oh, int ow, int cout, int ldy, int tile, void* stream);
+/* F(6x6,2x2) output transform of a head conv's DATA gradient that also makes the BatchNorm-backward statistics of the
+ * gradient it writes: y = the gradient g w.r.t. the output of the train-mode BatchNorm(+ReLU) that normalises x (raw conv
+ * output, geometry of y); partials [hnd_wino2_stats_blocks(n, oh, ow, cout, 6)][2][cout] = per-block sums of
+ * d = g * [x*scale+shift > 0] (mask only when relu_of_bn) and d * (x - mean) * rstd -- what hnd_bn_bwd_reduce computes in a
+ * pass of its own -- for hnd_bn_bwd_finalize (ntiles = that block count).  cout must divide 512. */
+int hnd_wino26_output_bnbwd_stats(const float* m, float* y, int n, int oh, int ow, int cout, int ldc, const float* x,
+                                  const float* scale, const float* shift, const float* mean, const float* rstd,
+                                  int relu_of_bn, float* partials, void* stream);
 /* BatchNorm backward "apply" fused into both consumers of its result (F(6x6,2x2) only): with d = g * [x*scale+shift > 0]
  * (mask only when relu) and dy = k1*d + k2*x + k3 (k123 from hnd_bn_bwd_finalize), writes
  *   v = the input transform of the conv's DATA gradient over dy with padding `pad` (what hnd_wino2_input(dy, pad) gives),

@@ -817,6 +817,46 @@ def test_fused_bn_backward_transforms_give_the_unfused_gradients(monkeypatch):
     record_achieved('[fused BN-backward transforms vs the unfused plan, 3x800x1333 b2] worst gradient rel-L2 %.1e' % worst)
 
 
+def test_folded_bn_backward_reduce_gives_the_unfolded_gradients(monkeypatch):
+    """engine.FOLD_BNBWD_REDUCE: the BatchNorm-backward sums of a head layer whose g comes out of an F(6x6,2x2) data
+    gradient are made by that launch's output transform (no separate pass over g and x): same loss, every gradient within
+    1e-5 relative L2 of the plan with the reduce kernel, and the fold must be in use for the layers below the three
+    Winograd data gradients of the full-size head"""
+    from hnd_ghnd_object_detectors_amd import engine as E
+    z, meta = G.load('full_ghnd_faster_b4')
+    meta = dict(meta, sizes=meta['sizes'][:2])
+    images, targets = G.case_inputs(meta)
+    runs = {}
+    for fold in (False, True):
+        monkeypatch.setattr(E, 'FOLD_BNBWD_REDUCE', fold)
+        cfg, t_sd, s_sd, teacher, student, box, opt, warm = _setup(meta)
+        ims, tgs = _to_dev(images, [dict(t) for t in targets])
+        loss = box(ims, tgs)
+        opt.zero_grad()
+        loss.backward()
+        head = student.backbone.body.layer1.head_engine()
+        folded = [i for i, st in enumerate(head.bsteps) if st['folded'] is not None]
+        assert folded == ([i - 1 for i, st in enumerate(head.bsteps)
+                           if i > 0 and st['dgrad'] and getattr(st['dgrad'][-1][0], 'kernel', '') == 'wino2_output'
+                           and 512 % head.layers[i - 1].cs_out == 0] if fold else []), folded
+        assert not fold or len(folded) >= 3, folded
+        runs[fold] = (loss.item(), OrderedDict((n, p.grad.clone()) for n, p in student.named_parameters()
+                                               if p.requires_grad))
+        if box.defer_fpn and box._fpn_stream is not None:
+            torch.cuda.current_stream().wait_stream(box._fpn_stream)
+    assert runs[True][0] == runs[False][0]
+    worst = 0.0
+    for n in runs[False][1]:
+        if n.endswith(G.ZERO_GRAD_SUFFIXES):
+            continue
+        a, b = runs[True][1][n].double(), runs[False][1][n].double()
+        worst = max(worst, float((a - b).norm() / b.norm()))
+    assert worst < 1e-5, worst
+    from tests.conftest import record_achieved
+    record_achieved('[BN-backward reduce folded into the data-gradient output transform vs the reduce kernel, '
+                    '3x800x1333 b2] worst gradient rel-L2 %.1e' % worst)
+
+
 def test_shared_trunk_is_dropped_when_the_frozen_weights_differ(monkeypatch):
     """the merged pass needs bit-equal frozen weights; a student whose layer3 was edited (a checkpoint that did not come
     from this teacher) runs its own pass -- and the pyramids of the merged pass equal the separate ones"""

@@ -795,6 +795,38 @@ def test_bn_backward_apply_fused_into_both_winograd_transforms(ops, n, oh, ow, c
         assert relerr(got.cpu(), ref.cpu()) < 2e-6, relerr(got.cpu(), ref.cpu())
 
 
+@pytest.mark.parametrize('n,cin,h,w,cout,pad,relu', [(2, 128, 37, 50, 128, 1, True), (1, 256, 44, 31, 64, 0, True),
+                                                     (2, 64, 20, 27, 256, 1, False)])
+def test_bn_backward_sums_folded_into_the_data_gradient_output_transform(ops, n, cin, h, w, cout, pad, relu):
+    """Wino2Conv(bwd_stats=...) -> hnd_wino26_output_bnbwd_stats: the data gradient g of a 2x2 conv (F(6x6,2x2)) and, from
+    the same launch, sum [bn(x) > 0] g and sum [bn(x) > 0] g xhat per channel of the BatchNorm before that conv -- g
+    bit-identical to the plain output transform, the sums those of hnd_bn_bwd_reduce over the stored g"""
+    g_ = gen(130 + h + cin)
+    # data gradient of conv(x: cin -> cout): input dy [n, oh, ow, cout], output g [n, h, w, cin]
+    oh, ow = h + 2 * pad - 1, w + 2 * pad - 1
+    dy = torch.randn(n, oh, ow, cout, generator=g_).to(DEV)
+    wt = torch.randn(cout, cin, 2, 2, generator=g_) / math.sqrt(cout * 4)
+    xr = torch.randn(n, h, w, cin, generator=g_).to(DEV)
+    sc, sh = (torch.rand(cin, generator=g_) + 0.5).to(DEV), (torch.randn(cin, generator=g_) * 0.5).to(DEV)
+    mu, rs = (torch.randn(cin, generator=g_) * 0.2).to(DEV), (torch.rand(cin, generator=g_) + 0.5).to(DEV)
+    ww = ops.Wino2Weights(wt.to(DEV).contiguous(), dgrad=True, tile=6)
+    nv, nm = ops.Wino2Conv.scratch_elems(n, h, w, cout, cin, 6)
+    v, m = torch.empty(nv, device=DEV), torch.empty(nm, device=DEV)
+    plain = torch.full((n, h, w, cin), float('nan'), device=DEV)
+    ops.Wino2Conv(dy, ww, plain, v, m, 1 - pad).run()
+    nblk = ops.Wino2Conv.stats_blocks(n, h, w, cin, 6)
+    part = torch.full((nblk, 2, cin), float('nan'), device=DEV)
+    got = torch.full_like(plain, float('nan'))
+    ops.Wino2Conv(dy, ww, got, v, m, 1 - pad, bwd_stats=(xr, sc, sh, mu, rs, relu, part)).run()
+    ref_part = torch.zeros(ops.bn_bwd_ntiles(n * h * w), 2, cin, device=DEV)
+    ops.bn_bwd_reduce(got, xr, sc, sh, mu, rs, relu, ref_part)
+    ops.sync_check()
+    assert torch.equal(got, plain)
+    a, b = part.double().sum(0).cpu(), ref_part.double().sum(0).cpu()
+    assert not bool(torch.isnan(a).any())
+    assert float((a - b).abs().max() / b.abs().max()) < 2e-6, float((a - b).abs().max() / b.abs().max())
+
+
 @pytest.mark.parametrize('n,cin,h,w,cout,pad', [(2, 64, 37, 50, 256, 1), (1, 64, 44, 31, 256, 0)])
 def test_winograd_wgrad_on_an_input_transform_of_its_own(ops, n, cin, h, w, cout, pad, monkeypatch):
     """ops.Wino2InputTransform + Wino2Wgrad: the Winograd-domain weight gradient of a conv whose FORWARD is direct (the
