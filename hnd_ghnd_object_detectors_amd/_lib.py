@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('HND_LIB_PATH') or os.path.join(_HERE, 'libhnd_hip.so')     # env: kernel experiments
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 c_float_p = C.POINTER(C.c_float)
 vp = C.c_void_p
@@ -22,7 +22,8 @@ class ConvDesc(C.Structure):
                                          'y_sh', 'y_oh', 'y_sw', 'y_ow', 'kh', 'kw',
                                          'sh', 'dh', 'bh', 'sw', 'dw', 'bw', 'kdim', 'pro_relu', 'relu',
                                          'res1_mode', 'res1_h', 'res1_w', 'w_group_rows', 'w_group_stride')] + \
-               [('relay_ws', vp), ('mask_bits', vp), ('mask_out', vp)]
+               [('relay_ws', vp), ('mask_bits', vp), ('mask_out', vp)] + \
+               [(k, vp) for k in ('bwd_x', 'bwd_scale', 'bwd_shift', 'bwd_mean', 'bwd_rstd')] + [('bwd_relu', C.c_int)]
 
 
 class ImageDesc(C.Structure):

@@ -31,13 +31,21 @@ __device__ __forceinline__ float sq_acc(float s2, float x) {
 // four channels -- a lane's NI = 4 consecutive channels are exactly one byte).  d.mask_out (the nibbles of the STORED
 // values; NI = 4 builds only -- the launcher keeps such launches on 128-column tiles) is a run-time branch around a
 // store: no load sits behind it, so it does not cost the drains described above.
-template <int NI, bool R1, bool R2, int MK>
+// BS (d.bwd_x): the statistics are the BatchNorm-BACKWARD partials of the stored value (sum d, sum d * xhat; see
+// hnd_conv_desc.bwd_x) -- one more operand of the output's geometry, plain epilogues only.
+template <int NI>
+struct BwdConsts {
+  float sc[NI], sh[NI], mu[NI], rs[NI];
+};
+
+template <int NI, bool R1, bool R2, int MK, bool BS = false>
 __device__ __forceinline__ void epilogue_rows_full(const hnd_conv_desc& d, const f32x4 (&acc)[NI], const int* rowoff,
                                                    const int* resoff, int rbase, int col0, const float (&es)[NI],
-                                                   const float (&eb)[NI], float (&s1)[NI], float (&s2)[NI]) {
+                                                   const float (&eb)[NI], float (&s1)[NI], float (&s2)[NI],
+                                                   const BwdConsts<NI>& bc) {
   typedef float vec __attribute__((ext_vector_type(NI)));
   unsigned off[4];
-  vec r1v[4], r2v[4], mkv[4];
+  vec r1v[4], r2v[4], mkv[4], bxv[4];
   unsigned mkb[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -66,6 +74,10 @@ __device__ __forceinline__ void epilogue_rows_full(const hnd_conv_desc& d, const
 #pragma unroll
     for (int i = 0; i < 4; ++i) mkb[i] = d.mask_bits[off[i] >> 2];
   }
+  if (BS) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bxv[i] = *(const vec*)(d.bwd_x + off[i]);
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     vec v;
@@ -78,8 +90,15 @@ __device__ __forceinline__ void epilogue_rows_full(const hnd_conv_desc& d, const
       if (MK == 2) x = ((mkb[i] >> ((off[i] & 3u) + ni)) & 1u) ? x : 0.f;      // (NI = 2: half a nibble per lane)
       x = d.relu ? fmaxf(x, 0.f) : x;
       v[ni] = x;
-      s1[ni] += x;
-      s2[ni] += x * x;
+      if (BS) {
+        const float xr = bxv[i][ni];
+        const float dd = (d.bwd_relu && !(xr * bc.sc[ni] + bc.sh[ni] > 0.f)) ? 0.f : x;
+        s1[ni] += dd;
+        s2[ni] += dd * ((xr - bc.mu[ni]) * bc.rs[ni]);
+      } else {
+        s1[ni] += x;
+        s2[ni] += x * x;
+      }
     }
     *(vec*)(d.y + off[i]) = v;
     if (NI == 4 && d.mask_out) {
@@ -93,7 +112,7 @@ __device__ __forceinline__ void epilogue_rows_full(const hnd_conv_desc& d, const
 }
 
 // tile edges, odd ldc (91-class logits), unaligned views: scalar, fully checked
-template <int NI>
+template <int NI, bool ALLOW_BS = false>
 __device__ __forceinline__ void epilogue_rows_checked(const hnd_conv_desc& d, const f32x4 (&acc)[NI], const int* rowoff,
                                                       const int* resoff, int rbase, int col0, const float (&es)[NI],
                                                       const float (&eb)[NI], float (&s1)[NI], float (&s2)[NI]) {
@@ -112,6 +131,13 @@ __device__ __forceinline__ void epilogue_rows_checked(const hnd_conv_desc& d, co
       if (d.mask_bits) x = ((d.mask_bits[o >> 2] >> (o & 3)) & 1u) ? x : 0.f;
       x = d.relu ? fmaxf(x, 0.f) : x;
       d.y[o] = x;
+      if (ALLOW_BS && d.bwd_x) {
+        const float xr = d.bwd_x[o];
+        const float dd = (d.bwd_relu && !(xr * d.bwd_scale[col] + d.bwd_shift[col] > 0.f)) ? 0.f : x;
+        s1[ni] += dd;
+        s2[ni] += dd * ((xr - d.bwd_mean[col]) * d.bwd_rstd[col]);
+        continue;
+      }
       s1[ni] += x;
       s2[ni] = sq_acc(s2[ni], x);
     }
@@ -128,23 +154,38 @@ __device__ __forceinline__ void epilogue_rows_checked(const hnd_conv_desc& d, co
 }
 
 // The wave's MI row groups (rows rbase0 + 16*mi + 0..3 of the tables), dispatched once on the operand set.
-template <int MI, int NI, bool R1, bool R2, int MK>
+template <int MI, int NI, bool R1, bool R2, int MK, bool BS = false>
 __device__ __forceinline__ void epilogue_tile_full(const hnd_conv_desc& d, const f32x4 (&acc)[MI][NI], const int* rowoff,
                                                    const int* resoff, int rbase0, int col0, const float (&es)[NI],
                                                    const float (&eb)[NI], float (&s1)[NI], float (&s2)[NI]) {
+  BwdConsts<NI> bc;
+  if (BS) {
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {            // (a full tile: col0 + ni < cout)
+      bc.sc[ni] = d.bwd_scale[col0 + ni];
+      bc.sh[ni] = d.bwd_shift[col0 + ni];
+      bc.mu[ni] = d.bwd_mean[col0 + ni];
+      bc.rs[ni] = d.bwd_rstd[col0 + ni];
+    }
+  }
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
-    epilogue_rows_full<NI, R1, R2, MK>(d, acc[mi], rowoff, resoff, rbase0 + 16 * mi, col0, es, eb, s1, s2);
+    epilogue_rows_full<NI, R1, R2, MK, BS>(d, acc[mi], rowoff, resoff, rbase0 + 16 * mi, col0, es, eb, s1, s2, bc);
 }
 
-template <int MI, int NI>
+// ALLOW_BS: only the tiled kernel is built with the BatchNorm-backward statistics (the persistent kernels never see `stats`)
+template <int MI, int NI, bool ALLOW_BS = false>
 __device__ __forceinline__ void epilogue_tile(const hnd_conv_desc& d, const f32x4 (&acc)[MI][NI], const int* rowoff,
                                               const int* resoff, int rbase0, int col0, const float (&es)[NI],
                                               const float (&eb)[NI], float (&s1)[NI], float (&s2)[NI], bool full) {
   if (!full) {
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
-      epilogue_rows_checked<NI>(d, acc[mi], rowoff, resoff, rbase0 + 16 * mi, col0, es, eb, s1, s2);
+      epilogue_rows_checked<NI, ALLOW_BS>(d, acc[mi], rowoff, resoff, rbase0 + 16 * mi, col0, es, eb, s1, s2);
+    return;
+  }
+  if (ALLOW_BS && d.bwd_x) {     // (the launcher admits plain epilogues only)
+    epilogue_tile_full<MI, NI, false, false, 0, true>(d, acc, rowoff, resoff, rbase0, col0, es, eb, s1, s2);
     return;
   }
   const int sel = (d.res1 ? 1 : 0) | (d.res2 ? 2 : 0) | (d.mask ? 4 : (d.mask_bits ? 8 : 0));

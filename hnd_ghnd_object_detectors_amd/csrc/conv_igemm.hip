@@ -314,7 +314,7 @@ igemm_kernel(const hnd_conv_desc d, const int ntiles) {
     s1[ni] = 0.f;
     s2[ni] = 0.f;
   }
-  hnd::epilogue_tile<MI, NI>(d, acc, rowoff, resoff, wm * WTM + 4 * g4, col0, es, eb, s1, s2, tile_full);
+  hnd::epilogue_tile<MI, NI, !CIN4>(d, acc, rowoff, resoff, wm * WTM + 4 * g4, col0, es, eb, s1, s2, tile_full);
   if (d.stats) {
     // per 128-row tile and channel: fold the four row groups of the wave (lane>>4), then the two row-waves
     const int cl = col0 - n0;                  // channel index inside the block tile
@@ -487,7 +487,7 @@ __global__ void __launch_bounds__(128, 4) thin_n_kernel(const hnd_conv_desc d) {
 
 bool thin_n_applies(const hnd_conv_desc& d) {
   static const int on = getenv("HND_THIN_N") ? atoi(getenv("HND_THIN_N")) : 1;
-  return on && !d.mask_bits && !d.mask_out && d.cin != 4 && d.cin % 64 == 0 && d.cout <= 4 && d.res1_mode == 0 &&
+  return on && !d.mask_bits && !d.mask_out && !d.bwd_x && d.cin != 4 && d.cin % 64 == 0 && d.cout <= 4 && d.res1_mode == 0 &&
          d.w_group_rows == 0 &&
          d.kdim == d.kh * d.kw * d.cin && d.kdim <= 4096;
 }
@@ -614,6 +614,9 @@ extern "C" int hnd_conv2d_igemm(const hnd_conv_desc* desc, void* stream) {
   HND_REQUIRE(!d.mask_out || d.cout % 128 == 0,
               "hnd_conv2d_igemm: mask_out needs cout %% 128 == 0 (a lane must own whole nibbles), cout=%d", d.cout);
   HND_REQUIRE((long long)d.n * d.h * d.w_ * d.cin < (1ll << 32) - 1, "hnd_conv2d_igemm: input exceeds 2^32 elements");
+  HND_REQUIRE(!d.bwd_x || (d.stats && d.bwd_scale && d.bwd_shift && d.bwd_mean && d.bwd_rstd && !d.res1 && !d.res2 &&
+                           !d.mask && !d.mask_bits && !d.relu && d.cin != 4),
+              "hnd_conv2d_igemm: bwd_x needs stats + the four per-channel vectors and a plain epilogue");
   hipStream_t s = hnd::as_stream(stream);
   if (d.cin == 4) {
     if (hnd::stem7_applies(d)) return hnd::launch_stem7(d, s);

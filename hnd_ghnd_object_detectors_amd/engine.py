@@ -942,6 +942,16 @@ class HeadEngine(object):
             elif tgt is not None:
                 pk = hc.wc.get(True, hc.cs_out)
                 ls, _ = _dgrad_with_pack(gbuf[i], hc, tgt, pk)
+                prev = self.layers[i - 1] if i > 0 else None
+                if (FOLD_BNBWD_REDUCE and prev is not None and prev.cs_out == prev.cout and tgt.shape[3] == prev.cs_out
+                        and ls[0].variant in ('igemm_128x128', 'igemm_128x64')):
+                    # a tiled launch: the BatchNorm-backward sums of layer i-1 come out of its epilogue (per 128 pixels)
+                    nblk = ops.stats_tiles(tgt.shape[0] * tgt.shape[1] * tgt.shape[2])
+                    part = b.get('bpart_folded%d' % (i - 1), (nblk, 2, prev.cs_out))
+                    ls, _ = _dgrad_with_pack(gbuf[i], hc, tgt, pk, stats=part, bwd_stats=(
+                        self.y[i - 1], self.scale[i - 1], self.shift[i - 1], self.mean[i - 1], self.rstd[i - 1], prev.relu))
+                    assert ls[0].variant in ('igemm_128x128', 'igemm_128x64'), ls[0].variant
+                    self.bsteps[i - 1]['folded'] = (part, nblk)
                 st['dgrad'] = [(l, 'layer1.conv%d.dgrad' % i) for l in ls]
                 flops += 2 * npix * hc.cout * 4 * hc.cin
             # both consumers of dy are F(6x6,2x2) transforms: fuse the BN-backward apply into them (conv6, conv7 at full size)
@@ -954,10 +964,10 @@ class HeadEngine(object):
         self.flops_bwd = flops
 
 
-def _dgrad_with_pack(dy, hc, dx, pk):
+def _dgrad_with_pack(dy, hc, dx, pk, **kw):
     """stride-1 dgrad of a head conv using the cached transposed pack (re-packed every training step)."""
     n, h, w, ldc = dx.shape
-    l = ops.conv_desc(dy, pk, dx, kh=2, kw=2, oh=h, ow=w, sh=1, dh=-1, bh=hc.pad, sw=1, dw=-1, bw=hc.pad, cout=ldc)
+    l = ops.conv_desc(dy, pk, dx, kh=2, kw=2, oh=h, ow=w, sh=1, dh=-1, bh=hc.pad, sw=1, dw=-1, bw=hc.pad, cout=ldc, **kw)
     return [l], [pk]
 
 

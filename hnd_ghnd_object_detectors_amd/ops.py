@@ -159,9 +159,12 @@ def _nhwc(t):
 
 def conv_desc(x, pw, y, *, kh, kw, oh, ow, sh, dh, bh, sw, dw, bw, cout, y_sh=1, y_oh=0, y_sw=1, y_ow=0,
               pro_scale=None, pro_shift=None, pro_relu=False, epi_scale=None, epi_shift=None, res1=None,
-              res1_up=False, res2=None, mask=None, relu=False, stats=None, mask_bits=None, mask_out=None):
+              res1_up=False, res2=None, mask=None, relu=False, stats=None, mask_bits=None, mask_out=None,
+              bwd_stats=None):
     """Generic descriptor (see include/hnd_hip.h).  x, y, res*, mask are NHWC tensors; mask_bits / mask_out are uint8
-    ReLU-mask nibble tensors of y's geometry with a quarter of its channels (mask_nibbles_like)."""
+    ReLU-mask nibble tensors of y's geometry with a quarter of its channels (mask_nibbles_like).
+    bwd_stats = (x_raw, scale, shift, mean, rstd, relu): `stats` receives the BatchNorm-backward partials of the stored
+    y (hnd_conv_desc.bwd_x) instead of its sum / sum of squares."""
     n, h, w, cin = _nhwc(x)
     ny, yh, yw, ldc = _nhwc(y)
     assert ny == n and pw.kdim >= kh * kw * cin and pw.chan_pad == cin, (pw.kdim, kh, kw, cin, pw.chan_pad)
@@ -193,7 +196,15 @@ def conv_desc(x, pw, y, *, kh, kw, oh, ow, sh, dh, bh, sw, dw, bw, cout, y_sh=1,
     d.mask_bits, d.mask_out = ptr(mask_bits), ptr(mask_out)
     if stats is not None:
         assert stats.numel() >= stats_tiles(n * oh * ow) * 2 * cout
-    keep = (x, pw, y, pro_scale, pro_shift, epi_scale, epi_shift, res1, res2, mask, stats, mask_bits, mask_out)
+    if bwd_stats is not None:
+        bx, bsc, bsh, bmu, brs, brelu = bwd_stats
+        assert stats is not None and tuple(bx.shape) == tuple(y.shape) and cout == ldc
+        assert res1 is None and res2 is None and mask is None and mask_bits is None and not relu
+        assert min(t.numel() for t in (bsc, bsh, bmu, brs)) >= ldc
+        d.bwd_x, d.bwd_scale, d.bwd_shift, d.bwd_mean, d.bwd_rstd = ptr(bx), ptr(bsc), ptr(bsh), ptr(bmu), ptr(brs)
+        d.bwd_relu = int(brelu)
+    keep = (x, pw, y, pro_scale, pro_shift, epi_scale, epi_shift, res1, res2, mask, stats, mask_bits, mask_out,
+            bwd_stats)
     return ConvLaunch(d, keep, flops=2 * n * oh * ow * min(cout, pw.rows) * kh * kw * min(cin, pw.chan_real))
 
 

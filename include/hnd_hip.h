@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define HND_ABI_VERSION 8
+#define HND_ABI_VERSION 9
 
 typedef enum hnd_status {
   HND_OK = 0,
@@ -116,6 +116,19 @@ typedef struct hnd_conv_desc {
    *   mask_out:  produced from the STORED value (after ReLU), next to y. */
   const uint8_t* mask_bits;
   uint8_t* mask_out;
+  /* BatchNorm-backward sums from the epilogue of the DATA gradient that produces g (ABI 9), or bwd_x = NULL.  With
+   * bwd_x (the raw input of a train-mode BatchNorm(+ReLU), same geometry and ldc as y) the launch writes into `stats`,
+   * instead of sum / sum of squares of y, the partials hnd_bn_bwd_reduce would make from the stored y:
+   *   stats[tile][0][ch] = sum d,  stats[tile][1][ch] = sum d * (x - mean) * rstd,
+   *   d = bwd_relu ? [x * scale + shift > 0] y : y      (per 128-pixel tile, ready for hnd_bn_bwd_finalize).
+   * Plain epilogues only (no residual, no mask, no ReLU); taken by the tiled kernels (the persistent ones leave any
+   * launch with `stats` to them).  bwd_scale / shift / mean / rstd: ldc floats each. */
+  const float* bwd_x;
+  const float* bwd_scale;
+  const float* bwd_shift;
+  const float* bwd_mean;
+  const float* bwd_rstd;
+  int bwd_relu;
 } hnd_conv_desc;
 
 int hnd_conv2d_igemm(const hnd_conv_desc* desc, void* stream);

@@ -836,10 +836,11 @@ def test_folded_bn_backward_reduce_gives_the_unfolded_gradients(monkeypatch):
         loss.backward()
         head = student.backbone.body.layer1.head_engine()
         folded = [i for i, st in enumerate(head.bsteps) if st['folded'] is not None]
-        assert folded == ([i - 1 for i, st in enumerate(head.bsteps)
-                           if i > 0 and st['dgrad'] and getattr(st['dgrad'][-1][0], 'kernel', '') == 'wino2_output'
-                           and 512 % head.layers[i - 1].cs_out == 0] if fold else []), folded
-        assert not fold or len(folded) >= 3, folded
+        # full-size head: g0, g5, g6 come out of F(6x6,2x2) data gradients, g1 out of a tiled direct one (conv2.dgrad)
+        assert folded == ([0, 1, 5, 6] if fold else []), folded
+        for i in folded:
+            last = head.bsteps[i + 1]['dgrad'][-1][0]
+            assert getattr(last, 'kernel', '') == 'wino2_output' or bool(last.desc.bwd_x), i
         runs[fold] = (loss.item(), OrderedDict((n, p.grad.clone()) for n, p in student.named_parameters()
                                                if p.requires_grad))
         if box.defer_fpn and box._fpn_stream is not None:

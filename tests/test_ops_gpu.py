@@ -827,6 +827,39 @@ def test_bn_backward_sums_folded_into_the_data_gradient_output_transform(ops, n,
     assert float((a - b).abs().max() / b.abs().max()) < 2e-6, float((a - b).abs().max() / b.abs().max())
 
 
+@pytest.mark.parametrize('n,cin,h,w,cout,relu', [(2, 256, 37, 50, 64, True), (1, 64, 44, 31, 64, False),
+                                                 (1, 128, 9, 14, 128, True)])
+def test_bn_backward_sums_from_the_tiled_data_gradient_epilogue(ops, n, cin, h, w, cout, relu):
+    """hnd_conv_desc.bwd_x (ABI 9): the data gradient of a 2x2 head conv on the tiled kernel writes, per 128-pixel tile,
+    the BatchNorm-backward partials of the g it stores (incl. the checked path of the last, partial tile) -- g bit-identical
+    to the launch without them, the sums those of hnd_bn_bwd_reduce"""
+    g_ = gen(170 + h + cin)
+    pad = 1
+    oh, ow = h + 2 * pad - 1, w + 2 * pad - 1
+    dy = torch.randn(n, oh, ow, cout, generator=g_).to(DEV)
+    wt = torch.randn(cout, cin, 2, 2, generator=g_) / math.sqrt(cout * 4)
+    xr = torch.randn(n, h, w, cin, generator=g_).to(DEV)
+    sc, sh = (torch.rand(cin, generator=g_) + 0.5).to(DEV), (torch.randn(cin, generator=g_) * 0.5).to(DEV)
+    mu, rs = (torch.randn(cin, generator=g_) * 0.2).to(DEV), (torch.rand(cin, generator=g_) + 0.5).to(DEV)
+    pk = ops.pack_weights(wt.to(DEV), transposed=True)
+    geo = dict(kh=2, kw=2, oh=h, ow=w, sh=1, dh=-1, bh=pad, sw=1, dw=-1, bw=pad, cout=cin)
+    plain = torch.full((n, h, w, cin), float('nan'), device=DEV)
+    dummy = torch.empty(ops.stats_tiles(n * h * w), 2, cin, device=DEV)
+    ops.conv_desc(dy, pk, plain, stats=dummy, **geo).run()           # (same kernel: `stats` keeps it on the tiled one)
+    part = torch.full((ops.stats_tiles(n * h * w), 2, cin), float('nan'), device=DEV)
+    got = torch.full_like(plain, float('nan'))
+    l = ops.conv_desc(dy, pk, got, stats=part, bwd_stats=(xr, sc, sh, mu, rs, relu), **geo)
+    assert l.variant.startswith('igemm_128'), l.variant
+    l.run()
+    ref_part = torch.zeros(ops.bn_bwd_ntiles(n * h * w), 2, cin, device=DEV)
+    ops.bn_bwd_reduce(got, xr, sc, sh, mu, rs, relu, ref_part)
+    ops.sync_check()
+    assert torch.equal(got, plain)
+    a, b = part.double().sum(0).cpu(), ref_part.double().sum(0).cpu()
+    assert not bool(torch.isnan(a).any())
+    assert float((a - b).abs().max() / b.abs().max()) < 2e-6, float((a - b).abs().max() / b.abs().max())
+
+
 @pytest.mark.parametrize('n,cin,h,w,cout,pad', [(2, 64, 37, 50, 256, 1), (1, 64, 44, 31, 256, 0)])
 def test_winograd_wgrad_on_an_input_transform_of_its_own(ops, n, cin, h, w, cout, pad, monkeypatch):
     """ops.Wino2InputTransform + Wino2Wgrad: the Winograd-domain weight gradient of a conv whose FORWARD is direct (the
