@@ -7,6 +7,8 @@ student tensor.  ``loss.backward()`` then replays the hand-written backward plan
 (hipnn.IntermediateLayerGetter.hnd_backward) and hands parameter gradients to autograd's AccumulateGrad, so
 ``optimizer.zero_grad(); loss.backward(); optimizer.step()`` (src/mimic_runner.py:52-54) works unchanged.
 """
+import os
+
 import torch
 from torch import nn
 
@@ -79,6 +81,41 @@ class _DistillLossFn(torch.autograd.Function):
             hook(arena, flat)
         # fresh views (refcount 1) so AccumulateGrad adopts them without a copy
         return (None, None) + tuple(arena.views(flat))
+
+
+class StepLoss(torch.Tensor):
+    """The loss tensor of a training step.  The reference reads it on the host once per step, AFTER optimizer.step()
+    (`metric_logger.update(loss=loss)` -> Tensor.item(), /root/reference/src/mimic_runner.py:58,
+    src/utils/misc_util.py:147-152).  A plain .item() there drains the stream -- backward and Adam included -- and the GPU
+    then idles until the host has enqueued the next step's first kernels (0.4 ms per step, tools/idle_gaps.py).  The value
+    exists right after the loss kernel, so it is copied to pinned memory at that point and .item() waits for THAT copy only:
+    same float, and the host is free to enqueue the next step while the backward pass still runs."""
+
+    def item(self):
+        host = self.__dict__.get('_host')
+        if host is None:
+            return super().item()
+        buf, ev = host
+        ev.synchronize()
+        return buf.item()
+
+    def __float__(self):
+        return float(self.item())
+
+
+EARLY_LOSS_COPY = os.environ.get('HND_EARLY_LOSS_COPY', '1') != '0'
+
+
+def _early_host_copy(body, loss_value):
+    """(pinned buffer, event) holding loss_value, enqueued now; four rotating buffers per student"""
+    ring = body.__dict__.setdefault('_loss_host_ring', [[], 0])
+    if len(ring[0]) < 4:
+        ring[0].append((torch.empty((), dtype=torch.float32).pin_memory(), torch.cuda.Event()))
+    buf, ev = ring[0][ring[1] % len(ring[0])]
+    ring[1] += 1
+    buf.copy_(loss_value.detach(), non_blocking=True)
+    ev.record()
+    return buf, ev
 
 
 _ORDER = ('layer1', 'layer2', 'layer3', 'layer4')
@@ -167,5 +204,9 @@ def distill_loss(terms):
     state = {'body': body, 'arena': arena, 'top': top[0], 'top_block': top[1], 'loss_grads': loss_grads,
              'block_grads': block_grads, 'grad_bufs': grad_bufs}
     loss = _DistillLossFn.apply(loss_value, state, *params)
+    if EARLY_LOSS_COPY and loss.is_cuda:
+        host = _early_host_copy(body, loss)
+        loss = loss.as_subclass(StepLoss)
+        loss._host = host
     loss.per_term = per_term
     return loss

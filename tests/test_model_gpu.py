@@ -858,6 +858,31 @@ def test_folded_bn_backward_reduce_gives_the_unfolded_gradients(monkeypatch):
                     '3x800x1333 b2] worst gradient rel-L2 %.1e' % worst)
 
 
+def test_step_loss_item_reads_the_early_host_copy_and_not_the_drained_stream():
+    """hip_loss.StepLoss: the reference reads loss.item() after optimizer.step() (mimic_runner.py:58 -> misc_util.py:150);
+    the value handed out is the float copied to pinned memory right after the loss kernel -- the same float Tensor.item()
+    would return -- for every step of a short run, with the buffers of the ring rotating"""
+    from hnd_ghnd_object_detectors_amd.distillation.hip_loss import StepLoss
+    z, meta = G.load('tiny_ghnd_faster')
+    images, targets = G.case_inputs(meta)
+    cfg, t_sd, s_sd, teacher, student, box, opt, warm = _setup(meta)
+    ims, tgs = _to_dev(images, targets)
+    seen, bufs = [], set()
+    for _ in range(6):
+        loss = box(ims, [dict(t) for t in tgs])
+        assert isinstance(loss, StepLoss) and loss.requires_grad
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        early = loss.item()
+        assert early == torch.Tensor.item(loss) == float(loss.detach().cpu())
+        assert float(loss) == early
+        bufs.add(loss._host[0].data_ptr())
+        seen.append(early)
+    assert len(bufs) == 4 and len(set(seen)) == 6           # (the loss moves: Adam updates the head every step)
+    assert abs(seen[0] - float(z['step0/loss'])) / float(z['step0/loss']) < 1e-4
+
+
 def test_shared_trunk_is_dropped_when_the_frozen_weights_differ(monkeypatch):
     """the merged pass needs bit-equal frozen weights; a student whose layer3 was edited (a checkpoint that did not come
     from this teacher) runs its own pass -- and the pyramids of the merged pass equal the separate ones"""
