@@ -8,6 +8,7 @@ student tensor.  ``loss.backward()`` then replays the hand-written backward plan
 ``optimizer.zero_grad(); loss.backward(); optimizer.step()`` (src/mimic_runner.py:52-54) works unchanged.
 """
 import os
+import weakref
 
 import torch
 from torch import nn
@@ -89,7 +90,8 @@ class StepLoss(torch.Tensor):
     src/utils/misc_util.py:147-152).  A plain .item() there drains the stream -- backward and Adam included -- and the GPU
     then idles until the host has enqueued the next step's first kernels (0.4 ms per step, tools/idle_gaps.py).  The value
     exists right after the loss kernel, so it is copied to pinned memory at that point and .item() waits for THAT copy only:
-    same float, and the host is free to enqueue the next step while the backward pass still runs."""
+    same float, and the host is free to enqueue the next step while the backward pass still runs.  (Every loss owns its
+    pinned scalar until it is collected, so losses kept unread across steps stay valid.)"""
 
     def item(self):
         host = self.__dict__.get('_host')
@@ -106,13 +108,12 @@ class StepLoss(torch.Tensor):
 EARLY_LOSS_COPY = os.environ.get('HND_EARLY_LOSS_COPY', '1') != '0'
 
 
-def _early_host_copy(body, loss_value):
-    """(pinned buffer, event) holding loss_value, enqueued now; four rotating buffers per student"""
-    ring = body.__dict__.setdefault('_loss_host_ring', [[], 0])
-    if len(ring[0]) < 4:
-        ring[0].append((torch.empty((), dtype=torch.float32).pin_memory(), torch.cuda.Event()))
-    buf, ev = ring[0][ring[1] % len(ring[0])]
-    ring[1] += 1
+_HOST_POOL = []         # free (pinned float32 scalar, event) pairs; a StepLoss owns one until it is garbage-collected
+
+
+def _early_host_copy(loss_value):
+    """(pinned buffer, event) holding loss_value, enqueued now on the current stream"""
+    buf, ev = _HOST_POOL.pop() if _HOST_POOL else (torch.empty((), dtype=torch.float32).pin_memory(), torch.cuda.Event())
     buf.copy_(loss_value.detach(), non_blocking=True)
     ev.record()
     return buf, ev
@@ -205,8 +206,9 @@ def distill_loss(terms):
              'block_grads': block_grads, 'grad_bufs': grad_bufs}
     loss = _DistillLossFn.apply(loss_value, state, *params)
     if EARLY_LOSS_COPY and loss.is_cuda:
-        host = _early_host_copy(body, loss)
+        host = _early_host_copy(loss)
         loss = loss.as_subclass(StepLoss)
         loss._host = host
+        weakref.finalize(loss, _HOST_POOL.append, host)     # the pair is reused only once nobody can read it any more
     loss.per_term = per_term
     return loss

@@ -867,8 +867,8 @@ def test_step_loss_item_reads_the_early_host_copy_and_not_the_drained_stream():
     images, targets = G.case_inputs(meta)
     cfg, t_sd, s_sd, teacher, student, box, opt, warm = _setup(meta)
     ims, tgs = _to_dev(images, targets)
-    seen, bufs = [], set()
-    for _ in range(6):
+    seen, bufs, kept = [], set(), []
+    for it in range(6):
         loss = box(ims, [dict(t) for t in tgs])
         assert isinstance(loss, StepLoss) and loss.requires_grad
         opt.zero_grad()
@@ -879,7 +879,11 @@ def test_step_loss_item_reads_the_early_host_copy_and_not_the_drained_stream():
         assert float(loss) == early
         bufs.add(loss._host[0].data_ptr())
         seen.append(early)
-    assert len(bufs) == 4 and len(set(seen)) == 6           # (the loss moves: Adam updates the head every step)
+        if it < 3:
+            kept.append(loss)                                # an unread-later loss keeps its pinned scalar to itself
+        del loss
+    assert [l.item() for l in kept] == seen[:3]
+    assert 4 <= len(bufs) <= 5 and len(set(seen)) == 6      # 3 kept + recycled ones; the loss moves with every Adam step
     assert abs(seen[0] - float(z['step0/loss'])) / float(z['step0/loss']) < 1e-4
 
 
