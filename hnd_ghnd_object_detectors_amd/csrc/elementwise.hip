@@ -20,6 +20,18 @@ inline int grid_for(long long work_items, int threads = 256) {
   return (int)b;
 }
 
+// Streaming loops (round 4): a workgroup takes a CONTIGUOUS chunk of 256 * kEwU vectors per iteration and every thread has
+// its kEwU 16-byte loads in flight before the first use; the channel of a lane is fixed when the channel groups per pixel
+// divide the block (no 64-bit modulo per element).  tools/bench_elementwise.py: 4.7 -> ~6 TB/s, torch's own elementwise
+// kernels reach 6.0-6.2 on the same tensors.
+constexpr int kEwU = 4;
+inline int grid_for_chunks(long long n4) {
+  long long b = (n4 + 256 * kEwU - 1) / (256 * kEwU);
+  if (b < 1) b = 1;
+  if (b > 256 * 64) b = 256 * 64;
+  return (int)b;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -178,84 +190,161 @@ __global__ void scale_packed_k_kernel(float* __restrict__ w, const float* __rest
 }
 
 // ------------------------------------------------------------------------------------ max pool
+// (32-bit indices with precomputed reciprocals: the 64-bit divisions by c/4, w, h of the first version cost more than the
+// memory accesses -- 4.6-4.9 TB/s where a plain streaming kernel reaches 6)
+struct PoolDivs {
+  hnd::FastDiv c4n, w, h;     // h, w of the tensor the thread index walks (output for fwd, input for bwd)
+};
+
+// Forward: one thread walks a strip of kPoolStrip output rows of one column and four channels; the input row shared by two
+// consecutive windows (2 oy + 1) stays in registers, so a row is loaded 1.125x instead of 1.5x and a window costs six
+// loads instead of nine.  Scan order inside a window as in torch (rows top to bottom, left to right; the first element is
+// always taken, then a strictly greater value or a NaN wins).
+constexpr int kPoolStrip = 8;
 __global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, uint8_t* __restrict__ idx,
-                                   int n, int h, int w, int c, int oh, int ow) {
-  const int c4n = c >> 2;
-  const long long total = (long long)n * oh * ow * c4n;
-  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
-       e += (long long)gridDim.x * blockDim.x) {
-    const int c4 = (int)(e % c4n);
-    long long p = e / c4n;
-    const int ox = (int)(p % ow);
-    p /= ow;
-    const int oy = (int)(p % oh), b = (int)(p / oh);
-    f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-    int bi[4] = {0, 0, 0, 0};
-    bool any = false;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int iy = oy * 2 - 1 + i;
-      if ((unsigned)iy >= (unsigned)h) continue;
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const int ix = ox * 2 - 1 + j;
-        if ((unsigned)ix >= (unsigned)w) continue;
-        const f32x4 v = *(const f32x4*)(x + (((size_t)b * h + iy) * w + ix) * c + c4 * 4);
-        const int tap = i * 3 + j;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          // torch: first element always taken, then strictly greater (or NaN) wins
-          if (!any || v[k] > best[k] || v[k] != v[k]) { best[k] = v[k]; bi[k] = tap; }
-        }
-        any = true;
-      }
+                                   int n, int h, int w, int c, int oh, int ow, int nstrips, const PoolDivs dv) {
+  const unsigned c4n = c >> 2;
+  const unsigned total = (unsigned)n * nstrips * ow * c4n;
+  for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    unsigned p = hnd::fdiv(e, dv.c4n);
+    const int c4 = (int)(e - p * c4n);
+    unsigned q = hnd::fdiv(p, dv.w);
+    const int ox = (int)(p - q * ow);
+    const unsigned b = hnd::fdiv(q, dv.h);
+    const int st = (int)(q - b * nstrips);
+    const int oy0 = st * kPoolStrip;
+    const int oy1 = oy0 + kPoolStrip < oh ? oy0 + kPoolStrip : oh;
+    const bool cv0 = ox > 0, cv2 = 2 * ox + 1 < w;                     // column 2 ox is always inside
+    const float* xc = x + ((size_t)b * h * w + (size_t)(2 * ox)) * c + c4 * 4;     // (row 0, column 2 ox)
+    const f32x4 ninf = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    f32x4 top[3] = {ninf, ninf, ninf};
+    bool topv = oy0 > 0;
+    if (topv) {
+      const float* r = xc + (size_t)(2 * oy0 - 1) * w * c;
+      if (cv0) top[0] = *(const f32x4*)(r - c);
+      top[1] = *(const f32x4*)r;
+      if (cv2) top[2] = *(const f32x4*)(r + c);
     }
-    const size_t o = (((size_t)b * oh + oy) * ow + ox) * c + c4 * 4;
-    *(f32x4*)(y + o) = best;
-    *(uchar4*)(idx + o) = make_uchar4((unsigned char)bi[0], (unsigned char)bi[1], (unsigned char)bi[2],
-                                      (unsigned char)bi[3]);
+    for (int oy = oy0; oy < oy1; ++oy) {
+      const float* rm = xc + (size_t)(2 * oy) * w * c;
+      const bool botv = 2 * oy + 1 < h;
+      f32x4 mid[3] = {ninf, ninf, ninf}, bot[3] = {ninf, ninf, ninf};
+      if (cv0) mid[0] = *(const f32x4*)(rm - c);
+      mid[1] = *(const f32x4*)rm;
+      if (cv2) mid[2] = *(const f32x4*)(rm + c);
+      if (botv) {
+        const float* rb = rm + (size_t)w * c;
+        if (cv0) bot[0] = *(const f32x4*)(rb - c);
+        bot[1] = *(const f32x4*)rb;
+        if (cv2) bot[2] = *(const f32x4*)(rb + c);
+      }
+      f32x4 best = ninf;
+      int bi[4] = {0, 0, 0, 0};
+      bool any = false;
+#define HND_POOL_TAP(v, ok, tap)                                                          \
+  if (ok) {                                                                               \
+    _Pragma("unroll") for (int k = 0; k < 4; ++k)                                         \
+      if (!any || (v)[k] > best[k] || (v)[k] != (v)[k]) { best[k] = (v)[k]; bi[k] = (tap); } \
+    any = true;                                                                           \
+  }
+      HND_POOL_TAP(top[0], topv && cv0, 0)
+      HND_POOL_TAP(top[1], topv, 1)
+      HND_POOL_TAP(top[2], topv && cv2, 2)
+      HND_POOL_TAP(mid[0], cv0, 3)
+      HND_POOL_TAP(mid[1], true, 4)
+      HND_POOL_TAP(mid[2], cv2, 5)
+      HND_POOL_TAP(bot[0], botv && cv0, 6)
+      HND_POOL_TAP(bot[1], botv, 7)
+      HND_POOL_TAP(bot[2], botv && cv2, 8)
+#undef HND_POOL_TAP
+      const size_t o = (((size_t)b * oh + oy) * ow + ox) * c + c4 * 4;
+      *(f32x4*)(y + o) = best;
+      *(uchar4*)(idx + o) = make_uchar4((unsigned char)bi[0], (unsigned char)bi[1], (unsigned char)bi[2],
+                                        (unsigned char)bi[3]);
+      top[0] = bot[0]; top[1] = bot[1]; top[2] = bot[2];
+      topv = botv;
+    }
   }
 }
 
+// Backward of the pool fused with the stem's ReLU and FrozenBN scale.  One thread owns the 2 x 2 input pixels (2a..2a+1,
+// 2b..2b+1) of four channels: they lie in the windows (a..a+1, b..b+1) and nowhere else (an even coordinate belongs to one
+// window, an odd one to two), so four (index, gradient) loads serve four outputs -- the one-pixel-per-thread version
+// loaded 2.25 windows per pixel behind data-dependent loop bounds.  Each pixel adds its windows in the order (a,b), (a,b+1),
+// (a+1,b), (a+1,b+1), as before.
 __global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ idx,
                                    const float* __restrict__ act, const float* __restrict__ scale,
-                                   float* __restrict__ dx, int n, int h, int w, int c, int oh, int ow) {
-  const int c4n = c >> 2;
-  const long long total = (long long)n * h * w * c4n;
-  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
-       e += (long long)gridDim.x * blockDim.x) {
-    const int c4 = (int)(e % c4n);
-    long long p = e / c4n;
-    const int ix = (int)(p % w);
-    p /= w;
-    const int iy = (int)(p % h), b = (int)(p / h);
-    f32x4 g = {0.f, 0.f, 0.f, 0.f};
-    // windows oy with oy*2-1 <= iy <= oy*2+1
-    const int oy_lo = (iy) >> 1, oy_hi = (iy + 1) >> 1;   // ceil((iy-1)/2) .. floor((iy+1)/2)
-    const int ox_lo = (ix) >> 1, ox_hi = (ix + 1) >> 1;
-    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
-      if (oy >= oh) continue;
-      for (int ox = ox_lo; ox <= ox_hi; ++ox) {
-        if (ox >= ow) continue;
-        const int tap = (iy - (oy * 2 - 1)) * 3 + (ix - (ox * 2 - 1));
-        const size_t o = (((size_t)b * oh + oy) * ow + ox) * c + c4 * 4;
-        const uchar4 id = *(const uchar4*)(idx + o);
-        const f32x4 d = *(const f32x4*)(dy + o);
-        if (id.x == tap) g.x += d.x;
-        if (id.y == tap) g.y += d.y;
-        if (id.z == tap) g.z += d.z;
-        if (id.w == tap) g.w += d.w;
-      }
-    }
-    const size_t xo = (size_t)e * 4;
-    const f32x4 a = *(const f32x4*)(act + xo);
+                                   float* __restrict__ dx, int n, int h, int w, int c, int oh, int ow,
+                                   const PoolDivs dv) {
+  const unsigned c4n = c >> 2;
+  const unsigned total = (unsigned)n * oh * ow * c4n;
+  for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    unsigned p = hnd::fdiv(e, dv.c4n);
+    const int c4 = (int)(e - p * c4n);
+    unsigned q = hnd::fdiv(p, dv.w);
+    const int qb = (int)(p - q * ow);
+    const unsigned b = hnd::fdiv(q, dv.h);
+    const int qa = (int)(q - b * oh);
+    const int iy = 2 * qa, ix = 2 * qb;
+    const bool row1 = iy + 1 < h, col1 = ix + 1 < w;            // (iy < h and ix < w always: oh = ceil(h / 2))
+    const bool wrow1 = qa + 1 < oh, wcol1 = qb + 1 < ow;
+    const size_t o00 = (((size_t)b * oh + qa) * ow + qb) * c + c4 * 4;
+    const size_t o01 = o00 + c, o10 = o00 + (size_t)ow * c, o11 = o10 + c;
+    const size_t x00 = (((size_t)b * h + iy) * w + ix) * c + c4 * 4;
+    const size_t x01 = x00 + c, x10 = x00 + (size_t)w * c, x11 = x10 + c;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    const uchar4 zu = make_uchar4(255, 255, 255, 255);
+    // all loads first
+    const uchar4 i00 = *(const uchar4*)(idx + o00);
+    const f32x4 d00 = *(const f32x4*)(dy + o00);
+    const uchar4 i01 = wcol1 ? *(const uchar4*)(idx + o01) : zu;
+    const f32x4 d01 = wcol1 ? *(const f32x4*)(dy + o01) : z4;
+    const uchar4 i10 = wrow1 ? *(const uchar4*)(idx + o10) : zu;
+    const f32x4 d10 = wrow1 ? *(const f32x4*)(dy + o10) : z4;
+    const uchar4 i11 = (wrow1 && wcol1) ? *(const uchar4*)(idx + o11) : zu;
+    const f32x4 d11 = (wrow1 && wcol1) ? *(const f32x4*)(dy + o11) : z4;
+    const f32x4 a00 = *(const f32x4*)(act + x00);
+    const f32x4 a01 = col1 ? *(const f32x4*)(act + x01) : z4;
+    const f32x4 a10 = row1 ? *(const f32x4*)(act + x10) : z4;
+    const f32x4 a11 = (row1 && col1) ? *(const f32x4*)(act + x11) : z4;
     const f32x4 s = *(const f32x4*)(scale + c4 * 4);
-    f32x4 r;
-    r.x = a.x > 0.f ? g.x * s.x : 0.f;
-    r.y = a.y > 0.f ? g.y * s.y : 0.f;
-    r.z = a.z > 0.f ? g.z * s.z : 0.f;
-    r.w = a.w > 0.f ? g.w * s.w : 0.f;
-    *(f32x4*)(dx + xo) = r;
+#define HND_TAKE(g, id, d, tap)            \
+  if ((id).x == (tap)) (g).x += (d).x;     \
+  if ((id).y == (tap)) (g).y += (d).y;     \
+  if ((id).z == (tap)) (g).z += (d).z;     \
+  if ((id).w == (tap)) (g).w += (d).w;
+#define HND_PUT(xo, a, g)                                                        \
+  {                                                                              \
+    f32x4 r;                                                                     \
+    r.x = (a).x > 0.f ? (g).x * s.x : 0.f; r.y = (a).y > 0.f ? (g).y * s.y : 0.f; \
+    r.z = (a).z > 0.f ? (g).z * s.z : 0.f; r.w = (a).w > 0.f ? (g).w * s.w : 0.f; \
+    *(f32x4*)(dx + (xo)) = r;                                                    \
+  }
+    f32x4 g = z4;                        // (2a, 2b): centre of window (a, b)
+    HND_TAKE(g, i00, d00, 4)
+    HND_PUT(x00, a00, g)
+    if (col1) {                          // (2a, 2b+1): right of (a, b), left of (a, b+1)
+      g = z4;
+      HND_TAKE(g, i00, d00, 5)
+      HND_TAKE(g, i01, d01, 3)
+      HND_PUT(x01, a01, g)
+    }
+    if (row1) {                          // (2a+1, 2b): below (a, b), above (a+1, b)
+      g = z4;
+      HND_TAKE(g, i00, d00, 7)
+      HND_TAKE(g, i10, d10, 1)
+      HND_PUT(x10, a10, g)
+    }
+    if (row1 && col1) {                  // (2a+1, 2b+1): a corner of all four windows
+      g = z4;
+      HND_TAKE(g, i00, d00, 8)
+      HND_TAKE(g, i01, d01, 6)
+      HND_TAKE(g, i10, d10, 2)
+      HND_TAKE(g, i11, d11, 0)
+      HND_PUT(x11, a11, g)
+    }
+#undef HND_TAKE
+#undef HND_PUT
   }
 }
 
@@ -324,15 +413,32 @@ __global__ void __launch_bounds__(1024) bn_finalize_kernel(const float* __restri
 __global__ void affine_relu_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                    const float* __restrict__ shift, float* __restrict__ y, long long n4, int cs4,
                                    int relu, uint8_t* __restrict__ mask_out) {
-  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < n4; e += (long long)gridDim.x * blockDim.x) {
-    const int c4 = (int)(e % cs4);
-    const f32x4 v = *(const f32x4*)(x + e * 4);
-    const f32x4 s = *(const f32x4*)(scale + c4 * 4), b = *(const f32x4*)(shift + c4 * 4);
-    f32x4 r = v * s + b;
-    if (relu) { r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f); }
-    *(f32x4*)(y + e * 4) = r;
-    if (mask_out)       // ReLU-mask nibble of these four channels (hnd_conv_desc.mask_out's layout)
-      mask_out[e] = (uint8_t)((r.x > 0.f ? 1 : 0) | (r.y > 0.f ? 2 : 0) | (r.z > 0.f ? 4 : 0) | (r.w > 0.f ? 8 : 0));
+  const bool fixed = (256 % cs4) == 0;               // this lane's channel group never changes
+  const int c4f = threadIdx.x % cs4;
+  f32x4 s = *(const f32x4*)(scale + c4f * 4), b = *(const f32x4*)(shift + c4f * 4);
+  const long long chunk = 256ll * kEwU;
+  for (long long base = blockIdx.x * chunk + threadIdx.x; base < n4; base += (long long)gridDim.x * chunk) {
+    f32x4 v[kEwU];
+#pragma unroll
+    for (int u = 0; u < kEwU; ++u) {
+      const long long e = base + 256ll * u;
+      if (e < n4) v[u] = *(const f32x4*)(x + e * 4);
+    }
+#pragma unroll
+    for (int u = 0; u < kEwU; ++u) {
+      const long long e = base + 256ll * u;
+      if (e >= n4) continue;
+      if (!fixed) {
+        const int c4 = (int)(e % cs4);
+        s = *(const f32x4*)(scale + c4 * 4);
+        b = *(const f32x4*)(shift + c4 * 4);
+      }
+      f32x4 r = v[u] * s + b;
+      if (relu) { r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f); }
+      *(f32x4*)(y + e * 4) = r;
+      if (mask_out)     // ReLU-mask nibble of these four channels (hnd_conv_desc.mask_out's layout)
+        mask_out[e] = (uint8_t)((r.x > 0.f ? 1 : 0) | (r.y > 0.f ? 2 : 0) | (r.z > 0.f ? 4 : 0) | (r.w > 0.f ? 8 : 0));
+    }
   }
 }
 
@@ -354,17 +460,31 @@ __global__ void bn_bwd_reduce_kernel(const float* __restrict__ g, const float* _
   long long p1 = p0 + kBnTilePix;
   if (p1 > npix) p1 = npix;
   f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
-  for (long long p = p0 + r; p < p1; p += rows) {
-    const size_t o = (size_t)p * cs + c4 * 4;
-    f32x4 d = *(const f32x4*)(g + o);
-    const f32x4 xv = *(const f32x4*)(x + o);
-    if (relu) {
-      const f32x4 out = xv * sc + sh;
-      d.x = out.x > 0.f ? d.x : 0.f; d.y = out.y > 0.f ? d.y : 0.f;
-      d.z = out.z > 0.f ? d.z : 0.f; d.w = out.w > 0.f ? d.w : 0.f;
+  // (kEwU pixels of both operands in flight per thread, summed in the original order)
+  for (long long pb = p0 + r; pb < p1; pb += (long long)rows * kEwU) {
+    f32x4 dv[kEwU], xq[kEwU];
+#pragma unroll
+    for (int u = 0; u < kEwU; ++u) {
+      const long long p = pb + (long long)rows * u;
+      if (p < p1) {
+        const size_t o = (size_t)p * cs + c4 * 4;
+        dv[u] = *(const f32x4*)(g + o);
+        xq[u] = *(const f32x4*)(x + o);
+      }
     }
-    s1 += d;
-    s2 += d * ((xv - mu) * rs);
+#pragma unroll
+    for (int u = 0; u < kEwU; ++u) {
+      if (pb + (long long)rows * u >= p1) continue;
+      f32x4 d = dv[u];
+      const f32x4 xv = xq[u];
+      if (relu) {
+        const f32x4 out = xv * sc + sh;
+        d.x = out.x > 0.f ? d.x : 0.f; d.y = out.y > 0.f ? d.y : 0.f;
+        d.z = out.z > 0.f ? d.z : 0.f; d.w = out.w > 0.f ? d.w : 0.f;
+      }
+      s1 += d;
+      s2 += d * ((xv - mu) * rs);
+    }
   }
 #pragma unroll
   for (int k = 0; k < 4; ++k) { red[0][threadIdx.x][k] = s1[k]; red[1][threadIdx.x][k] = s2[k]; }
@@ -412,23 +532,45 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __
                                     const float* __restrict__ k123, int relu, float* __restrict__ dx, long long n4,
                                     int cs) {
   const int cs4 = cs >> 2;
-  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < n4; e += (long long)gridDim.x * blockDim.x) {
-    const int c4 = (int)(e % cs4);
-    f32x4 d = *(const f32x4*)(g + e * 4);
-    const f32x4 xv = *(const f32x4*)(x + e * 4);
-    if (relu) {
-      const f32x4 out = xv * *(const f32x4*)(scale + c4 * 4) + *(const f32x4*)(shift + c4 * 4);
-      d.x = out.x > 0.f ? d.x : 0.f; d.y = out.y > 0.f ? d.y : 0.f;
-      d.z = out.z > 0.f ? d.z : 0.f; d.w = out.w > 0.f ? d.w : 0.f;
+  const bool fixed = (256 % cs4) == 0;
+  int c4 = threadIdx.x % cs4;
+  f32x4 sc = *(const f32x4*)(scale + c4 * 4), sh = *(const f32x4*)(shift + c4 * 4);
+  f32x4 k1 = *(const f32x4*)(k123 + c4 * 4), k2 = *(const f32x4*)(k123 + cs + c4 * 4),
+        k3 = *(const f32x4*)(k123 + 2 * cs + c4 * 4);
+  const long long chunk = 256ll * kEwU;
+  for (long long base = blockIdx.x * chunk + threadIdx.x; base < n4; base += (long long)gridDim.x * chunk) {
+    f32x4 dv[kEwU], xv[kEwU];
+#pragma unroll
+    for (int u = 0; u < kEwU; ++u) {
+      const long long e = base + 256ll * u;
+      if (e < n4) {
+        dv[u] = *(const f32x4*)(g + e * 4);
+        xv[u] = *(const f32x4*)(x + e * 4);
+      }
     }
-    const f32x4 k1 = *(const f32x4*)(k123 + c4 * 4), k2 = *(const f32x4*)(k123 + cs + c4 * 4),
-                k3 = *(const f32x4*)(k123 + 2 * cs + c4 * 4);
-    *(f32x4*)(dx + e * 4) = k1 * d + k2 * xv + k3;
+#pragma unroll
+    for (int u = 0; u < kEwU; ++u) {
+      const long long e = base + 256ll * u;
+      if (e >= n4) continue;
+      if (!fixed) {
+        c4 = (int)(e % cs4);
+        sc = *(const f32x4*)(scale + c4 * 4); sh = *(const f32x4*)(shift + c4 * 4);
+        k1 = *(const f32x4*)(k123 + c4 * 4); k2 = *(const f32x4*)(k123 + cs + c4 * 4);
+        k3 = *(const f32x4*)(k123 + 2 * cs + c4 * 4);
+      }
+      f32x4 d = dv[u];
+      if (relu) {
+        const f32x4 out = xv[u] * sc + sh;
+        d.x = out.x > 0.f ? d.x : 0.f; d.y = out.y > 0.f ? d.y : 0.f;
+        d.z = out.z > 0.f ? d.z : 0.f; d.w = out.w > 0.f ? d.w : 0.f;
+      }
+      *(f32x4*)(dx + e * 4) = k1 * d + k2 * xv[u] + k3;
+    }
   }
 }
 
 // ------------------------------------------------------------------------------------ loss
-constexpr int kMseBlocks = 2048;
+constexpr int kMseBlocks = 1024;   // (256 ... 16384 measured: 5.5 ... 4.8 TB/s, flat below 2048)
 constexpr int kMaxPairs = 8;
 struct MseArgs {
   hnd_mse_pair pair[kMaxPairs];
@@ -443,23 +585,38 @@ __global__ void mse_kernel(const MseArgs a, double* __restrict__ scratch) {
   const hnd_mse_pair P = a.pair[k];
   const int nb = a.first_block[k + 1] - a.first_block[k], lb = blockIdx.x - a.first_block[k];
   const long long n4 = P.numel >> 2;                 // numel is a multiple of 4 (NHWC, C % 4 == 0)
-  const long long per = (n4 + nb - 1) / nb;
-  const long long e0 = (long long)lb * per;
-  long long e1 = e0 + per;
-  if (e1 > n4) e1 = n4;
   const float gf = 2.f * P.factor;
   float acc = 0.f;
-  for (long long e = e0 + threadIdx.x; e < e1; e += blockDim.x) {
-    const f32x4 t = *(const f32x4*)(P.teacher + e * 4), s = *(const f32x4*)(P.student + e * 4);
-    const f32x4 df = s - t;
-    acc += (df.x * df.x + df.y * df.y) + (df.z * df.z + df.w * df.w);
-    if (P.grad) {
-      f32x4 gg = df * gf;
-      if (P.relu_mask) {
-        gg.x = s.x > 0.f ? gg.x : 0.f; gg.y = s.y > 0.f ? gg.y : 0.f;
-        gg.z = s.z > 0.f ? gg.z : 0.f; gg.w = s.w > 0.f ? gg.w : 0.f;
+  // The pair's nb workgroups take its 16 KB chunks (256 * kEwU vectors per tensor) round-robin, so the chunks in flight at
+  // any moment are neighbours in memory (a contiguous range per workgroup kept nb * 3 distant streams open: 4.9 TB/s
+  // against 6.0 of a plain elementwise kernel); kEwU vectors of each operand in flight per thread.  Fixed order: per thread
+  // in increasing chunk order, then the wave, then the four waves -- bit-reproducible run to run.
+  const long long chunk = 256ll * kEwU;
+  for (long long base = (long long)lb * chunk + threadIdx.x; base < n4; base += (long long)nb * chunk) {
+    f32x4 tv[kEwU], sv[kEwU];
+#pragma unroll
+    for (int u = 0; u < kEwU; ++u) {
+      const long long e = base + 256ll * u;
+      if (e < n4) {
+        tv[u] = *(const f32x4*)(P.teacher + e * 4);
+        sv[u] = *(const f32x4*)(P.student + e * 4);
       }
-      *(f32x4*)(P.grad + e * 4) = gg;
+    }
+#pragma unroll
+    for (int u = 0; u < kEwU; ++u) {
+      const long long e = base + 256ll * u;
+      if (e >= n4) continue;
+      const f32x4 s = sv[u];
+      const f32x4 df = s - tv[u];
+      acc += (df.x * df.x + df.y * df.y) + (df.z * df.z + df.w * df.w);
+      if (P.grad) {
+        f32x4 gg = df * gf;
+        if (P.relu_mask) {
+          gg.x = s.x > 0.f ? gg.x : 0.f; gg.y = s.y > 0.f ? gg.y : 0.f;
+          gg.z = s.z > 0.f ? gg.z : 0.f; gg.w = s.w > 0.f ? gg.w : 0.f;
+        }
+        *(f32x4*)(P.grad + e * 4) = gg;
+      }
     }
   }
   double dsum = wave_sum_d((double)acc);
@@ -792,8 +949,14 @@ int hnd_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* idx, int n, int h, i
   HND_REQUIRE(x && y && idx, "hnd_maxpool3x3s2_fwd: null pointer");
   HND_REQUIRE(c % 4 == 0 && oh == (h + 2 - 3) / 2 + 1 && ow == (w + 2 - 3) / 2 + 1,
               "hnd_maxpool3x3s2_fwd: bad geometry");
-  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for((long long)n * oh * ow * (c / 4))), dim3(256), 0,
-                     hnd::as_stream(stream), x, y, idx, n, h, w, c, oh, ow);
+  HND_REQUIRE((long long)n * h * w * (c / 4) < (1ll << 31), "hnd_maxpool3x3s2_fwd: more than 2^31 vectors");
+  PoolDivs dv;
+  dv.c4n = hnd::make_fastdiv((unsigned)(c / 4));
+  const int nstrips = (oh + kPoolStrip - 1) / kPoolStrip;
+  dv.w = hnd::make_fastdiv((unsigned)ow);
+  dv.h = hnd::make_fastdiv((unsigned)nstrips);
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for((long long)n * nstrips * ow * (c / 4))), dim3(256), 0,
+                     hnd::as_stream(stream), x, y, idx, n, h, w, c, oh, ow, nstrips, dv);
   return hnd::check_launch("hnd_maxpool3x3s2_fwd");
 }
 
@@ -801,8 +964,14 @@ int hnd_maxpool3x3s2_bwd_relu_scale(const float* dy, const uint8_t* idx, const f
                                     float* dx, int n, int h, int w, int c, int oh, int ow, void* stream) {
   HND_REQUIRE(dy && idx && act && fbn_scale && dx, "hnd_maxpool3x3s2_bwd_relu_scale: null pointer");
   HND_REQUIRE(c % 4 == 0, "hnd_maxpool3x3s2_bwd_relu_scale: c %% 4 != 0");
-  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for((long long)n * h * w * (c / 4))), dim3(256), 0,
-                     hnd::as_stream(stream), dy, idx, act, fbn_scale, dx, n, h, w, c, oh, ow);
+  HND_REQUIRE((long long)n * h * w * (c / 4) < (1ll << 31), "hnd_maxpool3x3s2_bwd_relu_scale: more than 2^31 vectors");
+  PoolDivs dv;
+  dv.c4n = hnd::make_fastdiv((unsigned)(c / 4));
+  HND_REQUIRE(oh == (h + 1) / 2 && ow == (w + 1) / 2, "hnd_maxpool3x3s2_bwd_relu_scale: bad geometry");
+  dv.w = hnd::make_fastdiv((unsigned)ow);
+  dv.h = hnd::make_fastdiv((unsigned)oh);
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for((long long)n * oh * ow * (c / 4))), dim3(256), 0,
+                     hnd::as_stream(stream), dy, idx, act, fbn_scale, dx, n, h, w, c, oh, ow, dv);
   return hnd::check_launch("hnd_maxpool3x3s2_bwd_relu_scale");
 }
 
@@ -823,8 +992,8 @@ int hnd_affine_relu(const float* x, const float* scale, const float* shift, floa
                     uint8_t* mask_out, void* stream) {
   HND_REQUIRE(x && scale && shift && y && npix > 0 && cs > 0 && cs % 4 == 0, "hnd_affine_relu: bad arguments");
   const long long n4 = (long long)npix * (cs / 4);
-  hipLaunchKernelGGL(affine_relu_kernel, dim3(grid_for(n4)), dim3(256), 0, hnd::as_stream(stream), x, scale, shift, y,
-                     n4, cs / 4, relu, mask_out);
+  hipLaunchKernelGGL(affine_relu_kernel, dim3(grid_for_chunks(n4)), dim3(256), 0, hnd::as_stream(stream), x, scale,
+                     shift, y, n4, cs / 4, relu, mask_out);
   return hnd::check_launch("hnd_affine_relu");
 }
 
@@ -853,8 +1022,8 @@ int hnd_bn_bwd_apply(const float* g, const float* x, const float* scale, const f
                      int relu, float* dx, int64_t npix, int cs, void* stream) {
   HND_REQUIRE(g && x && scale && shift && k123 && dx && npix > 0 && cs % 4 == 0, "hnd_bn_bwd_apply: bad arguments");
   const long long n4 = (long long)npix * (cs / 4);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(n4)), dim3(256), 0, hnd::as_stream(stream), g, x, scale, shift,
-                     k123, relu, dx, n4, cs);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for_chunks(n4)), dim3(256), 0, hnd::as_stream(stream), g, x, scale,
+                     shift, k123, relu, dx, n4, cs);
   return hnd::check_launch("hnd_bn_bwd_apply");
 }
 
@@ -876,7 +1045,7 @@ int hnd_mse_sum_fwd_bwd(const hnd_mse_pair* pairs, int npairs, double* loss_out,
   for (int k = 0; k < npairs; ++k) {
     a.first_block[k] = used;
     long long nb = (long long)(kMseBlocks - npairs) * pairs[k].numel / total + 1;
-    const long long maxb = (pairs[k].numel / 4 + 255) / 256;
+    const long long maxb = (pairs[k].numel / 4 + 256 * kEwU - 1) / (256 * kEwU);
     if (nb > maxb) nb = maxb;
     if (nb < 1) nb = 1;
     used += (int)nb;

@@ -442,9 +442,10 @@ def test_transform_u8_matches_oracle(ops, shape, size, max_size, hwc, flip):
     assert float(dst[..., 3].abs().max()) == 0.0
 
 
-def test_maxpool_fwd_bwd(ops):
-    g = gen(10)
-    n, c, h, w = 2, 64, 21, 30
+@pytest.mark.parametrize('n,c,h,w', [(2, 64, 21, 30), (1, 64, 20, 31), (3, 64, 7, 9), (1, 8, 1, 2)])
+def test_maxpool_fwd_bwd(ops, n, c, h, w):
+    """3x3 stride-2 pad-1 pool and its backward (one thread per 2 x 2 input quad) for even / odd extents"""
+    g = gen(10 + h)
     x = F.relu(torch.randn(n, c, h, w, generator=g)).requires_grad_(True)     # many exact-zero ties, as after ReLU
     y = F.max_pool2d(x, 3, 2, 1)
     dy = torch.randn(y.shape, generator=g)
