@@ -25,6 +25,7 @@ inline int grid_for(long long work_items, int threads = 256) {
 // divide the block (no 64-bit modulo per element).  tools/bench_elementwise.py: 4.7 -> ~6 TB/s, torch's own elementwise
 // kernels reach 6.0-6.2 on the same tensors.
 constexpr int kEwU = 4;
+#define HND_NT_LOAD4(p) __builtin_nontemporal_load((const f32x4*)(p))   // single-use operands of streaming passes
 inline int grid_for_chunks(long long n4) {
   long long b = (n4 + 256 * kEwU - 1) / (256 * kEwU);
   if (b < 1) b = 1;
@@ -303,10 +304,10 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const uint8_t* 
     const f32x4 d10 = wrow1 ? *(const f32x4*)(dy + o10) : z4;
     const uchar4 i11 = (wrow1 && wcol1) ? *(const uchar4*)(idx + o11) : zu;
     const f32x4 d11 = (wrow1 && wcol1) ? *(const f32x4*)(dy + o11) : z4;
-    const f32x4 a00 = *(const f32x4*)(act + x00);
-    const f32x4 a01 = col1 ? *(const f32x4*)(act + x01) : z4;
-    const f32x4 a10 = row1 ? *(const f32x4*)(act + x10) : z4;
-    const f32x4 a11 = (row1 && col1) ? *(const f32x4*)(act + x11) : z4;
+    const f32x4 a00 = HND_NT_LOAD4(act + x00);
+    const f32x4 a01 = col1 ? HND_NT_LOAD4(act + x01) : z4;
+    const f32x4 a10 = row1 ? HND_NT_LOAD4(act + x10) : z4;
+    const f32x4 a11 = (row1 && col1) ? HND_NT_LOAD4(act + x11) : z4;
     const f32x4 s = *(const f32x4*)(scale + c4 * 4);
 #define HND_TAKE(g, id, d, tap)            \
   if ((id).x == (tap)) (g).x += (d).x;     \
@@ -422,7 +423,7 @@ __global__ void affine_relu_kernel(const float* __restrict__ x, const float* __r
 #pragma unroll
     for (int u = 0; u < kEwU; ++u) {
       const long long e = base + 256ll * u;
-      if (e < n4) v[u] = *(const f32x4*)(x + e * 4);
+      if (e < n4) v[u] = HND_NT_LOAD4(x + e * 4);
     }
 #pragma unroll
     for (int u = 0; u < kEwU; ++u) {
@@ -468,8 +469,8 @@ __global__ void bn_bwd_reduce_kernel(const float* __restrict__ g, const float* _
       const long long p = pb + (long long)rows * u;
       if (p < p1) {
         const size_t o = (size_t)p * cs + c4 * 4;
-        dv[u] = *(const f32x4*)(g + o);
-        xq[u] = *(const f32x4*)(x + o);
+        dv[u] = HND_NT_LOAD4(g + o);
+        xq[u] = HND_NT_LOAD4(x + o);
       }
     }
 #pragma unroll
@@ -544,8 +545,8 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __
     for (int u = 0; u < kEwU; ++u) {
       const long long e = base + 256ll * u;
       if (e < n4) {
-        dv[u] = *(const f32x4*)(g + e * 4);
-        xv[u] = *(const f32x4*)(x + e * 4);
+        dv[u] = HND_NT_LOAD4(g + e * 4);
+        xv[u] = HND_NT_LOAD4(x + e * 4);
       }
     }
 #pragma unroll

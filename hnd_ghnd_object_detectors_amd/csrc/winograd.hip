@@ -71,6 +71,10 @@ struct WinoGeom {
 };
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+// The transformed product M is read exactly once, by the output transform: nontemporal loads keep it from displacing the
+// output rows being written (round 4, in-step A/B: wino_output 3.61 -> 3.30 ms; nontemporal STORES of V gained nothing
+// in the step -- the GEMM that follows wants V where it is).
+#define HND_NT_LOAD(p) __builtin_nontemporal_load((p))
 
 // A use of loaded values in the block that dominates a run of conditionally executed stores: hipcc's waitcnt pass
 // then waits for the loads here, once, instead of in front of every store that follows.
@@ -164,8 +168,8 @@ __global__ void wino_output_kernel(const float* __restrict__ m, float* __restric
     f32x4 s[2][4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {          // A^T m
-      const f32x4 m0 = *(const f32x4*)(src + (size_t)(0 * 4 + j) * fs), m1 = *(const f32x4*)(src + (size_t)(1 * 4 + j) * fs),
-                  m2 = *(const f32x4*)(src + (size_t)(2 * 4 + j) * fs), m3 = *(const f32x4*)(src + (size_t)(3 * 4 + j) * fs);
+      const f32x4 m0 = HND_NT_LOAD((const f32x4*)(src + (size_t)(0 * 4 + j) * fs)), m1 = HND_NT_LOAD((const f32x4*)(src + (size_t)(1 * 4 + j) * fs)),
+                  m2 = HND_NT_LOAD((const f32x4*)(src + (size_t)(2 * 4 + j) * fs)), m3 = HND_NT_LOAD((const f32x4*)(src + (size_t)(3 * 4 + j) * fs));
       s[0][j] = m0 + m1 + m2;
       s[1][j] = m1 - m2 - m3;
     }
@@ -348,9 +352,9 @@ __global__ void wino4_output_kernel(const float* __restrict__ m, float* __restri
     f32x2 s[4][6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) {          // A^T m (down the columns)
-      const f32x2 m0 = *(const f32x2*)(src + (size_t)(0 * 6 + j) * fs), m1 = *(const f32x2*)(src + (size_t)(1 * 6 + j) * fs),
-                  m2 = *(const f32x2*)(src + (size_t)(2 * 6 + j) * fs), m3 = *(const f32x2*)(src + (size_t)(3 * 6 + j) * fs),
-                  m4 = *(const f32x2*)(src + (size_t)(4 * 6 + j) * fs), m5 = *(const f32x2*)(src + (size_t)(5 * 6 + j) * fs);
+      const f32x2 m0 = HND_NT_LOAD((const f32x2*)(src + (size_t)(0 * 6 + j) * fs)), m1 = HND_NT_LOAD((const f32x2*)(src + (size_t)(1 * 6 + j) * fs)),
+                  m2 = HND_NT_LOAD((const f32x2*)(src + (size_t)(2 * 6 + j) * fs)), m3 = HND_NT_LOAD((const f32x2*)(src + (size_t)(3 * 6 + j) * fs)),
+                  m4 = HND_NT_LOAD((const f32x2*)(src + (size_t)(4 * 6 + j) * fs)), m5 = HND_NT_LOAD((const f32x2*)(src + (size_t)(5 * 6 + j) * fs));
       HND_WINO4_AT(m0, m1, m2, m3, m4, m5, s[0][j], s[1][j], s[2][j], s[3][j]);
     }
     arrive(es, eb);
@@ -558,7 +562,7 @@ __global__ void __launch_bounds__(256) wino6_output_kernel(const float* __restri
     for (int j = 0; j < 8; ++j) {          // A^T m (down the columns)
       f32x2 mm[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) mm[i] = *(const f32x2*)(src + (size_t)(i * 8 + j) * fs);
+      for (int i = 0; i < 8; ++i) mm[i] = HND_NT_LOAD((const f32x2*)(src + (size_t)(i * 8 + j) * fs));
       HND_WINO6_AT(mm[0], mm[1], mm[2], mm[3], mm[4], mm[5], mm[6], mm[7], s[0][j], s[1][j], s[2][j], s[3][j], s[4][j],
                    s[5][j]);
     }
@@ -764,9 +768,9 @@ __global__ void wino2_output_kernel(const float* __restrict__ m, float* __restri
     f32x2 s[4][5];
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
-      const f32x2 m0 = *(const f32x2*)(src + (size_t)(0 * 5 + j) * fs), m1 = *(const f32x2*)(src + (size_t)(1 * 5 + j) * fs),
-                  m2 = *(const f32x2*)(src + (size_t)(2 * 5 + j) * fs), m3 = *(const f32x2*)(src + (size_t)(3 * 5 + j) * fs),
-                  m4 = *(const f32x2*)(src + (size_t)(4 * 5 + j) * fs);
+      const f32x2 m0 = HND_NT_LOAD((const f32x2*)(src + (size_t)(0 * 5 + j) * fs)), m1 = HND_NT_LOAD((const f32x2*)(src + (size_t)(1 * 5 + j) * fs)),
+                  m2 = HND_NT_LOAD((const f32x2*)(src + (size_t)(2 * 5 + j) * fs)), m3 = HND_NT_LOAD((const f32x2*)(src + (size_t)(3 * 5 + j) * fs)),
+                  m4 = HND_NT_LOAD((const f32x2*)(src + (size_t)(4 * 5 + j) * fs));
       HND_WINO2_AT(m0, m1, m2, m3, m4, s[0][j], s[1][j], s[2][j], s[3][j]);
     }
     f32x2 es = {1.f, 1.f}, eb = {0.f, 0.f};
@@ -1086,7 +1090,7 @@ __global__ void __launch_bounds__(256) wino26_output_kernel(const float* __restr
     for (int j = 0; j < 7; ++j) {
       f32x2 col[7], o[6];
 #pragma unroll
-      for (int i = 0; i < 7; ++i) col[i] = *(const f32x2*)(src + (size_t)(i * 7 + j) * fs);
+      for (int i = 0; i < 7; ++i) col[i] = HND_NT_LOAD((const f32x2*)(src + (size_t)(i * 7 + j) * fs));
       mat_apply(W6_AT, col, o);
 #pragma unroll
       for (int a = 0; a < 6; ++a) s[a][j] = o[a];
