@@ -11,7 +11,8 @@
 // 16-pixel run, tap 4*kg + g4, 4 channels -- is then exactly ONE ds_read_b128 of the patch.  No k-loop staging, no
 // barrier after the fill.
 // The k order is the generic kernel's (k = 4*tap + channel; MFMA s of k group kg sums channel s of taps 4kg..4kg+3)
-// and the epilogue expression is the same, so the result is bit-identical (tests/test_ops_gpu.py).
+// and the epilogue expression is the same, so the result is bit-identical (tests/test_ops_gpu.py).  Round 4: the MFMAs of
+// the pad channel (s = 3: zero weights for a 3-channel image) are not issued -- 39 instead of 52 per row group.
 #include "common.h"
 
 #include <stdlib.h>
@@ -35,10 +36,17 @@ __global__ void __launch_bounds__(256, 2) stem7_kernel(const hnd_conv_desc d, co
 
   // ---- once per workgroup: the weights (k < 208 of the 64 packed rows).  Workgroups are persistent (two per CU
   // walk the tiles with the grid's stride), so the 54 KB are not re-read for each of the 16 800 tiles of a batch.
+  int w3 = 0;                                    // does any weight of the 4th input channel differ from 0?
   for (int e = tid; e < 64 * (KG * 4); e += 256) {
     const int r = e / (KG * 4), c = e - r * (KG * 4);
-    *(f32x4*)(ws + r * WLD + c * 4) = *(const f32x4*)(d.w + (size_t)r * d.kdim + c * 4);
+    const f32x4 wv = *(const f32x4*)(d.w + (size_t)r * d.kdim + c * 4);
+    *(f32x4*)(ws + r * WLD + c * 4) = wv;
+    w3 |= (wv.w != 0.f) ? 1 : 0;
   }
+  // MFMA s of a k group multiplies channel s of four taps.  For the 3-channel image stored NHWC4 (the only user:
+  // custom/resnet.py:26) the weights of channel 3 are exactly 0, so s = 3 -- a quarter of the matrix work -- adds 0 to
+  // every accumulator and is not issued; a genuine 4-channel conv keeps it.
+  const bool four = __syncthreads_or(w3) != 0;
   // this lane's tap of every k group: offset (floats) inside the patch; taps >= 49 read tap 48 (their weights are 0)
   int toff[KG];
 #pragma unroll
@@ -116,12 +124,18 @@ __global__ void __launch_bounds__(256, 2) stem7_kernel(const hnd_conv_desc d, co
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi) a[mi] = *(const f32x4*)(ap[mi] + toff[kg]);
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
+      for (int mi = 0; mi < 4; ++mi) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+        for (int s = 0; s < 3; ++s)
 #pragma unroll
           for (int ni = 0; ni < 4; ++ni)
             acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi][s], bq[ni][s], acc[mi][ni], 0, 0, 0);
+        if (four) {
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi][3], bq[ni][3], acc[mi][ni], 0, 0, 0);
+        }
+      }
     }
 
     // ---- epilogue: the lane holds pixels 4*g4 + i of each 16-pixel run and channels 4*l16 .. 4*l16 + 3
@@ -167,16 +181,25 @@ __global__ void __launch_bounds__(256, 3) stem7_wgrad_kernel(const hnd_wgrad_des
   const int l16 = lane & 15, g4 = lane >> 4;
   const int ntiles = d.n * tiles_x * tiles_y;
 
-  // this wave's column tiles nt = wave, wave + 4, wave + 8, (wave + 12): column n = 16 nt + l16 = 4 tap + c
-  int boff[4];
+  // Columns of the GEMM are (tap, channel) pairs.  With three real channels (cin_real == 3: the NHWC4 image; the
+  // reduce kernel reads only the real channels of a slab) they are enumerated channel-major, n = 49 c + tap: 147 columns
+  // = 10 column tiles instead of the 13 of the tap-major order 4 tap + c, whose every 4th column is the pad channel
+  // (round 4: the busiest wave owns 3 tiles instead of 4).  This wave's column tiles: nt = wave, wave + 4, wave + 8,
+  // (wave + 12).
+  const int ntn = d.cin_real == 3 ? 10 : 13;
+  int boff[4], ncol[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int n = (wave + 4 * q) * 16 + l16;
-    int t = n >> 2;
-    t = t < 49 ? t : 48;                             // columns >= 196 are never read back
-    boff[q] = ((t / 7) * WPW + (t % 7)) * 4 + (n & 3) + 32 * g4;      // + 2 * (4 g4) pixels of 4 floats
+    int t, c;
+    if (ntn == 13) { t = n >> 2; c = n & 3; }
+    else { c = n / 49; t = n - 49 * c; }
+    const bool real = ntn == 13 ? t < 49 : n < 147;
+    if (!real) { t = 48; c = ntn == 13 ? (n & 3) : 2; }           // padding columns: read something valid, never stored
+    boff[q] = ((t / 7) * WPW + (t % 7)) * 4 + c + 32 * g4;        // + 2 * (4 g4) pixels of 4 floats
+    ncol[q] = real ? 4 * t + c : -1;                              // column in the slab (the generic kernel's layout)
   }
-  const bool has4 = wave + 12 < 13;
+  const bool has[4] = {true, wave + 4 < ntn, wave + 8 < ntn, wave + 12 < ntn};
   f32x4 acc[4][4];
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi)
@@ -230,22 +253,23 @@ __global__ void __launch_bounds__(256, 3) stem7_wgrad_kernel(const hnd_wgrad_des
 #pragma unroll
         for (int s_ = 0; s_ < 4; ++s_) {
 #pragma unroll
-          for (int q = 0; q < 3; ++q)
+          for (int q = 0; q < 2; ++q)
             acc[mi][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi][s_], bq[q][s_], acc[mi][q], 0, 0, 0);
-          if (has4) acc[mi][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi][s_], bq[3][s_], acc[mi][3], 0, 0, 0);
+          if (has[2]) acc[mi][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi][s_], bq[2][s_], acc[mi][2], 0, 0, 0);
+          if (has[3]) acc[mi][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi][s_], bq[3][s_], acc[mi][3], 0, 0, 0);
         }
     }
   }
-  // ---- one slab per workgroup: [64][ncols_pad], column = 4 tap + c (the generic kernel's layout)
+  // ---- one slab per workgroup: [64][ncols_pad], column = 4 tap + c (the generic kernel's layout; with cin_real == 3 the
+  // pad-channel columns are neither computed nor written -- wgrad_reduce_kernel never reads them)
   float* slab = d.slabs + (size_t)blockIdx.x * 64 * ncols_pad;
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      if (q == 3 && !has4) continue;
-      const int ncol = (wave + 4 * q) * 16 + l16;
+      if (!has[q] || ncol[q] < 0) continue;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) slab[(size_t)(mi * 16 + 4 * g4 + i) * ncols_pad + ncol] = acc[mi][q][i];
+      for (int i = 0; i < 4; ++i) slab[(size_t)(mi * 16 + 4 * g4 + i) * ncols_pad + ncol[q]] = acc[mi][q][i];
     }
 }
 

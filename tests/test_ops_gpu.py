@@ -1415,6 +1415,29 @@ def test_stem_conv_from_lds_patch_is_bit_identical_and_matches_torch(ops, n, h, 
     assert relerr(nchw(outs['1']), ref) < 1e-5
 
 
+def test_stem_kernel_keeps_the_fourth_channel_of_a_genuine_four_channel_conv(ops, monkeypatch):
+    """the stem kernel does not issue the MFMAs of channel 3 when the packed weights of that channel are all zero (the
+    3-channel image stored NHWC4); a 7x7 stride-2 conv with FOUR real input channels takes the same kernel and must still
+    count the fourth: identical bits to the generic kernel, and equal to torch"""
+    g = torch.Generator().manual_seed(22)
+    n, h, w = 2, 75, 133
+    x = torch.randn(n, 4, h, w, generator=g)
+    wt = torch.randn(64, 4, 7, 7, generator=g) * (1.0 / 196 ** 0.5)
+    xd = nhwc(x, 4)
+    pk = ops.pack_weights(wt.to(DEV).contiguous(), chan_pad=4)
+    oh, ow = ops.conv_out_size(h, 7, 2, 3), ops.conv_out_size(w, 7, 2, 3)
+    outs = {}
+    for mode in ('0', '1'):
+        monkeypatch.setenv('HND_STEM7', mode)
+        y = torch.full((n, oh, ow, 64), float('nan'), device=DEV)
+        l = ops.conv_forward(xd, pk, y, 7, 2, 3)
+        l.run()
+        ops.sync_check()
+        outs[mode] = (y, l.variant)
+    assert outs['1'][1] == 'stem7_lds' and torch.equal(outs['0'][0], outs['1'][0])
+    assert relerr(nchw(outs['1'][0]), F.conv2d(x, wt, stride=2, padding=3)) < 1e-5
+
+
 @pytest.mark.parametrize('n,h,w', [(2, 800, 1344), (1, 75, 133), (3, 64, 96)])
 def test_stem_weight_gradient_from_lds_patch(ops, n, h, w, monkeypatch):
     """csrc/conv_stem.hip stem7_wgrad_kernel: dW of the 7x7 stride-2 stem with dy transposed into LDS and the input
@@ -1442,6 +1465,24 @@ def test_stem_weight_gradient_from_lds_patch(ops, n, h, w, monkeypatch):
     assert res['0'][1] == 'wgrad_m64' and res['1'][1] == 'stem7_wgrad'
     assert relerr(res['1'][0], wt.grad) < 2e-5, relerr(res['1'][0], wt.grad)
     assert relerr(res['1'][0], res['0'][0]) < 2e-5
+
+
+def test_stem_weight_gradient_with_four_real_input_channels(ops, monkeypatch):
+    """with cin_real == 3 the stem's weight-gradient kernel enumerates its columns channel-major and skips the pad channel
+    (10 column tiles); a conv with FOUR real input channels keeps the tap-major 13 tiles and every column"""
+    g = torch.Generator().manual_seed(32)
+    n, h, w = 2, 75, 133
+    x = torch.randn(n, 4, h, w, generator=g)
+    wt = (torch.randn(64, 4, 7, 7, generator=g) * (1.0 / 196 ** 0.5)).requires_grad_(True)
+    out = F.conv2d(x, wt, stride=2, padding=3)
+    dy = torch.randn(out.shape, generator=g)
+    out.backward(dy)
+    monkeypatch.setenv('HND_STEM7', '1')
+    dw = torch.full((64, 4, 7, 7), float('nan'), device=DEV)
+    l = ops.conv_wgrad(nhwc(x, 4), nhwc(dy), dw, 7, 2, 3)
+    l.run()
+    ops.sync_check()
+    assert l.variant == 'stem7_wgrad' and relerr(dw.cpu(), wt.grad) < 2e-5, (l.variant, relerr(dw.cpu(), wt.grad))
 
 
 def test_jpeg_codec_and_data_logger_follow_the_reference(tmp_path):
