@@ -38,16 +38,11 @@ def _defer_fpn_default():
     env = os.environ.get('HND_DEFER_FPN')
     if env is not None:
         return env != '0'
-    try:
-        local_world = int(os.environ.get('LOCAL_WORLD_SIZE') or os.environ.get('WORLD_SIZE') or 1)
-    except ValueError:
-        local_world = 1
-    devices = torch.cuda.device_count() if torch.cuda.is_available() else 1
-    if local_world > max(devices, 1):
+    if not E.process_owns_device():
         if not _WARNED['defer_fpn']:
             _WARNED['defer_fpn'] = True
-            print('DistillationBox: %d local ranks share %d GPU(s): feature pyramids stay on the main stream '
-                  '(HND_DEFER_FPN=1 forces the deferred stream)' % (local_world, devices))
+            print('DistillationBox: more local ranks than visible GPUs: feature pyramids and the head\'s weight gradients '
+                  'stay on the main stream (HND_DEFER_FPN=1 / HND_WGRAD_STREAM=1 force the side streams)')
         return False
     return True
 

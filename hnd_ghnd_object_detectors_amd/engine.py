@@ -191,6 +191,26 @@ MASK_BITS = os.environ.get('HND_MASK_BITS', '1') != '0'
 # BatchNorm backward "apply" of the two deep decoder convs fused into the two transforms that consume dy (ops.wino26_bnbwd_step)
 FUSE_BNBWD = os.environ.get('HND_FUSE_BNBWD', '1') != '0'
 WINO_WGRAD_OWN_V = os.environ.get('HND_WINO_WGRAD_OWN_V', '1') != '0'
+
+
+def process_owns_device():
+    """False when more local ranks than visible GPUs time-share a device: extra HIP streams then make a step ~50x slower
+    (distillation/tool.py), so the optional side streams stay off there"""
+    try:
+        local_world = int(os.environ.get('LOCAL_WORLD_SIZE') or os.environ.get('WORLD_SIZE') or 1)
+    except ValueError:
+        local_world = 1
+    devices = torch.cuda.device_count() if torch.cuda.is_available() else 1
+    return local_world <= max(devices, 1)
+
+
+def wgrad_stream_on():
+    """the head's weight-gradient chains (independent of the data-gradient chain given dy) on a stream of their own:
+    HND_WGRAD_STREAM=0/1 decides when set, else on when this process has its GPU to itself"""
+    env = os.environ.get('HND_WGRAD_STREAM')
+    return (env != '0') if env is not None else process_owns_device()
+
+
 # BatchNorm backward "reduce" of a head layer folded into the output transform of the data gradient that produces its g
 FOLD_BNBWD_REDUCE = os.environ.get('HND_FOLD_BNBWD_REDUCE', '1') != '0'
 WINOGRAD6 = os.environ.get('HND_WINOGRAD6', '1') != '0'       # F(6x6,3x3) on maps large enough (wino_tile_for)
@@ -841,6 +861,11 @@ class HeadEngine(object):
             self._build_backward(grad_dst, need_input_grad)
             self.bwd_key = key
         b = self.bufs
+        side = main = None
+        if self.bwd_side and not PROFILE['enabled']:
+            if getattr(self, '_wgrad_stream', None) is None:
+                self._wgrad_stream = torch.cuda.Stream(device=self.g_out.device)
+            side, main = self._wgrad_stream, torch.cuda.current_stream()
         for i in range(len(self.layers) - 1, -1, -1):
             hc, st = self.layers[i], self.bsteps[i]
             g = st['g']
@@ -856,15 +881,34 @@ class HeadEngine(object):
                 _run(st['fused'], 'layer1.conv%d.bnbwd_transforms' % i)
             else:
                 ops.bn_bwd_apply(g, self.y[i], self.scale[i], self.shift[i], st['k123'], hc.relu, g)   # in place -> dy
-            for l, tag in st['wgrad']:
-                _run(l, tag)
+            if side is not None and st['wgrad']:
+                # dy (or Z) of this layer is complete on the main stream here; the weight gradient reads it, the kept
+                # forward V and buffers of its own, and writes only dW: it runs beside the data-gradient chain
+                st['ev'].record(main)
+                side.wait_event(st['ev'])
+                with torch.cuda.stream(side):
+                    for l, tag in st['wgrad']:
+                        _run(l, tag)
+            else:
+                for l, tag in st['wgrad']:
+                    _run(l, tag)
             for l, tag in st['dgrad']:
                 _run(l, tag)
+        self._side_pending = side
         return self.g_in if need_input_grad else None
+
+    def join_wgrad_stream(self):
+        """the weight gradients enqueued beside the data-gradient chain are complete for whatever the caller's stream
+        does next (called after the stem's backward, which they also run beside)"""
+        side = getattr(self, '_side_pending', None)
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
+            self._side_pending = None
 
     def _build_backward(self, grad_dst, need_input_grad):
         b = self.bufs
         self.bsteps = [None] * len(self.layers)
+        self.bwd_side = bool(self.g_out.is_cuda and wgrad_stream_on())   # (the plan below gives Z buffers of their own)
         flops = 0
         nl = len(self.layers)
         # gradient buffers: g[i] = grad w.r.t. BN_i output (then, in place, w.r.t. raw conv_i output)
@@ -878,7 +922,7 @@ class HeadEngine(object):
             slab_bytes = max(slab_bytes, ops.wgrad_workspace_bytes(n, h, w, hc.cs_in, oh, ow, hc.cout, 2, 1, hc.pad))
         slabs = b.get('slabs', ((slab_bytes + 3) // 4,))
         for i, hc in enumerate(self.layers):
-            st = {'folded': None}
+            st = {'folded': None, 'ev': torch.cuda.Event() if self.bwd_side else None}
             npix = self.count[i]
             st['g'] = gbuf[i]
             st['ntiles'] = ops.bn_bwd_ntiles(npix)
@@ -899,6 +943,9 @@ class HeadEngine(object):
                 # Winograd-domain weight gradient: forward V x transformed dy, 25 grouped split-K reductions
                 fw = self.wino_fwd[i]
                 _, zbuf = self._wino_scratch(fw.geom[0], fw.geom[4], fw.geom[5], hc.cs_in, hc.cs_out, fw.tile)
+                if self.bwd_side:       # Z must outlive the data gradient's M (which the shared scratch aliases)
+                    zbuf = b.get('wino_z%d' % i, (ops.Wino2Conv.scratch_elems(fw.geom[0], fw.geom[4], fw.geom[5], hc.cs_in,
+                                                                             hc.cs_out, fw.tile)[1],))
                 sbuf = b.get('wino_s%d' % i, (fw.ww.ncomp * hc.cout * hc.cin,))
                 wg_obj = ops.Wino2Wgrad(fw, gbuf[i], dw, zbuf, sbuf, b.get('wino_slabs', (self._wino_slab_elems(fw, hc),)))
                 st['wgrad'] = wg_obj.launches('layer1.conv%d.wgrad' % i)
@@ -911,6 +958,8 @@ class HeadEngine(object):
                 own = ops.Wino2InputTransform(src, vw, hc.pad, hc.cout, 6, pro_scale=pro[0], pro_shift=pro[1],
                                               pro_relu=pro[2])
                 _, zbuf = self._wino_scratch(n_, oh_, ow_, hc.cs_in, hc.cs_out, 6)
+                if self.bwd_side:
+                    zbuf = b.get('wino_z%d' % i, (ops.Wino2Conv.scratch_elems(n_, oh_, ow_, hc.cs_in, hc.cs_out, 6)[1],))
                 sbuf = b.get('wino_s%d' % i, (own.ww.ncomp * hc.cout * hc.cin,))
                 wg_obj = ops.Wino2Wgrad(own, gbuf[i], dw, zbuf, sbuf, b.get('wino_slabs', (self._wino_slab_elems(own, hc),)))
                 wg = wg_obj.launches('layer1.conv%d.wgrad' % i)

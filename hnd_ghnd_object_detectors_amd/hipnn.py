@@ -289,6 +289,7 @@ class IntermediateLayerGetter(nn.ModuleDict):
                                       'distillation path')
         g_x0 = l1.head_engine().backward(grad_dst, need_input_grad=dw1 is not None)
         self.stem().backward(g_x0, dw1)
+        l1.head_engine().join_wgrad_stream()
 
 
 class LastLevelMaxPool(nn.Module):
