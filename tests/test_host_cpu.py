@@ -279,3 +279,75 @@ def test_relay_work_split_covers_every_unit_once_and_pairs_heads_with_tails():
         for lb, (tile, it1) in heads.items():
             assert tails.get(lb + 1) == (tile, it1), (lb, heads[lb], tails.get(lb + 1))
         assert len(tails) == len(heads)
+
+
+def test_side_streams_only_when_the_process_owns_its_gpu(monkeypatch):
+    """engine.process_owns_device / wgrad_stream_on and tool._defer_fpn_default: the optional side streams (pyramids,
+    the head's weight gradients) default on only when there are no more local ranks than visible devices; the
+    environment switches decide when set"""
+    from hnd_ghnd_object_detectors_amd import engine as E
+    from hnd_ghnd_object_detectors_amd.distillation import tool
+    for k in ('LOCAL_WORLD_SIZE', 'WORLD_SIZE', 'HND_WGRAD_STREAM', 'HND_DEFER_FPN'):
+        monkeypatch.delenv(k, raising=False)
+    assert E.process_owns_device() and E.wgrad_stream_on() and tool._defer_fpn_default()
+    monkeypatch.setenv('LOCAL_WORLD_SIZE', '4')             # (no GPU here: one "device")
+    assert not E.process_owns_device() and not E.wgrad_stream_on() and not tool._defer_fpn_default()
+    monkeypatch.setenv('HND_WGRAD_STREAM', '1')
+    monkeypatch.setenv('HND_DEFER_FPN', '1')
+    assert E.wgrad_stream_on() and tool._defer_fpn_default()
+    monkeypatch.setenv('LOCAL_WORLD_SIZE', '1')
+    monkeypatch.setenv('HND_WGRAD_STREAM', '0')
+    assert E.process_owns_device() and not E.wgrad_stream_on()
+
+
+def test_step_loss_without_a_host_copy_behaves_like_a_tensor():
+    """hip_loss.StepLoss: results of arithmetic on a loss (no early host copy of their own) fall back to Tensor.item();
+    a loss with a copy returns the copied float after waiting for its event; autograd still reaches the function"""
+    from hnd_ghnd_object_detectors_amd.distillation.hip_loss import StepLoss
+
+    class Fn(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, v, p):
+            return v.clone()
+
+        @staticmethod
+        def backward(ctx, g):
+            return None, torch.full((3,), 2.0) * g
+
+    waited = []
+    p = torch.zeros(3, requires_grad=True)
+    loss = Fn.apply(torch.tensor(2.5), p).as_subclass(StepLoss)
+    loss._host = (torch.tensor(2.5), type('Ev', (), {'synchronize': lambda self: waited.append(1)})())
+    assert isinstance(loss, StepLoss) and loss.requires_grad
+    assert loss.item() == 2.5 and float(loss) == 2.5 and waited == [1, 1]
+    doubled = loss * 2
+    assert doubled.item() == 5.0 and len(waited) == 2       # (no copy of its own: plain Tensor.item)
+    loss.backward()
+    assert torch.equal(p.grad, torch.full((3,), 2.0))
+
+
+def test_trace_and_picker_tools_on_synthetic_input(tmp_path):
+    """tools/idle_gaps.py and tools/compare_pickers.py parse what rocprofv3 / bench.py --detail write"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    trace = tmp_path / 'trace.csv'
+    rows = ['"Kind","Kernel_Name","Start_Timestamp","End_Timestamp"']
+    t = 0
+    for step in range(5):
+        for name, dur, gap in (('conv_a', 1000000, 0), ('conv_b', 2000000, 20000), ('adam_kernel', 10000, 0)):
+            t += gap
+            rows.append('"KERNEL_DISPATCH","%s",%d,%d' % (name, t, t + dur))
+            t += dur
+        t += 400000                                          # the host catches up between steps
+    trace.write_text('\n'.join(rows) + '\n')
+    out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'idle_gaps.py'), str(trace), '--steps', '2',
+                          '--skip_last', '1'], capture_output=True, text=True, check=True).stdout
+    assert 'window: 2 steps, 6 kernel launches' in out and 'idle 0.220' in out, out
+    a, b = tmp_path / 'a.txt', tmp_path / 'b.txt'
+    head = 'launch                             kernel           n        ms     GFLOP  TFLOP/s  shape\n'
+    a.write_text(head + 'layer2.0.conv2.dgrad  bstream_128  3  0.817  70.46  86.23\nfpn.layer0  bres2_128  2  4.0  511.1  127.0\n')
+    b.write_text(head + 'layer2.0.conv2.dgrad  igemm_128x128  4  0.780  79.27  101.5\nfpn.layer0  bres2_128  2  4.0  511.1  127.0\n')
+    out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'compare_pickers.py'), str(a), 'tiled=' + str(b)],
+                         capture_output=True, text=True, check=True).stdout
+    assert '+ layer2.0.conv2.dgrad' in out and "'tiled': 0.037" in out, out
