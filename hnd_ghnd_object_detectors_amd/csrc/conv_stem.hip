@@ -183,70 +183,105 @@ __global__ void __launch_bounds__(256, 3) stem7_wgrad_kernel(const hnd_wgrad_des
 
   // Columns of the GEMM are (tap, channel) pairs.  With three real channels (cin_real == 3: the NHWC4 image; the
   // reduce kernel reads only the real channels of a slab) they are enumerated channel-major, n = 49 c + tap: 147 columns
-  // = 10 column tiles instead of the 13 of the tap-major order 4 tap + c, whose every 4th column is the pad channel
-  // (round 4: the busiest wave owns 3 tiles instead of 4).  This wave's column tiles: nt = wave, wave + 4, wave + 8,
-  // (wave + 12).
+  // = 10 column tiles instead of the 13 of the tap-major order 4 tap + c, whose every 4th column is the pad channel.
+  // Work split (round 4): a wave owns all 64 output channels of the column tiles wave, wave + 4 (, wave + 8), and ONE row
+  // group (16 output channels: mi == wave) of the remaining tiles 8, 9 (tile 12 with four channels) -- 10 (13) units of
+  // 16 x 16 per wave and k step, where 3 + 3 + 2 + 2 whole tiles left two waves waiting at the barrier.
   const int ntn = d.cin_real == 3 ? 10 : 13;
-  int boff[4], ncol[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int n = (wave + 4 * q) * 16 + l16;
+  const int nown = ntn == 10 ? 2 : 3, nsh = ntn - 4 * nown;      // tiles owned whole / shared by row group
+  auto col_of = [&](int nt, int& boff_, int& ncol_) {
+    const int n = nt * 16 + l16;
     int t, c;
     if (ntn == 13) { t = n >> 2; c = n & 3; }
     else { c = n / 49; t = n - 49 * c; }
     const bool real = ntn == 13 ? t < 49 : n < 147;
     if (!real) { t = 48; c = ntn == 13 ? (n & 3) : 2; }           // padding columns: read something valid, never stored
-    boff[q] = ((t / 7) * WPW + (t % 7)) * 4 + c + 32 * g4;        // + 2 * (4 g4) pixels of 4 floats
-    ncol[q] = real ? 4 * t + c : -1;                              // column in the slab (the generic kernel's layout)
-  }
-  const bool has[4] = {true, wave + 4 < ntn, wave + 8 < ntn, wave + 12 < ntn};
-  f32x4 acc[4][4];
+    boff_ = ((t / 7) * WPW + (t % 7)) * 4 + c + 32 * g4;          // + 2 * (4 g4) pixels of 4 floats
+    ncol_ = real ? 4 * t + c : -1;                                // column in the slab (the generic kernel's layout)
+  };
+  int boff[3], ncol[3], boffs[2], ncols[2];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) col_of(wave + 4 * q, boff[q], ncol[q]);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) col_of(4 * nown + j, boffs[j], ncols[j]);
+  f32x4 acc[4][3], accs[2];
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) acc[mi][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < 3; ++q) acc[mi][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  accs[0] = accs[1] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  // the next tile's input patch (777 pixels: 4 float4 per thread) and dy tile (128 pixels x 64 channels: 8 float4 per
+  // thread) are requested before this tile's MFMAs and written to LDS after them (round 4: the wave spent 49 % of its
+  // life parked at the fill of the tile it was about to compute, SQ_WAIT_ANY in profiles/r04_wgrad_sq_counters.txt)
+  constexpr int PPT = (WPH * WPW + 255) / 256, DPT = (WTH * WTW) / 16;
+  f32x4 pre_p[PPT], pre_d[DPT];
+  const int c4 = tid & 15;
+  auto fetch = [&](int tile) {
     int b = tile;
     const int tx = b % tiles_x;
     b /= tiles_x;
     const int ty = b % tiles_y, n = b / tiles_y;
     const int oy0 = ty * WTH, ox0 = tx * WTW;
     const int iy0 = 2 * oy0 - 3, ix0 = 2 * ox0 - 3;
-    __syncthreads();                                 // the previous tile's fragment reads are done
     const float* img = d.x + (size_t)n * d.h * d.w_ * 4;
-    for (int e = tid; e < WPH * WPW; e += 256) {
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < PPT; ++q) {
+      const int e = tid + 256 * q;
       const int py = e / WPW, px = e - py * WPW;
       const int iy = iy0 + py, ix = ix0 + px;
-      const bool ok = (unsigned)iy < (unsigned)d.h && (unsigned)ix < (unsigned)d.w_;
+      const bool ok = e < WPH * WPW && (unsigned)iy < (unsigned)d.h && (unsigned)ix < (unsigned)d.w_;
       const f32x4 v = *(const f32x4*)(img + (ok ? ((size_t)iy * d.w_ + ix) * 4 : 0));
-      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      *(f32x4*)(patch + e * 4) = ok ? v : z;
+      pre_p[q] = ok ? v : z;
     }
-    {   // dy tile, transposed: thread = (pixel group, 4 channels); 16 threads read one pixel's 256 bytes
-      const int c4 = tid & 15;
 #pragma unroll
-      for (int j = 0; j < (WTH * WTW) / 16; ++j) {
-        const int p = (tid >> 4) + 16 * j;           // pixel of the tile: row p / 16, col p % 16
-        const int oy = oy0 + p / WTW, ox = ox0 + p % WTW;
-        const bool ok = oy < d.oh && ox < d.ow;
-        const f32x4 v = *(const f32x4*)(d.dy + (ok ? (((size_t)n * d.oh + oy) * d.ow + ox) * (size_t)d.ldy + c4 * 4 : 0));
-        dyt[(c4 * 4 + 0) * DYLD + p] = ok ? v.x : 0.f;
-        dyt[(c4 * 4 + 1) * DYLD + p] = ok ? v.y : 0.f;
-        dyt[(c4 * 4 + 2) * DYLD + p] = ok ? v.z : 0.f;
-        dyt[(c4 * 4 + 3) * DYLD + p] = ok ? v.w : 0.f;
-      }
+    for (int j = 0; j < DPT; ++j) {   // thread = (pixel group, 4 channels); 16 threads read one pixel's 256 bytes
+      const int p = (tid >> 4) + 16 * j;             // pixel of the tile: row p / 16, col p % 16
+      const int oy = oy0 + p / WTW, ox = ox0 + p % WTW;
+      const bool ok = oy < d.oh && ox < d.ow;
+      const f32x4 v = *(const f32x4*)(d.dy + (ok ? (((size_t)n * d.oh + oy) * d.ow + ox) * (size_t)d.ldy + c4 * 4 : 0));
+      pre_d[j] = ok ? v : z;
     }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int q = 0; q < PPT; ++q) {
+      const int e = tid + 256 * q;
+      if (e < WPH * WPW) *(f32x4*)(patch + e * 4) = pre_p[q];
+    }
+#pragma unroll
+    for (int j = 0; j < DPT; ++j) {                  // dy tile, transposed: [channel][pixel]
+      const int p = (tid >> 4) + 16 * j;
+      dyt[(c4 * 4 + 0) * DYLD + p] = pre_d[j].x;
+      dyt[(c4 * 4 + 1) * DYLD + p] = pre_d[j].y;
+      dyt[(c4 * 4 + 2) * DYLD + p] = pre_d[j].z;
+      dyt[(c4 * 4 + 3) * DYLD + p] = pre_d[j].w;
+    }
+  };
+
+  int tile = blockIdx.x;
+  if (tile < ntiles) fetch(tile);
+  for (; tile < ntiles; tile += gridDim.x) {
+    __syncthreads();                                 // the previous tile's fragment reads are done
+    commit();
     __syncthreads();
+    if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);       // in flight during this tile's MFMAs
 #pragma unroll
     for (int r = 0; r < WTH; ++r) {                  // one k group = the 16 pixels of tile row r
-      f32x4 a[4], bq[4];
+      f32x4 a[4], bq[3], bs[2];
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi) a[mi] = *(const f32x4*)(dyt + (mi * 16 + l16) * DYLD + r * WTW + 4 * g4);
+      const f32x4 as_ = *(const f32x4*)(dyt + (wave * 16 + l16) * DYLD + r * WTW + 4 * g4);    // row group mi == wave
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < 3; ++q) {
         const float* bp = patch + boff[q] + 2 * r * WPW * 4;
         bq[q] = f32x4{bp[0], bp[8], bp[16], bp[24]};     // pixels 4 g4 + s: two input pixels (8 floats) apart
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const float* bp = patch + boffs[j] + 2 * r * WPW * 4;
+        bs[j] = f32x4{bp[0], bp[8], bp[16], bp[24]};
       }
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi)
@@ -255,9 +290,13 @@ __global__ void __launch_bounds__(256, 3) stem7_wgrad_kernel(const hnd_wgrad_des
 #pragma unroll
           for (int q = 0; q < 2; ++q)
             acc[mi][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi][s_], bq[q][s_], acc[mi][q], 0, 0, 0);
-          if (has[2]) acc[mi][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi][s_], bq[2][s_], acc[mi][2], 0, 0, 0);
-          if (has[3]) acc[mi][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi][s_], bq[3][s_], acc[mi][3], 0, 0, 0);
+          if (nown == 3) acc[mi][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi][s_], bq[2][s_], acc[mi][2], 0, 0, 0);
         }
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_) {
+        accs[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(as_[s_], bs[0][s_], accs[0], 0, 0, 0);
+        if (nsh == 2) accs[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(as_[s_], bs[1][s_], accs[1], 0, 0, 0);
+      }
     }
   }
   // ---- one slab per workgroup: [64][ncols_pad], column = 4 tap + c (the generic kernel's layout; with cin_real == 3 the
@@ -266,11 +305,17 @@ __global__ void __launch_bounds__(256, 3) stem7_wgrad_kernel(const hnd_wgrad_des
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      if (!has[q] || ncol[q] < 0) continue;
+    for (int q = 0; q < 3; ++q) {
+      if (q >= nown || ncol[q] < 0) continue;
 #pragma unroll
       for (int i = 0; i < 4; ++i) slab[(size_t)(mi * 16 + 4 * g4 + i) * ncols_pad + ncol[q]] = acc[mi][q][i];
     }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    if (j >= nsh || ncols[j] < 0) continue;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) slab[(size_t)(wave * 16 + 4 * g4 + i) * ncols_pad + ncols[j]] = accs[j][i];
+  }
 }
 
 }  // namespace
