@@ -5,10 +5,11 @@ that stashes their output in ``module.__dict__['distillation_box']`` (:19-20, :2
 runs the teacher without targets, then the student with targets (Keypoint R-CNN: both with the same randomly
 drawn ``fixed_sizes``, :45-48), collects ``{loss_name: ((teacher_path, out), (student_path, out))}`` (:53-58) and
 returns ``criterion(output_dict, org_loss_dict)``.
-MI355X specifics: layers 2-4 and the feature pyramid of BOTH networks run as one pass over the concatenated batch
-whenever their (frozen) weights are bit-equal -- they are in every hnd / ghnd config, the student being initialised from
-the teacher -- see ``engine.SharedTrunk``: the teacher's hooks then stash views that are filled by the student's call, which
-is all the criterion needs.  The frozen teacher front (stem + layer1) is issued on a second HIP stream (it is independent of the student
+MI355X specifics: OPT-IN (``HND_MERGE_TRUNK=1``; off by default -- measured 1.0-1.5 ms slower per step than two
+independent chains on two streams, profiles/r04_trunk_sweep.txt), layers 2-4 and the feature pyramid of BOTH networks can
+run as one pass over the concatenated batch while their (frozen) weights are bit-equal -- they are in every hnd / ghnd
+config, the student being initialised from the teacher -- see ``engine.SharedTrunk``: the teacher's hooks then stash views
+that are filled by the student's call, which is all the criterion needs.  By default the frozen teacher front (stem + layer1) is issued on a second HIP stream (it is independent of the student
 forward, so the tails of one network's launches are filled by the other's); both models share one transformed
 batch inside a transform scope.  Both feature pyramids -- executed as written, but read by nobody when
 ``org_loss_factor`` is 0 -- are issued on a third stream so they trail into the backward pass and fill the last-round
@@ -76,12 +77,17 @@ class DistillationBox(nn.Module):
         self._trunk = None          # engine.SharedTrunk, built lazily when both backbones qualify
 
     def _shared_trunk(self):
-        """the SharedTrunk of this pair when layers 2-4 + FPN of teacher and student are frozen and bit-equal (every
-        hnd / ghnd config: the student is initialised from the teacher, src/models/org/rcnn.py:444-450), else None --
-        then each network runs its own pass as before.  HND_MERGE_TRUNK=0 turns it off (A/B)."""
+        """Opt-in (``HND_MERGE_TRUNK=1``; default off, see engine.MERGE_TRUNK): the SharedTrunk of this pair when layers
+        2-4 + FPN of teacher and student are frozen and bit-equal (every hnd / ghnd config: the student is initialised from
+        the teacher, src/models/org/rcnn.py:444-450), else None -- then each network runs its own pass.  The teacher's
+        layer2-4 / FPN calls return views that are FILLED ONLY BY THE STUDENT'S CALL, so the teacher must stop at its
+        backbone (``distill_backbone_only``): a teacher that went on into its RPN / RoI heads would read last step's
+        features."""
         if not E.MERGE_TRUNK:
             return None
         teacher, student = unwrap(self.teacher_model), unwrap(self.student_model)
+        if not getattr(teacher, 'distill_backbone_only', False):
+            return None
         t_bb, s_bb = getattr(teacher, 'backbone', None), getattr(student, 'backbone', None)
         if teacher.training or t_bb is None or s_bb is None or not E.SharedTrunk.structure_ok(t_bb, s_bb):
             return None

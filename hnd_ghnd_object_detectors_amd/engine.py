@@ -193,15 +193,41 @@ FUSE_BNBWD = os.environ.get('HND_FUSE_BNBWD', '1') != '0'
 WINO_WGRAD_OWN_V = os.environ.get('HND_WINO_WGRAD_OWN_V', '1') != '0'
 
 
-def process_owns_device():
-    """False when more local ranks than visible GPUs time-share a device: extra HIP streams then make a step ~50x slower
-    (distillation/tool.py), so the optional side streams stay off there"""
-    try:
-        local_world = int(os.environ.get('LOCAL_WORLD_SIZE') or os.environ.get('WORLD_SIZE') or 1)
-    except ValueError:
-        local_world = 1
-    devices = torch.cuda.device_count() if torch.cuda.is_available() else 1
-    return local_world <= max(devices, 1)
+def process_owns_device(verbose=[True]):
+    """False when several local ranks time-share this process's GPU: extra HIP streams then make a step ~50x slower
+    (distillation/tool.py), so the optional side streams stay off there.  Decided from what is actually shared:
+      1. a launcher that narrowed the visible-device list per rank (SLURM-style: HIP_/ROCR_/CUDA_VISIBLE_DEVICES names
+         exactly one device while LOCAL_WORLD_SIZE > 1) gave this rank a GPU of its own -> owned;
+      2. LOCAL_WORLD_SIZE known: owned iff it does not exceed the visible devices;
+      3. only WORLD_SIZE known (no LOCAL_WORLD_SIZE): it may span nodes, so it is used only when it fits the visible
+         devices; a WORLD_SIZE larger than this node's GPUs says nothing about sharing -> assumed owned.
+    ``HND_SHARED_DEVICE=1`` (bench.py --share_device, the one-GPU plumbing tests) declares the device shared whatever the
+    visible-device list says.  The rule that fired is printed once per process."""
+    def env_int(name):
+        try:
+            return int(os.environ[name])
+        except (KeyError, ValueError):
+            return None
+    devices = max(torch.cuda.device_count() if torch.cuda.is_available() else 1, 1)
+    local_world, world = env_int('LOCAL_WORLD_SIZE'), env_int('WORLD_SIZE')
+    narrowed = [v for v in (os.environ.get(k) for k in ('ROCR_VISIBLE_DEVICES', 'HIP_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'))
+                if v is not None and len([d for d in v.split(',') if d.strip() != '']) == 1]
+    if os.environ.get('HND_SHARED_DEVICE', '0') != '0':
+        owns, rule = False, 'HND_SHARED_DEVICE=1'
+    elif local_world is not None and local_world > 1 and narrowed and devices == 1:
+        owns, rule = True, 'visible devices narrowed to one per rank (LOCAL_WORLD_SIZE=%d)' % local_world
+    elif local_world is not None:
+        owns, rule = local_world <= devices, 'LOCAL_WORLD_SIZE=%d vs %d visible device(s)' % (local_world, devices)
+    elif world is not None and world <= devices:
+        owns, rule = True, 'WORLD_SIZE=%d <= %d visible device(s)' % (world, devices)
+    elif world is not None:
+        owns, rule = True, 'WORLD_SIZE=%d spans nodes (no LOCAL_WORLD_SIZE): assuming one rank per GPU' % world
+    else:
+        owns, rule = True, 'single process'
+    if verbose[0] and (local_world or world or 1) > 1:
+        verbose[0] = False
+        print('engine.process_owns_device: %s -> side streams %s' % (rule, 'on' if owns else 'off'))
+    return owns
 
 
 def wgrad_stream_on():
@@ -1179,12 +1205,23 @@ class SharedTrunk(object):
             pairs += [(t_sd[k], s_sd[k]) for k in t_sd]
         return pairs
 
+    RECHECK_EVERY = 256          # steps between unconditional device re-checks of the cached verdict
+
+    def invalidate(self):
+        """forget the cached 'equal' verdict: call after editing frozen weights through ``.data`` (which moves neither
+        a version counter nor an address)"""
+        self._equal_key = None
+
     def weights_equal(self):
-        """every tensor of layer2-4 and the FPN bit-equal between the two networks (re-checked on the device only when
-        a version counter or an address moved: load_state_dict, .to(), a hand edit)"""
+        """every tensor of layer2-4 and the FPN bit-equal between the two networks (re-checked on the device when a
+        version counter or an address moved -- load_state_dict, .to(), an in-place edit -- and every RECHECK_EVERY
+        steps regardless, so an edit through ``.data`` cannot go unnoticed for long; invalidate() forces it)"""
         pairs = self._tensor_pairs()
         if pairs is None:
             return False
+        self._checks = getattr(self, '_checks', 0) + 1
+        if self._checks % self.RECHECK_EVERY == 0:
+            self._equal_key = None
         key = tuple((a.data_ptr(), a._version, b.data_ptr(), b._version) for a, b in pairs)
         if key != self._equal_key:
             self._equal = all(a.shape == b.shape and a.dtype == b.dtype and torch.equal(a, b) for a, b in pairs)
@@ -1226,7 +1263,7 @@ class SharedTrunk(object):
     def _half(self, t, role):
         return t[role * self.n:(role + 1) * self.n]
 
-    def layer_forward(self, name, role, force_keep=False):
+    def layer_forward(self, name, role):
         eng = self.engines[name]
         idx = self.LAYERS.index(name)
         x = self.front[self.FRONT[-1]] if idx == 0 else self.engines[self.LAYERS[idx - 1]].out

@@ -67,8 +67,11 @@ def train_model(model, optimizer, data_loader, device, epoch, log_freq, wrapper=
     num_batches = len(data_loader)
     warmup = (main_util.warmup_lr_scheduler(optimizer, min(1000, num_batches - 1), 1.0 / 1000.0)
               if epoch == 0 and num_batches > 1 else None)
+    if torch.device(device).type == 'cuda':     # one pinned staging buffer + one async copy per batch, a step ahead
+        from .upload import DevicePrefetcher
+        data_loader = DevicePrefetcher(data_loader, device)
     for images, targets in meters.log_every(data_loader, log_freq, 'Epoch: [{}]'.format(epoch)):
-        images, targets = _upload(images, targets, device)
+        images, targets = _upload(images, targets, device)      # (no-ops behind the prefetcher)
         ext_logits = model(images, targets)
         ext_targets = convert_target2ext_targets(targets, device)
         loss = nn.functional.cross_entropy(ext_logits, ext_targets)
@@ -82,6 +85,9 @@ def train_model(model, optimizer, data_loader, device, epoch, log_freq, wrapper=
         if warmup is not None:
             warmup.step()
         meters.update(loss=logged, loss_ext_classifier=logged, lr=optimizer.param_groups[0]['lr'])
+    if torch.device(device).type == 'cuda':
+        from . import ops
+        ops.sync_check()            # epoch end: drain, and raise on anything a kernel reported asynchronously
     return meters.loss.global_avg
 
 

@@ -173,7 +173,7 @@ class ResLayer(nn.Sequential):
         if merged is not None and E.MERGE['trunk'] is merged[0]:
             # (trunk, role): this call is one half of a SharedTrunk pass (engine.SharedTrunk)
             trunk, role = merged
-            out = trunk.layer_forward(self._name, role, force_keep=hooked)
+            out = trunk.layer_forward(self._name, role)
             self._used_engine = trunk.engines[self._name]
             if hooked:
                 self._fire_block_hooks(self._used_engine, lambda t: trunk._half(t, role))

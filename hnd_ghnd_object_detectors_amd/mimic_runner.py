@@ -45,6 +45,10 @@ _FLAGS = (  # (flag, kwargs): the reference's CLI first, this build's additions 
     ('-host_float_input', dict(action='store_true', help='COCO loaders: convert images to float CHW on the host like '
                                                          'the reference instead of shipping uint8 to the device')),
     ('--num_epochs', dict(default=None, type=int, help='override train.num_epochs')),
+    ('--loader_workers', dict(default=4, type=int, help='background threads generating synthetic batches ahead of the '
+                                                        'step (the role of the DataLoader workers)')),
+    ('-no_prefetch', dict(action='store_true', help='upload every batch synchronously at the top of its step like the '
+                                                    'reference, instead of through upload.DevicePrefetcher')),
 )
 
 
@@ -66,13 +70,57 @@ def _epoch0_warmup(optimizer, num_batches):
     return main_util.warmup_lr_scheduler(optimizer, iters, 1.0 / 1000.0) if iters > 0 else None
 
 
-def distill_model(distillation_box, data_loader, optimizer, log_freq, device, epoch, student_wrapper=None):
-    """One epoch of optimisation steps; returns the mean loss of the epoch."""
+class StepClock(object):
+    """Device time of the iterations: one HIP event per iteration on the compute stream, read one iteration late so the
+    host never waits for it.  ``loss.item()`` no longer drains the stream (hip_loss.StepLoss reads an early pinned copy),
+    so a host-side iteration timer measures ENQUEUE time; this one measures what the GPU did."""
+
+    def __init__(self, device):
+        self.stream = torch.cuda.current_stream(device)
+        self.events, self.ms = [], []
+
+    def tick(self):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(self.stream)
+        self.events.append(ev)
+        while len(self.events) >= 3:             # the pair before last has certainly been reached by now or soon
+            if not self.events[1].query():
+                break
+            self.ms.append(self.events[0].elapsed_time(self.events[1]))
+            self.events.pop(0)
+
+    def finish(self):
+        while len(self.events) >= 2:
+            self.events[1].synchronize()
+            self.ms.append(self.events[0].elapsed_time(self.events[1]))
+            self.events.pop(0)
+        return self.ms
+
+
+LAST_EPOCH = {}            # device-time figures of the newest distill_model epoch (bench.py reads them)
+SYNC_CHECK_EVERY = 50      # iterations between hnd_sync_check calls (asynchronous faults / relay time-outs surface here)
+
+
+def distill_model(distillation_box, data_loader, optimizer, log_freq, device, epoch, student_wrapper=None,
+                  prefetch=True):
+    """One epoch of optimisation steps; returns the mean loss of the epoch.
+
+    reference src/mimic_runner.py:38-59.  ``prefetch``: batches reach the device through upload.DevicePrefetcher (one
+    pinned staging buffer and one asynchronous copy per batch, issued while the previous step computes) instead of the
+    reference's synchronous per-tensor ``.to(device)`` at the top of the step; the tensors are the same bits."""
+    from . import ops
+    from .upload import DevicePrefetcher
     meters = misc_util.MetricLogger(delimiter='  ')
     meters.add_meter('lr', misc_util.SmoothedValue(window_size=1, fmt='{value:.6f}'))
     warmup = _epoch0_warmup(optimizer, len(data_loader)) if epoch == 0 else None
-    for images, targets in meters.log_every(data_loader, log_freq, 'Epoch: [{}]'.format(epoch)):
-        images = [img.to(device, non_blocking=True) for img in images]
+    on_gpu = torch.device(device).type == 'cuda'
+    if prefetch and on_gpu and not isinstance(data_loader, DevicePrefetcher):
+        data_loader = DevicePrefetcher(data_loader, device)
+    clock = StepClock(device) if on_gpu else None
+    if clock is not None:
+        clock.tick()
+    for it, (images, targets) in enumerate(meters.log_every(data_loader, log_freq, 'Epoch: [{}]'.format(epoch))):
+        images = [img.to(device, non_blocking=True) for img in images]          # (no-ops behind the prefetcher)
         targets = [{key: value.to(device, non_blocking=True) for key, value in t.items()} for t in targets]
         loss = distillation_box(images, targets)
         optimizer.zero_grad()
@@ -81,6 +129,19 @@ def distill_model(distillation_box, data_loader, optimizer, log_freq, device, ep
         if warmup is not None:
             warmup.step()
         meters.update(loss=loss, lr=optimizer.param_groups[0]['lr'])
+        if clock is not None:
+            clock.tick()
+            if (it + 1) % SYNC_CHECK_EVERY == 0:
+                ops.sync_check()
+    if clock is not None:
+        ops.sync_check()            # epoch end: drain, and raise on anything a kernel reported asynchronously
+        ms = clock.finish()
+        if ms:
+            steady = ms[min(2, len(ms) - 1):]           # the first iterations build plans and allocate
+            per_it = sum(steady) / len(steady)
+            LAST_EPOCH.update(steady_ms_per_it=per_it, steady_iterations=len(steady), ms=list(ms))
+            print('Epoch: [{}] device time {:.2f} ms / it over {} steady iterations ({:.2f} img/s per GPU)'.format(
+                epoch, per_it, len(steady), len(images) / per_it * 1e3))
     return meters.loss.global_avg
 
 
@@ -114,7 +175,8 @@ def distill(teacher_model, student_model, train_loader, val_loader, device, dist
         student_model.train()
         teacher_model.distill_backbone_only = student.distill_backbone_only = distill_backbone_only
         student.backbone.body.layer1.use_bottleneck_transformer = False      # reference :90
-        mean_loss = distill_model(box, train_loader, optimizer, train_config['log_freq'], device, epoch, wrapper)
+        mean_loss = distill_model(box, train_loader, optimizer, train_config['log_freq'], device, epoch, wrapper,
+                                  prefetch=not getattr(args, 'no_prefetch', False))
         if val_loader is not None:                                            # reference :92-100
             student.distill_backbone_only = False
             student.backbone.body.layer1.use_bottleneck_transformer = use_bottleneck_transformer
@@ -171,7 +233,7 @@ def main(args):
         train_sampler = None
         train_loader = data_util.SyntheticDetectionLoader(args.synthetic_batches, batch_size, height, width,
                                                           student_config['name'], rank=misc_util.get_rank(),
-                                                          decoded=args.decoded_input)
+                                                          decoded=args.decoded_input, workers=args.loader_workers)
     else:       # COCO-format folders named by the yaml (reference :128-129); uint8 images unless -host_float_input
         train_sampler, train_loader, val_loader, test_loader = data_util.get_coco_data_loaders(
             config['dataset'], batch_size, distributed, decoded=not args.host_float_input)

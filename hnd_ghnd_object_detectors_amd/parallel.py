@@ -127,9 +127,15 @@ class _NativeComm(object):
 class DistributedStudent(nn.Module):
     """Drop-in for DistributedDataParallel(student): ``.module`` is the wrapped model."""
 
-    def __init__(self, module, optimizer=None):
+    def __init__(self, module, optimizer=None, broadcast_buffers=False):
+        """broadcast_buffers=True reproduces DDP's default (reference src/mimic_runner.py:141-143): rank 0's BatchNorm
+        running statistics (the 2 182 floats + 8 counters of the head's train-mode BatchNorm layers; frozen buffers
+        never change) are broadcast at the top of EVERY forward, so a checkpoint written mid-epoch by any rank holds
+        rank 0's statistics.  Default False: broadcast at construction and on sync_buffers() (before validation /
+        checkpointing, which is when mimic_runner reads them) -- training-mode outputs do not depend on them."""
         super().__init__()
         self.module = module
+        self.broadcast_buffers = broadcast_buffers
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.optimizer = optimizer
         self.native = None
@@ -177,7 +183,22 @@ class DistributedStudent(nn.Module):
             for b in self.module.buffers():
                 dist.broadcast(b, 0)
 
+    def _live_buffers(self):
+        """buffers that training changes: those of train-mode BatchNorm layers (FrozenBatchNorm2d buffers are constants)"""
+        out = []
+        for m in self.module.modules():
+            if isinstance(m, nn.modules.batchnorm._BatchNorm) and m.track_running_stats:
+                out += [m.running_mean, m.running_var, m.num_batches_tracked]
+        return out
+
+    def broadcast_live_buffers(self):
+        if self.world > 1:
+            for b in self._live_buffers():
+                dist.broadcast(b, 0)
+
     def forward(self, *args, **kwargs):
+        if self.broadcast_buffers and self.module.training:
+            self.broadcast_live_buffers()
         return self.module(*args, **kwargs)
 
     # ------------------------------------------------------------------ the exchange
@@ -221,16 +242,24 @@ class DistributedStudent(nn.Module):
 
     def reduce_gradients(self):
         """explicit form of round 1's loop (between loss.backward() and optimizer.step()).  The exchange fires from
-        inside backward, so there is nothing left to reduce here: this only VERIFIES that every gradient of the wrapped
-        model lies in an exchanged arena (every trainable tensor of this package's models does) and refuses otherwise
-        -- there is no per-tensor fallback that could silently mix exchanged and local gradients."""
+        inside backward, so for this package's models there is nothing left to reduce: every gradient of a GUARDED
+        parameter (trainable when the wrapper was built) must lie in an exchanged arena, and one that does not is
+        refused -- no fallback could tell an exchanged gradient from a local one there.  A trainable tensor that is
+        NOT guarded (a module the caller attached or unfroze afterwards, whose backward is plain autograd) is averaged
+        here per tensor, as DDP would have, so such a model keeps working; step it with an ordinary torch optimizer.
+        (A custom optimizer that calls parallel.finish_pending() must also call parallel.end_step() when its step()
+        is done -- FusedAdam / FusedSGD do -- or consumed exchanges would be served twice.)"""
         if self.world == 1:
             return
         for p in self.module.parameters():
             if p.grad is None or any(_covers(e[0], p.grad) for e in _PENDING.values()):
                 continue                     # exchanged (or being exchanged) through its arena
-            raise RuntimeError('reduce_gradients: a parameter has a gradient outside every exchanged arena; its '
-                               'backward bypassed the DistributedStudent hook')
+            if id(p) in _GUARDED:
+                raise RuntimeError('reduce_gradients: a data-parallel parameter has a gradient outside every exchanged '
+                                   'arena: its backward bypassed the DistributedStudent hook, or optimizer.step() (which '
+                                   'ends the exchange, parallel.end_step) already ran')
+            dist.all_reduce(p.grad)
+            p.grad.mul_(1.0 / self.world)
 
 
 def all_reduce_flat_(flat, world):

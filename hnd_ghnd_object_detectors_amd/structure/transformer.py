@@ -82,11 +82,12 @@ def flip_coco_person_keypoints(kps, width):
 class RandomHorizontalFlip(object):
     """reference :32-49.  A DecodedImage is flipped lazily (inside the device kernel); tensors are flipped here."""
 
-    def __init__(self, prob):
+    def __init__(self, prob, rng=None):
         self.prob = prob
+        self.rng = rng          # None: Python's global ``random`` like the reference; a random.Random: a stream of its own
 
     def __call__(self, image, target):
-        if random.random() >= self.prob:
+        if (self.rng or random).random() >= self.prob:
             return image, target
         width = image.shape[-1]
         if isinstance(image, DecodedImage):

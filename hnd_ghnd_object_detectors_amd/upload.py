@@ -1,0 +1,177 @@
+"""Host -> device feeding of the distillation step (the reference's ``images.to(device)`` / ``targets.to(device)``,
+src/mimic_runner.py:49-50, src/ext_runner.py:47-48), taken off the step's critical path.
+
+The reference uploads every tensor of a batch synchronously from pageable memory at the top of the step: 16 x 12.8 MB
+images + the targets, ~3.3 ms of PCIe time per step at batch 16 plus the pageable staging, all of it with the GPU idle.
+``DevicePrefetcher`` wraps any iterable of ``(images, targets)`` host batches (torch DataLoader, SyntheticDetectionLoader)
+and yields the same structure with every tensor already on the device:
+
+  * a feeder thread pulls batch k+1 from the source while step k is being enqueued / computed, lays ALL of its tensors
+    (images -- float CHW or ``DecodedImage`` uint8 -- and every target tensor) out in ONE pinned staging buffer and
+    issues ONE asynchronous copy of it on a copy stream of its own: one DMA of 205 MB (51 MB on the uint8 path) instead
+    of ~50 small ones, running under the previous step's kernels;
+  * ``depth`` slots (pinned buffer + device buffer + two events each) rotate; a slot's device buffer is rewritten only
+    after the step that consumed it has finished ON THE GPU (event recorded on the consumer's stream when it asks for
+    the next batch; the copy stream waits for it), its pinned buffer only after the copy out of it has completed;
+  * the consumer's stream waits for the copy's event -- never the host.
+
+The tensors handed out are views of the slot's device buffer: valid until ``depth - 1`` further batches have been
+requested, which is what a training loop does (one batch alive per step).  Nothing here computes: torch is used for
+pinned / device memory, streams and events only.
+"""
+import queue
+import threading
+
+import torch
+
+_ALIGN = 256
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+class _Slot(object):
+    __slots__ = ('pinned', 'dev', 'ready', 'consumed', 'free')
+
+    def __init__(self):
+        self.pinned = self.dev = None
+        self.ready = torch.cuda.Event()          # the copy into `dev` has completed (recorded on the copy stream)
+        self.consumed = None                     # the step that read `dev` has completed (consumer's stream), or None
+        self.free = threading.Semaphore(1)       # host side: the consumer no longer holds views of this slot
+
+
+def _leaves(images, targets):
+    """[(kind, index, key, tensor)] of every tensor of a batch, in a fixed order"""
+    out = []
+    for i, im in enumerate(images):
+        out.append(('image', i, None, im.data if hasattr(im, 'hwc') else im))
+    for i, t in enumerate(targets):
+        for k, v in t.items():
+            if torch.is_tensor(v):
+                out.append(('target', i, k, v))
+    return out
+
+
+class DevicePrefetcher(object):
+    """iterable of device-resident ``(images, targets)`` over a host-batch iterable; see the module docstring.
+
+    ``len()`` and ``set_epoch`` pass through to the source.  ``copied_bytes`` / ``batches`` count what went over the
+    link (bench.py reports them)."""
+
+    def __init__(self, source, device, depth=3):
+        assert depth >= 2, 'one slot is read by the step while the next is being filled'
+        self.source, self.device, self.depth = source, torch.device(device), depth
+        if self.device.type != 'cuda':
+            raise RuntimeError('DevicePrefetcher feeds the HIP path: it needs a cuda device, got %s' % (self.device,))
+        if self.device.index is None:
+            self.device = torch.device('cuda', torch.cuda.current_device())
+        self.copy_stream = torch.cuda.Stream(device=self.device)
+        self.slots = [_Slot() for _ in range(depth)]
+        self.copied_bytes = self.batches = 0
+        self._thread = self._queue = self._stop = None
+        self._held = None
+
+    def __len__(self):
+        return len(self.source)
+
+    def set_epoch(self, epoch):
+        if hasattr(self.source, 'set_epoch'):
+            self.source.set_epoch(epoch)
+
+    # ------------------------------------------------------------------ feeder thread
+    def _stage(self, slot, images, targets):
+        leaves = _leaves(images, targets)
+        offs, total = [], 0
+        for _, _, _, t in leaves:
+            offs.append(total)
+            total = _round_up(total + t.numel() * t.element_size(), _ALIGN)
+        total = max(total, _ALIGN)
+        slot.ready.synchronize()                 # the previous copy OUT of this pinned buffer is complete
+        if slot.pinned is None or slot.pinned.numel() < total:
+            slot.pinned = torch.empty(total, dtype=torch.uint8, pin_memory=True)
+            slot.dev = torch.empty(total, dtype=torch.uint8, device=self.device)
+        views = []
+        for (_, _, _, t), off in zip(leaves, offs):
+            nb = t.numel() * t.element_size()
+            slot.pinned[off:off + nb].view(t.dtype).view(t.shape).copy_(t)
+            views.append(slot.dev[off:off + nb].view(t.dtype).view(t.shape))
+        with torch.cuda.stream(self.copy_stream):
+            if slot.consumed is not None:        # the step that read this device buffer has finished on the GPU
+                self.copy_stream.wait_event(slot.consumed)
+            slot.dev[:total].copy_(slot.pinned[:total], non_blocking=True)
+            slot.ready.record(self.copy_stream)
+        self.copied_bytes += total
+        self.batches += 1
+        # the same structure as the host batch, tensors replaced by their device views
+        dev_images = list(images)
+        dev_targets = [dict(t) for t in targets]
+        for (kind, i, k, _), v in zip(leaves, views):
+            if kind == 'image':
+                im = images[i]
+                dev_images[i] = type(im)(v, im.hwc, im.flip) if hasattr(im, 'hwc') else v
+            else:
+                dev_targets[i][k] = v
+        return dev_images, dev_targets
+
+    def _feed(self, it, q, stop):
+        try:
+            torch.cuda.set_device(self.device)
+            k = 0
+            for images, targets in it:
+                slot = self.slots[k % self.depth]
+                while not slot.free.acquire(timeout=0.2):
+                    if stop.is_set():
+                        return
+                if stop.is_set():
+                    return
+                q.put(('batch', k, self._stage(slot, images, targets)))
+                k += 1
+            q.put(('end', k, None))
+        except BaseException as exc:             # surfaces in the consumer's next()
+            q.put(('error', -1, exc))
+
+    # ------------------------------------------------------------------ consumer
+    def __iter__(self):
+        self.close()
+        it = iter(self.source)                   # (in the caller's thread: a loader may seed here)
+        for s in self.slots:
+            s.free = threading.Semaphore(1)
+        self._queue, self._stop = queue.Queue(), threading.Event()
+        self._thread = threading.Thread(target=self._feed, args=(it, self._queue, self._stop), daemon=True)
+        self._thread.start()
+        return self._consume(self._queue)
+
+    def _release_held(self):
+        if self._held is not None:
+            slot, self._held = self._held, None
+            if slot.consumed is None:
+                slot.consumed = torch.cuda.Event()
+            slot.consumed.record(torch.cuda.current_stream(self.device))     # everything enqueued so far has used it
+            slot.free.release()
+
+    def _consume(self, q):
+        try:
+            while True:
+                self._release_held()
+                kind, k, payload = q.get()
+                if kind == 'end':
+                    return
+                if kind == 'error':
+                    raise payload
+                slot = self.slots[k % self.depth]
+                torch.cuda.current_stream(self.device).wait_event(slot.ready)
+                self._held = slot
+                yield payload
+        finally:
+            self._release_held()
+            self.close()
+
+    def close(self):
+        """stop the feeder (an abandoned epoch); idempotent"""
+        if self._thread is not None:
+            self._stop.set()
+            for s in self.slots:                 # wake a feeder parked on a slot
+                s.free.release()
+            self._thread.join(timeout=30.0)
+            self._thread = None

@@ -29,15 +29,23 @@ def get_transform(train=False, decoded=True):
 
 
 class SyntheticDetectionLoader(object):
-    """len()-able iterable of (images, targets) tuples, sharded by rank through the seed."""
+    """len()-able iterable of (images, targets) tuples, sharded by rank through the seed.
+
+    Batch k of epoch e is a function of (seed, rank, e, k) alone, so ``workers`` background threads may generate
+    batches ahead of the consumer (torch's generators release the GIL; 16 images of 3x800x1333 take ~0.26 s of one
+    core, three steps' worth) without changing a single value -- the role the reference's DataLoader workers play
+    (src/utils/data_util.py:40-41).  Flip decisions come from a generator of the loader's own, so the Python
+    ``random`` stream that DistillationBox draws Keypoint R-CNN sizes from (seeded here, at iter()) is not shared
+    with a feeder thread."""
 
     def __init__(self, num_batches, batch_size, height=800, width=1333, model_name='faster_rcnn', seed=1234, rank=0,
-                 device='cpu', decoded=False, train=True, positive_every=0):
+                 device='cpu', decoded=False, train=True, positive_every=0, workers=0):
         self.num_batches, self.batch_size, self.h, self.w = num_batches, batch_size, height, width
         self.model_name, self.seed, self.rank, self.device = model_name, seed, rank, device
         self.decoded, self.transform = decoded, get_transform(train)
         self.positive_every = positive_every       # neural filter: every k-th person has 17 visible keypoints
         self.epoch = 0
+        self.workers = workers
 
     def set_epoch(self, epoch):
         self.epoch = epoch
@@ -61,18 +69,48 @@ class SyntheticDetectionLoader(object):
             out.append(t)
         return out
 
+    def _epoch_seed(self):
+        return self.seed + self.rank + 7919 * self.epoch
+
+    def raw_images(self, k, epoch_seed=None):
+        """the images of batch k of the current epoch: float CHW in [0, 1), or uint8 HWC with ``decoded``"""
+        g = torch.Generator().manual_seed((self._epoch_seed() if epoch_seed is None else epoch_seed) + 1000003 * k)
+        if not self.decoded:
+            return [torch.rand(3, self.h, self.w, generator=g) for _ in range(self.batch_size)]
+        return [torch.randint(0, 256, (self.h, self.w, 3), generator=g, dtype=torch.uint8)
+                for _ in range(self.batch_size)]
+
+    def _finish(self, raw, flip_rng):
+        if not self.decoded:
+            return tuple(raw), tuple(self.make_targets())
+        for t in self.transform.transforms:
+            if isinstance(t, RandomHorizontalFlip):
+                t.rng = flip_rng
+        pairs = [self.transform(im, t) for im, t in zip(raw, self.make_targets())]
+        return tuple(p[0] for p in pairs), tuple(p[1] for p in pairs)
+
     def __iter__(self):
-        g = torch.Generator().manual_seed(self.seed + self.rank + 7919 * self.epoch)
-        random.seed(self.seed + self.rank + 7919 * self.epoch)
-        for _ in range(self.num_batches):
-            if not self.decoded:
-                images = [torch.rand(3, self.h, self.w, generator=g) for _ in range(self.batch_size)]
-                yield tuple(images), tuple(self.make_targets())
-                continue
-            raw = [torch.randint(0, 256, (self.h, self.w, 3), generator=g, dtype=torch.uint8)
-                   for _ in range(self.batch_size)]
-            pairs = [self.transform(im, t) for im, t in zip(raw, self.make_targets())]
-            yield tuple(p[0] for p in pairs), tuple(p[1] for p in pairs)
+        es = self._epoch_seed()
+        random.seed(es)                 # (the stream DistillationBox draws Keypoint sizes from; SURVEY.md 8d)
+        return self._batches(es, random.Random(es))
+
+    def _batches(self, es, flip_rng):
+        if self.workers <= 0:
+            for k in range(self.num_batches):
+                yield self._finish(self.raw_images(k, es), flip_rng)
+            return
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(self.workers, thread_name_prefix='synthetic-loader')
+        try:
+            ahead = [pool.submit(self.raw_images, k, es) for k in range(min(self.workers + 1, self.num_batches))]
+            for k in range(self.num_batches):
+                raw = ahead.pop(0).result()
+                nxt = k + self.workers + 1
+                if nxt < self.num_batches:
+                    ahead.append(pool.submit(self.raw_images, nxt, es))
+                yield self._finish(raw, flip_rng)
+        finally:
+            pool.shutdown(wait=False, cancel_futures=True)
 
 
 def get_coco_dataset(split_dict, is_train, decoded=True):

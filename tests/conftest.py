@@ -23,12 +23,17 @@ def golden_dir():
 ACHIEVED = []
 
 
+FLIPS = {}        # fixture name -> "k of n ReLU decisions differ" (filled by the ReLU-decision test, read at summary time)
+
+
 def record_achieved(line):
-    ACHIEVED.append(str(line))
+    """line: a string, or a callable evaluated when the summary is printed (so a figure measured by a later test can
+    stand beside it)"""
+    ACHIEVED.append(line if callable(line) else str(line))
 
 
 def pytest_terminal_summary(terminalreporter, exitstatus, config):
     if ACHIEVED:
         terminalreporter.write_sep('-', 'achieved parity figures (inside the asserted tolerances)')
         for line in ACHIEVED:
-            terminalreporter.write_line(line)
+            terminalreporter.write_line(line() if callable(line) else line)

@@ -287,9 +287,21 @@ def test_side_streams_only_when_the_process_owns_its_gpu(monkeypatch):
     environment switches decide when set"""
     from hnd_ghnd_object_detectors_amd import engine as E
     from hnd_ghnd_object_detectors_amd.distillation import tool
-    for k in ('LOCAL_WORLD_SIZE', 'WORLD_SIZE', 'HND_WGRAD_STREAM', 'HND_DEFER_FPN'):
+    for k in ('LOCAL_WORLD_SIZE', 'WORLD_SIZE', 'HND_WGRAD_STREAM', 'HND_DEFER_FPN', 'HND_SHARED_DEVICE',
+              'ROCR_VISIBLE_DEVICES', 'HIP_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
         monkeypatch.delenv(k, raising=False)
     assert E.process_owns_device() and E.wgrad_stream_on() and tool._defer_fpn_default()
+    # ADVICE r4: decide from what is actually shared
+    monkeypatch.setenv('WORLD_SIZE', '16')                  # multi-node launcher without LOCAL_WORLD_SIZE: says nothing
+    assert E.process_owns_device()
+    monkeypatch.setenv('LOCAL_WORLD_SIZE', '8')
+    assert not E.process_owns_device()                      # 8 local ranks, one visible "device", list not narrowed
+    monkeypatch.setenv('HIP_VISIBLE_DEVICES', '3')          # SLURM-style: one GPU per rank
+    assert E.process_owns_device()
+    monkeypatch.setenv('HND_SHARED_DEVICE', '1')            # bench.py --share_device
+    assert not E.process_owns_device()
+    for k in ('WORLD_SIZE', 'HIP_VISIBLE_DEVICES', 'HND_SHARED_DEVICE'):
+        monkeypatch.delenv(k)
     monkeypatch.setenv('LOCAL_WORLD_SIZE', '4')             # (no GPU here: one "device")
     assert not E.process_owns_device() and not E.wgrad_stream_on() and not tool._defer_fpn_default()
     monkeypatch.setenv('HND_WGRAD_STREAM', '1')

@@ -128,8 +128,9 @@ def test_distill_steps_match_reference_golden(name):
     # update then moves the small BatchNorm biases by several 1e-3 relative.  The flips are COUNTED by
     # test_relu_decisions_differ_from_the_fp32_oracle_only_where_the_value_is_rounding_noise (0 / 1 / 1 differing
     # decisions of 1-5 M for the three fixtures whose gradients sit at 2e-5 / 9e-4 / 4e-3).  The updated parameters are
-    # therefore held to 2e-3 only when no flip happened (all gradients within 1e-4), else to 2e-2.
-    ptol = 2e-2 if (gtol or worst['grad'] > 1e-4) else 2e-3
+    # therefore held to 1e-3 when no flip happened (all gradients within 1e-4; achieved 1.0e-4), else to 5e-3 (achieved
+    # 2.6e-5 / 8.1e-7 on the two fixtures with one flip each); the flip count of the fixture is printed beside it.
+    ptol = 5e-3 if (gtol or worst['grad'] > 1e-4) else 1e-3
     worst['param'] = 0.0
     for n in O.trainable_keys(s_sd):
         if not n.endswith(G.ZERO_GRAD_SUFFIXES):
@@ -146,8 +147,9 @@ def test_distill_steps_match_reference_golden(name):
             % (name, worst['feat'], FEAT_TOL, worst['loss'], LOSS_TOL, worst['grad'], gtol or GRAD_TOL, worst['param'], ptol, GRAD_TOL,
                WORST_GRAD_RATIO['ratio'], WORST_GRAD_RATIO['name']))
     print('\n' + line)
-    from tests.conftest import record_achieved
-    record_achieved(line)
+    from tests import conftest
+    conftest.record_achieved(lambda: line + '; ReLU decisions differing from the fp32 oracle: %s'
+                             % conftest.FLIPS.get(name, 'not counted for this fixture'))
 
 
 def test_eval_after_a_training_step_uses_the_updated_weights():
@@ -471,6 +473,19 @@ def _full_step(z, meta, repeat=1):
     return cfg, teacher, student, box, opt, warm, ims, tgs, loss
 
 
+# fingerprints (sum, sum of squares, 64 samples) of the reference's fp32 gradients at full size: no fp64 twin is stored,
+# so the bar is absolute -- 2.5e-3, a ReLU flip's worth (dense tests: 1.7e-3 ... 2.2e-3 vs fp64); achieved figures are printed
+FULL_GRAD_FP_TOL = 2.5e-3
+
+
+def _record_full(name, worst_g, worst_p):
+    from tests.conftest import record_achieved
+    line = ('[full size %s] gradient fingerprints vs the reference: worst %.2e (tol %.1e); parameters after Adam %.2e '
+            '(tol 2e-03)' % (name, worst_g, FULL_GRAD_FP_TOL, worst_p))
+    print('\n' + line)
+    record_achieved(line)
+
+
 @pytest.mark.parametrize('name', FULL)
 def test_full_size_step_matches_reference_checksums(name):
     """3x800x1333 inputs (padded 800x1344; Keypoint: sizes drawn per image as tool.py:45-48, padded 1248x1120) at the
@@ -499,14 +514,16 @@ def test_full_size_step_matches_reference_checksums(name):
     opt.zero_grad()
     loss.backward()
     assert abs(opt.param_groups[0]['lr'] - float(z['step0/lr'])) < 1e-12
+    worst_g = worst_p = 0.0
     for n, p in student.named_parameters():
         if p.requires_grad and not n.endswith(G.ZERO_GRAD_SUFFIXES):
-            G.compare(z, 'step0/grad/' + n, p.grad, 5e-3)
+            worst_g = max(worst_g, G.compare(z, 'step0/grad/' + n, p.grad, FULL_GRAD_FP_TOL))
     opt.step()
     sd = student.state_dict()
     for n in O.trainable_keys(sd):
         if not n.endswith(G.ZERO_GRAD_SUFFIXES):
-            G.compare(z, 'after/param/' + n, sd[n], 2e-3, atol=1e-6)
+            worst_p = max(worst_p, G.compare(z, 'after/param/' + n, sd[n], 2e-3, atol=1e-6))
+    _record_full(name, worst_g, worst_p)
     for n in z.files:
         if n.startswith('after/buffer/'):
             key = n[len('after/buffer/'):]
@@ -537,14 +554,16 @@ def test_batch16_is_the_reference_batch4_replicated():
                 assert torch.equal(out[4 * r:4 * r + 4], out[:4]), (who, k, r)
     opt.zero_grad()
     loss.backward()
+    worst_g = worst_p = 0.0
     for n, p in student.named_parameters():
         if p.requires_grad and not n.endswith(G.ZERO_GRAD_SUFFIXES):
-            G.compare(z, 'step0/grad/' + n, p.grad * 0.25, 5e-3)
+            worst_g = max(worst_g, G.compare(z, 'step0/grad/' + n, p.grad * 0.25, FULL_GRAD_FP_TOL))
     opt.step()
     sd = student.state_dict()
     for n in O.trainable_keys(sd):
         if not n.endswith(G.ZERO_GRAD_SUFFIXES):
-            G.compare(z, 'after/param/' + n, sd[n], 2e-3, atol=1e-6)
+            worst_p = max(worst_p, G.compare(z, 'after/param/' + n, sd[n], 2e-3, atol=1e-6))
+    _record_full('batch 16 = full_ghnd_faster_b4 x 4', worst_g, worst_p)
 
 
 def test_batch16_hnd_is_the_reference_batch2_replicated():
@@ -566,16 +585,19 @@ def test_batch16_hnd_is_the_reference_batch2_replicated():
             assert torch.equal(out[2 * r:2 * r + 2], out[:2]), (who, r)
     opt.zero_grad()
     loss.backward()
+    worst_g = worst_p = 0.0
     for n, p in student.named_parameters():
         if p.requires_grad and not n.endswith(G.ZERO_GRAD_SUFFIXES):
-            G.compare(z, 'step0/grad/' + n, p.grad * 0.125, 5e-3)
+            worst_g = max(worst_g, G.compare(z, 'step0/grad/' + n, p.grad * 0.125, FULL_GRAD_FP_TOL))
     opt.step()
     sd = student.state_dict()
     for n in O.trainable_keys(sd):
         if not n.endswith(G.ZERO_GRAD_SUFFIXES):
-            G.compare(z, 'after/param/' + n, sd[n], 2e-3, atol=1e-6)
+            worst_p = max(worst_p, G.compare(z, 'after/param/' + n, sd[n], 2e-3, atol=1e-6))
+    _record_full('batch 16 = full_hnd_faster_b2 x 8', worst_g, worst_p)
 
 
+DENSE_MAXABS_RMS = 1e-3      # worst |d| of any element, in units of its map's rms (achieved ~9e-5: a tail-tile bug is O(1))
 DENSE = {   # name -> (fixture whose seeded inputs / weights are reused, number of images taken from it)
     'ghnd_faster_b2': ('full_ghnd_faster_b4', 2),
     'hnd_faster_b2': ('full_hnd_faster_b2', 2),
@@ -613,6 +635,7 @@ def test_full_size_dense_parity_every_element(case):
     o_loss.backward()
     g32 = OrderedDict((k, orc32.s[k].grad.detach().clone()) for k in orc32.keys)
     report = []
+    worst_abs_rms = 0.0
     for i, k in enumerate(terms):
         assert abs(float(loss.per_term[i]) - float(o_terms[k])) / abs(float(o_terms[k])) < LOSS_TOL, k
         for who, model, hooked in (('teacher', teacher, t_hooked), ('student', student, s_hooked)):
@@ -631,7 +654,8 @@ def test_full_size_dense_parity_every_element(case):
             report.append('%s/%s rel %.1e img %.1e edge %.1e max|d| %.1e (rms %.2e)'
                           % (who, k, rel, per_img, rel_edge, worst_abs, rms))
             assert rel < FEAT_TOL and per_img < FEAT_TOL and rel_edge < FEAT_TOL, report[-1]
-            assert worst_abs < 2e-2 * rms + 1e-6, report[-1]
+            assert worst_abs < DENSE_MAXABS_RMS * rms + 1e-6, report[-1]
+            worst_abs_rms = max(worst_abs_rms, worst_abs / rms)
     assert abs(loss.item() - float(o_loss)) / abs(float(o_loss)) < LOSS_TOL
     del t_hooked, s_hooked, o_loss
     orc64 = O.DistillOracle(t_sd, s_sd, terms=terms, min_size=tuple(ms), max_size=meta['max_size'],
@@ -646,9 +670,12 @@ def test_full_size_dense_parity_every_element(case):
           % (case, tuple(x.shape), '\n  '.join(report), abs(loss.item() - float(l64)) / abs(float(l64)), worst_g))
     from tests.conftest import record_achieved
     worst_map = max(float(r.split('rel ')[1].split(' ')[0]) for r in report)
-    record_achieved('[dense %s] every element of %d maps: worst rel-L2 %.1e (tol %.0e); loss rel %.1e; worst gradient '
-                    'rel-L2 vs fp64 %.2e' % (case, len(report), worst_map, FEAT_TOL,
-                                             abs(loss.item() - float(l64)) / abs(float(l64)), worst_g))
+    record_achieved('[dense %s] every element of %d maps: worst rel-L2 %.1e (tol %.0e), worst max|d| / rms %.1e (tol %.0e); '
+                    'loss rel %.1e; worst gradient rel-L2 vs fp64 %.2e'
+                    % (case, len(report), worst_map, FEAT_TOL, worst_abs_rms, DENSE_MAXABS_RMS,
+                       abs(loss.item() - float(l64)) / abs(float(l64)), worst_g))
+    for r in report:
+        record_achieved('    ' + r)
 
 
 @pytest.mark.parametrize('first', [False, 'layer2', 'layer3'])
@@ -1001,6 +1028,8 @@ def test_relu_decisions_differ_from_the_fp32_oracle_only_where_the_value_is_roun
         opt.step()
         warm.step()
     assert worst_rel < 1e-5, (flips, total, worst_rel, where)
+    from tests import conftest
+    conftest.FLIPS[name] = '%d of %d' % (flips, total)
     record_achieved('[ReLU decisions, HIP vs fp32 oracle, all %d ReLU maps x %d steps of %s] %d of %d elements differ%s; the '
                     'largest differing value is %.1e of its map\'s max'
                     % (len(ref_pairs), meta['steps'], name, flips, total,

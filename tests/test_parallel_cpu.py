@@ -91,6 +91,34 @@ def _worker(rank, world, port, q):
     assert len(parallel._PENDING) == 1 and float(flat.min()) == 3.0
     assert parallel.finish_pending(flat2, params) == 0.5 and float(flat2.max()) == 3.0
     parallel.end_step()
+    # reduce_gradients() averages a NON-guarded tensor (attached after the wrapper was built) per tensor,
+    # and still refuses a guarded one whose gradient lies outside every exchanged arena
+    extra = torch.nn.Parameter(torch.zeros(3))
+    student.register_parameter('extra_head', extra)
+    extra.grad = torch.full((3,), float(rank + 1))
+    wrapped.reduce_gradients()
+    fallback_ok = bool((extra.grad == 1.5).all())
+    params[1].grad = torch.ones_like(params[1])
+    try:
+        wrapped.reduce_gradients()
+        guarded_refused = False
+    except RuntimeError:
+        guarded_refused = True
+    params[1].grad = None
+    extra.grad = None
+    del student._parameters['extra_head']
+    # DDP's per-forward buffer broadcast as an option -- only train-mode BatchNorm buffers travel
+    bn = student.backbone.body.layer1.decoder[0]
+    with torch.no_grad():
+        bn.running_mean.add_(float(rank))
+        bn.num_batches_tracked.add_(rank)
+    opt_in = DistributedStudent(student, broadcast_buffers=True)
+    live = opt_in._live_buffers()
+    opt_in.broadcast_live_buffers()
+    bcast_ok = (len(live) == 3 * 8 and sum(b.numel() for b in live if b.is_floating_point()) == 2182
+                and float(bn.running_mean.sum()) == float(rm.sum()) and int(bn.num_batches_tracked) == 0)
+    opt_in.close()
+    assert fallback_ok and guarded_refused and bcast_ok, (fallback_ok, guarded_refused, bcast_ok)
     wrapped.close()
     assert parallel.finish_pending(flat, params) == 1.0          # guard released with the wrapper
     wrapped._guarded = [id(q_) for q_ in params]
