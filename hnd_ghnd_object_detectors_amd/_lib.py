@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('HND_LIB_PATH') or os.path.join(_HERE, 'libhnd_hip.so')     # env: kernel experiments
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 c_float_p = C.POINTER(C.c_float)
 vp = C.c_void_p
@@ -116,6 +116,7 @@ _SIGNATURES = {
     'hnd_linear_fwd': (C.c_int, [vp] * 4 + [C.c_int] * 5 + [vp]),
     'hnd_linear_bwd': (C.c_int, [vp] * 6 + [C.c_int] * 5 + [vp]),
     'hnd_softmax_rows': (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),
+    'hnd_softmax_ce_rows_fwd_bwd': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int64, vp, vp, vp]),
     'hnd_channel_sum_scratch_elems': (C.c_size_t, [C.c_int]),
     'hnd_channel_sum': (C.c_int, [vp, vp, C.c_int64, C.c_int, C.c_int, vp, vp]),
     'hnd_sgd_step_flat': (C.c_int, [vp, vp, vp, C.c_int64] + [C.c_float] * 4 + [C.c_int, C.c_int, C.c_float, vp]),

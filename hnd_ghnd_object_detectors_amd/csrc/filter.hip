@@ -148,6 +148,57 @@ __global__ void softmax_rows_kernel(const float* __restrict__ x, float* __restri
   for (int j = 0; j < cols; ++j) y[(size_t)r * cols + j] = expf(x[(size_t)r * cols + j] - m) / s;
 }
 
+// ---------------------------------------------------------------------------- mean cross entropy of [rows, cols] logits
+// F.cross_entropy(logits, labels) (reference src/ext_runner.py:58) and its gradient in one launch of one workgroup:
+// loss = mean over the counted rows of (logsumexp(x) - x[label]); dlogits = (softmax(x) - onehot(label)) / counted.
+// Rows whose label is `ignore_index` (torch's default -100) contribute nothing.  Fixed summation order (row-strided
+// partials, LDS tree): bitwise reproducible.
+__global__ void softmax_ce_kernel(const float* __restrict__ x, const long long* __restrict__ labels, int rows, int cols,
+                                  long long ignore_index, float* __restrict__ loss, float* __restrict__ dx) {
+  __shared__ float red[256];
+  __shared__ int cnt[256];
+  float acc = 0.f;
+  int n = 0;
+  for (int r = threadIdx.x; r < rows; r += 256) {
+    const long long lab = labels[r];
+    if (lab == ignore_index || lab < 0 || lab >= cols) continue;
+    const float* xr = x + (size_t)r * cols;
+    float m = -INFINITY;
+    for (int j = 0; j < cols; ++j) m = fmaxf(m, xr[j]);
+    float s = 0.f;
+    for (int j = 0; j < cols; ++j) s += expf(xr[j] - m);
+    acc += (logf(s) + m) - xr[lab];
+    ++n;
+  }
+  red[threadIdx.x] = acc;
+  cnt[threadIdx.x] = n;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) {
+      red[threadIdx.x] += red[threadIdx.x + w];
+      cnt[threadIdx.x] += cnt[threadIdx.x + w];
+    }
+    __syncthreads();
+  }
+  const int counted = cnt[0];
+  const float inv = counted > 0 ? 1.f / (float)counted : 0.f;
+  if (threadIdx.x == 0) loss[0] = counted > 0 ? red[0] * inv : NAN;      // torch: mean over zero rows is nan
+  for (int r = threadIdx.x; r < rows; r += 256) {
+    const long long lab = labels[r];
+    const float* xr = x + (size_t)r * cols;
+    float* dr = dx + (size_t)r * cols;
+    if (lab == ignore_index || lab < 0 || lab >= cols) {
+      for (int j = 0; j < cols; ++j) dr[j] = 0.f;
+      continue;
+    }
+    float m = -INFINITY;
+    for (int j = 0; j < cols; ++j) m = fmaxf(m, xr[j]);
+    float s = 0.f;
+    for (int j = 0; j < cols; ++j) s += expf(xr[j] - m);
+    for (int j = 0; j < cols; ++j) dr[j] = (expf(xr[j] - m) / s - (j == (int)lab ? 1.f : 0.f)) * inv;
+  }
+}
+
 // ---------------------------------------------------------------------------- per-channel sum (conv bias gradient)
 // two passes, fixed summation order: grid (pixel chunk, 64-channel group) -> scratch[chunk][c]; then over chunks
 constexpr int kSumChunks = 128;
@@ -243,6 +294,14 @@ int hnd_softmax_rows(const float* x, float* y, int rows, int cols, void* stream)
   hipLaunchKernelGGL(softmax_rows_kernel, dim3((rows + 63) / 64), dim3(64), 0, hnd::as_stream(stream), x, y, rows,
                      cols);
   return hnd::check_launch("hnd_softmax_rows");
+}
+
+int hnd_softmax_ce_rows_fwd_bwd(const float* logits, const int64_t* labels, int rows, int cols, int64_t ignore_index,
+                                float* loss, float* dlogits, void* stream) {
+  HND_REQUIRE(logits && labels && loss && dlogits && rows > 0 && cols > 0, "hnd_softmax_ce_rows_fwd_bwd: bad arguments");
+  hipLaunchKernelGGL(softmax_ce_kernel, dim3(1), dim3(256), 0, hnd::as_stream(stream), logits,
+                     (const long long*)labels, rows, cols, (long long)ignore_index, loss, dlogits);
+  return hnd::check_launch("hnd_softmax_ce_rows_fwd_bwd");
 }
 
 size_t hnd_channel_sum_scratch_elems(int c) { return (size_t)kSumChunks * (size_t)(c > 0 ? c : 0); }

@@ -17,10 +17,11 @@ import time
 import numpy as np
 import torch
 from torch import distributed as dist
-from torch import nn
+
 
 from .models import get_model, load_ckpt, save_ckpt
 from .models.ext.backbone import check_if_valid_target
+from .models.ext.classifier import cross_entropy
 from .myutils.common import file_util, yaml_util
 from .myutils.pytorch import func_util, module_util
 from .parallel import DistributedStudent
@@ -74,7 +75,7 @@ def train_model(model, optimizer, data_loader, device, epoch, log_freq, wrapper=
         images, targets = _upload(images, targets, device)      # (no-ops behind the prefetcher)
         ext_logits = model(images, targets)
         ext_targets = convert_target2ext_targets(targets, device)
-        loss = nn.functional.cross_entropy(ext_logits, ext_targets)
+        loss = cross_entropy(ext_logits, ext_targets)          # one launch: loss + dlogits (hnd_softmax_ce_rows_fwd_bwd)
         logged = float(misc_util.reduce_dict({'loss_ext_classifier': loss.detach()})['loss_ext_classifier'])
         if not math.isfinite(logged):
             print('Loss is {}, stopping training'.format(logged))

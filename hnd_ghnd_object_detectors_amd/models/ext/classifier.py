@@ -42,6 +42,41 @@ class _FilterLogitsFn(torch.autograd.Function):
         return (None, None) + tuple(arena.views(flat))       # fresh views: AccumulateGrad adopts them uncopied
 
 
+class _CrossEntropyFn(torch.autograd.Function):
+    """loss and dlogits come out of ONE launch (hnd_softmax_ce_rows_fwd_bwd); backward hands dlogits on, scaled by the
+    incoming gradient on the device (no host read)"""
+
+    @staticmethod
+    def forward(ctx, logits, labels, ignore_index):
+        from ... import ops
+        logits = logits.detach()
+        if not logits.is_contiguous() or logits.dtype != torch.float32:
+            logits = logits.float().contiguous()
+        loss = torch.empty((), dtype=torch.float32, device=logits.device)
+        dlogits = torch.empty_like(logits)
+        ops.softmax_ce_rows(logits, labels.contiguous(), loss, dlogits, ignore_index)
+        ctx.dlogits = dlogits
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        from ... import ops
+        if ctx.dlogits is None:
+            raise RuntimeError('cross_entropy: backward ran twice (the gradient buffer is scaled in place)')
+        g = grad_output.detach().float().reshape(1).contiguous()
+        dlogits, ctx.dlogits = ctx.dlogits, None
+        ops.scale_by_device_scalar(dlogits, g)
+        return dlogits, None, None
+
+
+def cross_entropy(logits, labels, ignore_index=-100):
+    """``nn.functional.cross_entropy(logits, labels)`` (mean reduction) of the filter's training step, reference
+    src/ext_runner.py:58, on the HIP path: [N, C] fp32 logits, [N] int64 labels -> scalar loss with autograd."""
+    if not logits.is_cuda:
+        raise RuntimeError('models.ext.classifier.cross_entropy runs on the HIP path only (no CPU fallback)')
+    return _CrossEntropyFn.apply(logits, labels, ignore_index)
+
+
 class Ext4ResNet(BaseExtClassifier):
     def __init__(self, input_channel):
         super().__init__(ext_idx=0)

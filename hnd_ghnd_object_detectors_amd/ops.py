@@ -915,6 +915,15 @@ def softmax_rows(x, y):
     check(_L.hnd_softmax_rows(ptr(x), ptr(y), x.shape[0], x.shape[1], stream_ptr()), 'hnd_softmax_rows')
 
 
+def softmax_ce_rows(logits, labels, loss, dlogits, ignore_index=-100):
+    """mean cross entropy of [rows, cols] logits against int64 labels + its gradient, one launch"""
+    assert logits.dim() == 2 and logits.is_contiguous() and logits.dtype == torch.float32
+    assert labels.dtype == torch.int64 and labels.is_contiguous() and labels.numel() == logits.shape[0]
+    assert dlogits.shape == logits.shape and dlogits.is_contiguous() and loss.numel() == 1
+    check(_L.hnd_softmax_ce_rows_fwd_bwd(ptr(logits), ptr(labels), logits.shape[0], logits.shape[1], int(ignore_index),
+                                         ptr(loss), ptr(dlogits), stream_ptr()), 'hnd_softmax_ce_rows_fwd_bwd')
+
+
 def channel_sum(x, c, out, scratch=None):
     cs = x.shape[-1]
     need = _L.hnd_channel_sum_scratch_elems(c)

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define HND_ABI_VERSION 9
+#define HND_ABI_VERSION 10
 
 typedef enum hnd_status {
   HND_OK = 0,
@@ -51,7 +51,7 @@ int hnd_relay_timeouts(int reset);
 const char* hnd_device_arch(void);
 
 /* ------------------------------------------------------------------------------------------
- * Implicit-GEMM convolution, fp32 MFMA (v_mfma_f32_32x32x2_f32), NHWC.
+ * Implicit-GEMM convolution, fp32 MFMA (v_mfma_f32_16x16x4_f32 in every kernel since round 2), NHWC.
  * One kernel serves forward convs and data-gradients: the launch describes, per output pixel
  * (oh, ow) of a *virtual* output grid and per tap (i, j), the source pixel
  *      ih = oh*sh + i*dh + bh,   iw = ow*sw + j*dw + bw        (zero when out of range)
@@ -405,6 +405,13 @@ int hnd_linear_bwd(const float* x, const float* weight, const float* dout, float
                    int n, int hw, int c, int cs, int nout, void* stream);
 /* z.softmax(dim=1) of the eval-mode classifier (classifier.py:37) */
 int hnd_softmax_rows(const float* x, float* y, int rows, int cols, void* stream);
+/* ABI 10.  nn.functional.cross_entropy(ext_logits, ext_targets) of the filter's training step (reference
+ * src/ext_runner.py:58) and its gradient in one launch: loss[0] = mean over the counted rows of
+ * logsumexp(logits[r]) - logits[r][labels[r]]; dlogits[r] = (softmax(logits[r]) - onehot(labels[r])) / counted.  Rows
+ * whose label equals ignore_index (torch's default: -100) are not counted and get a zero gradient.  logits, dlogits:
+ * [rows, cols] fp32 row-major; labels: [rows] int64.  Fixed summation order. */
+int hnd_softmax_ce_rows_fwd_bwd(const float* logits, const int64_t* labels, int rows, int cols, int64_t ignore_index,
+                                float* loss, float* dlogits, void* stream);
 /* per-channel sum over pixels of x [npix][cs] -> out[c]: the bias gradient of nn.Conv2d (autograd, ext_runner.py:72).
  * Two passes in a fixed order (bit-reproducible); scratch: device float[hnd_channel_sum_scratch_elems(c)]. */
 size_t hnd_channel_sum_scratch_elems(int c);

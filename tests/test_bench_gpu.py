@@ -47,6 +47,39 @@ def test_affinity_probe_never_raises():
         os.sched_setaffinity(0, before)
 
 
+def test_print_topology_touches_no_gpu_and_needs_no_torch():
+    """--print_topology lists KFD GPU -> PCI BDF -> NUMA node -> cpulist from sysfs alone (the first thing to run on a
+    new 8-GPU node: it cannot hang on a sick device).  Here (no /sys/class/kfd) it says so and exits 1."""
+    code = ('import sys, runpy; sys.argv = ["bench.py", "--print_topology"]\n'
+            'try:\n    runpy.run_path(%r, run_name="__main__")\n'
+            'except SystemExit as e:\n    rc = e.code\n'
+            'assert "torch" not in sys.modules, "torch was imported"\nsys.exit(rc)' % os.path.join(ROOT, 'bench.py'))
+    r = subprocess.run([sys.executable, '-c', code], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    out = r.stdout.decode()
+    assert r.returncode in (0, 1), r.stderr.decode()[-2000:]
+    assert ('local_rank 0 -> kfd node' in out) if r.returncode == 0 else ('no readable KFD topology' in out)
+
+
+@pytest.mark.gpu
+def test_bench_eight_ranks_on_a_shared_device():
+    """the first-N=8-run rehearsal on one GPU -- 8 children through the launcher (gloo, batch 2, an
+    ungated geometry), 8 per-rank times, the exchange timed on every rank, every child reaped"""
+    r = _run(['--gpus', '8', '--share_device', '--dist_backend', 'gloo', '--batch', '2', '--steps', '2', '--warmup', '1',
+              '--no_cpu_baseline', '--no_runner'])
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    rk = out['ranks']
+    assert out['n_gpus'] == 8 and out['config']['global_batch'] == 16 and rk['world'] == 8
+    assert rk['launched_by'] == 'bench.py' and rk['backend'] == 'gloo'
+    assert len(rk['ms_per_step_per_rank']) == 8 and len(rk['exchange_ms_per_step_per_rank']) == 8
+    assert all(v > 0 for v in rk['ms_per_step_per_rank']) and 0 <= rk['ms_per_step_spread'] < 1
+    assert out['upload']['batches'] >= 3
+    print('\n[bench --gpus 8, shared device, batch 2] %.1f img/s, per-rank ms %s, spread %.3f, exchange %.3f ms/step (gloo)'
+          % (out['value'], rk['ms_per_step_per_rank'], rk['ms_per_step_spread'], rk['exchange_ms_per_step']))
+
+
 @pytest.mark.gpu
 def test_bench_launches_its_own_two_ranks_and_gates_both():
     r = _run(['--gpus', '2', '--share_device', '--dist_backend', 'gloo', '--steps', '2', '--warmup', '1',
@@ -80,7 +113,7 @@ def test_bench_four_ranks_on_a_shared_device_report_the_exchange():
     """the 4-rank line (plumbing: one GPU shared, gloo, batch 2 -- an ungated geometry) carries the
     event-timed exchange and the per-rank spread the first real N = 8 run will be read by"""
     r = _run(['--gpus', '4', '--share_device', '--dist_backend', 'gloo', '--batch', '2', '--steps', '2', '--warmup', '1',
-              '--no_cpu_baseline', '--ref_1gpu_img_s', '100'])
+              '--no_cpu_baseline', '--no_runner', '--ref_1gpu_img_s', '100'])
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     lines = [l for l in r.stdout.decode().splitlines() if l.strip()]
     assert len(lines) == 1

@@ -611,6 +611,36 @@ def test_softmax_rows_and_channel_sum(ops):
     assert relerr(out.cpu(), t.sum(dim=(0, 2, 3))) < 1e-5
 
 
+@pytest.mark.parametrize('rows,cols', [(2, 2), (16, 2), (300, 2), (700, 5)])
+def test_softmax_cross_entropy_matches_torch(ops, rows, cols):
+    """hnd_softmax_ce_rows_fwd_bwd == nn.functional.cross_entropy (mean) and its autograd, the loss of the filter's
+    step (reference src/ext_runner.py:58): fp32 arithmetic, tolerance 1e-6 relative on loss and gradient; rows with
+    torch's ignore_index are not counted; wide logits do not overflow; the product wrapper carries autograd"""
+    from hnd_ghnd_object_detectors_amd.models.ext.classifier import cross_entropy
+    g = gen(35 + rows)
+    x = (torch.randn(rows, cols, generator=g) * 6).double().requires_grad_(True)
+    x.data[0] *= 20                                               # |logit| ~ 100: needs the max subtraction
+    labels = torch.randint(0, cols, (rows,), generator=g)
+    if rows > 2:
+        labels[1] = -100
+    ref = torch.nn.functional.cross_entropy(x, labels)
+    ref.backward()
+    loss, dx = torch.empty((), device=DEV), torch.full((rows, cols), float('nan'), device=DEV)
+    ops.softmax_ce_rows(x.detach().float().to(DEV), labels.to(DEV), loss, dx)
+    ops.sync_check()
+    assert abs(float(loss) - float(ref)) <= 1e-6 * abs(float(ref)) + 1e-7
+    assert relerr(dx.cpu(), x.grad.float()) < 1e-6
+    if rows > 2:
+        assert float(dx[1].abs().max()) == 0.0
+    xd = x.detach().float().to(DEV).requires_grad_(True)
+    out = cross_entropy(xd, labels.to(DEV)) * 3.0                 # the incoming gradient is applied on the device
+    out.backward()
+    assert relerr(xd.grad.cpu(), 3.0 * x.grad.float()) < 1e-6
+    loss2, dx2 = torch.empty((), device=DEV), torch.empty(rows, cols, device=DEV)
+    ops.softmax_ce_rows(x.detach().float().to(DEV), labels.to(DEV), loss2, dx2)
+    assert torch.equal(loss2, loss) and torch.equal(dx2, dx)      # fixed summation order
+
+
 @pytest.mark.parametrize('momentum,wd,nesterov', [(0.9, 1e-4, False), (0.0, 0.0, False), (0.9, 0.0, True)])
 def test_sgd_matches_torch(ops, momentum, wd, nesterov):
     g = gen(34)

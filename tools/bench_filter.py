@@ -59,10 +59,12 @@ def main():
         model.transform(images, probe, None)
     labels = ext_runner.convert_target2ext_targets(probe, dev)
 
+    from hnd_ghnd_object_detectors_amd.models.ext.classifier import cross_entropy
+
     def body():
         tg = [dict(t) for t in targets]
         logits = model(images, tg)
-        loss = torch.nn.functional.cross_entropy(logits, labels)
+        loss = cross_entropy(logits, labels)              # the product kernel (hnd_softmax_ce_rows_fwd_bwd)
         opt.zero_grad()
         loss.backward()
         opt.step()
