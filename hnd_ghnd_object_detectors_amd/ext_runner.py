@@ -171,7 +171,7 @@ def _loaders(args, config, distributed):
         def synthetic(batch_size, seed):
             return data_util.SyntheticDetectionLoader(args.synthetic_batches, batch_size, height, width,
                                                       config['model']['name'], seed=seed, rank=misc_util.get_rank(),
-                                                      positive_every=2)
+                                                      positive_every=2, workers=4, pin_memory=True)
         held_out = synthetic(batch_eval, 4321)
         return synthetic(batch_train, 1234), held_out, held_out
     sampler, train_loader, val_loader, test_loader = data_util.get_coco_data_loaders(config['dataset'], batch_train,
@@ -196,6 +196,7 @@ def _filter_model(model_config, device):
 
 def main(args):
     distributed, _ = main_util.init_distributed_mode(args.world_size, args.dist_url)
+    main_util.limit_host_threads()
     config = yaml_util.load_yaml_file(args.config)
     if args.json is not None:
         main_util.overwrite_config(config, args.json)

@@ -16,6 +16,7 @@ exactly as in the reference's ``init_distributed_mode``.
 """
 import argparse
 import datetime
+import os
 import time
 
 import torch
@@ -45,7 +46,7 @@ _FLAGS = (  # (flag, kwargs): the reference's CLI first, this build's additions 
     ('-host_float_input', dict(action='store_true', help='COCO loaders: convert images to float CHW on the host like '
                                                          'the reference instead of shipping uint8 to the device')),
     ('--num_epochs', dict(default=None, type=int, help='override train.num_epochs')),
-    ('--loader_workers', dict(default=4, type=int, help='background threads generating synthetic batches ahead of the '
+    ('--loader_workers', dict(default=8, type=int, help='background threads generating synthetic batches ahead of the '
                                                         'step (the role of the DataLoader workers)')),
     ('-no_prefetch', dict(action='store_true', help='upload every batch synchronously at the top of its step like the '
                                                     'reference, instead of through upload.DevicePrefetcher')),
@@ -217,6 +218,7 @@ def main(args):
     if args.json is not None:
         main_util.overwrite_config(config, args.json)
     distributed, _ = main_util.init_distributed_mode(args.world_size, args.dist_url)
+    main_util.limit_host_threads(int(os.environ.get('LOCAL_WORLD_SIZE') or 1))
     if not torch.cuda.is_available():
         raise RuntimeError('the HIP distillation path needs an MI355X (no CPU fallback exists)')
     device = torch.device(args.device)
@@ -233,7 +235,8 @@ def main(args):
         train_sampler = None
         train_loader = data_util.SyntheticDetectionLoader(args.synthetic_batches, batch_size, height, width,
                                                           student_config['name'], rank=misc_util.get_rank(),
-                                                          decoded=args.decoded_input, workers=args.loader_workers)
+                                                          decoded=args.decoded_input, workers=args.loader_workers,
+                                                          pin_memory=not args.no_prefetch)
     else:       # COCO-format folders named by the yaml (reference :128-129); uint8 images unless -host_float_input
         train_sampler, train_loader, val_loader, test_loader = data_util.get_coco_data_loaders(
             config['dataset'], batch_size, distributed, decoded=not args.host_float_input)

@@ -63,6 +63,10 @@ class DecodedImage(object):
         args = tuple(a for a in args if not isinstance(a, torch.dtype))
         return DecodedImage(self.data.to(*args, **kwargs), self.hwc, self.flip)
 
+    def pin_memory(self, *args, **kwargs):
+        """DataLoader(pin_memory=True) calls this on batch elements that have it"""
+        return DecodedImage(self.data.pin_memory(*args, **kwargs), self.hwc, self.flip)
+
     def float_chw(self):
         """What the reference's ToTensor (+ flip) would have produced -- for checks, not used by the product path."""
         x = self.data.permute(2, 0, 1) if self.hwc else self.data

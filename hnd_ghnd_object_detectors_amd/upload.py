@@ -7,9 +7,11 @@ images + the targets, ~3.3 ms of PCIe time per step at batch 16 plus the pageabl
 and yields the same structure with every tensor already on the device:
 
   * a feeder thread pulls batch k+1 from the source while step k is being enqueued / computed, lays ALL of its tensors
-    (images -- float CHW or ``DecodedImage`` uint8 -- and every target tensor) out in ONE pinned staging buffer and
-    issues ONE asynchronous copy of it on a copy stream of its own: one DMA of 205 MB (51 MB on the uint8 path) instead
-    of ~50 small ones, running under the previous step's kernels;
+    (images -- float CHW or ``DecodedImage`` uint8 -- and every target tensor) out in ONE pinned staging buffer (big
+    tensors are copied in by a few helper threads) and issues ONE asynchronous copy of it on a copy stream of its own:
+    one DMA of 205 MB (51 MB on the uint8 path) instead of ~50 small ones, running under the previous step's kernels.
+    Tensors the loader already delivers in pinned memory (``DataLoader(pin_memory=True)``, ``SyntheticDetectionLoader(
+    pin_memory=True)``) skip the staging copy: they go to their place in the device buffer straight from where they are;
   * ``depth`` slots (pinned buffer + device buffer + two events each) rotate; a slot's device buffer is rewritten only
     after the step that consumed it has finished ON THE GPU (event recorded on the consumer's stream when it asks for
     the next batch; the copy stream waits for it), its pinned buffer only after the copy out of it has completed;
@@ -21,10 +23,12 @@ pinned / device memory, streams and events only.
 """
 import queue
 import threading
+from concurrent.futures import ThreadPoolExecutor
 
 import torch
 
 _ALIGN = 256
+_BIG = 1 << 20          # tensors of at least this many bytes are staged by the helper threads
 
 
 def _round_up(x, m):
@@ -32,10 +36,11 @@ def _round_up(x, m):
 
 
 class _Slot(object):
-    __slots__ = ('pinned', 'dev', 'ready', 'consumed', 'free')
+    __slots__ = ('pinned', 'dev', 'ready', 'consumed', 'free', 'keep')
 
     def __init__(self):
         self.pinned = self.dev = None
+        self.keep = None                         # pinned source tensors of the copy in flight (alive until `ready`)
         self.ready = torch.cuda.Event()          # the copy into `dev` has completed (recorded on the copy stream)
         self.consumed = None                     # the step that read `dev` has completed (consumer's stream), or None
         self.free = threading.Semaphore(1)       # host side: the consumer no longer holds views of this slot
@@ -59,7 +64,7 @@ class DevicePrefetcher(object):
     ``len()`` and ``set_epoch`` pass through to the source.  ``copied_bytes`` / ``batches`` count what went over the
     link (bench.py reports them)."""
 
-    def __init__(self, source, device, depth=3):
+    def __init__(self, source, device, depth=3, stagers=4):
         assert depth >= 2, 'one slot is read by the step while the next is being filled'
         self.source, self.device, self.depth = source, torch.device(device), depth
         if self.device.type != 'cuda':
@@ -71,6 +76,7 @@ class DevicePrefetcher(object):
         self.copied_bytes = self.batches = 0
         self._thread = self._queue = self._stop = None
         self._held = None
+        self._pool = ThreadPoolExecutor(stagers, thread_name_prefix='upload-stager') if stagers > 1 else None
 
     def __len__(self):
         return len(self.source)
@@ -82,24 +88,49 @@ class DevicePrefetcher(object):
     # ------------------------------------------------------------------ feeder thread
     def _stage(self, slot, images, targets):
         leaves = _leaves(images, targets)
-        offs, total = [], 0
-        for _, _, _, t in leaves:
-            offs.append(total)
-            total = _round_up(total + t.numel() * t.element_size(), _ALIGN)
+        nbytes = [t.numel() * t.element_size() for _, _, _, t in leaves]
+        # big tensors the loader already holds in pinned memory go straight to the device; everything else is staged.
+        # Layout: direct tensors first, the staged ones behind them in one contiguous range (= one copy)
+        is_direct = [nb >= _BIG and t.is_pinned() and t.is_contiguous() for (_, _, _, t), nb in zip(leaves, nbytes)]
+        offs, total = [0] * len(leaves), 0
+        for want in (True, False):
+            if not want:
+                stage_lo = total
+            for i, nb in enumerate(nbytes):
+                if is_direct[i] == want:
+                    offs[i] = total
+                    total = _round_up(total + nb, _ALIGN)
         total = max(total, _ALIGN)
-        slot.ready.synchronize()                 # the previous copy OUT of this pinned buffer is complete
+        slot.ready.synchronize()                 # the previous copy OUT of this slot's host memory is complete
+        slot.keep = None
         if slot.pinned is None or slot.pinned.numel() < total:
             slot.pinned = torch.empty(total, dtype=torch.uint8, pin_memory=True)
-            slot.dev = torch.empty(total, dtype=torch.uint8, device=self.device)
-        views = []
-        for (_, _, _, t), off in zip(leaves, offs):
-            nb = t.numel() * t.element_size()
-            slot.pinned[off:off + nb].view(t.dtype).view(t.shape).copy_(t)
+            # the device buffer belongs to the COPY stream's pool of the caching allocator: allocated under the thread's
+            # default stream it could be a block another thread has just freed with kernels still pending on it, and the
+            # copy stream (which is not ordered with them) would write into it first
+            with torch.cuda.stream(self.copy_stream):
+                slot.dev = torch.empty(total, dtype=torch.uint8, device=self.device)
+        views, jobs = [], []
+        for (_, _, _, t), off, nb, direct in zip(leaves, offs, nbytes, is_direct):
             views.append(slot.dev[off:off + nb].view(t.dtype).view(t.shape))
+            if direct:
+                continue
+            dst = slot.pinned[off:off + nb].view(t.dtype).view(t.shape)
+            if nb >= _BIG and self._pool is not None:
+                jobs.append(self._pool.submit(dst.copy_, t))
+            else:
+                dst.copy_(t)
+        for j in jobs:
+            j.result()
         with torch.cuda.stream(self.copy_stream):
             if slot.consumed is not None:        # the step that read this device buffer has finished on the GPU
                 self.copy_stream.wait_event(slot.consumed)
-            slot.dev[:total].copy_(slot.pinned[:total], non_blocking=True)
+            for (_, _, _, t), v, direct in zip(leaves, views, is_direct):
+                if direct:
+                    v.copy_(t, non_blocking=True)
+            if stage_lo < total:
+                slot.dev[stage_lo:total].copy_(slot.pinned[stage_lo:total], non_blocking=True)
+            slot.keep = [t for (_, _, _, t), direct in zip(leaves, is_direct) if direct]
             slot.ready.record(self.copy_stream)
         self.copied_bytes += total
         self.batches += 1
@@ -160,7 +191,9 @@ class DevicePrefetcher(object):
                 if kind == 'error':
                     raise payload
                 slot = self.slots[k % self.depth]
-                torch.cuda.current_stream(self.device).wait_event(slot.ready)
+                cur = torch.cuda.current_stream(self.device)
+                cur.wait_event(slot.ready)
+                slot.dev.record_stream(cur)      # (a regrown buffer is not recycled under this stream's readers)
                 self._held = slot
                 yield payload
         finally:

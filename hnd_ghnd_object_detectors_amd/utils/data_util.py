@@ -39,13 +39,16 @@ class SyntheticDetectionLoader(object):
     with a feeder thread."""
 
     def __init__(self, num_batches, batch_size, height=800, width=1333, model_name='faster_rcnn', seed=1234, rank=0,
-                 device='cpu', decoded=False, train=True, positive_every=0, workers=0):
+                 device='cpu', decoded=False, train=True, positive_every=0, workers=0, pin_memory=False):
         self.num_batches, self.batch_size, self.h, self.w = num_batches, batch_size, height, width
         self.model_name, self.seed, self.rank, self.device = model_name, seed, rank, device
         self.decoded, self.transform = decoded, get_transform(train)
         self.positive_every = positive_every       # neural filter: every k-th person has 17 visible keypoints
         self.epoch = 0
         self.workers = workers
+        # like DataLoader(pin_memory=True): images are generated straight into pinned host memory, so the uploader
+        # (upload.DevicePrefetcher) sends them to the device without a staging copy
+        self.pin_memory = bool(pin_memory) and torch.cuda.is_available()
 
     def set_epoch(self, epoch):
         self.epoch = epoch
@@ -75,9 +78,12 @@ class SyntheticDetectionLoader(object):
     def raw_images(self, k, epoch_seed=None):
         """the images of batch k of the current epoch: float CHW in [0, 1), or uint8 HWC with ``decoded``"""
         g = torch.Generator().manual_seed((self._epoch_seed() if epoch_seed is None else epoch_seed) + 1000003 * k)
+        pin = self.pin_memory
         if not self.decoded:
-            return [torch.rand(3, self.h, self.w, generator=g) for _ in range(self.batch_size)]
-        return [torch.randint(0, 256, (self.h, self.w, 3), generator=g, dtype=torch.uint8)
+            return [torch.rand(3, self.h, self.w, generator=g, out=torch.empty(3, self.h, self.w, pin_memory=pin))
+                    for _ in range(self.batch_size)]
+        return [torch.randint(0, 256, (self.h, self.w, 3), generator=g, dtype=torch.uint8,
+                              out=torch.empty(self.h, self.w, 3, dtype=torch.uint8, pin_memory=pin))
                 for _ in range(self.batch_size)]
 
     def _finish(self, raw, flip_rng):
@@ -151,7 +157,7 @@ def get_coco_data_loaders(dataset_config, batch_size, distributed, decoded=True)
         train_batch_sampler = BatchSampler(train_sampler, batch_size, drop_last=True)
     workers = dataset_config['num_workers']
     train_loader = DataLoader(train_dataset, batch_sampler=train_batch_sampler, num_workers=workers,
-                              collate_fn=misc_util.collate_fn)
+                              collate_fn=misc_util.collate_fn, pin_memory=torch.cuda.is_available())
     val_loader = DataLoader(val_dataset, batch_size=1, sampler=val_sampler, num_workers=workers,
                             collate_fn=misc_util.collate_fn)
     test_loader = DataLoader(test_dataset, batch_size=1, sampler=test_sampler, num_workers=workers,

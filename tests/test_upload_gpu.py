@@ -14,9 +14,10 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _host_batches(n, batch, h, w, model='mask_rcnn', decoded=False, workers=0):
+def _host_batches(n, batch, h, w, model='mask_rcnn', decoded=False, workers=0, pin=False):
     from hnd_ghnd_object_detectors_amd.utils import data_util
-    return data_util.SyntheticDetectionLoader(n, batch, h, w, model, seed=77, decoded=decoded, workers=workers)
+    return data_util.SyntheticDetectionLoader(n, batch, h, w, model, seed=77, decoded=decoded, workers=workers,
+                                              pin_memory=pin)
 
 
 def _same(dev_batch, host_batch):
@@ -53,13 +54,18 @@ def test_synthetic_loader_workers_change_no_value():
 @pytest.mark.gpu
 @pytest.mark.parametrize('depth', [2, 3])
 @pytest.mark.parametrize('decoded', [False, True])
-def test_prefetched_batches_equal_the_host_batches(depth, decoded):
+@pytest.mark.parametrize('pin', [False, True])
+def test_prefetched_batches_equal_the_host_batches(depth, decoded, pin):
     """every tensor of every batch (float or uint8 images, boxes, int64 labels, uint8 masks) bit for bit, while the
-    consumer's stream lags behind the feeder (a long sleep kernel per step): a slot is never rewritten under its reader"""
+    consumer's stream lags behind the feeder (a long sleep kernel per step): a slot is never rewritten under its reader.
+    pin: the loader delivers its images in pinned memory (big ones then skip the staging copy; 600x800 here so that they
+    count as big).  The temporaries this loop frees while their kernels are still queued are exactly what the caching
+    allocator would hand to a slot allocated on the wrong stream (round 5: that corrupted batch 1)."""
     from hnd_ghnd_object_detectors_amd.upload import DevicePrefetcher
     dev = torch.device('cuda', 0)
-    host = list(_host_batches(7, 3, 40, 56, 'mask_rcnn', decoded))
-    pf = DevicePrefetcher(_host_batches(7, 3, 40, 56, 'mask_rcnn', decoded, workers=2), dev, depth=depth)
+    h, w = (600, 800) if pin else (40, 56)
+    host = list(_host_batches(7, 3, h, w, 'mask_rcnn', decoded))
+    pf = DevicePrefetcher(_host_batches(7, 3, h, w, 'mask_rcnn', decoded, workers=2, pin=pin), dev, depth=depth)
     assert len(pf) == 7
     sums, n = [], 0
     for k, (images, targets) in enumerate(pf):

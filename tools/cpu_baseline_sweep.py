@@ -20,7 +20,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--threads', default='32,64,128')
+    ap.add_argument('--threads', default='8,12,16,24,32')
     ap.add_argument('--batch', type=int, default=2)
     ap.add_argument('--steps', type=int, default=2)
     ap.add_argument('--out', default=os.path.join(ROOT, 'profiles', 'r05_cpu_baseline_sweep.json'))

@@ -55,8 +55,10 @@ __device__ __forceinline__ void split8(const f4& x0, const f4& x1, bf8& h, bf8& 
   uint32_t xs[8], hs[8], ms[8], ls[8];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    xs[i] = __builtin_bit_cast(uint32_t, x0[i]);
-    xs[4 + i] = __builtin_bit_cast(uint32_t, x1[i]);
+    // (through a scalar: __builtin_bit_cast applied to a vector ELEMENT expression made hipcc 7.2 use element 0 for every i)
+    const float f0 = x0[i], f1 = x1[i];
+    xs[i] = __float_as_uint(f0);
+    xs[4 + i] = __float_as_uint(f1);
   }
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -65,12 +67,12 @@ __device__ __forceinline__ void split8(const f4& x0, const f4& x1, bf8& h, bf8& 
       continue;
     }
     const uint32_t hb = xs[i] & 0xffff0000u;
-    const float r1 = __builtin_bit_cast(float, xs[i]) - __builtin_bit_cast(float, hb);
-    const uint32_t mb = __builtin_bit_cast(uint32_t, r1) & 0xffff0000u;
-    const float r2 = r1 - __builtin_bit_cast(float, mb);
+    const float r1 = __uint_as_float(xs[i]) - __uint_as_float(hb);
+    const uint32_t mb = __float_as_uint(r1) & 0xffff0000u;
+    const float r2 = r1 - __uint_as_float(mb);
     hs[i] = hb;
     ms[i] = mb;
-    ls[i] = __builtin_bit_cast(uint32_t, r2);
+    ls[i] = __float_as_uint(r2);
     if (MODE == 1) {
       // Inf - Inf = NaN would turn an infinite input into NaN outputs, and a NaN whose payload sits in the low 16 bits
       // would truncate to Inf: non-finite inputs keep hi = the value (NaN made quiet), mid = lo = 0
@@ -259,6 +261,9 @@ int main(int argc, char** argv) {
 
   std::vector<float> W((size_t)N * K);
   for (auto& v : W) v = nrand() * 0.0625f;
+  if (getenv("PROBE_IDENTITY"))                 // debugging aid: W = I, so C must equal A
+    for (int n = 0; n < N; ++n)
+      for (int k = 0; k < K; ++k) W[(size_t)n * K + k] = n == k ? 1.f : 0.f;
   std::vector<uint16_t> img;
   make_wimg(W, img);
   float *dA, *dW, *dWp, *dC;
@@ -318,6 +323,38 @@ int main(int argc, char** argv) {
       CK(hipDeviceSynchronize());
       CK(hipMemcpy(got.data(), dC, got.size() * 4, hipMemcpyDeviceToHost));
       const Err e = compare(got, ref);
+      if (getenv("PROBE_DEBUG") && ds == 0 && kern == 1) {
+        // where the error lives: by 64-column slice, by channel % 4 (= accumulator tile ni), by 16-row group (mi)
+        double es[4] = {0}, en[4] = {0}, em[4] = {0}, rs[4] = {0}, rn[4] = {0}, rm[4] = {0};
+        for (int m = 0; m < 256; ++m)
+          for (int n = 0; n < N; ++n) {
+            const double d = got[(size_t)m * N + n] - ref[(size_t)m * N + n], r2 = ref[(size_t)m * N + n] * ref[(size_t)m * N + n];
+            es[n / 64] += d * d; rs[n / 64] += r2;
+            en[n % 4] += d * d; rn[n % 4] += r2;
+            em[(m % 64) / 16] += d * d; rm[(m % 64) / 16] += r2;
+          }
+        for (int i = 0; i < 4; ++i)
+          printf("  debug: slice %d rel %.2e | ni %d rel %.2e | mi %d rel %.2e\n", i, sqrt(es[i] / rs[i]), i, sqrt(en[i] / rn[i]), i,
+                 sqrt(em[i] / rm[i]));
+        if (getenv("PROBE_IDENTITY"))
+          for (int m = 0; m < 3; ++m) {
+            printf("  row %d: C[m][n] == A[m'][k'] at:", m);
+            for (int n = 0; n < 12; ++n) {
+              int hit = -1;
+              for (int q = 0; q < 64 * K && hit < 0; ++q)
+                if (A[q] == got[(size_t)m * N + n]) hit = q;
+              printf(" (%d,%d)", hit < 0 ? -1 : hit / K, hit < 0 ? -1 : hit % K);
+            }
+            printf("\n");
+          }
+        for (int m = 0; m < 2; ++m) {
+          printf("  row %d got:", m);
+          for (int n = 0; n < 8; ++n) printf(" %9.5f", got[(size_t)m * N + n]);
+          printf("\n  row %d ref:", m);
+          for (int n = 0; n < 8; ++n) printf(" %9.5f", ref[(size_t)m * N + n]);
+          printf("\n");
+        }
+      }
       printf("%-58s %-22s %10.2e %10.2e %10.2e   %ld / %ld / %ld\n", names[ds],
              kern == 0 ? "native fp32 MFMA" : (kern == 1 ? "bf16x3" : "bf16x3 + Inf/NaN guard"), e.rel_l2, e.max_rms, e.max_rel,
              e.nonfinite, e.nonfinite_ref, e.mismatch);
