@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
 
 #include "hnd_hip.h"
 
@@ -50,6 +52,26 @@ __device__ __forceinline__ int xcd_contiguous_block() {
 }
 
 inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }
+
+// HND_DEBUG_PICKER: the ONE switch behind which the kernel pickers' experiment / test overrides live (A/B tools and the
+// bit-identity tests force a variant with it; nothing in normal use sets it).  Comma-separated keys, optionally key=value:
+//   bres_all          every launch the B-resident kernels can take, not only where they were measured to win
+//   bstream_all       the same for the B-streamed kernel
+//   igemm_tile=0..3   block tile of the tiled kernel (128x128, 128x64, 64x128, 64x64)
+//   wgrad_ring_taps   the ring weight-gradient kernel also for tap (direct 2x2) problems
+// Returns -1 when `key` is absent, its value (1 without "=value") otherwise.  Read per call: in-process A/B.
+inline int debug_picker(const char* key) {
+  const char* e = getenv("HND_DEBUG_PICKER");
+  if (!e) return -1;
+  const size_t n = strlen(key);
+  for (const char* p = e; *p;) {
+    const char* q = p;
+    while (*q && *q != ',') ++q;
+    if ((size_t)(q - p) >= n && strncmp(p, key, n) == 0 && (p[n] == ',' || p[n] == 0 || p[n] == '=')) return p[n] == '=' ? atoi(p + n + 1) : 1;
+    p = *q ? q + 1 : q;
+  }
+  return -1;
+}
 
 #define HND_REQUIRE(cond, ...)                \
   do {                                        \

@@ -597,7 +597,7 @@ int bres_variant(const hnd_conv_desc& d) {
   const long long per_team = nchunks / nteams;
   const bool plain = !d.res2 && !d.mask && !d.mask_bits && !(d.res1 && d.pro_scale);  // one-wave kernel: optional res1 only
   const char* v2 = getenv("HND_BRES2");                   // 0 = never the one-wave kernel (A/B)
-  const bool all = getenv("HND_BRES_ALL") != nullptr;     // every eligible launch, not only where it was measured to win
+  const bool all = hnd::debug_picker("bres_all") > 0;     // every eligible launch, not only where it was measured to win
   if (plain && d.kdim >= 128 && !(v2 && atoi(v2) == 0) && per_team >= 2ll * (4 / wn)) {
     // measured (profiles/r03_bres_vs_tiled.txt): the one-wave kernel wins on long runs of chunks; its prologue form
     // (8 VALU per A fragment beside a single wave's MFMAs) does not, and K = 512 needs >= 48 chunks per team

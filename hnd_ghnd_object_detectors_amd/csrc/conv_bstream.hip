@@ -533,9 +533,9 @@ static void bstream_grid(const hnd_conv_desc& d, int wn, int& mtiles, int& ntile
 
 // 0 = not taken, 1 = 256 x 64 block tile (one wave column), 2 = 128 x 128 (two)
 int bstream_variant(const hnd_conv_desc& d) {
-  const char* e = getenv("HND_BSTREAM");                // 0 = off; "all" = every eligible launch (A/B tool, tests)
+  const char* e = getenv("HND_BSTREAM");                // 0 = off (A/B)
   if (e && e[0] == '0') return 0;
-  const bool all = e && e[0] == 'a';
+  const bool all = hnd::debug_picker("bstream_all") > 0;   // every eligible launch (A/B tools, tests)
   if (d.stats != nullptr || d.cin % 32 != 0) return 0;
   if (d.kdim % 128 != 0 || d.kdim < 256) return 0;
   const bool taps = d.kh * d.kw > 1 || d.bh != 0 || d.bw != 0;

@@ -536,8 +536,8 @@ int launch(const hnd_conv_desc& d, hipStream_t stream) {
 // (k-step depth per tile: 16 for 128x128 / 128x64 / 64x128 -- smaller LDS footprint, 3-4 resident blocks per CU -- and 32
 // for 64x64; measured in rounds 1-2)
 int pick_tile(const hnd_conv_desc& d) {
-  if (const char* f = getenv("HND_IGEMM_TILE")) {       // testing / tuning override: 0..3
-    const int t = atoi(f);
+  {                                                     // testing / tuning override (HND_DEBUG_PICKER=igemm_tile=0..3)
+    const int t = hnd::debug_picker("igemm_tile");
     if (t >= 0 && t <= 3) {
       if ((t == 0 || t == 2) && d.cout % 128 != 0) return t + 1;
       if (d.stats && (t == 2 || t == 3)) return t - 2;

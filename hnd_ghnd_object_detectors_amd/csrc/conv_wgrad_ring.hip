@@ -314,13 +314,14 @@ namespace hnd {
 // Taken for: cout a multiple of 128, cin a multiple of 64 with no channel padding, kh * kw * cin a multiple of 128;
 // 1x1 problems (the grouped Winograd-domain reductions) must be dense (stride 1, no padding, x pixel = dy pixel).
 bool wgrad_ring_applies(const hnd_wgrad_desc& d) {
-  // HND_WGRAD_RING: 0 = never (the LDS-staged kernel of conv_wgrad.hip: A/B, tests); 2 = also the tap form.  Default: the
+  // HND_WGRAD_RING=0: never (the LDS-staged kernel of conv_wgrad.hip: A/B, tests); HND_DEBUG_PICKER=wgrad_ring_taps: also
+  // the tap form.  Default: the
   // 1x1 (grouped Winograd-domain) form only -- in the step the tap form of the head's direct 2x2 convs is no faster than
   // the staged kernel (conv1 1.37 vs 1.31 ms, conv5 0.74 vs 0.69 ms, profiles/r04_per_launch_events*.txt; in isolation
   // it wins by 5-7 %, tools/bench_wgrad.py): its ~100 vector instructions per k-step are not hidden yet.
   const char* e = getenv("HND_WGRAD_RING");
-  const int mode = e ? atoi(e) : 1;
-  if (mode == 0) return false;
+  if (e && atoi(e) == 0) return false;
+  const int mode = hnd::debug_picker("wgrad_ring_taps") > 0 ? 2 : 1;
   if (mode != 2 && (d.kh * d.kw > 1 || d.pad != 0 || d.stride != 1)) return false;
   if (d.cout % 128 != 0 || d.cin % 64 != 0 || d.cin_real != d.cin || d.ldy % 4 != 0 || d.ldy < d.cout) return false;
   const bool taps = d.kh * d.kw > 1 || d.pad != 0 || d.stride != 1;

@@ -478,9 +478,10 @@ def _full_step(z, meta, repeat=1):
     return cfg, teacher, student, box, opt, warm, ims, tgs, loss
 
 
-# fingerprints (sum, sum of squares, 64 samples) of the reference's fp32 gradients at full size: no fp64 twin is stored,
-# so the bar is absolute -- 2.5e-3, a ReLU flip's worth (dense tests: 1.7e-3 ... 2.2e-3 vs fp64); achieved figures are printed
-FULL_GRAD_FP_TOL = 2.5e-3
+# fingerprints (sum, sum of squares, 64 strided samples / rms) of the reference's fp32 gradients at full size: no fp64 twin
+# is stored, so the bar is absolute -- 4e-3: the worst SAMPLE of a gradient that a ReLU flip moved by 1.7e-3 ... 2.2e-3 in
+# rel-L2 (dense tests, vs fp64) sits at 2.6e-3 of the tensor's rms (round 5, printed below); was 5e-3
+FULL_GRAD_FP_TOL = 4e-3
 
 
 def _record_full(name, worst_g, worst_p):

@@ -322,7 +322,8 @@ def test_wgrad_ring_matches_the_staged_kernel_and_torch(ops, case, monkeypatch):
         ref = wt.grad
         xd, dyd, psd, pbd = nhwc(x), nhwc(dy), ps.to(DEV), pb.to(DEV)
         for mode in ('0', '1', '1b'):
-            monkeypatch.setenv('HND_WGRAD_RING', '2' if mode[0] == '1' else '0')      # 2: the tap form too
+            monkeypatch.setenv('HND_WGRAD_RING', '1' if mode[0] == '1' else '0')
+            monkeypatch.setenv('HND_DEBUG_PICKER', 'wgrad_ring_taps')                  # the tap form too
             dw = torch.full((cout, cin, k, k), float('nan'), device=DEV)
             l = ops.conv_wgrad(xd, dyd, dw, k, 1, pad, pro_scale=psd, pro_shift=pbd, pro_relu=True)
             l.run()
@@ -974,7 +975,7 @@ def test_f16_roundtrip(ops):
 
 def test_conv_random_geometries_all_tiles(ops, monkeypatch):
     """seeded sweep over kernel size / stride / padding / odd extents / channel counts / fused options, on every
-    block-tile build (HND_IGEMM_TILE override), forward and data-gradient, vs torch CPU."""
+    block-tile build (HND_DEBUG_PICKER=igemm_tile=N override), forward and data-gradient, vs torch CPU."""
     import random
     rnd = random.Random(1234)
     worst = 0.0
@@ -1005,7 +1006,7 @@ def test_conv_random_geometries_all_tiles(ops, monkeypatch):
         dy = torch.randn(out.shape, generator=g)
         out.backward(dy)
         cp_in, cp_out = ops.chan_pad_of(cin), ops.chan_pad_of(cout)
-        monkeypatch.setenv('HND_IGEMM_TILE', str(it % 4))
+        monkeypatch.setenv('HND_DEBUG_PICKER', 'igemm_tile=%d' % (it % 4))
         xd, wd = nhwc(x.detach(), cp_in), wt.to(DEV).contiguous()
         y = torch.full((n, out.shape[2], out.shape[3], cp_out), float('nan'), device=DEV)
         pad_c = lambda v: F.pad(v, (0, cp_out - cout)).to(DEV)
@@ -1022,7 +1023,7 @@ def test_conv_random_geometries_all_tiles(ops, monkeypatch):
         e1, e2 = relerr(nchw(y, cout), ref), relerr(nchw(dx, cin), x.grad)
         worst = max(worst, e1, e2)
         assert e1 < 1e-4 and e2 < 1e-4, (it, k, s, p, cin, cout, n, h, w, e1, e2)
-    monkeypatch.delenv('HND_IGEMM_TILE')
+    monkeypatch.delenv('HND_DEBUG_PICKER')
 
 
 def test_conv_linearity_at_full_size(ops):
@@ -1130,7 +1131,7 @@ def test_bres_kernel_is_bit_identical_to_the_tiled_kernel(ops, case, monkeypatch
     epilogue code, so every output must be IDENTICAL BITS -- and both must match a torch fp32 convolution."""
     cin, h, w, cout, s, res, msk, pro, groups, n = case
     g = torch.Generator().manual_seed(11)
-    monkeypatch.setenv('HND_BRES_ALL', '1')
+    monkeypatch.setenv('HND_DEBUG_PICKER', 'bres_all')
     monkeypatch.setenv('HND_BSTREAM', '0')
     if groups > 1:
         tiles_pad = (n * h * w + 127) // 128 * 128
@@ -1248,7 +1249,8 @@ def test_bstream_kernel_is_bit_identical_to_the_tiled_kernel(ops, case, monkeypa
     pb = torch.randn(cin, generator=g).to(DEV) if pro else None
     outs, variants = {}, {}
     for mode in ('0', 'all'):
-        monkeypatch.setenv('HND_BSTREAM', mode)
+        monkeypatch.setenv('HND_BSTREAM', '0' if mode == '0' else '1')
+        monkeypatch.setenv('HND_DEBUG_PICKER', '' if mode == '0' else 'bstream_all')
         if groups > 1:
             l = ops.conv_desc(x, pk, y, kh=1, kw=1, oh=1, ow=groups * tiles_pad, sh=1, dh=1, bh=0, sw=1, dw=1, bw=0,
                               cout=cout)
@@ -1304,13 +1306,13 @@ def test_bstream_kernel_is_bit_identical_to_the_tiled_kernel(ops, case, monkeypa
 
 
 @pytest.mark.parametrize('case', [
-    # cin, h, w, cout, residual, n, forced kernel (HND_BRES / HND_BSTREAM / HND_IGEMM_TILE)
+    # cin, h, w, cout, residual, n, forced kernel (HND_BRES / HND_BSTREAM / HND_DEBUG_PICKER)
     (128, 50, 84, 512, True, 4, {}),                                  # layer2 conv3: bres2 + residual (own store path)
     (256, 37, 41, 1024, True, 3, {}),                                 # ragged rows: the checked path writes nibbles too
     (512, 25, 42, 2048, True, 4, {}),                                 # K = 512: the 8-wave kernel (shared epilogue)
     (128, 33, 47, 256, False, 2, {'HND_BRES': '0'}),                  # tiled kernel, picker restricted to 128 columns
-    (128, 33, 47, 256, True, 2, {'HND_BRES': '0', 'HND_IGEMM_TILE': '3'}),      # 64 x 64 asked for -> 64 x 128
-    (1024, 25, 42, 512, True, 8, {'HND_BRES': '0', 'HND_BSTREAM': 'all'}),      # B-streamed kernel
+    (128, 33, 47, 256, True, 2, {'HND_BRES': '0', 'HND_DEBUG_PICKER': 'igemm_tile=3'}),      # 64 x 64 asked for -> 64 x 128
+    (1024, 25, 42, 512, True, 8, {'HND_BRES': '0', 'HND_DEBUG_PICKER': 'bstream_all'}),      # B-streamed kernel
 ])
 def test_relu_mask_nibbles_written_by_the_forward_and_applied_by_the_data_gradient(ops, case, monkeypatch):
     """hnd_conv_desc.mask_out / mask_bits (ABI 8): the forward epilogue writes [y > 0] as one byte per pixel and four
@@ -1335,8 +1337,9 @@ def test_relu_mask_nibbles_written_by_the_forward_and_applied_by_the_data_gradie
     assert torch.equal(bits, want), (l.variant, int((bits != want).sum()))
     assert 0.2 < float((y > 0).float().mean()) < 0.8
     # consumer: a data-gradient-like launch masked by y (fp32) vs by its nibbles, on the default and on the tiled kernels
-    for env2 in ({}, {'HND_BRES': '0', 'HND_BSTREAM': '0'}, {'HND_BRES': '0', 'HND_BSTREAM': '0', 'HND_IGEMM_TILE': '3'}):
-        for k in ('HND_BRES', 'HND_BSTREAM', 'HND_IGEMM_TILE'):
+    for env2 in ({}, {'HND_BRES': '0', 'HND_BSTREAM': '0'},
+                 {'HND_BRES': '0', 'HND_BSTREAM': '0', 'HND_DEBUG_PICKER': 'igemm_tile=3'}):
+        for k in ('HND_BRES', 'HND_BSTREAM', 'HND_DEBUG_PICKER'):
             monkeypatch.delenv(k, raising=False)
         for k, v in env2.items():
             monkeypatch.setenv(k, v)
@@ -1380,7 +1383,8 @@ def test_bstream_relay_timeout_is_loud_and_does_not_poison_the_workspace(ops, mo
     monkeypatch.setenv('HND_BSTREAM', '0')
     ref = torch.empty(n, h, w, cout, device=DEV)
     ops.conv_forward(x, pk, ref, 1, 1, 0, relu=True).run()
-    monkeypatch.setenv('HND_BSTREAM', 'all')
+    monkeypatch.delenv('HND_BSTREAM')
+    monkeypatch.setenv('HND_DEBUG_PICKER', 'bstream_all')
     y = torch.empty_like(ref)
     l = ops.conv_forward(x, pk, y, 1, 1, 0, relu=True)
     assert l.variant == 'bstream_128' and l.relay is not None

@@ -42,7 +42,7 @@ def main():
     ap.add_argument('--only', default='')
     args = ap.parse_args()
     dev = 'cuda:0'
-    os.environ['HND_BRES_ALL'] = '1'            # A/B on every eligible shape, not only where the picker takes it
+    os.environ['HND_DEBUG_PICKER'] = 'bres_all'            # A/B on every eligible shape, not only where the picker takes it
     modes = (('tiled', '0', '1'), ('bres', '512', '0'), ('bres2', '512', '1'))      # name, HND_BRES, HND_BRES2
     tot = {m[0]: [0.0, 0.0] for m in modes}
     for name, (cin, h, w, cout, s, res, pro, groups) in SHAPES.items():

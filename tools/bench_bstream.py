@@ -82,7 +82,8 @@ def main():
                 os.environ.pop('HND_BRES', None)
             else:
                 os.environ['HND_BRES'] = e1
-            os.environ['HND_BSTREAM'] = e2
+            os.environ['HND_BSTREAM'] = '1' if e2 == 'all' else e2      # 'all' = HND_DEBUG_PICKER=bstream_all
+            os.environ['HND_DEBUG_PICKER'] = 'bstream_all' if e2 == 'all' else ''
             if groups > 1:
                 l = ops.conv_desc(x, pk, y, kh=1, kw=1, oh=1, ow=groups * tiles_pad, sh=1, dh=1, bh=0, sw=1, dw=1, bw=0,
                                   cout=cout)
@@ -112,6 +113,7 @@ def main():
                                                    % float((outs['tiled'] - outs['bstream']).abs().max())), flush=True)
     os.environ.pop('HND_BRES', None)
     os.environ.pop('HND_BSTREAM', None)
+    os.environ.pop('HND_DEBUG_PICKER', None)
     for mode, (ms, fl) in tot.items():
         if ms:
             print('TOTAL %-8s %8.3f ms  %7.1f TFLOP/s' % (mode, ms, fl / ms / 1e9))

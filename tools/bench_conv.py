@@ -44,7 +44,7 @@ def main():
     ap.add_argument('--iters', type=int, default=10)
     ap.add_argument('--batch', type=int, default=16)
     ap.add_argument('--only', default='')
-    ap.add_argument('--tiles', default='', help="comma list of HND_IGEMM_TILE overrides to sweep, e.g. '0,1,2,3'")
+    ap.add_argument('--tiles', default='', help="comma list of HND_DEBUG_PICKER=igemm_tile=N overrides to sweep, e.g. '0,1,2,3'")
     args = ap.parse_args()
     dev = 'cuda:0'
     only = [s for s in args.only.split(',') if s]
@@ -63,9 +63,9 @@ def main():
         line = '%-26s' % name
         for tile in ([t for t in args.tiles.split(',') if t] or [None]):
             if tile is None:
-                os.environ.pop('HND_IGEMM_TILE', None)
+                os.environ.pop('HND_DEBUG_PICKER', None)
             else:
-                os.environ['HND_IGEMM_TILE'] = tile
+                os.environ['HND_DEBUG_PICKER'] = 'igemm_tile=%s' % tile
             l = ops.conv_forward(x, pk, y, k, s, p, epi_scale=sc, epi_shift=sh, res1=r, relu=True)
             for _ in range(2):
                 l.run()

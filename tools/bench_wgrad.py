@@ -41,7 +41,8 @@ def main():
         line, outs = '%-34s' % name, {}
         for mode in ('0', '1'):
             torch.manual_seed(0)
-            os.environ['HND_WGRAD_RING'] = '2' if mode == '1' else '0'      # 2 = the tap form too
+            os.environ['HND_WGRAD_RING'] = mode
+            os.environ['HND_DEBUG_PICKER'] = 'wgrad_ring_taps'      # the tap form too
             if groups == 1:
                 n = args.batch
                 oh, ow = ops.conv_out_size(h, k, s, p), ops.conv_out_size(w, k, s, p)
@@ -80,6 +81,7 @@ def main():
         rel = float((outs['0'] - outs['1']).norm() / outs['0'].norm())
         print(line + '   rel diff %.1e' % rel, flush=True)
     os.environ.pop('HND_WGRAD_RING', None)
+    os.environ.pop('HND_DEBUG_PICKER', None)
     for mode, (ms, fl) in tot.items():
         if ms:
             print('TOTAL HND_WGRAD_RING=%s %8.3f ms  %7.1f TFLOP/s' % (mode, ms, fl / ms / 1e9))

@@ -27,6 +27,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "hnd_hip.h"
@@ -180,6 +182,188 @@ __global__ void __launch_bounds__(NT, 1) bf16x3_kernel(const float* __restrict__
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// v2: the structure of the library's one-wave-per-SIMD fp32 kernel (conv_bres.hip, bres2) carried over: 4 waves per
+// workgroup (512 registers per lane), A fragments through a counted inline-asm register ring 4 k steps deep that runs
+// across tile boundaries (hipcc drains every load it can see at a loop header: the plain kernel above overlaps nothing),
+// and the split of k step s+1 software-pipelined into the MFMAs of k step s: per group of 6 MFMAs (one accumulator tile:
+// 96 matrix-pipe cycles, 48 of them free for vector issue) one pair of elements is split (11 vector instructions).
+template <int N_, class F, int... I>
+__device__ __forceinline__ void sfor_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N_, class F>
+__device__ __forceinline__ void sfor(F&& f) { sfor_impl<N_>(f, std::make_integer_sequence<int, N_>{}); }
+
+template <int OFF, bool ACC>
+__device__ __forceinline__ void rload(f4& dst, const float* p) {
+  if (ACC) asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=a"(dst) : "v"(p), "n"(OFF));
+  else asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(dst) : "v"(p), "n"(OFF));
+}
+template <int CNT, bool ACC>
+__device__ __forceinline__ void rwait(f4& a0, f4& a1, f4& a2, f4& a3, f4& a4, f4& a5, f4& a6, f4& a7) {
+  if (ACC) asm volatile("s_waitcnt vmcnt(%8)" : "+a"(a0), "+a"(a1), "+a"(a2), "+a"(a3), "+a"(a4), "+a"(a5), "+a"(a6), "+a"(a7) : "n"(CNT));
+  else asm volatile("s_waitcnt vmcnt(%8)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "n"(CNT));
+}
+
+// one pair of fp32 values -> one dword of each plane (used for the very first k step only)
+template <int MODE>
+__device__ __forceinline__ void split_pair(float x0, float x1, uint32_t& hp, uint32_t& mp, uint32_t& lp) {
+  const uint32_t a0 = __float_as_uint(x0), a1 = __float_as_uint(x1);
+  if (MODE == 2) { hp = mp = lp = __builtin_amdgcn_perm(a1, a0, 0x07060302u); return; }
+  const uint32_t h0 = a0 & 0xffff0000u, h1 = a1 & 0xffff0000u;
+  const float r0 = x0 - __uint_as_float(h0), r1 = x1 - __uint_as_float(h1);
+  const uint32_t m0 = __float_as_uint(r0) & 0xffff0000u, m1 = __float_as_uint(r1) & 0xffff0000u;
+  const float q0 = r0 - __uint_as_float(m0), q1 = r1 - __uint_as_float(m1);
+  hp = __builtin_amdgcn_perm(h1, h0, 0x07060302u);
+  mp = __builtin_amdgcn_perm(m1, m0, 0x07060302u);
+  lp = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u);
+}
+
+// STORES = the previous tile's 16 row stores were issued before this tile's first refill: they sit in the in-order
+// memory stream between the slots the first three k steps wait for and the youngest refills (exact counts: full tiles only)
+template <int MODE>
+__global__ void __launch_bounds__(256, 1) bf16x3_ring_kernel(const float* __restrict__ A, const uint16_t* __restrict__ wimg,
+                                                             float* __restrict__ C, int M) {
+  constexpr int RING = 4, KS = K / 32, MI = 4, NI = 4;
+  extern __shared__ __attribute__((aligned(16))) uint16_t Bs[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l16 = lane & 15, g4 = lane >> 4;
+  const int b = blockIdx.x, xcd = b & 7, idx = b >> 3, per_xcd = gridDim.x >> 3;
+  const int slice = idx % NSL, tpx = per_xcd / NSL;
+  const int team = xcd * tpx + idx / NSL, nteams = 8 * tpx;
+  const int nchunks = M / 64;                           // (the host checks M % 64 == 0)
+  const int c_lo = (int)((long long)nchunks * team / nteams), c_hi = (int)((long long)nchunks * (team + 1) / nteams);
+  {
+    const u4* src = (const u4*)(wimg + (size_t)slice * 3 * PLANE);
+    u4* dst = (u4*)Bs;
+    for (int i = tid; i < 3 * PLANE / 8; i += 256) dst[i] = src[i];
+  }
+  __syncthreads();
+  const int n0 = slice * BN;
+  auto a_ptr = [&](int cc, int mi) -> const float* { return A + (size_t)(cc * 64 + mi * 16 + l16) * K + g4 * 8; };
+  int cc = c_lo + wave;
+  if (cc >= c_hi) return;
+  const float* aptr[MI];
+  f4 ring[RING][MI][2];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) aptr[mi] = a_ptr(cc, mi);
+  sfor<RING>([&](auto U) __attribute__((always_inline)) {
+    constexpr int u = decltype(U)::value;
+    sfor<MI>([&](auto I) __attribute__((always_inline)) {
+      constexpr int mi = decltype(I)::value;
+      rload<u * 128, (u & 1) != 0>(ring[u][mi][0], aptr[mi]);
+      rload<u * 128 + 16, (u & 1) != 0>(ring[u][mi][1], aptr[mi]);
+    });
+  });
+  uint32_t pl[2][3][MI][4];                 // [parity][hi / mid / lo][row group]: 4 dwords = 8 bf16 each
+  rwait<8 * (RING - 1), false>(ring[0][0][0], ring[0][0][1], ring[0][1][0], ring[0][1][1], ring[0][2][0], ring[0][2][1],
+                               ring[0][3][0], ring[0][3][1]);
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const f4 v = ring[0][mi][j >> 1];
+      const float x0 = (j & 1) ? v.z : v.x, x1 = (j & 1) ? v.w : v.y;
+      split_pair<MODE>(x0, x1, pl[0][0][mi][j], pl[0][1][mi][j], pl[0][2][mi][j]);
+    }
+  bool stored = false;
+  f4 acc[MI][NI];
+  for (; cc < c_hi; cc += 4) {
+    const int cn = cc + 4 < c_hi ? cc + 4 : cc;
+    const float* nptr[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) nptr[mi] = a_ptr(cn, mi);
+    sfor<KS>([&](auto G) __attribute__((always_inline)) {
+      constexpr int ks = decltype(G)::value, slot = ks % RING, par = ks & 1;
+      constexpr int slot1 = (ks + 1) % RING;            // the step whose planes are made during this one
+      // slot `slot` was split during the previous step: refill it for the step RING ahead
+      sfor<MI>([&](auto I) __attribute__((always_inline)) {
+        constexpr int mi = decltype(I)::value;
+        if constexpr (ks + RING < KS) {
+          rload<(ks + RING) * 128, (slot & 1) != 0>(ring[slot][mi][0], aptr[mi]);
+          rload<(ks + RING) * 128 + 16, (slot & 1) != 0>(ring[slot][mi][1], aptr[mi]);
+        } else {
+          rload<(ks + RING - KS) * 128, (slot & 1) != 0>(ring[slot][mi][0], nptr[mi]);
+          rload<(ks + RING - KS) * 128 + 16, (slot & 1) != 0>(ring[slot][mi][1], nptr[mi]);
+        }
+      });
+      // the next step's slot was requested RING - 1 steps ago: 8 (RING - 1) younger ring loads may still be in flight,
+      // plus the previous tile's 16 stores while they are younger than it (k steps 0 .. 2 of every tile but the first)
+      if (ks < RING - 1 && stored)
+        rwait<8 * (RING - 1) + 16, (slot1 & 1) != 0>(ring[slot1][0][0], ring[slot1][0][1], ring[slot1][1][0], ring[slot1][1][1],
+                                                     ring[slot1][2][0], ring[slot1][2][1], ring[slot1][3][0], ring[slot1][3][1]);
+      else
+        rwait<8 * (RING - 1), (slot1 & 1) != 0>(ring[slot1][0][0], ring[slot1][0][1], ring[slot1][1][0], ring[slot1][1][1],
+                                                ring[slot1][2][0], ring[slot1][2][1], ring[slot1][3][0], ring[slot1][3][1]);
+      const int pos = ((ks * 4 + g4) ^ l16) * 8;
+      bf8 bcur[3], bnxt[3];
+      {
+        const uint16_t* br = Bs + l16 * K + pos;
+        bcur[0] = *(const bf8*)(br); bcur[1] = *(const bf8*)(br + PLANE); bcur[2] = *(const bf8*)(br + 2 * PLANE);
+      }
+      sfor<NI>([&](auto NIc) __attribute__((always_inline)) {
+        constexpr int ni = decltype(NIc)::value;
+        if constexpr (ni + 1 < NI) {
+          const uint16_t* br = Bs + ((ni + 1) * 16 + l16) * K + pos;
+          bnxt[0] = *(const bf8*)(br); bnxt[1] = *(const bf8*)(br + PLANE); bnxt[2] = *(const bf8*)(br + 2 * PLANE);
+        }
+        sfor<MI>([&](auto MIc) __attribute__((always_inline)) {
+          constexpr int mi = decltype(MIc)::value;
+          auto frag = [&](int q) __attribute__((always_inline)) {
+            const u4 t = {pl[par][q][mi][0], pl[par][q][mi][1], pl[par][q][mi][2], pl[par][q][mi][3]};
+            return __builtin_bit_cast(bf8, t);
+          };
+          const bf8 ah = frag(0), am = frag(1), al = frag(2);
+          // one pair of the NEXT step's elements rides between this tile's six MFMAs: piece p = ni * 4 + mi -> row group
+          // p / 4, pair p % 4
+          constexpr int p = ni * 4 + mi, rg = p >> 2, j = p & 3;
+          const f4 v = ring[slot1][rg][j >> 1];
+          const float x0 = (j & 1) ? v.z : v.x, x1 = (j & 1) ? v.w : v.y;
+          f4 c = (ks == 0) ? f4{0.f, 0.f, 0.f, 0.f} : acc[mi][ni];
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bcur[0], c, 0, 0, 0);      // smallest terms first
+          const uint32_t h0 = __float_as_uint(x0) & 0xffff0000u, h1 = __float_as_uint(x1) & 0xffff0000u;
+          __builtin_amdgcn_sched_barrier(0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bcur[2], c, 0, 0, 0);
+          const float r0 = x0 - __uint_as_float(h0), r1 = x1 - __uint_as_float(h1);
+          __builtin_amdgcn_sched_barrier(0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bcur[1], c, 0, 0, 0);
+          const uint32_t m0 = __float_as_uint(r0) & 0xffff0000u, m1 = __float_as_uint(r1) & 0xffff0000u;
+          __builtin_amdgcn_sched_barrier(0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bcur[0], c, 0, 0, 0);
+          const float q0 = r0 - __uint_as_float(m0), q1 = r1 - __uint_as_float(m1);
+          __builtin_amdgcn_sched_barrier(0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bcur[1], c, 0, 0, 0);
+          if (MODE == 2) {
+            pl[par ^ 1][0][rg][j] = pl[par ^ 1][1][rg][j] = pl[par ^ 1][2][rg][j] =
+                __builtin_amdgcn_perm(__float_as_uint(x1), __float_as_uint(x0), 0x07060302u);
+          } else {
+            pl[par ^ 1][0][rg][j] = __builtin_amdgcn_perm(h1, h0, 0x07060302u);
+            pl[par ^ 1][1][rg][j] = __builtin_amdgcn_perm(m1, m0, 0x07060302u);
+            pl[par ^ 1][2][rg][j] = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bcur[0], c, 0, 0, 0);
+          acc[mi][ni] = c;
+          __builtin_amdgcn_sched_barrier(0);
+        });
+        if constexpr (ni + 1 < NI) { bcur[0] = bnxt[0]; bcur[1] = bnxt[1]; bcur[2] = bnxt[2]; }
+      });
+    });
+    // the tile's 16 row stores (full tiles only); the next tile's first refills come after them in the memory stream
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = cc * 64 + mi * 16 + g4 * 4 + r;
+        *(f4*)(C + (size_t)m * N + n0 + l16 * 4) = f4{acc[mi][0][r], acc[mi][1][r], acc[mi][2][r], acc[mi][3][r]};
+      }
+    stored = true;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) aptr[mi] = nptr[mi];
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 __global__ void ref64_kernel(const float* A, const float* W, double* C, int M) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= M * N) return;
@@ -258,6 +442,9 @@ int main(int argc, char** argv) {
   CK(hipFuncSetAttribute((const void*)bf16x3_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   CK(hipFuncSetAttribute((const void*)bf16x3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   CK(hipFuncSetAttribute((const void*)bf16x3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  CK(hipFuncSetAttribute((const void*)bf16x3_ring_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  CK(hipFuncSetAttribute((const void*)bf16x3_ring_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  static_assert((16 * 200 * 336) % 64 == 0 && 8192 % 64 == 0, "the ring kernel takes full 64-row tiles only");
 
   std::vector<float> W((size_t)N * K);
   for (auto& v : W) v = nrand() * 0.0625f;
@@ -315,11 +502,12 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(dA, A.data(), A.size() * 4, hipMemcpyHostToDevice));
     ref64_kernel<<<(Mref * N + 255) / 256, 256>>>(dA, dW, dRef, Mref);
     CK(hipMemcpy(ref.data(), dRef, ref.size() * 8, hipMemcpyDeviceToHost));
-    for (int kern = 0; kern < 3; ++kern) {
+    for (int kern = 0; kern < 4; ++kern) {
       CK(hipMemset(dC, 0xff, (size_t)Mref * N * 4));
       if (kern == 0) native(1, 64, 128);
       else if (kern == 1) bf16x3_kernel<0><<<grid, NT, lds>>>(dA, dImg, dC, Mref);
-      else bf16x3_kernel<1><<<grid, NT, lds>>>(dA, dImg, dC, Mref);
+      else if (kern == 2) bf16x3_kernel<1><<<grid, NT, lds>>>(dA, dImg, dC, Mref);
+      else bf16x3_ring_kernel<0><<<grid, 256, lds>>>(dA, dImg, dC, Mref);
       CK(hipDeviceSynchronize());
       CK(hipMemcpy(got.data(), dC, got.size() * 4, hipMemcpyDeviceToHost));
       const Err e = compare(got, ref);
@@ -356,7 +544,8 @@ int main(int argc, char** argv) {
         }
       }
       printf("%-58s %-22s %10.2e %10.2e %10.2e   %ld / %ld / %ld\n", names[ds],
-             kern == 0 ? "native fp32 MFMA" : (kern == 1 ? "bf16x3" : "bf16x3 + Inf/NaN guard"), e.rel_l2, e.max_rms, e.max_rel,
+             kern == 0 ? "native fp32 MFMA" : (kern == 1 ? "bf16x3" : (kern == 2 ? "bf16x3 + Inf/NaN guard" : "bf16x3 v2 (asm ring)")),
+             e.rel_l2, e.max_rms, e.max_rel,
              e.nonfinite, e.nonfinite_ref, e.mismatch);
     }
   }
@@ -374,12 +563,14 @@ int main(int argc, char** argv) {
   const double flop = 2.0 * Mbig * N * K;
   printf("\n%-44s %10s %14s\n", "kernel (M = 1 075 200)", "ms", "TFLOP/s-equiv");
   double t_native = 0;
-  for (int kern = 0; kern < 4; ++kern) {
+  for (int kern = 0; kern < 6; ++kern) {
     auto run = [&]() {
       if (kern == 0) native(16, 200, 336);
       else if (kern == 1) bf16x3_kernel<0><<<grid, NT, lds>>>(dA, dImg, dC, Mbig);
       else if (kern == 2) bf16x3_kernel<1><<<grid, NT, lds>>>(dA, dImg, dC, Mbig);
-      else bf16x3_kernel<2><<<grid, NT, lds>>>(dA, dImg, dC, Mbig);
+      else if (kern == 3) bf16x3_kernel<2><<<grid, NT, lds>>>(dA, dImg, dC, Mbig);
+      else if (kern == 4) bf16x3_ring_kernel<0><<<grid, 256, lds>>>(dA, dImg, dC, Mbig);
+      else bf16x3_ring_kernel<2><<<grid, 256, lds>>>(dA, dImg, dC, Mbig);
     };
     for (int i = 0; i < 3; ++i) run();
     CK(hipDeviceSynchronize());
@@ -393,7 +584,8 @@ int main(int argc, char** argv) {
     if (kern == 0) t_native = ms;
     printf("%-44s %10.4f %14.1f   (x%.2f native)\n",
            kern == 0 ? "native fp32 MFMA (libhnd_hip.so, bres2)" : kern == 1 ? "bf16x3, split in registers"
-           : kern == 2 ? "bf16x3 + Inf/NaN guard" : "bf16x3 MFMAs without the split's VALU work",
+           : kern == 2 ? "bf16x3 + Inf/NaN guard" : kern == 3 ? "bf16x3 MFMAs without the split's VALU work"
+           : kern == 4 ? "bf16x3 v2: asm ring, split between the MFMAs" : "bf16x3 v2 without the split's VALU work",
            ms, flop / ms / 1e9, t_native / ms);
   }
   printf("\nsplit cost per A fragment (static): per fp32 element 2 v_and + 2 v_sub + 1.5 v_perm = 5.5 vector instructions; per wave\n"

@@ -15,7 +15,8 @@ cout = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 dev = 'cuda:0'
 os.environ['HND_BRES'] = '0'
 for mode in ('all',):
-    os.environ['HND_BSTREAM'] = mode
+    os.environ['HND_BSTREAM'] = '1' if mode == 'all' else mode
+    os.environ['HND_DEBUG_PICKER'] = 'bstream_all' if mode == 'all' else ''
     for r in (2, 4, 8):
         rows = 256 * r * 128 // (cout // 128)
         x = torch.randn(1, 128, rows // 128, K, device=dev)

@@ -12,7 +12,7 @@ sys.path.insert(0, ROOT)
 from hnd_ghnd_object_detectors_amd import ops  # noqa: E402
 
 os.environ['HND_BRES'] = '0'
-os.environ['HND_BSTREAM'] = 'all'
+os.environ['HND_DEBUG_PICKER'] = 'bstream_all'
 dev = 'cuda:0'
 K, cout, r = 4096, 256, 8
 rows = 256 * r * 128 // (cout // 128)

@@ -13,7 +13,7 @@ from hnd_ghnd_object_detectors_amd import ops  # noqa: E402
 cout = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 dev = 'cuda:0'
 os.environ['HND_BRES'] = '0'
-os.environ['HND_BSTREAM'] = 'all'
+os.environ['HND_DEBUG_PICKER'] = 'bstream_all'
 for rep in range(2):
     for K, r in ((256, 32), (512, 16), (1024, 8), (2048, 4), (4096, 2)):
         rows = 256 * r * 128 // (cout // 128)

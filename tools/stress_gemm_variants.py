@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Randomised bit-identity stress of the hnd_conv2d_igemm kernel variants: for random geometries / epilogues the tiled
-kernel (HND_BRES=0 HND_BSTREAM=0), the default dispatch and the B-streamed kernel forced on (HND_BSTREAM=all, with and
+kernel (HND_BRES=0 HND_BSTREAM=0), the default dispatch and the B-streamed kernel forced on (HND_DEBUG_PICKER=bstream_all, with and
 without its work-balancing relay) must produce IDENTICAL bits, and launching twice on one workspace must too.
 usage: python tools/stress_gemm_variants.py [--cases 200] [--seed 0]"""
 import argparse
@@ -37,8 +37,8 @@ def main():
         pk.kdim, pk.rows, pk.chan_pad, pk.chan_real = pks[0].kdim, cout, cin, cin
         outs, variants = {}, {}
         for mode, env in (('tiled', {'HND_BRES': '0', 'HND_BSTREAM': '0'}), ('default', {}),
-                          ('bstream', {'HND_BRES': '0', 'HND_BSTREAM': 'all'})):
-            for key in ('HND_BRES', 'HND_BSTREAM'):
+                          ('bstream', {'HND_BRES': '0', 'HND_DEBUG_PICKER': 'bstream_all'})):
+            for key in ('HND_BRES', 'HND_BSTREAM', 'HND_DEBUG_PICKER'):
                 os.environ.pop(key, None)
             os.environ.update(env)
             l = ops.conv_desc(x, pk, y, kh=1, kw=1, oh=1, ow=groups * tiles_pad, sh=1, dh=1, bh=0, sw=1, dw=1, bw=0,
@@ -88,9 +88,9 @@ def main():
         pb = torch.randn(cin, generator=g).to(dev) if pro else None
         outs, variants = {}, {}
         for mode, env in (('tiled', {'HND_BRES': '0', 'HND_BSTREAM': '0'}), ('default', {}),
-                          ('bstream', {'HND_BRES': '0', 'HND_BSTREAM': 'all'}),
-                          ('bstream_rr', {'HND_BRES': '0', 'HND_BSTREAM': 'all'})):      # round-robin tiles: no workspace
-            for key in ('HND_BRES', 'HND_BSTREAM'):
+                          ('bstream', {'HND_BRES': '0', 'HND_DEBUG_PICKER': 'bstream_all'}),
+                          ('bstream_rr', {'HND_BRES': '0', 'HND_DEBUG_PICKER': 'bstream_all'})):      # round-robin tiles: no workspace
+            for key in ('HND_BRES', 'HND_BSTREAM', 'HND_DEBUG_PICKER'):
                 os.environ.pop(key, None)
             os.environ.update(env)
             l = ops.conv_forward(x, pk, y, k, s, p, epi_scale=sc, epi_shift=sh, res1=r, mask=mk, relu=not msk,
@@ -116,7 +116,7 @@ def main():
         elif case % 20 == 0:
             print('case %d ok  M=%d N=%d K=%d  %s' % (case, n * oh * ow, cout, k * k * cin, variants), flush=True)
         del x, y, r, mk, outs
-    for key in ('HND_BRES', 'HND_BSTREAM'):
+    for key in ('HND_BRES', 'HND_BSTREAM', 'HND_DEBUG_PICKER'):
         os.environ.pop(key, None)
     print('variants exercised:', counts)
     print('%d mismatch(es) in %d cases' % (bad, args.cases))
