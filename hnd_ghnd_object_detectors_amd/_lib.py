@@ -92,6 +92,7 @@ _SIGNATURES = {
     'hnd_wino26_output_bnbwd_stats': (C.c_int, [vp, vp] + [C.c_int] * 5 + [vp] * 5 + [C.c_int, vp, vp]),
     'hnd_wino26_bnbwd_transforms': (C.c_int, [vp] * 5 + [C.c_int] * 6 + [vp, vp, vp]),
     'hnd_wino2_wgrad_output': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp]),
+    'hnd_wino2_wgrad_output_t': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     'hnd_maxpool3x3s2_fwd': (C.c_int, [vp, vp, vp] + [C.c_int] * 6 + [vp]),
     'hnd_maxpool3x3s2_bwd_relu_scale': (C.c_int, [vp] * 5 + [C.c_int] * 6 + [vp]),
     'hnd_bn_finalize': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int64, vp, vp, vp, vp, vp,

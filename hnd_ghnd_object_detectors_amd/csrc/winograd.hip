@@ -877,11 +877,13 @@ __global__ void wino2_dy_kernel(const float* __restrict__ dy, float* __restrict_
 }
 
 // dW[co][ci][i][j] = (A'^T S A')[i][j],  S_f[co][ci] at s[f*cout*cin + co*cin + ci]
-__global__ void wino2_wgrad_out_kernel(const float* __restrict__ s, float* __restrict__ dw, int cout, int cin) {
+// st: s is stored [component][cin][cout] (the grouped reduction ran with its operands swapped: hnd_wino2_wgrad_output_t)
+__global__ void wino2_wgrad_out_kernel(const float* __restrict__ s_, float* __restrict__ dw, int cout, int cin, int st) {
   const long long total = (long long)cout * cin;
   const size_t fs = (size_t)total;
   for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
        e += (long long)gridDim.x * blockDim.x) {
+    const float* s = s_ + (st ? (e % cin) * cout + e / cin : e) - e;
     float t[2][5];
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
@@ -1290,11 +1292,12 @@ __global__ void __launch_bounds__(256) wino26_bnbwd_transforms_kernel(
 }
 
 // dW[co][ci][i][j] = (A'^T S A')[i][j],  S_f[co][ci] at s[f*cout*cin + co*cin + ci], f = 0..48
-__global__ void wino26_wgrad_out_kernel(const float* __restrict__ s, float* __restrict__ dw, int cout, int cin) {
+__global__ void wino26_wgrad_out_kernel(const float* __restrict__ s_, float* __restrict__ dw, int cout, int cin, int st) {
   const long long total = (long long)cout * cin;
   const size_t fs = (size_t)total;
   for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
        e += (long long)gridDim.x * blockDim.x) {
+    const float* s = s_ + (st ? (e % cin) * cout + e / cin : e) - e;
     float t[2][7];
 #pragma unroll
     for (int j = 0; j < 7; ++j) {
@@ -1505,15 +1508,19 @@ int hnd_wino26_bnbwd_transforms(const float* g, const float* x, const float* sca
   return hnd::check_launch("hnd_wino26_bnbwd_transforms");
 }
 
-int hnd_wino2_wgrad_output(const float* s, float* dw, int cout, int cin, int tile, void* stream) {
+int hnd_wino2_wgrad_output_t(const float* s, float* dw, int cout, int cin, int tile, int s_transposed, void* stream) {
   HND_REQUIRE(s && dw && cout > 0 && cin > 0 && wino2_tile_ok(tile), "hnd_wino2_wgrad_output: bad arguments");
   if (tile == 4)
     hipLaunchKernelGGL(wino2_wgrad_out_kernel, dim3(grid_for((long long)cout * cin)), dim3(256), 0,
-                       hnd::as_stream(stream), s, dw, cout, cin);
+                       hnd::as_stream(stream), s, dw, cout, cin, s_transposed ? 1 : 0);
   else
     hipLaunchKernelGGL(wino26_wgrad_out_kernel, dim3(grid_for((long long)cout * cin)), dim3(256), 0,
-                       hnd::as_stream(stream), s, dw, cout, cin);
+                       hnd::as_stream(stream), s, dw, cout, cin, s_transposed ? 1 : 0);
   return hnd::check_launch("hnd_wino2_wgrad_output");
+}
+
+int hnd_wino2_wgrad_output(const float* s, float* dw, int cout, int cin, int tile, void* stream) {
+  return hnd_wino2_wgrad_output_t(s, dw, cout, cin, tile, 0, stream);
 }
 
 }  // extern "C"

@@ -803,13 +803,26 @@ class Wino2Wgrad(object):
         assert z.numel() >= nc * tp * cout and s.numel() >= nc * cout * cin
         self.fwd, self.dy, self.dw, self.z, self.s = fwd, dy, dw, z, s
         self.geom = (n, oh, ow, cout, dy.shape[3], cin)
-        d = WgradDesc()
-        d.x, d.dy, d.dw = ptr(fwd.v), ptr(z), ptr(s)
-        d.n, d.h, d.w_, d.cin, d.cin_real = 1, 1, tiles, c, cin
-        d.oh, d.ow, d.cout, d.ldy = 1, tiles, cout, cout
-        d.kh, d.kw, d.stride, d.pad, d.splitk = 1, 1, 1, 0, 0
-        d.groups = nc
-        d.x_group_stride, d.dy_group_stride, d.dw_group_stride = tp * c, tp * cout, cout * cin
+        def grouped(swap):
+            """descriptor of the nc grouped reductions; swap: operands exchanged -> s comes out [comp][cin][cout]"""
+            d = WgradDesc()
+            d.x, d.dy, d.dw = (ptr(z), ptr(fwd.v), ptr(s)) if swap else (ptr(fwd.v), ptr(z), ptr(s))
+            kc, kr = (cout, c) if swap else (c, cout)          # columns ("cin" of the descriptor), rows ("cout")
+            d.n, d.h, d.w_, d.cin, d.cin_real = 1, 1, tiles, kc, kc
+            d.oh, d.ow, d.cout, d.ldy = 1, tiles, kr, kr
+            d.kh, d.kw, d.stride, d.pad, d.splitk = 1, 1, 1, 0, 0
+            d.groups = nc
+            d.x_group_stride, d.dy_group_stride, d.dw_group_stride = tp * kc, tp * kr, cout * cin
+            return d
+        # A conv with 64 OUTPUT channels (encoder.5: 256 -> 64) is 64 rows x 256 columns, which only the LDS-staged kernel
+        # takes (0.50 of the matrix peak); with the operands swapped it is the 64-column x 256-row shape of the ring
+        # kernel (round 5).  The output transform then reads s transposed.
+        d = grouped(False)
+        self.swapped = False
+        if (cin == c and int(_L.hnd_conv2d_wgrad_variant(C.byref(d))) != 3
+                and int(_L.hnd_conv2d_wgrad_variant(C.byref(grouped(True)))) == 3
+                and os.environ.get('HND_WGRAD_SWAP', '1') != '0'):
+            d, self.swapped = grouped(True), True
         need = _L.hnd_conv2d_wgrad_workspace(C.byref(d))
         if slabs is None or slabs.numel() * 4 < need:
             slabs = torch.empty((need + 3) // 4, dtype=torch.float32, device=dy.device)
@@ -825,8 +838,8 @@ class Wino2Wgrad(object):
 
     def _run_out(self, stream=None):
         n, oh, ow, cout, ldy, cin = self.geom
-        check(_L.hnd_wino2_wgrad_output(ptr(self.s), ptr(self.dw), cout, cin, self.tile,
-                                        stream if stream is not None else stream_ptr()), 'hnd_wino2_wgrad_output')
+        check(_L.hnd_wino2_wgrad_output_t(ptr(self.s), ptr(self.dw), cout, cin, self.tile, int(self.swapped),
+                                          stream if stream is not None else stream_ptr()), 'hnd_wino2_wgrad_output')
 
     def launches(self, tag):
         n, oh, ow, cout, ldy, cin = self.geom

@@ -309,6 +309,10 @@ int hnd_wino26_bnbwd_transforms(const float* g, const float* x, const float* sca
                                 const float* k123, int relu, int n, int oh, int ow, int c, int pad, float* v, float* z,
                                 void* stream);
 int hnd_wino2_wgrad_output(const float* s, float* dw, int cout, int cin, int tile, void* stream);
+/* ABI 10.  The same with s stored [groups][cin][cout] (s_transposed != 0): what the grouped reductions give when they
+ * are run with the operands SWAPPED (hnd_conv2d_wgrad with x = z, dy = v) -- a 256 -> 64 conv (encoder.5,
+ * resnet_layer.py:48) then presents 64 columns x 256 rows, the shape the ring weight-gradient kernel takes. */
+int hnd_wino2_wgrad_output_t(const float* s, float* dw, int cout, int cin, int tile, int s_transposed, void* stream);
 
 /* nn.MaxPool2d(3, 2, 1) (custom/resnet.py:30,99) NHWC; idx (uint8 tap 0..8) kept for backward. */
 int hnd_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* idx, int n, int h, int w, int c, int oh, int ow,

@@ -482,12 +482,15 @@ def _full_step(z, meta, repeat=1):
 # is stored, so the bar is absolute -- 4e-3: the worst SAMPLE of a gradient that a ReLU flip moved by 1.7e-3 ... 2.2e-3 in
 # rel-L2 (dense tests, vs fp64) sits at 2.6e-3 of the tensor's rms (round 5, printed below); was 5e-3
 FULL_GRAD_FP_TOL = 4e-3
+# parameters after one Adam step at full size vs the reference's: achieved 0.8e-6 ... 2.3e-6 (Adam's update is bounded by
+# lr whatever the gradient's error); was 2e-3
+FULL_PARAM_TOL = 2e-5
 
 
 def _record_full(name, worst_g, worst_p):
     from tests.conftest import record_achieved
     line = ('[full size %s] gradient fingerprints vs the reference: worst %.2e (tol %.1e); parameters after Adam %.2e '
-            '(tol 2e-03)' % (name, worst_g, FULL_GRAD_FP_TOL, worst_p))
+            '(tol %.0e)' % (name, worst_g, FULL_GRAD_FP_TOL, worst_p, FULL_PARAM_TOL))
     print('\n' + line)
     record_achieved(line)
 
@@ -528,7 +531,7 @@ def test_full_size_step_matches_reference_checksums(name):
     sd = student.state_dict()
     for n in O.trainable_keys(sd):
         if not n.endswith(G.ZERO_GRAD_SUFFIXES):
-            worst_p = max(worst_p, G.compare(z, 'after/param/' + n, sd[n], 2e-3, atol=1e-6))
+            worst_p = max(worst_p, G.compare(z, 'after/param/' + n, sd[n], FULL_PARAM_TOL, atol=1e-6))
     _record_full(name, worst_g, worst_p)
     for n in z.files:
         if n.startswith('after/buffer/'):
@@ -568,7 +571,7 @@ def test_batch16_is_the_reference_batch4_replicated():
     sd = student.state_dict()
     for n in O.trainable_keys(sd):
         if not n.endswith(G.ZERO_GRAD_SUFFIXES):
-            worst_p = max(worst_p, G.compare(z, 'after/param/' + n, sd[n], 2e-3, atol=1e-6))
+            worst_p = max(worst_p, G.compare(z, 'after/param/' + n, sd[n], FULL_PARAM_TOL, atol=1e-6))
     _record_full('batch 16 = full_ghnd_faster_b4 x 4', worst_g, worst_p)
 
 
@@ -599,7 +602,7 @@ def test_batch16_hnd_is_the_reference_batch2_replicated():
     sd = student.state_dict()
     for n in O.trainable_keys(sd):
         if not n.endswith(G.ZERO_GRAD_SUFFIXES):
-            worst_p = max(worst_p, G.compare(z, 'after/param/' + n, sd[n], 2e-3, atol=1e-6))
+            worst_p = max(worst_p, G.compare(z, 'after/param/' + n, sd[n], FULL_PARAM_TOL, atol=1e-6))
     _record_full('batch 16 = full_hnd_faster_b2 x 8', worst_g, worst_p)
 
 

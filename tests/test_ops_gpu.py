@@ -923,6 +923,41 @@ def test_winograd_wgrad_on_an_input_transform_of_its_own(ops, n, cin, h, w, cout
     assert relerr(res['1'][0], res['0'][0]) < 2e-5
 
 
+@pytest.mark.parametrize('n,cin,h,w,cout,pad', [(2, 256, 37, 50, 64, 1), (1, 256, 44, 31, 64, 0)])
+def test_winograd_wgrad_of_a_64_output_channel_conv_runs_swapped_on_the_ring_kernel(ops, n, cin, h, w, cout, pad, monkeypatch):
+    """round 5: the head's 256 -> 64 conv (encoder.5, /root/reference/src/models/mimic/resnet_layer.py:48) in the Winograd
+    domain is 64 rows x 256 columns per component -- the LDS-staged kernel's case (0.50 of the matrix peak).  With the
+    grouped reductions' operands swapped (x = z, dy = v) it is the ring kernel's 64-column shape; the output transform
+    reads s transposed (hnd_wino2_wgrad_output_t).  Against autograd and against the unswapped staged kernel."""
+    g = gen(190 + h)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = (torch.randn(cout, cin, 2, 2, generator=g) / math.sqrt(cin * 4)).requires_grad_(True)
+    out = F.conv2d(x, wt, None, 1, pad)
+    dy = torch.randn(out.shape, generator=g)
+    out.backward(dy)
+    oh, ow = out.shape[2], out.shape[3]
+    res = {}
+    for swap in ('0', '1'):
+        monkeypatch.setenv('HND_WGRAD_SWAP', swap)
+        v = torch.empty(ops.Wino2InputTransform.scratch_elems(n, oh, ow, cin, 6), device=DEV)
+        own = ops.Wino2InputTransform(nhwc(x), v, pad, cout, 6)
+        z = torch.empty(49 * own.tiles_pad * cout, device=DEV)
+        sbuf = torch.full((49 * cout * cin,), float('nan'), device=DEV)
+        dw = torch.full((cout, cin, 2, 2), float('nan'), device=DEV)
+        wg = ops.Wino2Wgrad(own, nhwc(dy), dw, z, sbuf)
+        own._run_input()
+        wg.run()
+        ops.sync_check()
+        res[swap] = (dw.cpu().clone(), wg.gemm.variant, wg.swapped)
+    assert res['0'][1] == 'wgrad_m64' and not res['0'][2], res['0'][1:]
+    assert res['1'][1] == 'wgrad_ring' and res['1'][2], res['1'][1:]
+    assert relerr(res['1'][0], wt.grad) < 2e-4 and relerr(res['0'][0], wt.grad) < 2e-4, relerr(res['1'][0], wt.grad)
+    assert relerr(res['1'][0], res['0'][0]) < 2e-5
+    wg.run()                                                  # fixed summation order
+    ops.sync_check()
+    assert torch.equal(dw.cpu(), res['1'][0])
+
+
 def test_subsample_and_fill(ops):
     x = torch.randn(2, 256, 7, 9, generator=gen(14))
     y = torch.empty(2, 4, 5, 256, device=DEV)

@@ -221,6 +221,13 @@ __device__ __forceinline__ void split_pair(float x0, float x1, uint32_t& hp, uin
 
 // STORES = the previous tile's 16 row stores were issued before this tile's first refill: they sit in the in-order
 // memory stream between the slots the first three k steps wait for and the youngest refills (exact counts: full tiles only)
+// which ring slots live in the accumulator half of the register file (VMEM can target it; vector instructions reach it
+// through v_accvgpr_read).  With half of the ring in architectural registers hipcc sat at 256 of them and moved
+// just-requested ring registers away before their wait (garbage results): all four slots in AGPRs.
+#ifndef RING_ACC_MASK
+#define RING_ACC_MASK 0xf
+#endif
+#define RACC(slot_) (((RING_ACC_MASK >> (slot_)) & 1) != 0)
 template <int MODE>
 __global__ void __launch_bounds__(256, 1) bf16x3_ring_kernel(const float* __restrict__ A, const uint16_t* __restrict__ wimg,
                                                              float* __restrict__ C, int M) {
@@ -251,12 +258,12 @@ __global__ void __launch_bounds__(256, 1) bf16x3_ring_kernel(const float* __rest
     constexpr int u = decltype(U)::value;
     sfor<MI>([&](auto I) __attribute__((always_inline)) {
       constexpr int mi = decltype(I)::value;
-      rload<u * 128, (u & 1) != 0>(ring[u][mi][0], aptr[mi]);
-      rload<u * 128 + 16, (u & 1) != 0>(ring[u][mi][1], aptr[mi]);
+      rload<u * 128, RACC(u)>(ring[u][mi][0], aptr[mi]);
+      rload<u * 128 + 16, RACC(u)>(ring[u][mi][1], aptr[mi]);
     });
   });
   uint32_t pl[2][3][MI][4];                 // [parity][hi / mid / lo][row group]: 4 dwords = 8 bf16 each
-  rwait<8 * (RING - 1), false>(ring[0][0][0], ring[0][0][1], ring[0][1][0], ring[0][1][1], ring[0][2][0], ring[0][2][1],
+  rwait<8 * (RING - 1), RACC(0)>(ring[0][0][0], ring[0][0][1], ring[0][1][0], ring[0][1][1], ring[0][2][0], ring[0][2][1],
                                ring[0][3][0], ring[0][3][1]);
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
@@ -280,21 +287,26 @@ __global__ void __launch_bounds__(256, 1) bf16x3_ring_kernel(const float* __rest
       sfor<MI>([&](auto I) __attribute__((always_inline)) {
         constexpr int mi = decltype(I)::value;
         if constexpr (ks + RING < KS) {
-          rload<(ks + RING) * 128, (slot & 1) != 0>(ring[slot][mi][0], aptr[mi]);
-          rload<(ks + RING) * 128 + 16, (slot & 1) != 0>(ring[slot][mi][1], aptr[mi]);
+          rload<(ks + RING) * 128, RACC(slot)>(ring[slot][mi][0], aptr[mi]);
+          rload<(ks + RING) * 128 + 16, RACC(slot)>(ring[slot][mi][1], aptr[mi]);
         } else {
-          rload<(ks + RING - KS) * 128, (slot & 1) != 0>(ring[slot][mi][0], nptr[mi]);
-          rload<(ks + RING - KS) * 128 + 16, (slot & 1) != 0>(ring[slot][mi][1], nptr[mi]);
+          rload<(ks + RING - KS) * 128, RACC(slot)>(ring[slot][mi][0], nptr[mi]);
+          rload<(ks + RING - KS) * 128 + 16, RACC(slot)>(ring[slot][mi][1], nptr[mi]);
         }
       });
       // the next step's slot was requested RING - 1 steps ago: 8 (RING - 1) younger ring loads may still be in flight,
       // plus the previous tile's 16 stores while they are younger than it (k steps 0 .. 2 of every tile but the first)
-      if (ks < RING - 1 && stored)
-        rwait<8 * (RING - 1) + 16, (slot1 & 1) != 0>(ring[slot1][0][0], ring[slot1][0][1], ring[slot1][1][0], ring[slot1][1][1],
-                                                     ring[slot1][2][0], ring[slot1][2][1], ring[slot1][3][0], ring[slot1][3][1]);
-      else
-        rwait<8 * (RING - 1), (slot1 & 1) != 0>(ring[slot1][0][0], ring[slot1][0][1], ring[slot1][1][0], ring[slot1][1][1],
-                                                ring[slot1][2][0], ring[slot1][2][1], ring[slot1][3][0], ring[slot1][3][1]);
+      // The register-tied wait must be ONE statement on every path: tied waits in the two arms of a branch made hipcc merge
+      // the ring registers with copies placed BEFORE the wait in one arm (reads of data still in flight).  So the tile
+      // without stores ahead of it first waits untied for the smaller count.
+      if constexpr (ks < RING - 1) {
+        if (!stored) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * (RING - 1)));
+        rwait<8 * (RING - 1) + 16, RACC(slot1)>(ring[slot1][0][0], ring[slot1][0][1], ring[slot1][1][0], ring[slot1][1][1],
+                                               ring[slot1][2][0], ring[slot1][2][1], ring[slot1][3][0], ring[slot1][3][1]);
+      } else {
+        rwait<8 * (RING - 1), RACC(slot1)>(ring[slot1][0][0], ring[slot1][0][1], ring[slot1][1][0], ring[slot1][1][1],
+                                          ring[slot1][2][0], ring[slot1][2][1], ring[slot1][3][0], ring[slot1][3][1]);
+      }
       const int pos = ((ks * 4 + g4) ^ l16) * 8;
       bf8 bcur[3], bnxt[3];
       {
@@ -511,7 +523,7 @@ int main(int argc, char** argv) {
       CK(hipDeviceSynchronize());
       CK(hipMemcpy(got.data(), dC, got.size() * 4, hipMemcpyDeviceToHost));
       const Err e = compare(got, ref);
-      if (getenv("PROBE_DEBUG") && ds == 0 && kern == 1) {
+      if (getenv("PROBE_DEBUG") && ds == 0 && kern == atoi(getenv("PROBE_DEBUG"))) {
         // where the error lives: by 64-column slice, by channel % 4 (= accumulator tile ni), by 16-row group (mi)
         double es[4] = {0}, en[4] = {0}, em[4] = {0}, rs[4] = {0}, rn[4] = {0}, rm[4] = {0};
         for (int m = 0; m < 256; ++m)

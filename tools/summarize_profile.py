@@ -64,16 +64,36 @@ def steps_label(json_name, default):
 
 
 print('# rocprofv3 summary %s (bench.py GHND Faster R-CNN b3ch, batch 16, 1 x MI355X)\n' % tag)
-stats = glob.glob(os.path.join(out, 'trace', '*kernel_stats.csv'))
-if stats:
+def stats_table(sub, json_name, title):
+    """one kernel-stats table + the sum of ALL kernel durations per step next to bench.py's own per-step kernel times"""
+    stats = glob.glob(os.path.join(out, sub, '*kernel_stats.csv'))
+    if not stats:
+        return
     rows = list(csv.DictReader(open(stats[0])))
-    print('## kernel-trace --stats (%s; teacher/student stream overlap off)\n'
-          % steps_label('bench_trace.json', '12 steps in the process: 2 warm-up + 6 timed + 3 enqueue-probe + 1 event-profiled'))
+    print('## kernel-trace --stats, %s (%s)\n' % (title, steps_label(json_name, 'steps unknown')))
+    try:
+        d = json.loads(open(os.path.join(out, json_name)).read().strip().splitlines()[-1])
+        nsteps = int(d['warmup']) + int(d['steps']) + 4
+        total = sum(float(r['TotalDurationNs']) for r in rows) / 1e6
+        print('sum of all kernel durations %.1f ms = %.2f ms per step over %d steps; bench.py in the same process: wall %.2f '
+              'ms/step, per-launch HIP events of its single-stream step: MFMA kernels %.2f + HBM-bound kernels %.2f = %.2f ms '
+              '(the trace also holds the small launches bench.py does not time: packs, folds, finalizes)\n'
+              % (total, total / nsteps, nsteps, d['ms_per_step'], d['conv_kernel_ms_per_step'], d['hbm_kernel_ms_per_step'],
+                 d['conv_kernel_ms_per_step'] + d['hbm_kernel_ms_per_step']))
+    except Exception as e:      # noqa
+        print('(bench json unreadable: %s)\n' % e)
     print('| kernel | calls | total ms | avg us | % |')
     print('|---|---|---|---|---|')
     for r in rows[:24]:
         print('| %s | %s | %.2f | %.1f | %s |' % (short(r['Name']), r['Calls'], float(r['TotalDurationNs']) / 1e6,
                                                    float(r['AverageNs']) / 1e3, r['Percentage']))
+    print()
+
+
+stats_table('trace', 'bench_trace.json', 'SINGLE stream (HND_TEACHER_STREAM=0 HND_DEFER_FPN=0 HND_WGRAD_STREAM=0): kernels run '
+            'alone -- per-kernel durations and fractions are read from THIS table')
+stats_table('trace_ms', 'bench_trace_ms.json', 'the step as it runs (teacher, pyramid and weight-gradient side streams ON): '
+            'co-running kernels are time-sliced, their durations are inflated -- do not compute per-kernel fractions from it')
 FULLNAMES = False      # traffic is keyed by the bench variant names
 traffic = {}
 for label, sub, col in (('FETCH_SIZE', 'pmc_fetch', 'FETCH_SIZE'), ('WRITE_SIZE', 'pmc_write', 'WRITE_SIZE')):
