@@ -23,7 +23,8 @@ class ConvDesc(C.Structure):
                                          'sh', 'dh', 'bh', 'sw', 'dw', 'bw', 'kdim', 'pro_relu', 'relu',
                                          'res1_mode', 'res1_h', 'res1_w', 'w_group_rows', 'w_group_stride')] + \
                [('relay_ws', vp), ('mask_bits', vp), ('mask_out', vp)] + \
-               [(k, vp) for k in ('bwd_x', 'bwd_scale', 'bwd_shift', 'bwd_mean', 'bwd_rstd')] + [('bwd_relu', C.c_int)]
+               [(k, vp) for k in ('bwd_x', 'bwd_scale', 'bwd_shift', 'bwd_mean', 'bwd_rstd')] + [('bwd_relu', C.c_int)] + \
+               [('w_bf16x3', vp)]
 
 
 class ImageDesc(C.Structure):
@@ -70,6 +71,8 @@ _SIGNATURES = {
     'hnd_conv2d_wgrad': (C.c_int, [C.POINTER(WgradDesc), vp]),
     'hnd_conv2d_wgrad_variant': (C.c_int, [C.POINTER(WgradDesc)]),
     'hnd_pack_weights': (C.c_int, [vp, vp] + [C.c_int] * 12 + [vp]),
+    'hnd_pack_bf16x3_elems': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    'hnd_pack_bf16x3': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int64, vp]),
     'hnd_scale_packed_k': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]),
     'hnd_pack_weights_batched': (C.c_int, [C.POINTER(PackDesc), C.c_int, vp]),
     'hnd_fbn_fold': (C.c_int, [vp] * 6 + [C.c_int, C.c_int, C.c_float, vp]),

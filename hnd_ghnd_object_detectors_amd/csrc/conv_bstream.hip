@@ -556,11 +556,12 @@ int bstream_variant(const hnd_conv_desc& d) {
   // gain 3 % alone and nothing in the step (the teacher / FPN streams already fill the tiled kernel's partial last
   // round, and a persistent one-wave-per-SIMD kernel shares a CU with nobody): they stay on the tiled kernel, as does
   // K <= 512 without taps (the B-resident kernels).
-  if (!taps && (d.kdim < 1024 || (d.kdim < 2048 && d.cout < 512))) return 0;
+  // (HND_DEBUG_PICKER=bstream_k1024: the K = 1024 -> 256 launches too; re-measured in round 5, profiles/r05_picker_ab.txt)
+  if (!taps && (d.kdim < 1024 || (d.kdim < 2048 && d.cout < 512 && hnd::debug_picker("bstream_k1024") <= 0))) return 0;
   // The parity launches of a stride-2 data gradient (strided output, 1 / 2 / 4 taps: K = 128 ... 2048) are short: per
   // layer, all four on the tiled kernel beat three here + one tiled (round 4, per-launch events of the step: layer2.0
   // 0.925 -> 0.785 ms, layer3.0 0.801 -> 0.745, layer4.0 0.814 -> 0.789 with only its K = 2048 launch kept here).
-  if (taps && d.y_sh > 1 && d.kdim < 2048) return 0;
+  if (taps && d.y_sh > 1 && d.kdim < 2048 && hnd::debug_picker("bstream_parity") <= 0) return 0;
   // (K = 1024 -> 256 with >= 4 tiles per workgroup was tried again in round 4, with and without the shared trunk: 95.2 vs
   // 94.5-95.3 ms, nothing)
   // ... and only with at least one tile per workgroup (the relay's condition): a persistent kernel that leaves CUs

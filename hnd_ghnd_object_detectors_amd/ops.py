@@ -46,9 +46,28 @@ def device_arch():
 
 
 # --------------------------------------------------------------------------------------- weights
+# OPT-IN, never the default (VERDICT r4 item 3 / profiles/r05_bf16x3_probe.txt): HND_BF16X3=1 attaches a three-plane bf16
+# image to every packed operand the emulation kernel can use (csrc/conv_bx3.hip); the launches it covers then compute on
+# the bf16 matrix pipe with fp32-level accuracy but NOT the fp32 kernels' bits.  Unset: no image, native fp32 MFMA everywhere.
+BF16X3 = os.environ.get('HND_BF16X3', '0') == '1'
+
+
+def bx3_image(buf, rows_pad, kdim, groups=1, group_stride=0, out=None, force=False):
+    """(re)build the bf16x3 image of a packed fp32 operand; None when the emulation is off (unless `force`: tests) or
+    cannot use this operand"""
+    if not (BF16X3 or force) or kdim not in (128, 256) or rows_pad % 64 != 0:
+        return None
+    n = int(_L.hnd_pack_bf16x3_elems(rows_pad, kdim, groups))
+    if out is None or out.numel() != n:
+        out = torch.empty(n, dtype=torch.int16, device=buf.device)
+    check(_L.hnd_pack_bf16x3(buf.data_ptr(), out.data_ptr(), rows_pad, kdim, groups, int(group_stride), stream_ptr()),
+          'hnd_pack_bf16x3')
+    return out
+
+
 class PackedWeight(object):
     """K-contiguous GEMM operand made by hnd_pack_weights."""
-    __slots__ = ('buf', 'rows', 'kdim', 'ni', 'nj', 'chan_pad', 'chan_real', 'src', 'args', 'kscale')
+    __slots__ = ('buf', 'rows', 'kdim', 'ni', 'nj', 'chan_pad', 'chan_real', 'src', 'args', 'kscale', 'bx3')
 
     def repack(self):
         if PACK_BATCH['open'] and getattr(self, 'kscale', None) is None:
@@ -60,6 +79,11 @@ class PackedWeight(object):
             check(_L.hnd_scale_packed_k(self.buf.data_ptr(), round_up(self.rows, 64), self.kdim, self.ni * self.nj,
                                         self.chan_pad, self.kscale.data_ptr(), min(self.kscale.numel(), self.chan_pad),
                                         stream_ptr()), 'hnd_scale_packed_k')
+        self.refresh_bx3()
+
+    def refresh_bx3(self):
+        if BF16X3 and self.ni * self.nj == 1 and self.kdim == self.chan_pad:          # tap-free operands only
+            self.bx3 = bx3_image(self.buf, round_up(self.rows, 64), self.kdim, out=getattr(self, 'bx3', None))
 
 
 # A caller that refreshes many small operands in a row (the trainable head after every optimizer step) brackets the loop
@@ -81,6 +105,8 @@ def pack_batch_end():
         d.src, d.dst = pw.src.data_ptr(), pw.buf.data_ptr()
         (d.cout, d.cin, d.kh, d.kw, d.transposed, d.chan_pad, d.i0, d.istep, d.ni, d.j0, d.jstep, d.nj) = pw.args
     check(_L.hnd_pack_weights_batched(arr, len(items), stream_ptr()), 'hnd_pack_weights_batched')
+    for pw in items:
+        pw.refresh_bx3()
 
 
 def pack_weights(w, transposed=False, chan_pad=None, taps=None, kscale=None):
@@ -144,7 +170,7 @@ class ConvLaunch(object):
         tile = _L.hnd_conv2d_igemm_tile(self.ref)
         self.variant = ('stem7_lds' if tile == 9 else 'igemm_c4_128x64') if self.desc.cin == 4 else \
             ('igemm_128x128', 'igemm_128x64', 'igemm_64x128', 'igemm_64x64', 'thin_n4', 'bres_128',
-             'bres_64', 'bres2_128', 'bres2_64', 'stem7_lds', 'unused', 'bstream_128', 'bstream_64')[tile]
+             'bres_64', 'bres2_128', 'bres2_64', 'stem7_lds', 'unused', 'bstream_128', 'bstream_64', 'bx3_64')[tile]
 
     def run(self, stream=None):
         rc = _L.hnd_conv2d_igemm(self.ref, stream if stream is not None else stream_ptr())
@@ -194,6 +220,7 @@ def conv_desc(x, pw, y, *, kh, kw, oh, ow, sh, dh, bh, sw, dw, bw, cout, y_sh=1,
                              and tuple(t.shape) == (ny, yh, yw, ldc // 4)), (None if t is None else t.shape, y.shape)
     assert mask is None or mask_bits is None
     d.mask_bits, d.mask_out = ptr(mask_bits), ptr(mask_out)
+    d.w_bf16x3 = ptr(getattr(pw, 'bx3', None))          # HND_BF16X3=1 only (opt-in emulation on the bf16 matrix pipe)
     if stats is not None:
         assert stats.numel() >= stats_tiles(n * oh * ow) * 2 * cout
     if bwd_stats is not None:
@@ -557,12 +584,14 @@ class WinoWeights(object):
         assert self.depth % 32 == 0, 'Winograd path needs a GEMM depth that is a multiple of 32'
         self.rows_pad = round_up(self.rows, 64)
         self.buf = torch.empty(self.ncomp * self.rows_pad * self.depth, dtype=torch.float32, device=weight.device)
+        self.bx3 = None
         self.repack()
 
     def repack(self):
         cout, cin = self.src.shape[0], self.src.shape[1]
         check(_L.hnd_wino_weights(ptr(self.src), ptr(self.buf), cout, cin, int(self.dgrad), self.tile, stream_ptr()),
               'hnd_wino_weights')
+        self.bx3 = bx3_image(self.buf, self.rows_pad, self.depth, self.ncomp, self.rows_pad * self.depth, out=self.bx3)
 
 
 class WinoConv(object):
@@ -592,6 +621,7 @@ class WinoConv(object):
         self.m = m[:need_m].view(1, 1, nc * self.tiles_pad, self.cout)
         pw = PackedWeight.__new__(PackedWeight)
         pw.buf, pw.kdim, pw.rows, pw.chan_pad, pw.chan_real = ww.buf, ww.depth, ww.rows, c, c
+        pw.bx3 = ww.bx3
         self.gemm = conv_desc(self.v, pw, self.m, kh=1, kw=1, oh=1, ow=nc * self.tiles_pad, sh=1, dh=1, bh=0, sw=1,
                               dw=1, bw=0, cout=self.cout)
         self.gemm.desc.w_group_rows = self.tiles_pad
@@ -649,6 +679,7 @@ class Wino2Weights(object):
         assert self.depth % 32 == 0, 'Winograd path needs a GEMM depth that is a multiple of 32'
         self.rows_pad = round_up(self.rows, 64)
         self.buf = torch.empty(self.ncomp * self.rows_pad * self.depth, dtype=torch.float32, device=weight.device)
+        self.bx3 = None
         self.repack()
 
     def repack(self):
@@ -656,6 +687,7 @@ class Wino2Weights(object):
         check(_L.hnd_wino2_weights(self.src.data_ptr(), ptr(self.buf), cout, cin, int(self.dgrad), self.tile,
                                    stream_ptr()),
               'hnd_wino2_weights')
+        self.bx3 = bx3_image(self.buf, self.rows_pad, self.depth, self.ncomp, self.rows_pad * self.depth, out=self.bx3)
 
 
 class Wino2Conv(object):
@@ -695,6 +727,7 @@ class Wino2Conv(object):
         self.m = m[:need_m].view(1, 1, nc * self.tiles_pad, self.cout)
         pw = PackedWeight.__new__(PackedWeight)
         pw.buf, pw.kdim, pw.rows, pw.chan_pad, pw.chan_real = ww.buf, ww.depth, ww.rows, c, c
+        pw.bx3 = ww.bx3
         self.gemm = conv_desc(self.v, pw, self.m, kh=1, kw=1, oh=1, ow=nc * self.tiles_pad, sh=1, dh=1, bh=0, sw=1,
                               dw=1, bw=0, cout=self.cout)
         self.gemm.desc.w_group_rows = self.tiles_pad

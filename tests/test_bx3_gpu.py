@@ -1,0 +1,149 @@
+"""OPT-IN fp32 emulation on the bf16 matrix pipe (csrc/conv_bx3.hip, hnd_conv_desc.w_bf16x3).
+
+Never the default: every other test runs native fp32 MFMA.  Here the emulation kernel is held to an fp64 reference BESIDE
+the native kernel on the same operands (its error may be at most 1.5x the native one's), and one full-size reference
+fixture is replayed with HND_BF16X3=1 in a subprocess under the ordinary parity bars."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEV = torch.device('cuda:0')
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from hnd_ghnd_object_detectors_amd import ops as O
+    return O
+
+
+def _nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous().to(DEV)
+
+
+@pytest.mark.parametrize('cin,cout,n,h,w,stride,epi', [
+    (256, 256, 4, 96, 128, 1, False),        # fpn.inner0-like (without its residual)
+    (256, 128, 8, 96, 128, 1, True),         # layer2.0.conv1: FrozenBN scale / shift + ReLU
+    (256, 512, 8, 192, 256, 2, True),        # layer2.0.downsample: stride 2
+    (128, 64, 16, 96, 128, 1, False),        # K = 128, one 64-column slice
+    (256, 1024, 8, 64, 64, 1, True),         # 16 slices per team
+])
+def test_bx3_1x1_conv_against_fp64_beside_the_native_kernel(ops, cin, cout, n, h, w, stride, epi):
+    g = torch.Generator().manual_seed(5 + cin + cout)
+    x = torch.randn(n, cin, h, w, generator=g) * torch.exp2(torch.randn(n, 1, h, w, generator=g) * 3)     # wide range
+    wt = torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5
+    es = torch.rand(cout, generator=g) + 0.5 if epi else None
+    eb = torch.randn(cout, generator=g) if epi else None
+    ref = F.conv2d(x.double(), wt.double(), None, stride)
+    if epi:
+        ref = F.relu(ref * es.double()[None, :, None, None] + eb.double()[None, :, None, None])
+    xd, pk = _nhwc(x), ops.pack_weights(wt.to(DEV).contiguous())
+    oh, ow = ref.shape[2], ref.shape[3]
+    kw = dict(epi_scale=es.to(DEV) if epi else None, epi_shift=eb.to(DEV) if epi else None, relu=epi)
+    y0 = torch.full((n, oh, ow, cout), float('nan'), device=DEV)
+    l0 = ops.conv_forward(xd, pk, y0, 1, stride, 0, **kw)
+    assert not l0.variant.startswith('bx3')
+    l0.run()
+    pk.bx3 = ops.bx3_image(pk.buf, ops.round_up(cout, 64), cin, force=True)
+    assert pk.bx3 is not None
+    y1 = torch.full_like(y0, float('nan'))
+    l1 = ops.conv_forward(xd, pk, y1, 1, stride, 0, **kw)
+    assert l1.variant == 'bx3_64', l1.variant
+    l1.run()
+    ops.sync_check()
+    want = ref.permute(0, 2, 3, 1)
+    e0 = float((y0.cpu().double() - want).norm() / want.norm())
+    e1 = float((y1.cpu().double() - want).norm() / want.norm())
+    assert not bool(torch.isnan(y1).any())
+    assert e1 < 1e-6 and e1 <= 1.5 * e0 + 1e-8, (e1, e0)
+    y2 = torch.empty_like(y1)
+    ops.conv_forward(xd, pk, y2, 1, stride, 0, **kw).run()
+    assert torch.equal(y2, y1)                        # a fixed summation order: reproducible bits
+    from tests.conftest import record_achieved
+    record_achieved('[bf16x3 emulation, 1x1 %d -> %d @%dx%d s%d] rel-L2 vs fp64 %.2e (native fp32 MFMA %.2e)'
+                    % (cin, cout, h, w, stride, e1, e0))
+
+
+@pytest.mark.parametrize('cin,cout,n,h,w', [(128, 512, 8, 96, 128), (256, 1024, 8, 64, 96)])
+def test_bx3_bottleneck_conv3_with_residual_relu_and_mask_nibbles(ops, cin, cout, n, h, w):
+    """conv3 of a frozen Bottleneck: FrozenBN scale / shift, + identity, ReLU, and the ReLU-mask nibbles of the stored values
+    (hnd_conv_desc.mask_out) -- the residual rows travel as asm loads in the ring's in-order stream"""
+    g = torch.Generator().manual_seed(9 + cin)
+    x = torch.randn(n, cin, h, w, generator=g).relu()
+    wt = torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5
+    es, eb = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.2
+    res = torch.randn(n, cout, h, w, generator=g)
+    ref = F.relu(F.conv2d(x.double(), wt.double()) * es.double()[None, :, None, None] + eb.double()[None, :, None, None]
+                 + res.double()).permute(0, 2, 3, 1)
+    xd, rd, pk = _nhwc(x), _nhwc(res), ops.pack_weights(wt.to(DEV).contiguous())
+    outs = {}
+    for emu in (False, True):
+        if emu:
+            pk.bx3 = ops.bx3_image(pk.buf, cout, cin, force=True)
+        y = torch.full((n, h, w, cout), float('nan'), device=DEV)
+        bits = torch.full((n, h, w, cout // 4), 255, dtype=torch.uint8, device=DEV)
+        l = ops.conv_forward(xd, pk, y, 1, 1, 0, epi_scale=es.to(DEV), epi_shift=eb.to(DEV), res1=rd, relu=True, mask_out=bits)
+        assert (l.variant == 'bx3_64') == emu, l.variant
+        l.run()
+        ops.sync_check()
+        outs[emu] = (y.cpu().double(), bits.cpu(), y)
+    e0 = float((outs[False][0] - ref).norm() / ref.norm())
+    e1 = float((outs[True][0] - ref).norm() / ref.norm())
+    assert e1 < 1e-6 and e1 <= 1.5 * e0 + 1e-8, (e1, e0)
+    yv = outs[True][2].view(n, h, w, cout // 4, 4)
+    want = ((yv[..., 0] > 0).to(torch.uint8) | ((yv[..., 1] > 0).to(torch.uint8) << 1) | ((yv[..., 2] > 0).to(torch.uint8) << 2)
+            | ((yv[..., 3] > 0).to(torch.uint8) << 3)).cpu()
+    assert torch.equal(outs[True][1], want)                       # the nibbles describe the values this kernel stored
+    from tests.conftest import record_achieved
+    record_achieved('[bf16x3 emulation, conv3 %d -> %d + residual + ReLU + mask nibbles] rel-L2 vs fp64 %.2e (native %.2e)'
+                    % (cin, cout, e1, e0))
+
+
+@pytest.mark.parametrize('c,n,h,w', [(256, 8, 96, 132), (128, 8, 102, 168)])
+def test_bx3_winograd_component_gemms_match_the_native_path(ops, c, n, h, w):
+    """a frozen 3x3 conv through F(6x6,3x3): the 64 component GEMMs on the emulation vs on the native kernel; both held to
+    the direct fp64 convolution"""
+    g = torch.Generator().manual_seed(77 + c)
+    x = torch.randn(n, c, h, w, generator=g).relu()
+    wt = torch.randn(c, c, 3, 3, generator=g) / (9 * c) ** 0.5
+    ref = F.conv2d(x.double(), wt.double(), None, 1, 1).permute(0, 2, 3, 1)
+    xd, wd = _nhwc(x), wt.to(DEV).contiguous()
+    outs = {}
+    for emu in (False, True):
+        ww = ops.WinoWeights(wd, False, 6)
+        if emu:
+            ww.bx3 = ops.bx3_image(ww.buf, ww.rows_pad, ww.depth, ww.ncomp, ww.rows_pad * ww.depth, force=True)
+        nv, nm = ops.WinoConv.scratch_elems(n, h, w, c, c, 6)
+        v, m = torch.empty(nv, device=DEV), torch.empty(nm, device=DEV)
+        y = torch.full((n, h, w, c), float('nan'), device=DEV)
+        conv = ops.WinoConv(xd, ww, y, v, m)
+        assert (conv.gemm.variant == 'bx3_64') == emu, conv.gemm.variant
+        conv.run()
+        ops.sync_check()
+        outs[emu] = y.cpu().double()
+    e0 = float((outs[False] - ref).norm() / ref.norm())
+    e1 = float((outs[True] - ref).norm() / ref.norm())
+    assert e1 < 2e-5 and e1 <= 1.5 * e0, (e1, e0)                 # (the Winograd transforms' own fp32 error dominates)
+    from tests.conftest import record_achieved
+    record_achieved('[bf16x3 emulation, F(6x6,3x3) %d ch @%dx%d] rel-L2 vs the direct fp64 conv %.2e (native %.2e)' % (c, h, w, e1, e0))
+
+
+def test_full_size_reference_fixture_passes_with_the_emulation_switched_on():
+    """the reference-made full-size fixture (batch 4, 3x800x1333; maps, loss terms, gradient fingerprints, parameters after
+    Adam) under HND_BF16X3=1: the ordinary bars, nothing relaxed"""
+    env = dict(os.environ, HND_BF16X3='1')
+    r = subprocess.run([sys.executable, '-m', 'pytest', '-q', '-x', '-m', 'gpu',
+                        'tests/test_model_gpu.py::test_full_size_step_matches_reference_checksums',
+                        '-k', 'full_ghnd_faster_b4 or full_hnd_faster_b2'], cwd=ROOT, env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, timeout=1500)
+    text = r.stdout.decode()
+    assert r.returncode == 0, text[-3000:]
+    from tests.conftest import record_achieved
+    for line in text.splitlines():
+        if line.startswith('[full size'):
+            record_achieved('[HND_BF16X3=1] ' + line)
