@@ -94,8 +94,7 @@ __device__ __forceinline__ void split_pair(float x0, float x1, uint32_t& hp, uin
 // would be waited for with counts that ignore the ring and drain it).  MO: mask_out (the ReLU-mask nibbles of the stored
 // values): 16 more byte stores per tile in the same stream.
 // In-order bookkeeping of a wait at k step ks for slot ks + 1 (requested at step ks + 1 - RING): younger operations are the
-// 3 x 8 refills since, + the previous tile's STORES when the tile boundary lies in between (ks <= RING - 2, not the
-// segment's first tile), + the 16 residual loads when their issue point does (KS - 4 <= ks <= KS - 4 + RING - 2).
+// (RING - 1) x 8 refills since, + the previous tile's STORES when the tile boundary lies in between (ks <= RING - 2), + the 16 residual loads when their issue point does (KS - 4 <= ks <= KS - 4 + RING - 2).
 template <int KS, bool RES, bool MO>
 __global__ void __launch_bounds__(256, 1) bx3_kernel(const hnd_conv_desc d, const Bx3Args a) {
   // (RES: ring 128 + accumulators 64 + residual rows 64 = all 256 accumulator registers, and hipcc then parks just-requested
@@ -168,8 +167,18 @@ __global__ void __launch_bounds__(256, 1) bx3_kernel(const hnd_conv_desc d, cons
         });
       });
       uint32_t pl[2][3][MI][4];                 // [parity][hi / mid / lo][row group]: 4 dwords = 8 bf16
-      rwait<8 * (RING - 1)>(ring[0][0][0], ring[0][0][1], ring[0][1][0], ring[0][1][1], ring[0][2][0], ring[0][2][1],
-                            ring[0][3][0], ring[0][3][1]);
+      // The waits of a tile's first RING - 1 k steps name the previous tile's STORES stores, which sit in the in-order
+      // stream between the slots they wait for and the youngest refills.  A segment's first tile has no previous tile:
+      // STORES throw-away 4-byte loads (one register, cache hits) take the stores' place, so that every tile runs the SAME
+      // counts -- a run-time "first tile" flag made hipcc duplicate the tied waits over a branch and park ring registers in
+      // one arm before their wait, and no path-insensitive audit of the assembly could follow it.
+      // (their one destination register stays reserved until the segment's final drain: the data lands later, whatever
+      // the compiler believes)
+      float dummy = 0.f;
+#pragma unroll
+      for (int i = 0; i < STORES; ++i) asm volatile("global_load_dword %0, %1, off" : "+v"(dummy) : "v"(aptr[0]));
+      rwait<8 * (RING - 1) + STORES>(ring[0][0][0], ring[0][0][1], ring[0][1][0], ring[0][1][1], ring[0][2][0], ring[0][2][1],
+                                     ring[0][3][0], ring[0][3][1]);
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -178,7 +187,6 @@ __global__ void __launch_bounds__(256, 1) bx3_kernel(const hnd_conv_desc d, cons
           const float x0 = (j & 1) ? v.z : v.x, x1 = (j & 1) ? v.w : v.y;
           split_pair(x0, x1, pl[0][0][mi][j], pl[0][1][mi][j], pl[0][2][mi][j]);
         }
-      bool stored = false;
       f32x4 acc[MI][NI];
       f32x4 resv[MI][4];                        // RES: the tile's residual rows (row 4 g4 + r of row group mi)
       for (; cc < seg_hi; cc += 4) {
@@ -208,15 +216,14 @@ __global__ void __launch_bounds__(256, 1) bx3_kernel(const hnd_conv_desc d, cons
             }
           });
           // The next step's slot was requested RING - 1 steps ago: 8 (RING - 1) younger ring loads may be in flight, plus
-          // the previous tile's 16 stores while they are younger than it (k steps 0 .. RING - 2 of every tile but the
-          // segment's first).  Exact counts: full tiles only (the launcher requires M % 64 == 0).
+          // the previous tile's STORES stores (the segment's first tile: as many throw-away loads) while they are younger
+          // than it (k steps 0 .. RING - 2).  Exact counts: full tiles only (the launcher requires M % 64 == 0).
           constexpr int kResYounger = (RES && ks >= KS - 4 && ks <= KS - 4 + RING - 2) ? 16 : 0;
           if constexpr (ks < RING - 1) {
-            if (!stored) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * (RING - 1) + kResYounger));
             // (the counter holds 6 bits: a larger allowance is clipped to 63 -- a stronger, still correct wait)
-            rwait<(8 * (RING - 1) + STORES + kResYounger < 63 ? 8 * (RING - 1) + STORES + kResYounger : 63)>(ring[slot1][0][0], ring[slot1][0][1], ring[slot1][1][0],
-                                                         ring[slot1][1][1], ring[slot1][2][0], ring[slot1][2][1],
-                                                         ring[slot1][3][0], ring[slot1][3][1]);
+            rwait<(8 * (RING - 1) + STORES + kResYounger < 63 ? 8 * (RING - 1) + STORES + kResYounger : 63)>(
+                ring[slot1][0][0], ring[slot1][0][1], ring[slot1][1][0], ring[slot1][1][1], ring[slot1][2][0],
+                ring[slot1][2][1], ring[slot1][3][0], ring[slot1][3][1]);
           } else {
             rwait<8 * (RING - 1) + kResYounger>(ring[slot1][0][0], ring[slot1][0][1], ring[slot1][1][0], ring[slot1][1][1],
                                                 ring[slot1][2][0], ring[slot1][2][1], ring[slot1][3][0], ring[slot1][3][1]);
@@ -295,11 +302,10 @@ __global__ void __launch_bounds__(256, 1) bx3_kernel(const hnd_conv_desc d, cons
               d.mask_out[yo >> 2] = (uint8_t)((v[0] > 0.f ? 1 : 0) | (v[1] > 0.f ? 2 : 0) | (v[2] > 0.f ? 4 : 0) |
                                               (v[3] > 0.f ? 8 : 0));
           }
-        stored = true;
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) aptr[mi] = nptr[mi];
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the ring's last (unused) prefetches land before reuse
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(dummy)::"memory");   // the ring's last (unused) prefetches land before reuse
     }
     c = seg_hi;
   }

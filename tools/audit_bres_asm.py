@@ -1,12 +1,17 @@
 #!/usr/bin/env python
 """Audit of the inline-asm register rings of bres2_kernel (csrc/conv_bres.hip), bstream_kernel
-(csrc/conv_bstream.hip) and wgrad_ring_kernel (csrc/conv_wgrad_ring.hip) in hipcc's assembly output.
+(csrc/conv_bstream.hip), wgrad_ring_kernel (csrc/conv_wgrad_ring.hip) and bx3_kernel (csrc/conv_bx3.hip, the opt-in
+bf16x3 emulation) in hipcc's assembly output.
 
 hipcc does not know that a `global_load_dwordx4` inside an asm statement writes its destination LATER: between that
 statement and the `s_waitcnt vmcnt(N)` statement that names the same registers it is free to copy / spill / reuse them.
 This script walks the control-flow graph of every such kernel in the .s file (every path, loop back edges included, each
 basic block once per distinct set of loads in flight) and fails if any instruction reads or writes a ring register
 between its asm load and the wait that releases it (a second asm load into a still-pending register also fails).
+The three fp32 kernels' counts ignore their stores (a store in the window only makes a wait stronger) and so does the walk;
+bx3_kernel's counts are EXACT -- they name the previous tile's stores (vector memory operations of one wave retire in issue
+order through the one counter; LLVM's own wait insertion relies on the same on gfx9) -- so for it the walk puts every
+compiler-emitted global store / load into the in-order queue as well.
 
 usage: python tools/audit_bres_asm.py [file.s ...]      (without a file: compiles the two sources to assembly first)
 """
@@ -33,7 +38,7 @@ def regs_of(text):
 def audit(path):
     kernels, cur, name = {}, None, None
     for line in open(path):
-        m = re.match(r'^(_ZN\S*(?:bres2|bstream|wgrad_ring)_kernel\S*):', line)
+        m = re.match(r'^(_ZN\S*(?:bres2|bstream|wgrad_ring|bx3)_kernel\S*):', line)
         if m:
             name, cur = m.group(1), []
             kernels[name] = cur
@@ -52,6 +57,7 @@ def audit(path):
         starts = sorted(set([0] + list(label_at.values())))
         loads, waits = 0, 0
         seen, found = set(), set()
+        exact = 'bx3_kernel' in name            # stores / compiler loads take their place in the in-order queue
 
         def step_block(lo, state):
             """simulate lines from `lo` to the end of its block; returns [(next line index, state)]"""
@@ -76,6 +82,12 @@ def audit(path):
                             _, dst = order.pop(0)
                             for r in dst:
                                 pending.pop(r, None)
+                    elif in_asm and exact and re.match(r'global_(load_dword|store_)\S*\s', text) and not text.startswith('global_load_dwordx4'):
+                        # an asm store: a place in the queue; a throw-away 4-byte load: its register is pending as well
+                        dst = regs_of(text.split(',')[0]) if text.startswith('global_load') else set()
+                        for r in dst:
+                            pending[r] = no
+                        order.append((no, frozenset(dst)))
                     elif in_asm and text.startswith('global_load_dwordx4'):
                         dst = regs_of(text.split(',')[0])
                         clash = dst & set(pending)
@@ -87,6 +99,8 @@ def audit(path):
                             pending[r] = no
                         order.append((no, frozenset(dst)))
                     elif not in_asm:
+                        if exact and re.match(r'global_(store|load)_', text):
+                            order.append((no, frozenset()))
                         touched = regs_of(text) & set(pending)
                         if touched:     # a compiler instruction reads / writes a register whose asm load may be in flight
                             found.add('%s:%d `%s` touches %s (asm load at line %d)'
@@ -127,7 +141,7 @@ def main():
     paths = sys.argv[1:]
     if not paths:
         tmp = tempfile.mkdtemp()
-        for stem in ('conv_bres', 'conv_bstream', 'conv_wgrad_ring'):
+        for stem in ('conv_bres', 'conv_bstream', 'conv_wgrad_ring', 'conv_bx3'):
             path = os.path.join(tmp, stem + '.s')
             src = os.path.join(ROOT, 'hnd_ghnd_object_detectors_amd', 'csrc', stem + '.hip')
             subprocess.check_call(['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950',
