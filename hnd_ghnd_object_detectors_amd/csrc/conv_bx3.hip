@@ -41,6 +41,7 @@ struct Bx3Args {
   int nsl;                    // 64-column weight slices = workgroups per team
   int nchunks;                // M / 64
   int cpg;                    // chunks per weight group (Winograd component), 0 = one group
+  int res_up;                 // RES: res1 is the exactly 2x coarser map, nearest-upsampled (the FPN's top-down path)
 };
 
 template <int N, class F, int... I>
@@ -199,10 +200,24 @@ __global__ void __launch_bounds__(256, 1) bx3_kernel(const hnd_conv_desc d, cons
           constexpr int slot1 = (ks + 1) % RING;            // the step whose planes are made during this one
           if constexpr (RES && ks == KS - 4) {
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
+            for (int mi = 0; mi < MI; ++mi) {
+              const unsigned m0 = (unsigned)(cc * 64 + mi * 16 + g4 * 4);      // four consecutive output pixels
+              if (!a.res_up) {
 #pragma unroll
-              for (int r = 0; r < 4; ++r)
-                rload<0>(resv[mi][r], d.res1 + (size_t)(cc * 64 + mi * 16 + g4 * 4 + r) * (size_t)d.ldc + col0);
+                for (int r = 0; r < 4; ++r) rload<0>(resv[mi][r], d.res1 + (size_t)(m0 + r) * (size_t)d.ldc + col0);
+              } else {
+                // nearest 2x upsampling (yh = 2 res1_h, yw = 2 res1_w, ow % 4 == 0: the four pixels share a row and start at
+                // an even column): pixel (n, y, x) reads (n, y / 2, x / 2)
+                const unsigned t = hnd::fdiv(m0, a.div_ow), ow_ = m0 - t * (unsigned)d.ow;
+                const unsigned n_ = hnd::fdiv(t, a.div_oh), oh_ = t - n_ * (unsigned)d.oh;
+                const size_t p0 = ((size_t)n_ * d.res1_h + (oh_ >> 1)) * (size_t)d.res1_w + (ow_ >> 1);
+                const float* rp = d.res1 + p0 * (size_t)d.ldc + col0;
+                rload<0>(resv[mi][0], rp);
+                rload<0>(resv[mi][1], rp);
+                rload<0>(resv[mi][2], rp + d.ldc);
+                rload<0>(resv[mi][3], rp + d.ldc);
+              }
+            }
           }
           // slot `slot` was split during the previous step: refill it for the step RING ahead (this tile or the next)
           xfor<MI>([&](auto I) __attribute__((always_inline)) {
@@ -311,12 +326,13 @@ __global__ void __launch_bounds__(256, 1) bx3_kernel(const hnd_conv_desc d, cons
   }
 }
 
-// packed fp32 operand [groups][rows_pad][K] -> per (group, 64-row slice) the LDS image [3 planes][64 rows][K] of bf16, chunk
-// c (8 values) of row r at position c ^ (r & 15)
-__global__ void pack_bx3_kernel(const float* __restrict__ w, uint16_t* __restrict__ img, int rows_pad, int K,
+// packed fp32 operand [groups][rows_pad][K] -> per (k part, group, 64-row slice) the LDS image [3 planes][64 rows][KI] of
+// bf16, chunk c (8 values) of row r at position c ^ (r & 15).  KI = K for K = 128 / 256; K = 512 is two k parts of 256 (the
+// launch runs two passes, the second adding the first one's partial result): image part p starts at p * groups * nsl slices.
+__global__ void pack_bx3_kernel(const float* __restrict__ w, uint16_t* __restrict__ img, int rows_pad, int K, int KI, int groups,
                                 long long group_stride, long long total) {
   const int nsl = rows_pad / 64;
-  const size_t plane = (size_t)64 * K;
+  const size_t plane = (size_t)64 * KI;
   for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
     const int k = (int)(e % K);
     long long t = e / K;
@@ -326,8 +342,9 @@ __global__ void pack_bx3_kernel(const float* __restrict__ w, uint16_t* __restric
     const float r1 = x - __uint_as_float(hb);
     const uint32_t mb = __float_as_uint(r1) & 0xffff0000u;
     const float r2 = r1 - __uint_as_float(mb);
-    const int s = row / 64, r = row % 64, c = k >> 3, pos = c ^ (r & 15);
-    uint16_t* o = img + ((size_t)g * nsl + s) * 3 * plane + (size_t)r * K + pos * 8 + (k & 7);
+    const int part = k / KI, kk = k - part * KI;
+    const int s = row / 64, r = row % 64, c = kk >> 3, pos = c ^ (r & 15);
+    uint16_t* o = img + (((size_t)part * groups + g) * nsl + s) * 3 * plane + (size_t)r * KI + pos * 8 + (kk & 7);
     o[0] = (uint16_t)(hb >> 16);
     o[plane] = (uint16_t)(mb >> 16);
     o[2 * plane] = (uint16_t)(__float_as_uint(r2) >> 16);
@@ -370,15 +387,18 @@ int launch_bx3_t(const hnd_conv_desc& d, const Bx3Args& a, int grid, hipStream_t
 
 namespace hnd {
 
-// Taken (only with a weight image attached): tap-free K = 128 / 256, cout a power-of-two multiple of 64, whole 64-row
-// chunks, a dense output (output pixel = GEMM row), and an epilogue of scale / shift, a same-geometry residual, ReLU and
-// the ReLU-mask nibbles.
+// Taken (only with a weight image attached): tap-free K = 128 / 256 (512 without a residual: two passes), cout a power-of-two multiple of 64, whole 64-row
+// chunks, a dense output (output pixel = GEMM row), and an epilogue of scale / shift, a residual (same geometry, or the FPN's
+// 2x nearest-upsampled coarser map), ReLU and the ReLU-mask nibbles.
 bool bx3_applies(const hnd_conv_desc& d) {
   if (!d.w_bf16x3) return false;
   if (d.kh != 1 || d.kw != 1 || d.bh != 0 || d.bw != 0 || d.cin != d.kdim) return false;
-  if (d.kdim != 128 && d.kdim != 256) return false;
+  if (d.kdim != 128 && d.kdim != 256 && d.kdim != 512) return false;
+  if (d.kdim == 512 && d.res1) return false;            // (two passes over k: the second one's residual is the first's result)
   if (d.stats || d.pro_scale || d.res2 || d.mask || d.mask_bits || d.bwd_x) return false;
-  if (d.res1 && (d.res1_mode != 0 || ((uintptr_t)d.res1 % 16) != 0)) return false;       // (same geometry as y only)
+  if (d.res1 && ((uintptr_t)d.res1 % 16) != 0) return false;
+  // a residual of y's geometry, or the exactly 2x coarser map of the FPN's top-down path
+  if (d.res1 && d.res1_mode == 1 && (d.yh != 2 * d.res1_h || d.yw != 2 * d.res1_w || d.ow % 4 != 0)) return false;
   if (d.cout % 64 != 0 || d.ldc % 4 != 0 || ((uintptr_t)d.y % 16) != 0) return false;
   const int per_xcd = cu_count_bx3() / 8, nsl = d.cout / 64;
   if (per_xcd < 1 || nsl > per_xcd || per_xcd % nsl != 0) return false;
@@ -391,19 +411,16 @@ bool bx3_applies(const hnd_conv_desc& d) {
   return true;
 }
 
-int launch_bx3(const hnd_conv_desc& d, hipStream_t stream) {
-  if (!bx3_applies(d)) {
-    set_error("launch_bx3: descriptor not eligible");
-    return HND_ERR_INVALID;
-  }
+static int launch_bx3_one(const hnd_conv_desc& d, int kpart, hipStream_t stream) {
   Bx3Args a;
   a.div_ow = make_fastdiv((unsigned)d.ow);
   a.div_oh = make_fastdiv((unsigned)d.oh);
   a.nsl = d.cout / 64;
   a.nchunks = (int)(((long long)d.n * d.oh * d.ow) / 64);
   a.cpg = d.w_group_rows / 64;
+  a.res_up = d.res1 && d.res1_mode == 1;
   const int grid = (cu_count_bx3() / 8) * 8;
-  const int sel = (d.kdim == 128 ? 0 : 4) | (d.res1 ? 2 : 0) | (d.mask_out ? 1 : 0);
+  const int sel = (kpart == 128 ? 0 : 4) | (d.res1 ? 2 : 0) | (d.mask_out ? 1 : 0);
   switch (sel) {
     case 0: return launch_bx3_t<4, false, false>(d, a, grid, stream);
     case 1: return launch_bx3_t<4, false, true>(d, a, grid, stream);
@@ -416,6 +433,29 @@ int launch_bx3(const hnd_conv_desc& d, hipStream_t stream) {
   }
 }
 
+int launch_bx3(const hnd_conv_desc& d, hipStream_t stream) {
+  if (!bx3_applies(d)) {
+    set_error("launch_bx3: descriptor not eligible");
+    return HND_ERR_INVALID;
+  }
+  if (d.kdim != 512) return launch_bx3_one(d, d.kdim, stream);
+  // K = 512: the resident slice of three planes holds 256 k.  Pass 1: k 0 .. 255, y = acc1 * scale (no shift, no ReLU, no
+  // mask); pass 2: k 256 .. 511 with res1 = y: y = acc2 * scale + shift + y -> ReLU / mask nibbles.  The kernel takes the
+  // row stride of x from cin and the depth from its template, so the second pass is the same launch 256 floats further on.
+  const long long groups = d.w_group_rows > 0 ? ((long long)d.n * d.oh * d.ow) / d.w_group_rows : 1;
+  hnd_conv_desc p1 = d, p2 = d;
+  p1.epi_shift = nullptr;
+  p1.relu = 0;
+  p1.mask_out = nullptr;
+  const int rc = launch_bx3_one(p1, 256, stream);
+  if (rc) return rc;
+  p2.x = d.x + 256;
+  p2.w_bf16x3 = d.w_bf16x3 + (size_t)groups * (size_t)(d.cout / 64) * (size_t)3 * 64 * 256;
+  p2.res1 = d.y;
+  p2.res1_mode = 0;
+  return launch_bx3_one(p2, 256, stream);
+}
+
 }  // namespace hnd
 
 extern "C" size_t hnd_pack_bf16x3_elems(int rows_pad, int kdim, int groups) {
@@ -425,13 +465,13 @@ extern "C" size_t hnd_pack_bf16x3_elems(int rows_pad, int kdim, int groups) {
 
 extern "C" int hnd_pack_bf16x3(const float* w_packed, uint16_t* img, int rows_pad, int kdim, int groups,
                                int64_t group_stride, void* stream) {
-  HND_REQUIRE(w_packed && img && rows_pad > 0 && rows_pad % 64 == 0 && kdim >= 128 && kdim % 128 == 0 && groups >= 1 &&
-                  (groups == 1 || group_stride >= (int64_t)rows_pad * kdim),
-              "hnd_pack_bf16x3: bad arguments");
+  HND_REQUIRE(w_packed && img && rows_pad > 0 && rows_pad % 64 == 0 && (kdim == 128 || kdim == 256 || kdim == 512) &&
+                  groups >= 1 && (groups == 1 || group_stride >= (int64_t)rows_pad * kdim),
+              "hnd_pack_bf16x3: bad arguments (kdim must be 128, 256 or 512)");
   const long long total = (long long)groups * rows_pad * kdim;
   long long blocks = (total + 255) / 256;
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(pack_bx3_kernel, dim3((unsigned)blocks), dim3(256), 0, hnd::as_stream(stream), w_packed, img, rows_pad,
-                     kdim, (long long)group_stride, total);
+                     kdim, kdim == 512 ? 256 : kdim, groups, (long long)group_stride, total);
   return hnd::check_launch("hnd_pack_bf16x3");
 }

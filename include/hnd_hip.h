@@ -130,8 +130,8 @@ typedef struct hnd_conv_desc {
   const float* bwd_rstd;
   int bwd_relu;
   /* OPT-IN, ABI 10 (csrc/conv_bx3.hip): the weight operand pre-split into three bf16 planes by hnd_pack_bf16x3, or NULL (the
-   * default: native fp32 MFMA).  With it, launches the emulation covers (tap-free K = 128 / 256, scale / shift / ReLU
-   * epilogue, whole 64-row chunks, dense output) compute every product as six bf16 MFMAs of the operands' exact 8+8+8-bit
+   * default: native fp32 MFMA).  With it, launches the emulation covers (tap-free K = 128 / 256 / 512, scale / shift / residual /
+   * ReLU / mask-nibble epilogue, whole 64-row chunks, dense output) compute every product as six bf16 MFMAs of the operands' exact 8+8+8-bit
    * planes with fp32 accumulation: fp32-level accuracy (rel-L2 2.4e-7 vs fp64, native 2.9e-7), not bit-identical to the
    * fp32 kernels, 1.65x their rate (profiles/r05_bf16x3_probe.txt).  Layout: hnd_pack_bf16x3. */
   const uint16_t* w_bf16x3;
@@ -154,7 +154,8 @@ int hnd_conv2d_igemm_tile(const hnd_conv_desc* desc);      /* (13 = the opt-in b
 /* The three-plane bf16 image of a packed weight operand for hnd_conv_desc.w_bf16x3: w_packed [groups][rows_pad][kdim]
  * fp32 (hnd_pack_weights / hnd_wino*_weights; group g at w_packed + g * group_stride floats) -> img: per (group, 64-row
  * slice) [3 planes hi / mid / lo][64 rows][kdim] bf16, 16-byte chunk c of row r stored at position c ^ (r & 15) (the
- * kernel's conflict-free LDS image, copied linearly).  x == hi + mid + lo exactly (truncation split).
+ * kernel's conflict-free LDS image, copied linearly).  x == hi + mid + lo exactly (truncation split).  kdim 128 / 256, or 512
+ * as two k parts of 256 (part p at p * groups * (rows_pad / 64) slices; the launch then runs two passes).
  * hnd_pack_bf16x3_elems: uint16 elements of img. */
 size_t hnd_pack_bf16x3_elems(int rows_pad, int kdim, int groups);
 int hnd_pack_bf16x3(const float* w_packed, uint16_t* img, int rows_pad, int kdim, int groups, int64_t group_stride,

@@ -32,6 +32,8 @@ def _nhwc(t):
     (256, 512, 8, 192, 256, 2, True),        # layer2.0.downsample: stride 2
     (128, 64, 16, 96, 128, 1, False),        # K = 128, one 64-column slice
     (256, 1024, 8, 64, 64, 1, True),         # 16 slices per team
+    (512, 256, 8, 96, 128, 1, True),         # K = 512: two passes over k, the second adds the first one's partial result
+    (512, 1024, 8, 96, 128, 2, True),        # layer3.0.downsample: K = 512, stride 2
 ])
 def test_bx3_1x1_conv_against_fp64_beside_the_native_kernel(ops, cin, cout, n, h, w, stride, epi):
     g = torch.Generator().manual_seed(5 + cin + cout)
@@ -104,7 +106,34 @@ def test_bx3_bottleneck_conv3_with_residual_relu_and_mask_nibbles(ops, cin, cout
                     % (cin, cout, e1, e0))
 
 
-@pytest.mark.parametrize('c,n,h,w', [(256, 8, 96, 132), (128, 8, 102, 168)])
+def test_bx3_fpn_lateral_with_the_upsampled_top_down_map(ops):
+    """FeaturePyramidNetwork inner block (torchvision 0.4.2 ops/feature_pyramid_network.py via
+    /root/reference/src/models/org/rcnn.py:399-414): 1x1 conv + bias + F.interpolate(coarser, size=..., mode='nearest')"""
+    g = torch.Generator().manual_seed(31)
+    n, cin, cout, h, w = 8, 256, 256, 96, 128
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5
+    bias = torch.randn(cout, generator=g)
+    top = torch.randn(n, cout, h // 2, w // 2, generator=g)
+    ref = (F.conv2d(x.double(), wt.double(), bias.double()) + F.interpolate(top.double(), size=(h, w), mode='nearest')).permute(0, 2, 3, 1)
+    xd, td, pk = _nhwc(x), _nhwc(top), ops.pack_weights(wt.to(DEV).contiguous())
+    errs = {}
+    for emu in (False, True):
+        if emu:
+            pk.bx3 = ops.bx3_image(pk.buf, cout, cin, force=True)
+        y = torch.full((n, h, w, cout), float('nan'), device=DEV)
+        l = ops.conv_forward(xd, pk, y, 1, 1, 0, epi_shift=bias.to(DEV), res1=td, res1_up=True)
+        assert (l.variant == 'bx3_64') == emu, l.variant
+        l.run()
+        ops.sync_check()
+        errs[emu] = float((y.cpu().double() - ref).norm() / ref.norm())
+    assert errs[True] < 1e-6 and errs[True] <= 1.5 * errs[False] + 1e-8, errs
+    from tests.conftest import record_achieved
+    record_achieved('[bf16x3 emulation, FPN lateral 256 -> 256 + upsampled top-down map] rel-L2 vs fp64 %.2e (native %.2e)'
+                    % (errs[True], errs[False]))
+
+
+@pytest.mark.parametrize('c,n,h,w', [(256, 8, 96, 132), (128, 8, 102, 168), (512, 16, 48, 66)])
 def test_bx3_winograd_component_gemms_match_the_native_path(ops, c, n, h, w):
     """a frozen 3x3 conv through F(6x6,3x3): the 64 component GEMMs on the emulation vs on the native kernel; both held to
     the direct fp64 convolution"""
