@@ -70,6 +70,17 @@ __device__ __forceinline__ void rwait(f32x4& a0, f32x4& a1, f32x4& a2, f32x4& a3
                : "n"(CNT));
 }
 
+__device__ __forceinline__ void bload(uint32_t& dst, const uint8_t* p) {
+  asm volatile("global_load_ubyte %0, %1, off" : "=a"(dst) : "v"(p));
+}
+template <int CNT>
+__device__ __forceinline__ void bwait8(uint32_t& a0, uint32_t& a1, uint32_t& a2, uint32_t& a3, uint32_t& a4, uint32_t& a5,
+                                       uint32_t& a6, uint32_t& a7) {
+  asm volatile("s_waitcnt vmcnt(%8)"
+               : "+a"(a0), "+a"(a1), "+a"(a2), "+a"(a3), "+a"(a4), "+a"(a5), "+a"(a6), "+a"(a7)
+               : "n"(CNT));
+}
+
 // STORES: global stores per tile (16 rows, + 16 mask bytes with mask_out)
 template <int CNT>
 __device__ __forceinline__ void rwait8(f32x4& a0, f32x4& a1, f32x4& a2, f32x4& a3, f32x4& a4, f32x4& a5, f32x4& a6,
@@ -96,8 +107,12 @@ __device__ __forceinline__ void split_pair(float x0, float x1, uint32_t& hp, uin
 // values): 16 more byte stores per tile in the same stream.
 // In-order bookkeeping of a wait at k step ks for slot ks + 1 (requested at step ks + 1 - RING): younger operations are the
 // (RING - 1) x 8 refills since, + the previous tile's STORES when the tile boundary lies in between (ks <= RING - 2), + the 16 residual loads when their issue point does (KS - 4 <= ks <= KS - 4 + RING - 2).
-template <int KS, bool RES, bool MO>
+// MK (with RES): mask_bits -- the ReLU-backward mask as nibbles, one byte per row and lane; 16 byte loads per tile issued
+// right BEFORE the residual loads (so the residual's wait covers them), applied before the store.
+template <int KS, bool RES, bool MO, bool MK = false>
 __global__ void __launch_bounds__(256, 1) bx3_kernel(const hnd_conv_desc d, const Bx3Args a) {
+  static_assert(!MK || RES, "the mask build rides on the residual build's bookkeeping");
+  constexpr int RESLOADS = RES ? (MK ? 32 : 16) : 0;
   // (RES: ring 128 + accumulators 64 + residual rows 64 = all 256 accumulator registers, and hipcc then parks just-requested
   // ring registers elsewhere before their wait; the residual builds run a ring of 2 -- their A operand was written by the
   // previous launch and comes from the memory-side cache)
@@ -190,6 +205,7 @@ __global__ void __launch_bounds__(256, 1) bx3_kernel(const hnd_conv_desc d, cons
         }
       f32x4 acc[MI][NI];
       f32x4 resv[MI][4];                        // RES: the tile's residual rows (row 4 g4 + r of row group mi)
+      uint32_t resm[MI][4];                     // MK: ... and their mask bytes
       for (; cc < seg_hi; cc += 4) {
         const int cn = cc + 4 < seg_hi ? cc + 4 : cc;       // the wave's next chunk (itself at the end: harmless)
         const float* nptr[MI];
@@ -198,25 +214,31 @@ __global__ void __launch_bounds__(256, 1) bx3_kernel(const hnd_conv_desc d, cons
         xfor<KS>([&](auto G) __attribute__((always_inline)) {
           constexpr int ks = decltype(G)::value, slot = ks % RING, par = ks & 1;
           constexpr int slot1 = (ks + 1) % RING;            // the step whose planes are made during this one
+          if constexpr (MK && ks == KS - 4) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                bload(resm[mi][r], d.mask_bits + (((size_t)(cc * 64 + mi * 16 + g4 * 4 + r) * (size_t)d.ldc + col0) >> 2));
+          }
           if constexpr (RES && ks == KS - 4) {
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) {
               const unsigned m0 = (unsigned)(cc * 64 + mi * 16 + g4 * 4);      // four consecutive output pixels
-              if (!a.res_up) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) rload<0>(resv[mi][r], d.res1 + (size_t)(m0 + r) * (size_t)d.ldc + col0);
-              } else {
-                // nearest 2x upsampling (yh = 2 res1_h, yw = 2 res1_w, ow % 4 == 0: the four pixels share a row and start at
-                // an even column): pixel (n, y, x) reads (n, y / 2, x / 2)
-                const unsigned t = hnd::fdiv(m0, a.div_ow), ow_ = m0 - t * (unsigned)d.ow;
-                const unsigned n_ = hnd::fdiv(t, a.div_oh), oh_ = t - n_ * (unsigned)d.oh;
-                const size_t p0 = ((size_t)n_ * d.res1_h + (oh_ >> 1)) * (size_t)d.res1_w + (ow_ >> 1);
-                const float* rp = d.res1 + p0 * (size_t)d.ldc + col0;
-                rload<0>(resv[mi][0], rp);
-                rload<0>(resv[mi][1], rp);
-                rload<0>(resv[mi][2], rp + d.ldc);
-                rload<0>(resv[mi][3], rp + d.ldc);
-              }
+              // dense: pixel m0 + r.  Nearest 2x upsampling (yh = 2 res1_h, yw = 2 res1_w, ow % 4 == 0: the four pixels share
+              // a row and start at an even column): pixel (n, y, x) reads (n, y / 2, x / 2).  Both addresses are computed
+              // and one is SELECTED, so that the asm loads sit in one straight block whatever the mode (an if / else here
+              // comes out as two correlated branches, which tools/audit_bres_asm.py cannot follow)
+              const unsigned t = hnd::fdiv(m0, a.div_ow), ow_ = m0 - t * (unsigned)d.ow;
+              const unsigned n_ = hnd::fdiv(t, a.div_oh), oh_ = t - n_ * (unsigned)d.oh;
+              const size_t pu = ((size_t)n_ * d.res1_h + (oh_ >> 1)) * (size_t)d.res1_w + (ow_ >> 1);
+              const bool up = a.res_up != 0;
+              const size_t p0 = up ? pu : (size_t)m0, p1 = up ? pu : (size_t)m0 + 1, p2 = up ? pu + 1 : (size_t)m0 + 2,
+                           p3 = up ? pu + 1 : (size_t)m0 + 3;
+              rload<0>(resv[mi][0], d.res1 + p0 * (size_t)d.ldc + col0);
+              rload<0>(resv[mi][1], d.res1 + p1 * (size_t)d.ldc + col0);
+              rload<0>(resv[mi][2], d.res1 + p2 * (size_t)d.ldc + col0);
+              rload<0>(resv[mi][3], d.res1 + p3 * (size_t)d.ldc + col0);
             }
           }
           // slot `slot` was split during the previous step: refill it for the step RING ahead (this tile or the next)
@@ -233,7 +255,7 @@ __global__ void __launch_bounds__(256, 1) bx3_kernel(const hnd_conv_desc d, cons
           // The next step's slot was requested RING - 1 steps ago: 8 (RING - 1) younger ring loads may be in flight, plus
           // the previous tile's STORES stores (the segment's first tile: as many throw-away loads) while they are younger
           // than it (k steps 0 .. RING - 2).  Exact counts: full tiles only (the launcher requires M % 64 == 0).
-          constexpr int kResYounger = (RES && ks >= KS - 4 && ks <= KS - 4 + RING - 2) ? 16 : 0;
+          constexpr int kResYounger = (RES && ks >= KS - 4 && ks <= KS - 4 + RING - 2) ? RESLOADS : 0;
           if constexpr (ks < RING - 1) {
             // (the counter holds 6 bits: a larger allowance is clipped to 63 -- a stronger, still correct wait)
             rwait<(8 * (RING - 1) + STORES + kResYounger < 63 ? 8 * (RING - 1) + STORES + kResYounger : 63)>(
@@ -296,6 +318,10 @@ __global__ void __launch_bounds__(256, 1) bx3_kernel(const hnd_conv_desc d, cons
         if constexpr (RES) {
           rwait8<32>(resv[0][0], resv[0][1], resv[0][2], resv[0][3], resv[1][0], resv[1][1], resv[1][2], resv[1][3]);
           rwait8<32>(resv[2][0], resv[2][1], resv[2][2], resv[2][3], resv[3][0], resv[3][1], resv[3][2], resv[3][3]);
+          if constexpr (MK) {                        // (older than the residual rows: landed with them)
+            bwait8<32>(resm[0][0], resm[0][1], resm[0][2], resm[0][3], resm[1][0], resm[1][1], resm[1][2], resm[1][3]);
+            bwait8<32>(resm[2][0], resm[2][1], resm[2][2], resm[2][3], resm[3][0], resm[3][1], resm[3][2], resm[3][3]);
+          }
         }
         // the tile's 16 row stores: C/D layout row = 4 g4 + reg of a 16-row group, column = l16 -> channels col0 .. col0 + 3;
         // dense output (the launcher requires it): output pixel = GEMM row
@@ -309,6 +335,7 @@ __global__ void __launch_bounds__(256, 1) bx3_kernel(const hnd_conv_desc d, cons
             for (int ni = 0; ni < NI; ++ni) {
               float x = acc[mi][ni][r] * es[ni] + eb[ni];
               if (RES) x += resv[mi][r][ni];
+              if (MK) x = ((resm[mi][r] >> ni) & 1u) ? x : 0.f;
               v[ni] = d.relu ? fmaxf(x, 0.f) : x;
             }
             const size_t yo = m * (size_t)d.ldc + col0;
@@ -363,10 +390,10 @@ int cu_count_bx3() {
   return v;
 }
 
-template <int KS, bool RES, bool MO>
+template <int KS, bool RES, bool MO, bool MK = false>
 int launch_bx3_t(const hnd_conv_desc& d, const Bx3Args& a, int grid, hipStream_t stream) {
   static std::atomic<unsigned long long> attr_set{0};
-  auto kern = bx3_kernel<KS, RES, MO>;
+  auto kern = bx3_kernel<KS, RES, MO, MK>;
   const size_t lds = (size_t)3 * 64 * 32 * KS * sizeof(uint16_t);
   int dev = 0;
   (void)hipGetDevice(&dev);
@@ -387,15 +414,15 @@ int launch_bx3_t(const hnd_conv_desc& d, const Bx3Args& a, int grid, hipStream_t
 
 namespace hnd {
 
-// Taken (only with a weight image attached): tap-free K = 128 / 256 (512 without a residual: two passes), cout a power-of-two multiple of 64, whole 64-row
+// Taken (only with a weight image attached): tap-free K = 128 / 256 / 512 (512: two passes over k), cout a power-of-two multiple of 64, whole 64-row
 // chunks, a dense output (output pixel = GEMM row), and an epilogue of scale / shift, a residual (same geometry, or the FPN's
-// 2x nearest-upsampled coarser map), ReLU and the ReLU-mask nibbles.
+// 2x nearest-upsampled coarser map), the ReLU-backward mask as nibbles (with a residual), ReLU and the ReLU-mask nibbles.
 bool bx3_applies(const hnd_conv_desc& d) {
   if (!d.w_bf16x3) return false;
   if (d.kh != 1 || d.kw != 1 || d.bh != 0 || d.bw != 0 || d.cin != d.kdim) return false;
   if (d.kdim != 128 && d.kdim != 256 && d.kdim != 512) return false;
-  if (d.kdim == 512 && d.res1) return false;            // (two passes over k: the second one's residual is the first's result)
-  if (d.stats || d.pro_scale || d.res2 || d.mask || d.mask_bits || d.bwd_x) return false;
+  if (d.stats || d.pro_scale || d.res2 || d.mask || d.bwd_x) return false;
+  if (d.mask_bits && (!d.res1 || d.res1_mode != 0 || d.mask_out)) return false;      // (the mask build needs the residual build)
   if (d.res1 && ((uintptr_t)d.res1 % 16) != 0) return false;
   // a residual of y's geometry, or the exactly 2x coarser map of the FPN's top-down path
   if (d.res1 && d.res1_mode == 1 && (d.yh != 2 * d.res1_h || d.yw != 2 * d.res1_w || d.ow % 4 != 0)) return false;
@@ -420,6 +447,9 @@ static int launch_bx3_one(const hnd_conv_desc& d, int kpart, hipStream_t stream)
   a.cpg = d.w_group_rows / 64;
   a.res_up = d.res1 && d.res1_mode == 1;
   const int grid = (cu_count_bx3() / 8) * 8;
+  if (d.mask_bits)      // (with a residual of y's geometry and no mask_out: bx3_applies)
+    return kpart == 128 ? launch_bx3_t<4, true, false, true>(d, a, grid, stream)
+                        : launch_bx3_t<8, true, false, true>(d, a, grid, stream);
   const int sel = (kpart == 128 ? 0 : 4) | (d.res1 ? 2 : 0) | (d.mask_out ? 1 : 0);
   switch (sel) {
     case 0: return launch_bx3_t<4, false, false>(d, a, grid, stream);
@@ -439,18 +469,20 @@ int launch_bx3(const hnd_conv_desc& d, hipStream_t stream) {
     return HND_ERR_INVALID;
   }
   if (d.kdim != 512) return launch_bx3_one(d, d.kdim, stream);
-  // K = 512: the resident slice of three planes holds 256 k.  Pass 1: k 0 .. 255, y = acc1 * scale (no shift, no ReLU, no
-  // mask); pass 2: k 256 .. 511 with res1 = y: y = acc2 * scale + shift + y -> ReLU / mask nibbles.  The kernel takes the
-  // row stride of x from cin and the depth from its template, so the second pass is the same launch 256 floats further on.
+  // K = 512: the resident slice of three planes holds 256 k.  Pass 1: k 0 .. 255, y = acc1 * scale + shift (+ the launch's
+  // own residual; no ReLU, no mask); pass 2: k 256 .. 511 with res1 = y: y = acc2 * scale + y -> ReLU / mask nibbles.  The
+  // kernel takes the row stride of x from cin and the depth from its template, so the second pass is the same launch 256
+  // floats further on.
   const long long groups = d.w_group_rows > 0 ? ((long long)d.n * d.oh * d.ow) / d.w_group_rows : 1;
   hnd_conv_desc p1 = d, p2 = d;
-  p1.epi_shift = nullptr;
   p1.relu = 0;
   p1.mask_out = nullptr;
+  p1.mask_bits = nullptr;
   const int rc = launch_bx3_one(p1, 256, stream);
   if (rc) return rc;
   p2.x = d.x + 256;
   p2.w_bf16x3 = d.w_bf16x3 + (size_t)groups * (size_t)(d.cout / 64) * (size_t)3 * 64 * 256;
+  p2.epi_shift = nullptr;
   p2.res1 = d.y;
   p2.res1_mode = 0;
   return launch_bx3_one(p2, 256, stream);

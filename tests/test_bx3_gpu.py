@@ -71,7 +71,7 @@ def test_bx3_1x1_conv_against_fp64_beside_the_native_kernel(ops, cin, cout, n, h
                     % (cin, cout, h, w, stride, e1, e0))
 
 
-@pytest.mark.parametrize('cin,cout,n,h,w', [(128, 512, 8, 96, 128), (256, 1024, 8, 64, 96)])
+@pytest.mark.parametrize('cin,cout,n,h,w', [(128, 512, 8, 96, 128), (256, 1024, 8, 64, 96), (512, 2048, 16, 32, 48)])
 def test_bx3_bottleneck_conv3_with_residual_relu_and_mask_nibbles(ops, cin, cout, n, h, w):
     """conv3 of a frozen Bottleneck: FrozenBN scale / shift, + identity, ReLU, and the ReLU-mask nibbles of the stored values
     (hnd_conv_desc.mask_out) -- the residual rows travel as asm loads in the ring's in-order stream"""
@@ -104,6 +104,37 @@ def test_bx3_bottleneck_conv3_with_residual_relu_and_mask_nibbles(ops, cin, cout
     from tests.conftest import record_achieved
     record_achieved('[bf16x3 emulation, conv3 %d -> %d + residual + ReLU + mask nibbles] rel-L2 vs fp64 %.2e (native %.2e)'
                     % (cin, cout, e1, e0))
+
+
+@pytest.mark.parametrize('cin,cout,n,h,w', [(128, 512, 8, 96, 128), (256, 1024, 8, 64, 96), (512, 2048, 16, 32, 48)])
+def test_bx3_masked_data_gradient_with_residual(ops, cin, cout, n, h, w):
+    """conv1's data gradient in a frozen Bottleneck: W1^T g_a1 (FrozenBN scale folded into the weights) + the gradient of
+    the identity path, masked by the block input's ReLU given as nibbles (hnd_conv_desc.mask_bits)"""
+    g = torch.Generator().manual_seed(13 + cin)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5
+    res = torch.randn(n, cout, h, w, generator=g)
+    act = torch.randn(n, cout, h, w, generator=g)                       # the activation whose sign is the mask
+    ref = torch.where(act.double() > 0, F.conv2d(x.double(), wt.double()) + res.double(),
+                      torch.zeros((), dtype=torch.float64)).permute(0, 2, 3, 1)
+    xd, rd, ad, pk = _nhwc(x), _nhwc(res), _nhwc(act), ops.pack_weights(wt.to(DEV).contiguous())
+    av = ad.view(n, h, w, cout // 4, 4)
+    bits = ((av[..., 0] > 0).to(torch.uint8) | ((av[..., 1] > 0).to(torch.uint8) << 1) | ((av[..., 2] > 0).to(torch.uint8) << 2)
+            | ((av[..., 3] > 0).to(torch.uint8) << 3)).contiguous()
+    errs = {}
+    for emu in (False, True):
+        if emu:
+            pk.bx3 = ops.bx3_image(pk.buf, cout, cin, force=True)
+        y = torch.full((n, h, w, cout), float('nan'), device=DEV)
+        l = ops.conv_forward(xd, pk, y, 1, 1, 0, res1=rd, mask_bits=bits)
+        assert (l.variant == 'bx3_64') == emu, l.variant
+        l.run()
+        ops.sync_check()
+        errs[emu] = float((y.cpu().double() - ref).norm() / ref.norm())
+    assert errs[True] < 1e-6 and errs[True] <= 1.5 * errs[False] + 1e-8, errs
+    from tests.conftest import record_achieved
+    record_achieved('[bf16x3 emulation, masked data gradient %d -> %d + residual, mask nibbles] rel-L2 vs fp64 %.2e (native %.2e)'
+                    % (cin, cout, errs[True], errs[False]))
 
 
 def test_bx3_fpn_lateral_with_the_upsampled_top_down_map(ops):

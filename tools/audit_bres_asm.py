@@ -38,7 +38,7 @@ def regs_of(text):
 def audit(path):
     kernels, cur, name = {}, None, None
     for line in open(path):
-        m = re.match(r'^(_ZN\S*(?:bres2|bstream|wgrad_ring|bx3)_kernel\S*):', line)
+        m = re.match(r'^(_ZN\S*(?:bres2|bstream|wgrad_ring|(?<!pack_)bx3)_kernel\S*):', line)
         if m:
             name, cur = m.group(1), []
             kernels[name] = cur
@@ -82,8 +82,9 @@ def audit(path):
                             _, dst = order.pop(0)
                             for r in dst:
                                 pending.pop(r, None)
-                    elif in_asm and exact and re.match(r'global_(load_dword|store_)\S*\s', text) and not text.startswith('global_load_dwordx4'):
-                        # an asm store: a place in the queue; a throw-away 4-byte load: its register is pending as well
+                    elif in_asm and exact and re.match(r'global_(load_dword|load_ubyte|store_)\S*\s', text) and not text.startswith('global_load_dwordx4'):
+                        # an asm store: a place in the queue; a throw-away 4-byte load or a mask-byte load: its register is
+                        # pending as well
                         dst = regs_of(text.split(',')[0]) if text.startswith('global_load') else set()
                         for r in dst:
                             pending[r] = no
@@ -110,6 +111,12 @@ def audit(path):
                         b = re.match(r's_branch\s+(\.LBB\S+)', text)
                         if b:
                             return [(label_at[b.group(1)], (pending, order))] if b.group(1) in label_at else []
+                        # `s_cbranch_execnz L; s_branch M` is how hipcc closes the arm of a wave-uniform if / else: the
+                        # fall-through would need EXEC == 0, and a wave that runs this code has live lanes (the kernels have no
+                        # lane-divergent control flow: a wave is inside `if (cc < seg_hi)` with all of its lanes or not at all)
+                        b = re.match(r's_cbranch_execnz\s+(\.LBB\S+)', text)
+                        if b and b.group(1) in label_at:
+                            return [(label_at[b.group(1)], (pending, order))]
                         b = re.match(r's_cbranch_\w+\s+(\.LBB\S+)', text)
                         if b and b.group(1) in label_at:
                             return [(label_at[b.group(1)], (dict(pending), list(order))), (idx + 1, (pending, order))]
