@@ -39,7 +39,10 @@ typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 struct Bx3Args {
   FastDiv div_ow, div_oh;     // m -> (n, oh, ow) of the A rows
   int nsl;                    // 64-column weight slices = workgroups per team
-  int nchunks;                // M / 64
+  int nchunks;                // ceil(M / 64)
+  int mrows;                  // M.  Rows past it (the last chunk's tail) are CLAMPED to row M - 1 in every address -- A rows,
+                              // residual rows, mask bytes, stores -- so the tail lanes recompute and rewrite row M - 1 with
+                              // identical bits and every tile runs the same number of memory operations (exact waits)
   int cpg;                    // chunks per weight group (Winograd component), 0 = one group
   int res_up;                 // RES: res1 is the exactly 2x coarser map, nearest-upsampled (the FPN's top-down path)
 };
@@ -130,7 +133,7 @@ __global__ void __launch_bounds__(256, 1) bx3_kernel(const hnd_conv_desc d, cons
 
   // A row m -> its first element (1x1 taps, no padding: always in range); 8 consecutive k per lane and k step
   auto a_ptr = [&](int cc, int mi) -> const float* {
-    const unsigned m = (unsigned)(cc * 64 + mi * 16 + l16);
+    const unsigned m = min((unsigned)(cc * 64 + mi * 16 + l16), (unsigned)(a.mrows - 1));
     const unsigned t = hnd::fdiv(m, a.div_ow), ow_ = m - t * (unsigned)d.ow;
     const unsigned n_ = hnd::fdiv(t, a.div_oh), oh_ = t - n_ * (unsigned)d.oh;
     const size_t pix = ((size_t)n_ * d.h + oh_ * (unsigned)d.sh) * (size_t)d.w_ + ow_ * (unsigned)d.sw;
@@ -219,12 +222,13 @@ __global__ void __launch_bounds__(256, 1) bx3_kernel(const hnd_conv_desc d, cons
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
               for (int r = 0; r < 4; ++r)
-                bload(resm[mi][r], d.mask_bits + (((size_t)(cc * 64 + mi * 16 + g4 * 4 + r) * (size_t)d.ldc + col0) >> 2));
+                bload(resm[mi][r], d.mask_bits + (((size_t)min(cc * 64 + mi * 16 + g4 * 4 + r, a.mrows - 1) * (size_t)d.ldc + col0) >> 2));
           }
           if constexpr (RES && ks == KS - 4) {
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) {
-              const unsigned m0 = (unsigned)(cc * 64 + mi * 16 + g4 * 4);      // four consecutive output pixels
+              const unsigned mr = (unsigned)(cc * 64 + mi * 16 + g4 * 4);      // four consecutive output pixels
+              const unsigned m0 = min(mr, (unsigned)(a.mrows - 4));          // (upsampled: M % 4 == 0, whole groups clamp)
               // dense: pixel m0 + r.  Nearest 2x upsampling (yh = 2 res1_h, yw = 2 res1_w, ow % 4 == 0: the four pixels share
               // a row and start at an even column): pixel (n, y, x) reads (n, y / 2, x / 2).  Both addresses are computed
               // and one is SELECTED, so that the asm loads sit in one straight block whatever the mode (an if / else here
@@ -233,8 +237,9 @@ __global__ void __launch_bounds__(256, 1) bx3_kernel(const hnd_conv_desc d, cons
               const unsigned n_ = hnd::fdiv(t, a.div_oh), oh_ = t - n_ * (unsigned)d.oh;
               const size_t pu = ((size_t)n_ * d.res1_h + (oh_ >> 1)) * (size_t)d.res1_w + (ow_ >> 1);
               const bool up = a.res_up != 0;
-              const size_t p0 = up ? pu : (size_t)m0, p1 = up ? pu : (size_t)m0 + 1, p2 = up ? pu + 1 : (size_t)m0 + 2,
-                           p3 = up ? pu + 1 : (size_t)m0 + 3;
+              const unsigned ml = (unsigned)(a.mrows - 1);
+              const size_t p0 = up ? pu : (size_t)min(mr, ml), p1 = up ? pu : (size_t)min(mr + 1, ml),
+                           p2 = up ? pu + 1 : (size_t)min(mr + 2, ml), p3 = up ? pu + 1 : (size_t)min(mr + 3, ml);
               rload<0>(resv[mi][0], d.res1 + p0 * (size_t)d.ldc + col0);
               rload<0>(resv[mi][1], d.res1 + p1 * (size_t)d.ldc + col0);
               rload<0>(resv[mi][2], d.res1 + p2 * (size_t)d.ldc + col0);
@@ -329,7 +334,7 @@ __global__ void __launch_bounds__(256, 1) bx3_kernel(const hnd_conv_desc d, cons
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const size_t m = (size_t)(cc * 64 + mi * 16 + g4 * 4 + r);
+            const size_t m = (size_t)min(cc * 64 + mi * 16 + g4 * 4 + r, a.mrows - 1);
             f32x4 v;
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
@@ -420,9 +425,11 @@ namespace hnd {
 bool bx3_applies(const hnd_conv_desc& d) {
   if (!d.w_bf16x3) return false;
   if (d.kh != 1 || d.kw != 1 || d.bh != 0 || d.bw != 0 || d.cin != d.kdim) return false;
-  if (d.kdim != 128 && d.kdim != 256 && d.kdim != 512) return false;
+  if (d.kdim != 128 && (d.kdim % 256 != 0 || d.kdim > 2048)) return false;
   if (d.stats || d.pro_scale || d.res2 || d.mask || d.bwd_x) return false;
-  if (d.mask_bits && (!d.res1 || d.res1_mode != 0 || d.mask_out)) return false;      // (the mask build needs the residual build)
+  if (d.mask_bits && d.mask_out) return false;
+  // (the mask build rides on the residual build: the launch's own same-geometry residual, or the partial result of K > 256)
+  if (d.mask_bits && d.kdim <= 256 && (!d.res1 || d.res1_mode != 0)) return false;
   if (d.res1 && ((uintptr_t)d.res1 % 16) != 0) return false;
   // a residual of y's geometry, or the exactly 2x coarser map of the FPN's top-down path
   if (d.res1 && d.res1_mode == 1 && (d.yh != 2 * d.res1_h || d.yw != 2 * d.res1_w || d.ow % 4 != 0)) return false;
@@ -432,9 +439,12 @@ bool bx3_applies(const hnd_conv_desc& d) {
   if (d.y_sh != 1 || d.y_sw != 1 || d.y_oh != 0 || d.y_ow != 0 || d.yh != d.oh || d.yw != d.ow) return false;
   if ((long long)(d.oh - 1) * d.sh >= d.h || (long long)(d.ow - 1) * d.sw >= d.w_) return false;
   const long long M = (long long)d.n * d.oh * d.ow;
-  if (M % 64 != 0 || d.w_group_rows % 64 != 0) return false;
+  if (M < 64 || d.w_group_rows % 64 != 0) return false;
+  if (M % 64 != 0 && (d.w_group_rows != 0 || M % 4 != 0)) return false;      // (a tail: one weight group, whole 4-pixel groups)
   const long long nteams = 8ll * (per_xcd / nsl);
-  if ((M / 64) / nteams < 8) return false;              // every wave gets at least two chunks
+  // every wave gets at least two chunks; a launch of several passes over k (K > 256) pays the slice load and the ramp once per
+  // pass: four chunks per wave
+  if (((M + 63) / 64) / nteams < (d.kdim > 512 ? 16 : 8)) return false;
   return true;
 }
 
@@ -443,7 +453,8 @@ static int launch_bx3_one(const hnd_conv_desc& d, int kpart, hipStream_t stream)
   a.div_ow = make_fastdiv((unsigned)d.ow);
   a.div_oh = make_fastdiv((unsigned)d.oh);
   a.nsl = d.cout / 64;
-  a.nchunks = (int)(((long long)d.n * d.oh * d.ow) / 64);
+  a.mrows = (int)((long long)d.n * d.oh * d.ow);
+  a.nchunks = (a.mrows + 63) / 64;
   a.cpg = d.w_group_rows / 64;
   a.res_up = d.res1 && d.res1_mode == 1;
   const int grid = (cu_count_bx3() / 8) * 8;
@@ -468,24 +479,33 @@ int launch_bx3(const hnd_conv_desc& d, hipStream_t stream) {
     set_error("launch_bx3: descriptor not eligible");
     return HND_ERR_INVALID;
   }
-  if (d.kdim != 512) return launch_bx3_one(d, d.kdim, stream);
-  // K = 512: the resident slice of three planes holds 256 k.  Pass 1: k 0 .. 255, y = acc1 * scale + shift (+ the launch's
-  // own residual; no ReLU, no mask); pass 2: k 256 .. 511 with res1 = y: y = acc2 * scale + y -> ReLU / mask nibbles.  The
-  // kernel takes the row stride of x from cin and the depth from its template, so the second pass is the same launch 256
-  // floats further on.
+  if (d.kdim <= 256) return launch_bx3_one(d, d.kdim, stream);
+  // K = 256 P: the resident slice of three planes holds 256 k.  Pass 1: k 0 .. 255, y = acc * scale + shift (+ the launch's
+  // own residual; no ReLU, no mask); pass p: k 256 (p - 1) .. with res1 = y: y = acc * scale + y; the last pass applies the
+  // ReLU-backward mask, the ReLU and writes the mask nibbles.  The kernel takes the row stride of x from cin and the depth
+  // from its template, so a later pass is the same launch 256 floats further on.  (fp32 partial sums in y between passes:
+  // what the accumulator holds anyway)
   const long long groups = d.w_group_rows > 0 ? ((long long)d.n * d.oh * d.ow) / d.w_group_rows : 1;
-  hnd_conv_desc p1 = d, p2 = d;
-  p1.relu = 0;
-  p1.mask_out = nullptr;
-  p1.mask_bits = nullptr;
-  const int rc = launch_bx3_one(p1, 256, stream);
-  if (rc) return rc;
-  p2.x = d.x + 256;
-  p2.w_bf16x3 = d.w_bf16x3 + (size_t)groups * (size_t)(d.cout / 64) * (size_t)3 * 64 * 256;
-  p2.epi_shift = nullptr;
-  p2.res1 = d.y;
-  p2.res1_mode = 0;
-  return launch_bx3_one(p2, 256, stream);
+  const int parts = d.kdim / 256;
+  const size_t part_elems = (size_t)groups * (size_t)(d.cout / 64) * (size_t)3 * 64 * 256;
+  for (int p = 0; p < parts; ++p) {
+    hnd_conv_desc q = d;
+    if (p + 1 < parts) {
+      q.relu = 0;
+      q.mask_out = nullptr;
+      q.mask_bits = nullptr;
+    }
+    if (p > 0) {
+      q.x = d.x + (size_t)256 * p;
+      q.w_bf16x3 = d.w_bf16x3 + part_elems * (size_t)p;
+      q.epi_shift = nullptr;
+      q.res1 = d.y;
+      q.res1_mode = 0;
+    }
+    const int rc = launch_bx3_one(q, 256, stream);
+    if (rc) return rc;
+  }
+  return 0;
 }
 
 }  // namespace hnd
@@ -497,13 +517,13 @@ extern "C" size_t hnd_pack_bf16x3_elems(int rows_pad, int kdim, int groups) {
 
 extern "C" int hnd_pack_bf16x3(const float* w_packed, uint16_t* img, int rows_pad, int kdim, int groups,
                                int64_t group_stride, void* stream) {
-  HND_REQUIRE(w_packed && img && rows_pad > 0 && rows_pad % 64 == 0 && (kdim == 128 || kdim == 256 || kdim == 512) &&
+  HND_REQUIRE(w_packed && img && rows_pad > 0 && rows_pad % 64 == 0 && (kdim == 128 || (kdim % 256 == 0 && kdim <= 2048)) &&
                   groups >= 1 && (groups == 1 || group_stride >= (int64_t)rows_pad * kdim),
-              "hnd_pack_bf16x3: bad arguments (kdim must be 128, 256 or 512)");
+              "hnd_pack_bf16x3: bad arguments (kdim must be 128 or a multiple of 256 up to 2048)");
   const long long total = (long long)groups * rows_pad * kdim;
   long long blocks = (total + 255) / 256;
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(pack_bx3_kernel, dim3((unsigned)blocks), dim3(256), 0, hnd::as_stream(stream), w_packed, img, rows_pad,
-                     kdim, kdim == 512 ? 256 : kdim, groups, (long long)group_stride, total);
+                     kdim, kdim > 256 ? 256 : kdim, groups, (long long)group_stride, total);
   return hnd::check_launch("hnd_pack_bf16x3");
 }

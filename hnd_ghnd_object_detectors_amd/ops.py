@@ -55,7 +55,7 @@ BF16X3 = os.environ.get('HND_BF16X3', '0') == '1'
 def bx3_image(buf, rows_pad, kdim, groups=1, group_stride=0, out=None, force=False):
     """(re)build the bf16x3 image of a packed fp32 operand; None when the emulation is off (unless `force`: tests) or
     cannot use this operand"""
-    if not (BF16X3 or force) or kdim not in (128, 256, 512) or rows_pad % 64 != 0:
+    if not (BF16X3 or force) or (kdim != 128 and (kdim % 256 != 0 or kdim > 2048)) or rows_pad % 64 != 0:
         return None
     n = int(_L.hnd_pack_bf16x3_elems(rows_pad, kdim, groups))
     if out is None or out.numel() != n:

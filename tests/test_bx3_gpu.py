@@ -34,6 +34,10 @@ def _nhwc(t):
     (256, 1024, 8, 64, 64, 1, True),         # 16 slices per team
     (512, 256, 8, 96, 128, 1, True),         # K = 512: two passes over k, the second adds the first one's partial result
     (512, 1024, 8, 96, 128, 2, True),        # layer3.0.downsample: K = 512, stride 2
+    (1024, 256, 16, 50, 84, 1, True),        # layer3.x.conv1: four passes over k
+    (1024, 2048, 16, 50, 84, 2, True),       # layer4.0.downsample: four passes, stride 2, M = 16 800 = 262.5 chunks (a tail)
+    (256, 256, 4, 99, 84, 1, True),          # M = 33 264: the last chunk holds 48 rows
+    (128, 64, 16, 91, 93, 1, False),         # M = 135 408: 2 115 chunks + 48 rows
 ])
 def test_bx3_1x1_conv_against_fp64_beside_the_native_kernel(ops, cin, cout, n, h, w, stride, epi):
     g = torch.Generator().manual_seed(5 + cin + cout)
@@ -71,7 +75,8 @@ def test_bx3_1x1_conv_against_fp64_beside_the_native_kernel(ops, cin, cout, n, h
                     % (cin, cout, h, w, stride, e1, e0))
 
 
-@pytest.mark.parametrize('cin,cout,n,h,w', [(128, 512, 8, 96, 128), (256, 1024, 8, 64, 96), (512, 2048, 16, 32, 48)])
+@pytest.mark.parametrize('cin,cout,n,h,w', [(128, 512, 8, 96, 128), (256, 1024, 8, 64, 96), (512, 2048, 16, 32, 48),
+                                            (512, 2048, 16, 25, 42)])          # layer4: M = 16 800, a 32-row tail
 def test_bx3_bottleneck_conv3_with_residual_relu_and_mask_nibbles(ops, cin, cout, n, h, w):
     """conv3 of a frozen Bottleneck: FrozenBN scale / shift, + identity, ReLU, and the ReLU-mask nibbles of the stored values
     (hnd_conv_desc.mask_out) -- the residual rows travel as asm loads in the ring's in-order stream"""
@@ -106,7 +111,8 @@ def test_bx3_bottleneck_conv3_with_residual_relu_and_mask_nibbles(ops, cin, cout
                     % (cin, cout, e1, e0))
 
 
-@pytest.mark.parametrize('cin,cout,n,h,w', [(128, 512, 8, 96, 128), (256, 1024, 8, 64, 96), (512, 2048, 16, 32, 48)])
+@pytest.mark.parametrize('cin,cout,n,h,w', [(128, 512, 8, 96, 128), (256, 1024, 8, 64, 96), (512, 2048, 16, 32, 48),
+                                            (512, 2048, 16, 25, 42), (1024, 256, 16, 50, 84)])
 def test_bx3_masked_data_gradient_with_residual(ops, cin, cout, n, h, w):
     """conv1's data gradient in a frozen Bottleneck: W1^T g_a1 (FrozenBN scale folded into the weights) + the gradient of
     the identity path, masked by the block input's ReLU given as nibbles (hnd_conv_desc.mask_bits)"""
