@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('HND_LIB_PATH') or os.path.join(_HERE, 'libhnd_hip.so')     # env: kernel experiments
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 c_float_p = C.POINTER(C.c_float)
 vp = C.c_void_p
@@ -101,6 +101,7 @@ _SIGNATURES = {
     'hnd_bn_finalize': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int64, vp, vp, vp, vp, vp,
                                   C.c_float, C.c_float, vp, vp, vp, vp, vp]),
     'hnd_affine_relu': (C.c_int, [vp, vp, vp, vp, C.c_int64, C.c_int, C.c_int, vp, vp]),
+    'hnd_relu_mask_nibbles': (C.c_int, [vp, vp, C.c_int64, vp]),
     'hnd_bn_bwd_ntiles': (C.c_int, [C.c_int64]),
     'hnd_bn_bwd_reduce': (C.c_int, [vp] * 6 + [C.c_int, C.c_int64, C.c_int, vp, vp]),
     'hnd_bn_bwd_finalize': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int64, vp, vp, vp, vp, vp, vp, vp]),

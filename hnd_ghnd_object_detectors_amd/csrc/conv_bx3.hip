@@ -444,7 +444,7 @@ bool bx3_applies(const hnd_conv_desc& d) {
   const long long nteams = 8ll * (per_xcd / nsl);
   // every wave gets at least two chunks; a launch of several passes over k (K > 256) pays the slice load and the ramp once per
   // pass: four chunks per wave
-  if (((M + 63) / 64) / nteams < (d.kdim > 512 ? 16 : 8)) return false;
+  if (((M + 63) / 64) / nteams < ((d.kdim > 512 && hnd::debug_picker("bx3_short_passes") <= 0) ? 16 : 8)) return false;
   return true;
 }
 

@@ -443,6 +443,24 @@ __global__ void affine_relu_kernel(const float* __restrict__ x, const float* __r
   }
 }
 
+__global__ void relu_mask_nibbles_kernel(const float* __restrict__ x, uint8_t* __restrict__ bits, long long n4) {
+  const long long chunk = 256ll * kEwU;
+  for (long long base = blockIdx.x * chunk + threadIdx.x; base < n4; base += (long long)gridDim.x * chunk) {
+    f32x4 v[kEwU];
+#pragma unroll
+    for (int u = 0; u < kEwU; ++u) {
+      const long long e = base + 256ll * u;
+      if (e < n4) v[u] = *(const f32x4*)(x + e * 4);        // (default policy: the data gradient re-reads nothing of x)
+    }
+#pragma unroll
+    for (int u = 0; u < kEwU; ++u) {
+      const long long e = base + 256ll * u;
+      if (e < n4)
+        bits[e] = (uint8_t)((v[u].x > 0.f ? 1 : 0) | (v[u].y > 0.f ? 2 : 0) | (v[u].z > 0.f ? 4 : 0) | (v[u].w > 0.f ? 8 : 0));
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------ BN backward
 constexpr int kBnTilePix = 1024;   // pixels per block in the reduce pass
 
@@ -996,6 +1014,13 @@ int hnd_affine_relu(const float* x, const float* scale, const float* shift, floa
   hipLaunchKernelGGL(affine_relu_kernel, dim3(grid_for_chunks(n4)), dim3(256), 0, hnd::as_stream(stream), x, scale,
                      shift, y, n4, cs / 4, relu, mask_out);
   return hnd::check_launch("hnd_affine_relu");
+}
+
+int hnd_relu_mask_nibbles(const float* x, uint8_t* bits, int64_t n4, void* stream) {
+  HND_REQUIRE(x && bits && n4 > 0 && ((uintptr_t)x % 16) == 0, "hnd_relu_mask_nibbles: bad arguments");
+  hipLaunchKernelGGL(relu_mask_nibbles_kernel, dim3(grid_for_chunks(n4)), dim3(256), 0, hnd::as_stream(stream), x, bits,
+                     (long long)n4);
+  return hnd::check_launch("hnd_relu_mask_nibbles");
 }
 
 int hnd_bn_bwd_ntiles(int64_t npix) { return (int)((npix + kBnTilePix - 1) / kBnTilePix); }

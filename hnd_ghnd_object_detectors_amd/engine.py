@@ -480,8 +480,8 @@ class FrozenLayerEngine(object):
             if b.wino is not None:          # (its packs are made by the plans, for the tile the geometry picks)
                 b.wino.refresh()
         self._out_buf = self.out_provider(self.out_shape(x)) if self.out_provider is not None else None
-        key = (x.data_ptr(), tuple(x.shape), keep, tuple(a[0][0].data_ptr() for a in affs),
-               None if self._out_buf is None else self._out_buf.data_ptr())
+        key = (x.data_ptr(), tuple(x.shape), keep, getattr(self, 'for_backward', True),
+               tuple(a[0][0].data_ptr() for a in affs), None if self._out_buf is None else self._out_buf.data_ptr())
         if key != self.plan_key:
             self._build_forward(x, keep, affs)
             self.plan_key = key
@@ -496,7 +496,7 @@ class FrozenLayerEngine(object):
         return self.out
 
     def _build_forward(self, x, keep, affs):
-        self.fwd, self.acts, self.out_bits = [], [], []
+        self.fwd, self.acts, self.out_bits, self.a2_bits = [], [], [], []
         n = x.shape[0]
         cur = x
         flops = 0
@@ -521,6 +521,15 @@ class FrozenLayerEngine(object):
             else:
                 self.fwd.append((ops.conv_forward(a1, b.w2.get(), a2, 3, b.stride, 1, epi_scale=a2f[0],
                                                   epi_shift=a2f[1], relu=True), tagp + '.conv2'))
+            # opt-in bf16x3 emulation only: [a2 > 0] as nibbles for conv3's data gradient -- the emulation kernel's masked build
+            # reads mask BYTES (a second fp32 row set does not fit its registers); made here, where a2 is cache-hot
+            a2b = None
+            if (keep and getattr(self, 'for_backward', True) and ops.BF16X3 and MASK_BITS
+                    and b.planes % 128 == 0):
+                a2b = self.bufs.get('a2bits_' + sfx, tuple(a2.shape[:3]) + (a2.shape[3] // 4,), torch.uint8)
+                self.fwd.append((ops._Step(lambda s, a2=a2, a2b=a2b: ops.relu_mask_nibbles(a2, a2b, s), 'relu_mask_nibbles',
+                                           a2.numel() * 4 + a2b.numel()), tagp + '.conv2.bits'))
+            self.a2_bits.append(a2b)
             if b.has_ds:
                 ds = self.bufs.get('ds_' + sfx, (n, oh, ow, b.planes * 4))
                 self.fwd.append((ops.conv_forward(cur, b.wd.get(), ds, 1, b.stride, 0, epi_scale=adf[0],
@@ -601,7 +610,9 @@ class FrozenLayerEngine(object):
             g_a2 = self.bufs.get('g_a2_%d_%d' % (oh, b.planes), a2.shape)
             g_a1 = self.bufs.get('g_a1_%d_%d' % (h, b.planes), a1.shape)
             # conv3 (1x1): g_a2 = [a2>0] * W3^T (g * s3)
-            ls, _ = ops.conv_dgrad(g, b.w3, g_a2, 1, 1, 0, mask=a2, **fold(s3))
+            a2b = self.a2_bits[i] if getattr(self, 'a2_bits', None) else None
+            mk3 = {'mask_bits': self._b(a2b)} if a2b is not None else {'mask': a2}
+            ls, _ = ops.conv_dgrad(g, b.w3, g_a2, 1, 1, 0, **mk3, **fold(s3))
             self.bwd += [(l, tagp + '.conv3.dgrad') for l in ls]
             # conv2 (3x3, stride s): g_a1 = [a1>0] * dgrad(g_a2 * s2)
             if b.wino is not None:

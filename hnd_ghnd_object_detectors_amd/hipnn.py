@@ -180,6 +180,7 @@ class ResLayer(nn.Sequential):
             return attach(E.logical(out), out)
         eng = self.engine()
         self._used_engine = eng
+        eng.for_backward = bool(self._keep)          # (a teacher layer is kept for its hooks only: no backward-only extras)
         out = eng.forward(to_nhwc(x), self._keep or hooked)
         if hooked:
             self._fire_block_hooks(eng)

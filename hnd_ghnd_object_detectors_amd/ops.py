@@ -471,6 +471,14 @@ def mask_nibbles_like(y):
     return torch.empty(tuple(y.shape[:-1]) + (y.shape[-1] // 4,), dtype=torch.uint8, device=y.device)
 
 
+def relu_mask_nibbles(x, bits, stream=None):
+    """bits = [x > 0] as nibbles (mask_nibbles_like(x)): for an activation that was stored without its mask"""
+    assert bits.dtype == torch.uint8 and bits.numel() * 4 == x.numel() and x.is_contiguous()
+    _hbm('relu_mask_nibbles', x.numel() * 4 + bits.numel(), lambda: check(
+        _L.hnd_relu_mask_nibbles(ptr(x), ptr(bits), bits.numel(), stream if stream is not None else stream_ptr()),
+        'hnd_relu_mask_nibbles'))
+
+
 def affine_relu(x, scale, shift, y, relu, mask_out=None):
     cs = x.shape[-1]
     assert mask_out is None or (mask_out.dtype == torch.uint8 and mask_out.numel() * 4 == y.numel())

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define HND_ABI_VERSION 10
+#define HND_ABI_VERSION 11
 
 typedef enum hnd_status {
   HND_OK = 0,
@@ -352,6 +352,10 @@ int hnd_bn_finalize(const float* partials, int ntiles, int c, int cs, int64_t co
 /* mask_out (or NULL): the ReLU-mask nibbles of y, see hnd_conv_desc.mask_out */
 int hnd_affine_relu(const float* x, const float* scale, const float* shift, float* y, int64_t npix, int cs,
                     int relu, uint8_t* mask_out, void* stream);
+/* bits[e] = the nibble [x[4e] > 0, x[4e+1] > 0, x[4e+2] > 0, x[4e+3] > 0] (bit 0 = the first): the mask of an activation that
+ * was stored without one, in hnd_conv_desc.mask_bits' layout (1/16 of the bytes for the data-gradient launch that applies
+ * it).  n4 = elements / 4; x 16-byte aligned.  ABI 11. */
+int hnd_relu_mask_nibbles(const float* x, uint8_t* bits, int64_t n4, void* stream);
 
 /* BatchNorm backward, pass 1: with d = g * [ (x*scale+shift) > 0 ] (mask only when relu),
  * partial sums over pixels of  d  and  d * xhat  (xhat = (x-mean)*rstd) per channel. */

@@ -143,6 +143,41 @@ def test_bx3_masked_data_gradient_with_residual(ops, cin, cout, n, h, w):
                     % (cin, cout, errs[True], errs[False]))
 
 
+@pytest.mark.parametrize('cin,cout,n,h,w', [(512, 128, 16, 100, 168), (1024, 256, 16, 50, 84)])
+def test_bx3_conv3_data_gradient_masked_by_nibbles_made_from_the_activation(ops, cin, cout, n, h, w):
+    """conv3's data gradient of a frozen Bottleneck: g_a2 = [a2 > 0] W3^T g (K = 4 x planes: passes over k, the mask in the last
+    one beside the partial result).  The nibbles come from hnd_relu_mask_nibbles(a2) (byte-exact against torch), the result
+    equals the native kernel's fp32-mask launch within the emulation's error."""
+    g = torch.Generator().manual_seed(17 + cin)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5
+    act = torch.randn(n, cout, h, w, generator=g).relu()                # a2: post-ReLU, half of it exact zeros
+    ref = torch.where(act.double() > 0, F.conv2d(x.double(), wt.double()), torch.zeros((), dtype=torch.float64)).permute(0, 2, 3, 1)
+    xd, ad, pk = _nhwc(x), _nhwc(act), ops.pack_weights(wt.to(DEV).contiguous())
+    bits = ops.mask_nibbles_like(ad)
+    ops.relu_mask_nibbles(ad, bits)
+    av = ad.view(n, h, w, cout // 4, 4) > 0
+    want_bits = (av[..., 0].to(torch.uint8) | (av[..., 1].to(torch.uint8) << 1) | (av[..., 2].to(torch.uint8) << 2)
+                 | (av[..., 3].to(torch.uint8) << 3))
+    assert torch.equal(bits, want_bits)
+    y0 = torch.full((n, h, w, cout), float('nan'), device=DEV)
+    l0 = ops.conv_forward(xd, pk, y0, 1, 1, 0, mask=ad)
+    l0.run()
+    pk.bx3 = ops.bx3_image(pk.buf, cout, cin, force=True)
+    y1 = torch.full_like(y0, float('nan'))
+    l1 = ops.conv_forward(xd, pk, y1, 1, 1, 0, mask_bits=bits)
+    assert l1.variant == 'bx3_64' and not l0.variant.startswith('bx3'), (l0.variant, l1.variant)
+    l1.run()
+    ops.sync_check()
+    e0 = float((y0.cpu().double() - ref).norm() / ref.norm())
+    e1 = float((y1.cpu().double() - ref).norm() / ref.norm())
+    assert torch.equal(y1 == 0, y0 == 0) or float(((y1 == 0) != (y0 == 0)).float().mean()) < 1e-6
+    assert e1 < 1e-6 and e1 <= 1.5 * e0 + 1e-8, (e1, e0)
+    from tests.conftest import record_achieved
+    record_achieved('[bf16x3 emulation, conv3 data gradient %d -> %d, nibbles of a2] rel-L2 vs fp64 %.2e (native, fp32 mask %.2e)'
+                    % (cin, cout, e1, e0))
+
+
 def test_bx3_fpn_lateral_with_the_upsampled_top_down_map(ops):
     """FeaturePyramidNetwork inner block (torchvision 0.4.2 ops/feature_pyramid_network.py via
     /root/reference/src/models/org/rcnn.py:399-414): 1x1 conv + bias + F.interpolate(coarser, size=..., mode='nearest')"""

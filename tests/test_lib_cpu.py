@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert sorted(_lib.EXPORTED_SYMBOLS) == declared
-    assert lib.hnd_abi_version() == _lib.ABI_VERSION == 10
+    assert lib.hnd_abi_version() == _lib.ABI_VERSION == 11
 
 
 def test_ctypes_structs_match_header_layout():
