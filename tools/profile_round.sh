@@ -18,6 +18,13 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- p
 # PMC passes: counters only with --kernel-trace (FETCH_SIZE needs 3 TCC slots, WRITE_SIZE 2: separate passes)
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o bench -- python3 bench.py --steps 1 --warmup 1 --no_cpu_baseline --resident --no_runner > $OUT/bench_fetch.json 2> $OUT/fetch.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o bench -- python3 bench.py --steps 1 --warmup 1 --no_cpu_baseline --resident --no_runner > $OUT/bench_write.json 2> $OUT/write.err
+# effective clock under each kernel family (DVFS: the chip lowers its clock under load): GRBM_GUI_ACTIVE / 8 / wall
+rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_clock -o bench -- python3 bench.py --steps 2 --warmup 1 --no_cpu_baseline --resident --no_runner > $OUT/bench_clock.json 2> $OUT/clock.err
+python3 tools/effective_clock.py $OUT/pmc_clock "native fp32 MFMA step" > $OUT/effective_clock.md 2>> $OUT/clock.err
+rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_clock_bx3 -o bench -- python3 bench.py --steps 2 --warmup 1 --no_cpu_baseline --resident --no_runner --bf16x3 > $OUT/bench_clock_bx3.json 2>> $OUT/clock.err
+python3 tools/effective_clock.py $OUT/pmc_clock_bx3 "HND_BF16X3=1 step (opt-in proposal)" >> $OUT/effective_clock.md 2>> $OUT/clock.err
+rm -f $OUT/pmc_clock/*kernel_trace.csv $OUT/pmc_clock_bx3/*kernel_trace.csv
+find $OUT/pmc_clock $OUT/pmc_clock_bx3 -name "*counter_collection.csv" -delete
 # neural filter training step, batch 16: kernel stats only
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/filter -o filter -- python3 tools/bench_filter.py --batch 16 --steps 10 --cpu_steps 0 > $OUT/bench_filter.json 2> $OUT/filter.err
 rm -f $OUT/filter/filter_kernel_trace.csv
