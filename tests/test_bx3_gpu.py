@@ -178,6 +178,70 @@ def test_bx3_conv3_data_gradient_masked_by_nibbles_made_from_the_activation(ops,
                     % (cin, cout, e1, e0))
 
 
+def test_bx3_randomised_shapes_and_epilogues_against_the_native_kernel(ops):
+    """seeded sweep over what bx3_applies admits: K in {128 ... 1024} (1 - 4 passes), 64 ... 1024 columns, row counts with and
+    without a tail, stride 1 / 2, every epilogue combination -- each beside the native kernel on the same operands (the two
+    agree to the two roundings: every element within 3e-5 of the result's rms -- achieved 7e-6), twice for reproducible bits.  Hand-counted waits
+    that were wrong for ONE combination of tail / passes / operands would show here as garbage, not as a small error."""
+    import random
+    rnd = random.Random(20261004)
+    g = torch.Generator().manual_seed(99)
+    done = 0
+    for case in range(40):
+        cin = rnd.choice([128, 256, 256, 512, 768, 1024])
+        cout = rnd.choice([64, 128, 256, 512, 1024])
+        stride = rnd.choice([1, 1, 1, 2])
+        n = rnd.choice([2, 3, 5, 8])
+        oh, ow = rnd.randrange(40, 120), 4 * rnd.randrange(12, 40)
+        m = n * oh * ow
+        nteams = 8 * (32 // (cout // 64))
+        if ((m + 63) // 64) // nteams < (16 if cin > 512 else 8) or m * max(cin, cout) * 4 > 1.5e9:
+            continue
+        h, w = (oh - 1) * stride + 1 + rnd.randrange(0, stride), (ow - 1) * stride + 1 + rnd.randrange(0, stride)
+        res = rnd.random() < 0.6
+        relu = rnd.random() < 0.5
+        mask_out = res and relu and rnd.random() < 0.5
+        mask_bits = (res or cin > 256) and not mask_out and rnd.random() < 0.4
+        epi = rnd.random() < 0.7
+        x = (torch.randn(n, h, w, cin, generator=g) * 2.0).to(DEV)
+        wt = (torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5).to(DEV)
+        kw = dict(relu=relu)
+        if epi:
+            kw.update(epi_scale=(torch.rand(cout, generator=g) + 0.5).to(DEV), epi_shift=torch.randn(cout, generator=g).to(DEV))
+        if res:
+            kw['res1'] = torch.randn(n, oh, ow, cout, generator=g).to(DEV)
+        bits_in = None
+        if mask_bits:
+            bits_in = torch.randint(0, 16, (n, oh, ow, cout // 4), generator=g, dtype=torch.uint8).to(DEV)
+            kw['mask_bits'] = bits_in
+        pk = ops.pack_weights(wt)
+        outs = []
+        for emu in (False, True, True):
+            if emu and getattr(pk, 'bx3', None) is None:
+                pk.bx3 = ops.bx3_image(pk.buf, ops.round_up(cout, 64), cin, force=True)
+            y = torch.full((n, oh, ow, cout), float('nan'), device=DEV)
+            mo = torch.full((n, oh, ow, cout // 4), 255, dtype=torch.uint8, device=DEV) if mask_out else None
+            l = ops.conv_forward(x, pk, y, 1, stride, 0, mask_out=mo, **kw)
+            assert l.variant.startswith('bx3') == emu, (case, cin, cout, m, stride, res, relu, mask_out, mask_bits, l.variant)
+            l.run()
+            outs.append((y, mo))
+        ops.sync_check()
+        (y0, m0), (y1, m1), (y2, m2) = outs
+        rms = float(y0.double().pow(2).mean().sqrt()) + 1e-30
+        err = float((y1.double() - y0.double()).abs().max()) / rms
+        assert not bool(torch.isnan(y1).any()) and err < 3e-5, (case, cin, cout, m, stride, res, relu, mask_out, mask_bits, err)
+        assert torch.equal(y1, y2) and (m1 is None or torch.equal(m1, m2))
+        if mask_out:        # the nibbles describe the values stored beside them
+            yv = y1.view(n, oh, ow, cout // 4, 4) > 0
+            want = (yv[..., 0].to(torch.uint8) | (yv[..., 1].to(torch.uint8) << 1) | (yv[..., 2].to(torch.uint8) << 2)
+                    | (yv[..., 3].to(torch.uint8) << 3))
+            assert torch.equal(m1, want)
+        done += 1
+    assert done >= 12, done
+    from tests.conftest import record_achieved
+    record_achieved('[bf16x3 emulation] %d randomised shape / epilogue cases agree with the native kernel within 3e-5 rms per element' % done)
+
+
 def test_bx3_fpn_lateral_with_the_upsampled_top_down_map(ops):
     """FeaturePyramidNetwork inner block (torchvision 0.4.2 ops/feature_pyramid_network.py via
     /root/reference/src/models/org/rcnn.py:399-414): 1x1 conv + bias + F.interpolate(coarser, size=..., mode='nearest')"""
