@@ -398,16 +398,7 @@ __global__ void __launch_bounds__(256, 1) bres2_kernel(const hnd_conv_desc d, co
           constexpr int g = decltype(G)::value, slot = g % RING;
           constexpr int kn = g + 1 < KG ? g + 1 : 0;
           const int bo = (kn & ~3) * 16 + bsw[kn & 3];
-#ifdef HND_EXP_BRES2_EXACT
-          if constexpr (g >= 1 && g < RING) {
-            if (!have_out) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (RING - 1)));
-            ring_wait<4 * (RING - 1) + 16, (slot & 1) != 0>(ring[slot][0], ring[slot][1], ring[slot][2], ring[slot][3]);
-          } else {
-            ring_wait<4 * (RING - 1), (slot & 1) != 0>(ring[slot][0], ring[slot][1], ring[slot][2], ring[slot][3]);
-          }
-#else
           ring_wait<4 * (RING - 1), (slot & 1) != 0>(ring[slot][0], ring[slot][1], ring[slot][2], ring[slot][3]);
-#endif
           static_for<MI>([&](auto MIc) __attribute__((always_inline)) {
             constexpr int mi = decltype(MIc)::value;
             f32x4 av = ring[slot][mi];
