@@ -43,7 +43,6 @@ struct BresArgs {
   int nsl;                    // weight slices = workgroups per team
   int nchunks;                // ceil(M / 64)
   int cpg;                    // chunks per weight group (Winograd component), 0 = one group
-  int dbg;                    // tuning experiments (HND_BRES_DBG): 1 = no epilogue, 2 = A always from chunk 0
 };
 
 // The workgroup's [BN x K] weight slice -> LDS (chunk c of row r at position c ^ (r & 15)).  Up to 16 loads per thread are
@@ -102,7 +101,6 @@ __global__ void __launch_bounds__(512, 1) bres_kernel(const hnd_conv_desc d, con
   // A row m -> element offset of its input pixel (1x1 taps, no padding: always in range)
   auto a_off = [&](int m) -> unsigned {
     m = m < M ? m : M - 1;
-    if (a.dbg & 2) m &= 63;
     const unsigned t = hnd::fdiv((unsigned)m, a.div_ow), ow_ = (unsigned)m - t * (unsigned)d.ow;
     const unsigned n_ = hnd::fdiv(t, a.div_oh), oh_ = t - n_ * (unsigned)d.oh;
     return ((n_ * (unsigned)d.h + oh_ * (unsigned)d.sh) * (unsigned)d.w_ + ow_ * (unsigned)d.sw) * (unsigned)d.cin +
@@ -212,7 +210,7 @@ __global__ void __launch_bounds__(512, 1) bres_kernel(const hnd_conv_desc d, con
           }
         }
         // ---- epilogue of this 64 x 64 wave tile (the next chunk's first k groups are already in flight)
-        if (!(a.dbg & 1) || acc[0][0][0] == 1234.5f) {
+        {
           const int m = cc * 64 + lane;
           int po = -1, pr = 0;
           if (m < M) {
@@ -637,7 +635,6 @@ int launch_bres(const hnd_conv_desc& d, hipStream_t stream) {
   a.nsl = d.cout / (64 * wn);
   a.nchunks = (int)((M + 63) / 64);
   a.cpg = d.w_group_rows / 64;
-  a.dbg = 0;
   const bool pro = d.pro_scale != nullptr;
   const size_t lds = ((size_t)64 * wn * d.kdim + (pro ? 2 * (size_t)d.kdim : 0) + 8 * 256) * sizeof(float);
   const int grid = (cu_count() / 8) * 8;

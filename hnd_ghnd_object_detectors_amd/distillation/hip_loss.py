@@ -105,7 +105,7 @@ class StepLoss(torch.Tensor):
         return float(self.item())
 
 
-EARLY_LOSS_COPY = os.environ.get('HND_EARLY_LOSS_COPY', '1') != '0'
+EARLY_LOSS_COPY = True      # (settled in round 4; was HND_EARLY_LOSS_COPY)
 
 
 _HOST_POOL = []         # free (pinned float32 scalar, event) pairs; a StepLoss owns one until it is garbage-collected

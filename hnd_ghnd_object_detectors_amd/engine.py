@@ -23,7 +23,7 @@ from . import ops
 
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1
 WINOGRAD = int(os.environ.get('HND_WINOGRAD', '4'))      # output tile of the Winograd 3x3 path: 4, 2, or 0 = off
-WINOGRAD_HEAD = os.environ.get('HND_WINOGRAD_HEAD', '1') != '0'     # F(4x4,2x2) for the two deep head convs
+WINOGRAD_HEAD = True     # F(4x4,2x2) / F(6x6,2x2) for the deep head convs (settled in round 2; was HND_WINOGRAD_HEAD)
 PROFILE = {'enabled': False, 'records': []}     # bench.py: per-launch HIP events on the launch stream
 # DistillationBox sets 'stream' while it runs teacher + student: their feature pyramids (whose outputs the
 # distillation criterion never reads) are then issued on that stream and overlap the backward pass
@@ -183,14 +183,14 @@ class Wino2Cache(object):
             self.ver = ver
 
 
-FOLD_DGRAD_SCALE = os.environ.get('HND_FOLD_DGRAD_SCALE', '1') != '0'     # 0: FrozenBN scale as a launch prologue
+FOLD_DGRAD_SCALE = True     # (False: FrozenBN scale as a launch prologue; settled in round 3, was HND_FOLD_DGRAD_SCALE)
 # ReLU masks of the Bottleneck outputs as nibbles (one byte per pixel and 4 channels, written by the forward epilogue that
 # stores the output) instead of re-reading the fp32 activation in the conv1 data gradients -- HBM-bound launches (out +
 # residual + mask at K = 128): 1/16 of the mask's bytes.  Same decisions (x > 0), same bits.  0: fp32 masks (A/B, tests)
-MASK_BITS = os.environ.get('HND_MASK_BITS', '1') != '0'
+MASK_BITS = True            # (settled in round 4; was HND_MASK_BITS)
 # BatchNorm backward "apply" of the two deep decoder convs fused into the two transforms that consume dy (ops.wino26_bnbwd_step)
-FUSE_BNBWD = os.environ.get('HND_FUSE_BNBWD', '1') != '0'
-WINO_WGRAD_OWN_V = os.environ.get('HND_WINO_WGRAD_OWN_V', '1') != '0'
+FUSE_BNBWD = True           # (settled in round 4; was HND_FUSE_BNBWD)
+WINO_WGRAD_OWN_V = True     # (settled in round 4; was HND_WINO_WGRAD_OWN_V)
 
 
 def process_owns_device(verbose=[True]):
@@ -238,7 +238,7 @@ def wgrad_stream_on():
 
 
 # BatchNorm backward "reduce" of a head layer folded into the output transform of the data gradient that produces its g
-FOLD_BNBWD_REDUCE = os.environ.get('HND_FOLD_BNBWD_REDUCE', '1') != '0'
+FOLD_BNBWD_REDUCE = True    # (settled in round 4; was HND_FOLD_BNBWD_REDUCE)
 WINOGRAD6 = os.environ.get('HND_WINOGRAD6', '1') != '0'       # F(6x6,3x3) on maps large enough (wino_tile_for)
 
 
@@ -270,7 +270,7 @@ def wino_tile_for(tile, n, h, w):
     return 6 if ((h + 5) // 6) * ((w + 5) // 6) >= WINOGRAD6_MIN_TILES else 4
 
 
-WINOGRAD2_6 = os.environ.get('HND_WINOGRAD2_6', '1') != '0'
+WINOGRAD2_6 = True          # (settled in round 3; was HND_WINOGRAD2_6)
 
 
 def wino2_tile_for(oh, ow):
