@@ -13,6 +13,8 @@
 // The k order is the generic kernel's (k = 4*tap + channel; MFMA s of k group kg sums channel s of taps 4kg..4kg+3)
 // and the epilogue expression is the same, so the result is bit-identical (tests/test_ops_gpu.py).  Round 4: the MFMAs of
 // the pad channel (s = 3: zero weights for a 3-channel image) are not issued -- 39 instead of 52 per row group.
+#include <type_traits>
+
 #include "common.h"
 
 #include <stdlib.h>
@@ -98,6 +100,10 @@ __global__ void __launch_bounds__(256, 2) stem7_kernel(const hnd_conv_desc d, co
     }
   };
 
+  // The tile loop exists twice, for `four` as a compile-time constant: as a run-time test it put a branch behind every 12
+  // MFMAs (4 per k group: 52 x 4 restarts of the matrix pipe per tile, round 5).
+  auto run = [&](auto FOURc) __attribute__((always_inline)) {
+  constexpr bool kFour = decltype(FOURc)::value;
   int tile = blockIdx.x;
   if (tile < ntiles) fetch(tile);
   for (; tile < ntiles; tile += gridDim.x) {
@@ -130,7 +136,7 @@ __global__ void __launch_bounds__(256, 2) stem7_kernel(const hnd_conv_desc d, co
 #pragma unroll
           for (int ni = 0; ni < 4; ++ni)
             acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi][s], bq[ni][s], acc[mi][ni], 0, 0, 0);
-        if (four) {
+        if constexpr (kFour) {
 #pragma unroll
           for (int ni = 0; ni < 4; ++ni)
             acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi][3], bq[ni][3], acc[mi][ni], 0, 0, 0);
@@ -156,6 +162,9 @@ __global__ void __launch_bounds__(256, 2) stem7_kernel(const hnd_conv_desc d, co
       }
     }
   }
+  };
+  if (four) run(std::true_type{});
+  else run(std::false_type{});
 }
 
 
@@ -172,6 +181,10 @@ constexpr int WTH = 8, WTW = 16;                     // output tile (rows x cols
 constexpr int WPH = 2 * WTH + 5, WPW = 2 * WTW + 5;  // input patch 21 x 37
 constexpr int DYLD = WTH * WTW + 4;                  // row stride of the transposed dy tile: 33 sixteen-byte slots
 
+// NTN = column tiles: 10 (three real channels, channel-major columns) or 13 -- a template parameter: as a run-time value
+// every "third owned tile" / "second shared tile" MFMA sat behind a branch of its own (16 per k group), and the matrix
+// pipe restarted after each (round 5: 0.59 of peak)
+template <int NTN>
 __global__ void __launch_bounds__(256, 3) stem7_wgrad_kernel(const hnd_wgrad_desc d, const int tiles_x, const int tiles_y,
                                                              const int ncols_pad) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -187,8 +200,8 @@ __global__ void __launch_bounds__(256, 3) stem7_wgrad_kernel(const hnd_wgrad_des
   // Work split (round 4): a wave owns all 64 output channels of the column tiles wave, wave + 4 (, wave + 8), and ONE row
   // group (16 output channels: mi == wave) of the remaining tiles 8, 9 (tile 12 with four channels) -- 10 (13) units of
   // 16 x 16 per wave and k step, where 3 + 3 + 2 + 2 whole tiles left two waves waiting at the barrier.
-  const int ntn = d.cin_real == 3 ? 10 : 13;
-  const int nown = ntn == 10 ? 2 : 3, nsh = ntn - 4 * nown;      // tiles owned whole / shared by row group
+  constexpr int ntn = NTN;
+  constexpr int nown = ntn == 10 ? 2 : 3, nsh = ntn - 4 * nown;  // tiles owned whole / shared by row group
   auto col_of = [&](int nt, int& boff_, int& ncol_) {
     const int n = nt * 16 + l16;
     int t, c;
@@ -380,7 +393,9 @@ int launch_stem7_wgrad(const hnd_wgrad_desc& d, int ncols_pad, hipStream_t strea
   (void)hipGetDevice(&dev);
   const size_t lds = ((size_t)((WPH * WPW * 4 + 3) & ~3) + 64 * DYLD) * sizeof(float);
   if (!attr_done[dev & 63]) {
-    hipError_t e = hipFuncSetAttribute((const void*)stem7_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void*)stem7_wgrad_kernel<10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)stem7_wgrad_kernel<13>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       set_error("hipFuncSetAttribute(stem7_wgrad) failed: %s", hipGetErrorString(e));
       return HND_ERR_LAUNCH;
@@ -388,8 +403,12 @@ int launch_stem7_wgrad(const hnd_wgrad_desc& d, int ncols_pad, hipStream_t strea
     attr_done[dev & 63] = true;
   }
   const int tiles_x = (d.ow + WTW - 1) / WTW, tiles_y = (d.oh + WTH - 1) / WTH;
-  hipLaunchKernelGGL(stem7_wgrad_kernel, dim3((unsigned)stem7_wgrad_blocks(d)), dim3(256), lds, stream, d, tiles_x, tiles_y,
-                     ncols_pad);
+  if (d.cin_real == 3)
+    hipLaunchKernelGGL(stem7_wgrad_kernel<10>, dim3((unsigned)stem7_wgrad_blocks(d)), dim3(256), lds, stream, d, tiles_x,
+                       tiles_y, ncols_pad);
+  else
+    hipLaunchKernelGGL(stem7_wgrad_kernel<13>, dim3((unsigned)stem7_wgrad_blocks(d)), dim3(256), lds, stream, d, tiles_x,
+                       tiles_y, ncols_pad);
   return check_launch("hnd_conv2d_wgrad(stem7)");
 }
 
