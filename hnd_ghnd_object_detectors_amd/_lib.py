@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('HND_LIB_PATH') or os.path.join(_HERE, 'libhnd_hip.so')     # env: kernel experiments
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 c_float_p = C.POINTER(C.c_float)
 vp = C.c_void_p
@@ -24,7 +24,7 @@ class ConvDesc(C.Structure):
                                          'res1_mode', 'res1_h', 'res1_w', 'w_group_rows', 'w_group_stride')] + \
                [('relay_ws', vp), ('mask_bits', vp), ('mask_out', vp)] + \
                [(k, vp) for k in ('bwd_x', 'bwd_scale', 'bwd_shift', 'bwd_mean', 'bwd_rstd')] + [('bwd_relu', C.c_int)] + \
-               [('w_bf16x3', vp)]
+               [('w_bf16x3', vp), ('w_bf16x3s', vp)]
 
 
 class ImageDesc(C.Structure):
@@ -71,8 +71,11 @@ _SIGNATURES = {
     'hnd_conv2d_wgrad': (C.c_int, [C.POINTER(WgradDesc), vp]),
     'hnd_conv2d_wgrad_variant': (C.c_int, [C.POINTER(WgradDesc)]),
     'hnd_pack_weights': (C.c_int, [vp, vp] + [C.c_int] * 12 + [vp]),
+    'hnd_bf16x3_recommended': (C.c_int, [C.c_int64, C.c_int, C.c_int]),
     'hnd_pack_bf16x3_elems': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     'hnd_pack_bf16x3': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int64, vp]),
+    'hnd_pack_bf16x3s_elems': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    'hnd_pack_bf16x3s': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int64, vp]),
     'hnd_scale_packed_k': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]),
     'hnd_pack_weights_batched': (C.c_int, [C.POINTER(PackDesc), C.c_int, vp]),
     'hnd_fbn_fold': (C.c_int, [vp] * 6 + [C.c_int, C.c_int, C.c_float, vp]),

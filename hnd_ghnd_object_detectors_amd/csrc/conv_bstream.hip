@@ -582,6 +582,13 @@ size_t bstream_workspace(const hnd_conv_desc& d) {
   return (size_t)grid * (16384 * sizeof(float) + sizeof(int)) + 16 * sizeof(int);     // sets, flags, counter + ticket
 }
 
+// the same sticky error word for the emulated B-streamed kernel (conv_bxs.hip)
+int* relay_err_host() { return relay_error_word(); }
+int* relay_err_dev() {
+  (void)relay_error_word();
+  return g_err_dev;
+}
+
 int relay_timeouts(int reset) {
   int* h = g_err_host.load(std::memory_order_acquire);
   if (!h) return 0;

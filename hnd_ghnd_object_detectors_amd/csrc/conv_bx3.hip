@@ -419,9 +419,26 @@ int launch_bx3_t(const hnd_conv_desc& d, const Bx3Args& a, int grid, hipStream_t
 
 namespace hnd {
 
-// Taken (only with a weight image attached): tap-free K = 128 / 256 / 512 (512: two passes over k), cout a power-of-two multiple of 64, whole 64-row
-// chunks, a dense output (output pixel = GEMM row), and an epilogue of scale / shift, a residual (same geometry, or the FPN's
-// 2x nearest-upsampled coarser map), the ReLU-backward mask as nibbles (with a residual), ReLU and the ReLU-mask nibbles.
+// Which launches SHOULD run on the emulation: decided from the LAYER alone -- depth, output channels and the GEMM rows ONE image
+// contributes -- never from the batch of the launch, so that image i's maps are the same bits alone and inside any batch
+// (DESIGN section 4 rule 4).  Priced at the path's design point, 16 images per GPU (BASELINE.json configs[1]): the launch
+// pays when a team of cout / 64 workgroups gets at least 8 chunks of 64 rows there (16 with several passes over k: the
+// slice load and the ramp are paid once per pass) -- profiles/r05_bf16x3_shapes.txt.
+static bool bx3_recommended(long long rows_per_image, int kdim, int cout) {
+  if (rows_per_image <= 0 || cout <= 0 || cout % 64 != 0) return false;
+  if (kdim != 128 && (kdim % 256 != 0 || kdim > 2048)) return false;
+  const int per_xcd = cu_count_bx3() / 8, nsl = cout / 64;
+  if (per_xcd < 1 || nsl > per_xcd || per_xcd % nsl != 0) return false;
+  const long long nteams = 8ll * (per_xcd / nsl);
+  const long long chunks_at_16 = (rows_per_image * 16 + 63) / 64;
+  return chunks_at_16 / nteams >= (kdim > 512 ? 16 : 8);
+}
+
+// CAN the emulation take this launch (a weight image attached = the caller asks for it; nothing here reads the row count
+// beyond "at least one chunk"): tap-free K = 128 or 256 P <= 2048 (P passes over k), cout a multiple of 64 that divides an
+// XCD's CUs, a dense output (output pixel = GEMM row; any row count -- the last chunk's tail is clamped to row M - 1), and
+// an epilogue of scale / shift, a residual (same geometry, or the FPN's 2x nearest-upsampled coarser map), the
+// ReLU-backward mask as nibbles (with a residual), ReLU and the ReLU-mask nibbles.
 bool bx3_applies(const hnd_conv_desc& d) {
   if (!d.w_bf16x3) return false;
   if (d.kh != 1 || d.kw != 1 || d.bh != 0 || d.bw != 0 || d.cin != d.kdim) return false;
@@ -431,7 +448,7 @@ bool bx3_applies(const hnd_conv_desc& d) {
   // (the mask build rides on the residual build: the launch's own same-geometry residual, or the partial result of K > 256)
   if (d.mask_bits && d.kdim <= 256 && (!d.res1 || d.res1_mode != 0)) return false;
   if (d.res1 && ((uintptr_t)d.res1 % 16) != 0) return false;
-  // a residual of y's geometry, or the exactly 2x coarser map of the FPN's top-down path
+  // a residual of y's geometry, or the exactly 2x coarser map of the FPN's top-down path (whole 4-pixel groups per row)
   if (d.res1 && d.res1_mode == 1 && (d.yh != 2 * d.res1_h || d.yw != 2 * d.res1_w || d.ow % 4 != 0)) return false;
   if (d.cout % 64 != 0 || d.ldc % 4 != 0 || ((uintptr_t)d.y % 16) != 0) return false;
   const int per_xcd = cu_count_bx3() / 8, nsl = d.cout / 64;
@@ -440,11 +457,7 @@ bool bx3_applies(const hnd_conv_desc& d) {
   if ((long long)(d.oh - 1) * d.sh >= d.h || (long long)(d.ow - 1) * d.sw >= d.w_) return false;
   const long long M = (long long)d.n * d.oh * d.ow;
   if (M < 64 || d.w_group_rows % 64 != 0) return false;
-  if (M % 64 != 0 && (d.w_group_rows != 0 || M % 4 != 0)) return false;      // (a tail: one weight group, whole 4-pixel groups)
-  const long long nteams = 8ll * (per_xcd / nsl);
-  // every wave gets at least two chunks; a launch of several passes over k (K > 256) pays the slice load and the ramp once per
-  // pass: four chunks per wave
-  if (((M + 63) / 64) / nteams < ((d.kdim > 512 && hnd::debug_picker("bx3_short_passes") <= 0) ? 16 : 8)) return false;
+  if (M % 64 != 0 && d.w_group_rows != 0) return false;      // (a tail: one weight group)
   return true;
 }
 
@@ -509,6 +522,10 @@ int launch_bx3(const hnd_conv_desc& d, hipStream_t stream) {
 }
 
 }  // namespace hnd
+
+extern "C" int hnd_bf16x3_recommended(int64_t rows_per_image, int kdim, int cout) {
+  return hnd::bx3_recommended((long long)rows_per_image, kdim, cout) ? 1 : 0;
+}
 
 extern "C" size_t hnd_pack_bf16x3_elems(int rows_pad, int kdim, int groups) {
   if (rows_pad <= 0 || rows_pad % 64 != 0 || kdim <= 0 || kdim % 8 != 0 || groups < 1) return 0;

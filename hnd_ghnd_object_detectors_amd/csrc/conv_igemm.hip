@@ -586,8 +586,11 @@ int launch_stem7(const hnd_conv_desc& d, hipStream_t stream);
 int bstream_variant(const hnd_conv_desc& d);                   // conv_bstream.hip: B-streamed persistent GEMM (long K)
 int launch_bstream(const hnd_conv_desc& d, hipStream_t stream);
 size_t bstream_workspace(const hnd_conv_desc& d);
-bool bx3_applies(const hnd_conv_desc& d);                      // conv_bx3.hip: opt-in fp32 emulation on the bf16 pipe
+bool bx3_applies(const hnd_conv_desc& d);                      // conv_bx3.hip: fp32 emulated on the bf16 pipe, B resident
 int launch_bx3(const hnd_conv_desc& d, hipStream_t stream);
+int bxs_variant(const hnd_conv_desc& d);                       // conv_bxs.hip: ... B streamed (taps, long K, any epilogue)
+int launch_bxs(const hnd_conv_desc& d, hipStream_t stream);
+size_t bxs_workspace(const hnd_conv_desc& d);
 }  // namespace hnd
 
 extern "C" int hnd_conv2d_igemm(const hnd_conv_desc* desc, void* stream) {
@@ -625,7 +628,8 @@ extern "C" int hnd_conv2d_igemm(const hnd_conv_desc* desc, void* stream) {
     return launch<128, 64, 32, true>(d, s);   // the 3->64 decoder conv (and any other 4-channel-input conv)
   }
   if (thin_n_applies(d)) return launch_thin_n(d, s);
-  if (hnd::bx3_applies(d)) return hnd::launch_bx3(d, s);        // only with hnd_conv_desc.w_bf16x3 attached (opt-in)
+  if (hnd::bx3_applies(d)) return hnd::launch_bx3(d, s);        // only with hnd_conv_desc.w_bf16x3 attached
+  if (hnd::bxs_variant(d)) return hnd::launch_bxs(d, s);        // only with hnd_conv_desc.w_bf16x3s attached
   if (hnd::bres_variant(d)) return hnd::launch_bres(d, s);
   if (hnd::bstream_variant(d)) return hnd::launch_bstream(d, s);
   switch (pick_tile(d)) {
@@ -637,7 +641,9 @@ extern "C" int hnd_conv2d_igemm(const hnd_conv_desc* desc, void* stream) {
 }
 
 extern "C" size_t hnd_conv2d_igemm_workspace(const hnd_conv_desc* desc) {
-  if (!desc || desc->cin == 4 || thin_n_applies(*desc) || hnd::bx3_applies(*desc) || hnd::bres_variant(*desc)) return 0;
+  if (!desc || desc->cin == 4 || thin_n_applies(*desc) || hnd::bx3_applies(*desc)) return 0;
+  if (hnd::bxs_variant(*desc)) return hnd::bxs_workspace(*desc);
+  if (hnd::bres_variant(*desc)) return 0;
   return hnd::bstream_workspace(*desc);
 }
 
@@ -646,6 +652,7 @@ extern "C" int hnd_conv2d_igemm_tile(const hnd_conv_desc* desc) {
   if (desc->cin == 4) return hnd::stem7_applies(*desc) ? 9 : 1;
   if (thin_n_applies(*desc)) return 4;
   if (hnd::bx3_applies(*desc)) return 13;
+  if (const int v = hnd::bxs_variant(*desc)) return v == 2 ? 14 : 15;
   if (const int v = hnd::bres_variant(*desc)) return v == 2 ? 5 : (v == 1 ? 6 : (v == 4 ? 7 : 8));
   if (const int v = hnd::bstream_variant(*desc)) return v == 2 ? 11 : 12;
   return pick_tile(*desc);

@@ -240,6 +240,10 @@ def wgrad_stream_on():
 # BatchNorm backward "reduce" of a head layer folded into the output transform of the data gradient that produces its g
 FOLD_BNBWD_REDUCE = True    # (settled in round 4; was HND_FOLD_BNBWD_REDUCE)
 WINOGRAD6 = os.environ.get('HND_WINOGRAD6', '1') != '0'       # F(6x6,3x3) on maps large enough (wino_tile_for)
+# Which of the STUDENT's forward launches the bf16x3 emulation may take (the teacher, the backward pass and the loss-dead
+# pyramid always may): the student's forward pass makes the ReLU / BatchNorm decisions every gradient hangs on
+BX3_STUDENT_FWD = os.environ.get('HND_BX3_STUDENT_FWD', '1') != '0'
+BX3_HEAD_FWD = os.environ.get('HND_BX3_HEAD_FWD', '1') != '0' 
 
 
 def use_winograd(cin, cout, stride):
@@ -483,7 +487,8 @@ class FrozenLayerEngine(object):
         key = (x.data_ptr(), tuple(x.shape), keep, getattr(self, 'for_backward', True),
                tuple(a[0][0].data_ptr() for a in affs), None if self._out_buf is None else self._out_buf.data_ptr())
         if key != self.plan_key:
-            self._build_forward(x, keep, affs)
+            with ops.emulation_unless(not keep or BX3_STUDENT_FWD):
+                self._build_forward(x, keep, affs)
             self.plan_key = key
             self.bwd_key = None
         return self.out
@@ -521,10 +526,10 @@ class FrozenLayerEngine(object):
             else:
                 self.fwd.append((ops.conv_forward(a1, b.w2.get(), a2, 3, b.stride, 1, epi_scale=a2f[0],
                                                   epi_shift=a2f[1], relu=True), tagp + '.conv2'))
-            # opt-in bf16x3 emulation only: [a2 > 0] as nibbles for conv3's data gradient -- the emulation kernel's masked build
+            # with the bf16x3 emulation (the default): [a2 > 0] as nibbles for conv3's data gradient -- the emulation kernel's masked build
             # reads mask BYTES (a second fp32 row set does not fit its registers); made here, where a2 is cache-hot
             a2b = None
-            if (keep and getattr(self, 'for_backward', True) and ops.BF16X3 and MASK_BITS
+            if (keep and getattr(self, 'for_backward', True) and ops.bx3_on() and MASK_BITS
                     and b.planes % 128 == 0):
                 a2b = self.bufs.get('a2bits_' + sfx, tuple(a2.shape[:3]) + (a2.shape[3] // 4,), torch.uint8)
                 self.fwd.append((ops._Step(lambda s, a2=a2, a2b=a2b: ops.relu_mask_nibbles(a2, a2b, s), 'relu_mask_nibbles',
@@ -723,7 +728,8 @@ class HeadEngine(object):
         self._out_buf = self.out_provider(self.out_shape(x)) if self.out_provider is not None else None
         key = (x.data_ptr(), tuple(x.shape), training, ptrs, None if self._out_buf is None else self._out_buf.data_ptr())
         if key != self.plan_key:
-            self._build_forward(x, training)
+            with ops.emulation_unless(BX3_HEAD_FWD):
+                self._build_forward(x, training)
             self.plan_key = key
             self.bwd_key = None
         b = self.bufs

@@ -46,16 +46,50 @@ def device_arch():
 
 
 # --------------------------------------------------------------------------------------- weights
-# OPT-IN, never the default (VERDICT r4 item 3 / profiles/r05_bf16x3_probe.txt): HND_BF16X3=1 attaches a three-plane bf16
-# image to every packed operand the emulation kernel can use (csrc/conv_bx3.hip); the launches it covers then compute on
-# the bf16 matrix pipe with fp32-level accuracy but NOT the fp32 kernels' bits.  Unset: no image, native fp32 MFMA everywhere.
-BF16X3 = os.environ.get('HND_BF16X3', '0') == '1'
+# fp32 EMULATED on the bf16 matrix pipe (csrc/conv_bx3.hip) is the DEFAULT for the launches it covers since round 6
+# (VERDICT r5 item 1): every packed operand the kernel can use gets a three-plane bf16 image, and a launch carries it when
+# hnd_bf16x3_recommended says so for its LAYER (rows one image contributes, depth, output channels -- never the batch).
+# Covered launches compute with fp32-level accuracy (0.8x the native kernel's error against fp64) but NOT the fp32 kernels'
+# bits.  HND_BF16X3=0: no image anywhere, native fp32 MFMA everywhere (the `value_native_fp32` leg of bench.py).
+#   mode 'policy' (default) / 'off' / 'force' (tests: attach whenever an image exists, whatever the policy says)
+BX3_MODE = ['policy' if os.environ.get('HND_BF16X3', '1') != '0' else 'off']
+
+
+def bx3_on():
+    return BX3_MODE[0] != 'off'
+
+
+class emulation(object):
+    """with ops.emulation('off' | 'force' | 'policy'): ... -- launches and packed operands BUILT inside take that mode
+    (tests hold the native and the emulated family side by side with it)."""
+
+    def __init__(self, mode):
+        assert mode in ('policy', 'off', 'force'), mode
+        self.mode = mode
+
+    def __enter__(self):
+        self.saved, BX3_MODE[0] = BX3_MODE[0], self.mode
+        return self
+
+    def __exit__(self, *exc):
+        BX3_MODE[0] = self.saved
+        return False
+
+
+def emulation_unless(allowed):
+    """context: launches built inside stay on native fp32 MFMA unless `allowed`"""
+    import contextlib
+    return contextlib.nullcontext() if allowed else emulation('off')
+
+
+def bx3_recommended(rows_per_image, kdim, cout):
+    return bool(_L.hnd_bf16x3_recommended(int(rows_per_image), int(kdim), int(cout)))
 
 
 def bx3_image(buf, rows_pad, kdim, groups=1, group_stride=0, out=None, force=False):
     """(re)build the bf16x3 image of a packed fp32 operand; None when the emulation is off (unless `force`: tests) or
     cannot use this operand"""
-    if not (BF16X3 or force) or (kdim != 128 and (kdim % 256 != 0 or kdim > 2048)) or rows_pad % 64 != 0:
+    if not (bx3_on() or force) or (kdim != 128 and (kdim % 256 != 0 or kdim > 2048)) or rows_pad % 64 != 0:
         return None
     n = int(_L.hnd_pack_bf16x3_elems(rows_pad, kdim, groups))
     if out is None or out.numel() != n:
@@ -82,8 +116,9 @@ class PackedWeight(object):
         self.refresh_bx3()
 
     def refresh_bx3(self):
-        if BF16X3 and self.ni * self.nj == 1 and self.kdim == self.chan_pad:          # tap-free operands only
-            self.bx3 = bx3_image(self.buf, round_up(self.rows, 64), self.kdim, out=getattr(self, 'bx3', None))
+        if self.ni * self.nj == 1 and self.kdim == self.chan_pad:          # tap-free operands only
+            if bx3_on() or getattr(self, 'bx3', None) is not None:          # (an image made once is kept in step with the weights)
+                self.bx3 = bx3_image(self.buf, round_up(self.rows, 64), self.kdim, out=getattr(self, 'bx3', None), force=True)
 
 
 # A caller that refreshes many small operands in a row (the trainable head after every optimizer step) brackets the loop
@@ -186,11 +221,13 @@ def _nhwc(t):
 def conv_desc(x, pw, y, *, kh, kw, oh, ow, sh, dh, bh, sw, dw, bw, cout, y_sh=1, y_oh=0, y_sw=1, y_ow=0,
               pro_scale=None, pro_shift=None, pro_relu=False, epi_scale=None, epi_shift=None, res1=None,
               res1_up=False, res2=None, mask=None, relu=False, stats=None, mask_bits=None, mask_out=None,
-              bwd_stats=None):
+              bwd_stats=None, rows_per_image=None):
     """Generic descriptor (see include/hnd_hip.h).  x, y, res*, mask are NHWC tensors; mask_bits / mask_out are uint8
     ReLU-mask nibble tensors of y's geometry with a quarter of its channels (mask_nibbles_like).
     bwd_stats = (x_raw, scale, shift, mean, rstd, relu): `stats` receives the BatchNorm-backward partials of the stored
-    y (hnd_conv_desc.bwd_x) instead of its sum / sum of squares."""
+    y (hnd_conv_desc.bwd_x) instead of its sum / sum of squares.
+    rows_per_image: GEMM rows ONE image contributes (default oh * ow; the Winograd launches fold the batch into ow and say
+    components x tiles per image): what hnd_bf16x3_recommended prices the emulation kernel on -- never the batch."""
     n, h, w, cin = _nhwc(x)
     ny, yh, yw, ldc = _nhwc(y)
     assert ny == n and pw.kdim >= kh * kw * cin and pw.chan_pad == cin, (pw.kdim, kh, kw, cin, pw.chan_pad)
@@ -220,7 +257,11 @@ def conv_desc(x, pw, y, *, kh, kw, oh, ow, sh, dh, bh, sw, dw, bw, cout, y_sh=1,
                              and tuple(t.shape) == (ny, yh, yw, ldc // 4)), (None if t is None else t.shape, y.shape)
     assert mask is None or mask_bits is None
     d.mask_bits, d.mask_out = ptr(mask_bits), ptr(mask_out)
-    d.w_bf16x3 = ptr(getattr(pw, 'bx3', None))          # HND_BF16X3=1 only (opt-in emulation on the bf16 matrix pipe)
+    img = getattr(pw, 'bx3', None)          # fp32 emulated on the bf16 matrix pipe: by layer, never by batch
+    if img is not None and not (BX3_MODE[0] == 'force' or (BX3_MODE[0] == 'policy' and bx3_recommended(
+            oh * ow if rows_per_image is None else rows_per_image, pw.kdim, cout))):
+        img = None
+    d.w_bf16x3 = ptr(img)
     if stats is not None:
         assert stats.numel() >= stats_tiles(n * oh * ow) * 2 * cout
     if bwd_stats is not None:
@@ -231,7 +272,7 @@ def conv_desc(x, pw, y, *, kh, kw, oh, ow, sh, dh, bh, sw, dw, bw, cout, y_sh=1,
         d.bwd_x, d.bwd_scale, d.bwd_shift, d.bwd_mean, d.bwd_rstd = ptr(bx), ptr(bsc), ptr(bsh), ptr(bmu), ptr(brs)
         d.bwd_relu = int(brelu)
     keep = (x, pw, y, pro_scale, pro_shift, epi_scale, epi_shift, res1, res2, mask, stats, mask_bits, mask_out,
-            bwd_stats)
+            bwd_stats, img)
     return ConvLaunch(d, keep, flops=2 * n * oh * ow * min(cout, pw.rows) * kh * kw * min(cin, pw.chan_real))
 
 
@@ -631,7 +672,8 @@ class WinoConv(object):
         pw.buf, pw.kdim, pw.rows, pw.chan_pad, pw.chan_real = ww.buf, ww.depth, ww.rows, c, c
         pw.bx3 = ww.bx3
         self.gemm = conv_desc(self.v, pw, self.m, kh=1, kw=1, oh=1, ow=nc * self.tiles_pad, sh=1, dh=1, bh=0, sw=1,
-                              dw=1, bw=0, cout=self.cout)
+                              dw=1, bw=0, cout=self.cout,
+                              rows_per_image=nc * ((h + tile - 1) // tile) * ((w + tile - 1) // tile))
         self.gemm.desc.w_group_rows = self.tiles_pad
         self.gemm.desc.w_group_stride = ww.rows_pad * ww.depth
         self.gemm.refresh_variant()
@@ -737,7 +779,8 @@ class Wino2Conv(object):
         pw.buf, pw.kdim, pw.rows, pw.chan_pad, pw.chan_real = ww.buf, ww.depth, ww.rows, c, c
         pw.bx3 = ww.bx3
         self.gemm = conv_desc(self.v, pw, self.m, kh=1, kw=1, oh=1, ow=nc * self.tiles_pad, sh=1, dh=1, bh=0, sw=1,
-                              dw=1, bw=0, cout=self.cout)
+                              dw=1, bw=0, cout=self.cout,
+                              rows_per_image=nc * ((oh + self.tile - 1) // self.tile) * ((ow + self.tile - 1) // self.tile))
         self.gemm.desc.w_group_rows = self.tiles_pad
         self.gemm.desc.w_group_stride = ww.rows_pad * ww.depth
         self.gemm.refresh_variant()

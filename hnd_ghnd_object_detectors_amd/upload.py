@@ -23,6 +23,7 @@ pinned / device memory, streams and events only.
 """
 import queue
 import threading
+import time
 from concurrent.futures import ThreadPoolExecutor
 
 import torch
@@ -62,7 +63,8 @@ class DevicePrefetcher(object):
     """iterable of device-resident ``(images, targets)`` over a host-batch iterable; see the module docstring.
 
     ``len()`` and ``set_epoch`` pass through to the source.  ``copied_bytes`` / ``batches`` count what went over the
-    link (bench.py reports them)."""
+    link, ``wait_s`` / ``waits`` the host time ``next()`` spent blocked on the feeder (bench.py reports them;
+    ``reset_wait()`` zeroes the latter at the start of a timed region)."""
 
     def __init__(self, source, device, depth=3, stagers=4):
         assert depth >= 2, 'one slot is read by the step while the next is being filled'
@@ -74,12 +76,16 @@ class DevicePrefetcher(object):
         self.copy_stream = torch.cuda.Stream(device=self.device)
         self.slots = [_Slot() for _ in range(depth)]
         self.copied_bytes = self.batches = 0
+        self.wait_s, self.waits = 0.0, 0         # host time the consumer spent blocked on the feeder (bench.py: data_wait_ms)
         self._thread = self._queue = self._stop = None
         self._held = None
         self._pool = ThreadPoolExecutor(stagers, thread_name_prefix='upload-stager') if stagers > 1 else None
 
     def __len__(self):
         return len(self.source)
+
+    def reset_wait(self):
+        self.wait_s, self.waits = 0.0, 0
 
     def set_epoch(self, epoch):
         if hasattr(self.source, 'set_epoch'):
@@ -185,7 +191,10 @@ class DevicePrefetcher(object):
         try:
             while True:
                 self._release_held()
+                t0 = time.perf_counter()
                 kind, k, payload = q.get()
+                self.wait_s += time.perf_counter() - t0
+                self.waits += 1
                 if kind == 'end':
                     return
                 if kind == 'error':

@@ -39,7 +39,7 @@ class SyntheticDetectionLoader(object):
     with a feeder thread."""
 
     def __init__(self, num_batches, batch_size, height=800, width=1333, model_name='faster_rcnn', seed=1234, rank=0,
-                 device='cpu', decoded=False, train=True, positive_every=0, workers=0, pin_memory=False):
+                 device='cpu', decoded=False, train=True, positive_every=0, workers=0, pin_memory=False, pool_batches=0):
         self.num_batches, self.batch_size, self.h, self.w = num_batches, batch_size, height, width
         self.model_name, self.seed, self.rank, self.device = model_name, seed, rank, device
         self.decoded, self.transform = decoded, get_transform(train)
@@ -49,6 +49,15 @@ class SyntheticDetectionLoader(object):
         # like DataLoader(pin_memory=True): images are generated straight into pinned host memory, so the uploader
         # (upload.DevicePrefetcher) sends them to the device without a staging copy
         self.pin_memory = bool(pin_memory) and torch.cuda.is_available()
+        # pool_batches = P > 0: batches 0 .. P-1 of the epoch are generated ONCE (the same values as without a pool) and
+        # batch k hands out pool[k % P] -- for hosts whose CPU share per rank cannot generate 205 MB of random numbers per
+        # step (8 ranks on a 16-CPU container: bench.py's `upload.mode`).  What the reference's step pays is the upload
+        # of the batch (src/mimic_runner.py:49-50), which still happens every step; random-number generation is its
+        # DataLoader workers' cost, not the step's.
+        self.pool_batches = int(pool_batches)
+        self._pool, self._pool_seed = None, None
+        # host cost of making batches: thread CPU seconds spent in raw_images / batches made (bench.py reports it)
+        self.gen_cpu_s, self.gen_batches = 0.0, 0
 
     def set_epoch(self, epoch):
         self.epoch = epoch
@@ -77,7 +86,23 @@ class SyntheticDetectionLoader(object):
 
     def raw_images(self, k, epoch_seed=None):
         """the images of batch k of the current epoch: float CHW in [0, 1), or uint8 HWC with ``decoded``"""
-        g = torch.Generator().manual_seed((self._epoch_seed() if epoch_seed is None else epoch_seed) + 1000003 * k)
+        import time
+        es = self._epoch_seed() if epoch_seed is None else epoch_seed
+        if self.pool_batches > 0:
+            if self._pool_seed != es:
+                self._pool, self._pool_seed = {}, es
+            j = k % self.pool_batches
+            if j not in self._pool:             # (workers may race for a slot: both make the same values, one wins)
+                self._pool[j] = self._generate(j, es)
+            return self._pool[j]
+        t0 = time.thread_time()
+        out = self._generate(k, es)
+        self.gen_cpu_s += time.thread_time() - t0
+        self.gen_batches += 1
+        return out
+
+    def _generate(self, k, es):
+        g = torch.Generator().manual_seed(es + 1000003 * k)
         pin = self.pin_memory
         if not self.decoded:
             return [torch.rand(3, self.h, self.w, generator=g, out=torch.empty(3, self.h, self.w, pin_memory=pin))

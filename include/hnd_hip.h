@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define HND_ABI_VERSION 11
+#define HND_ABI_VERSION 12
 
 typedef enum hnd_status {
   HND_OK = 0,
@@ -129,12 +129,25 @@ typedef struct hnd_conv_desc {
   const float* bwd_mean;
   const float* bwd_rstd;
   int bwd_relu;
-  /* OPT-IN, ABI 10 (csrc/conv_bx3.hip): the weight operand pre-split into three bf16 planes by hnd_pack_bf16x3, or NULL (the
-   * default: native fp32 MFMA).  With it, launches the emulation covers (tap-free K = 128 / 256 / 512, scale / shift / residual /
-   * ReLU / mask-nibble epilogue, whole 64-row chunks, dense output) compute every product as six bf16 MFMAs of the operands' exact 8+8+8-bit
-   * planes with fp32 accumulation: fp32-level accuracy (rel-L2 2.4e-7 vs fp64, native 2.9e-7), not bit-identical to the
-   * fp32 kernels, 1.65x their rate (profiles/r05_bf16x3_probe.txt).  Layout: hnd_pack_bf16x3. */
+  /* fp32 EMULATED on the bf16 matrix pipe (csrc/conv_bx3.hip; ABI 10 opt-in, the Python host's default since ABI 12): the
+   * weight operand pre-split into three bf16 planes by hnd_pack_bf16x3, or NULL = native fp32 MFMA.  Attaching the image ASKS
+   * for the emulation: every launch it can take (tap-free K = 128 or 256 P <= 2048; scale / shift / residual / ReLU /
+   * mask-nibble epilogue; dense output; any row count) then computes each product as six bf16 MFMAs of the operands' exact
+   * 8+8+8-bit planes with fp32 accumulation -- fp32-level accuracy (rel-L2 2.4e-7 vs fp64, native 2.9e-7), a different
+   * summation from the fp32 kernels' (not their bits), 1.4-1.7x their rate.  Attach it by LAYER (hnd_bf16x3_recommended),
+   * never by batch, so that an image's maps do not depend on the batch it is computed in.
+   * DEVIATIONS from fp32 arithmetic, both outside a healthy training step (tests/test_bx3_gpu.py):
+   *   non-finite: an Inf or NaN in an A row (or in a weight row) makes EVERY output of that row (that channel) NaN -- never
+   *     a finite value; native fp32 gives +-Inf where no Inf - Inf / 0 * Inf occurs.  (Inf splits into Inf + NaN + NaN.)
+   *   denormal / tiny: the bf16 pipe flushes denormal plane values.  An operand element |x| < 2^-126 counts as 0; for
+   *     2^-126 <= |x| < 2^-110 its mid / lo planes (|.| < 2^-8 |x|, 2^-16 |x|) may flush, i.e. x is used with relative error
+   *     <= 2^-8: absolute error per product <= 2^-118 |b|.  Elements >= 2^-110 (7.7e-34) are exact. */
   const uint16_t* w_bf16x3;
+  /* ABI 12: the STREAM image of the same three planes (hnd_pack_bf16x3s), or NULL.  Attached, it asks for the B-streamed
+   * emulation kernel (csrc/conv_bxs.hip) on launches the B-resident one above does not take: convolutions over taps (cin %
+   * 64 == 0), any K % 128 == 0, strided outputs, every prologue / epilogue operand of this descriptor including `stats`
+   * and `bwd_x`.  Same arithmetic and deviations as w_bf16x3; the relay workspace works as for the native B-streamed kernel. */
+  const uint16_t* w_bf16x3s;
 } hnd_conv_desc;
 
 int hnd_conv2d_igemm(const hnd_conv_desc* desc, void* stream);
@@ -150,7 +163,12 @@ size_t hnd_conv2d_igemm_workspace(const hnd_conv_desc* desc);
  * (csrc/conv_bstream.hip: 128 x 128 / 256 x 64 block tile, the weight slice streams through three LDS stages, A
  * fragments straight from global memory; K % 128 == 0, K >= 1024 or taps; bit-identical to the tiled kernel;
  * HND_BSTREAM=0 turns it off). */
-int hnd_conv2d_igemm_tile(const hnd_conv_desc* desc);      /* (13 = the opt-in bf16x3 kernel, csrc/conv_bx3.hip) */
+int hnd_conv2d_igemm_tile(const hnd_conv_desc* desc);      /* (13 = the bf16x3 emulation kernel, csrc/conv_bx3.hip; 14 / 15 =
+                                                             * its B-streamed build, 128 x 128 / 256 x 64 tile, csrc/conv_bxs.hip) */
+/* ABI 12: should a layer's launches carry a weight image (run on the emulation)?  Decided from the LAYER alone: GEMM rows ONE
+ * image contributes (oh * ow of a 1x1 conv; components x tiles of a Winograd launch), depth and output channels -- priced
+ * at 16 images per GPU, never at the launch's own batch.  1 = attach hnd_conv_desc.w_bf16x3, 0 = leave it NULL. */
+int hnd_bf16x3_recommended(int64_t rows_per_image, int kdim, int cout);
 /* The three-plane bf16 image of a packed weight operand for hnd_conv_desc.w_bf16x3: w_packed [groups][rows_pad][kdim]
  * fp32 (hnd_pack_weights / hnd_wino*_weights; group g at w_packed + g * group_stride floats) -> img: per (group, 64-row
  * slice) [3 planes hi / mid / lo][64 rows][kdim] bf16, 16-byte chunk c of row r stored at position c ^ (r & 15) (the
@@ -160,6 +178,12 @@ int hnd_conv2d_igemm_tile(const hnd_conv_desc* desc);      /* (13 = the opt-in b
 size_t hnd_pack_bf16x3_elems(int rows_pad, int kdim, int groups);
 int hnd_pack_bf16x3(const float* w_packed, uint16_t* img, int rows_pad, int kdim, int groups, int64_t group_stride,
                     void* stream);
+
+/* The STREAM image for hnd_conv_desc.w_bf16x3s (ABI 12): per (group, 64-row slice, 64-k stage) three planes [64 rows][64 k]
+ * of bf16, 16-byte chunk c of row r at position c ^ ((r >> 1) & 7); any packed operand with kdim % 128 == 0 (taps included). */
+size_t hnd_pack_bf16x3s_elems(int rows_pad, int kdim, int groups);
+int hnd_pack_bf16x3s(const float* w_packed, uint16_t* img, int rows_pad, int kdim, int groups, int64_t group_stride,
+                     void* stream);
 
 /* Weight gradient (autograd conv backward(weight), src/mimic_runner.py:53) of the trainable convs:
  * student stem conv1 (custom/resnet.py:26) and the eight 2x2 convs (resnet_layer.py:43-62).

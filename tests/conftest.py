@@ -13,6 +13,20 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'reference: needs /root/reference (build container only)')
 
 
+def pytest_runtest_setup(item):
+    """Several GPU tests start child processes on the same card (ranks of a data-parallel run, bench.py and its
+    native-fp32 leg).  This process's caching allocator never returns memory by itself, and after a few full-size tests it
+    can hold most of the 288 GB -- a child then dies with 'HIP out of memory ... 0 bytes free' (seen in round 6).  Before
+    every GPU test: if more than 64 GiB are cached, give the cache back."""
+    if item.get_closest_marker('gpu') is None or 'torch' not in sys.modules:
+        return
+    import torch
+    if torch.cuda.is_available() and torch.cuda.is_initialized() and torch.cuda.memory_reserved() > (64 << 30):
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+
+
 @pytest.fixture(scope='session')
 def golden_dir():
     return os.path.join(ROOT, 'tests', 'golden')

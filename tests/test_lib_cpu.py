@@ -21,13 +21,13 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert sorted(_lib.EXPORTED_SYMBOLS) == declared
-    assert lib.hnd_abi_version() == _lib.ABI_VERSION == 11
+    assert lib.hnd_abi_version() == _lib.ABI_VERSION == 12
 
 
 def test_ctypes_structs_match_header_layout():
     from hnd_ghnd_object_detectors_amd import _lib
     import ctypes
-    assert ctypes.sizeof(_lib.ConvDesc) == 11 * 8 + 30 * 4 + 3 * 8 + 5 * 8 + 8 + 8          # (+ w_bf16x3, ABI 10)
+    assert ctypes.sizeof(_lib.ConvDesc) == 11 * 8 + 30 * 4 + 3 * 8 + 5 * 8 + 8 + 8 + 8      # (+ w_bf16x3, ABI 10; + w_bf16x3s, ABI 12)
     assert ctypes.sizeof(_lib.WgradDesc) == 6 * 8 + 16 * 4 + 3 * 8
     assert ctypes.sizeof(_lib.MsePair) == 3 * 8 + 8 + 4 + 4
     assert ctypes.sizeof(_lib.ImageDesc) == 8 + 7 * 4 + 2 * 4 + 4        # hnd_image_desc (padded to 8)

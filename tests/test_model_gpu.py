@@ -606,6 +606,69 @@ def test_batch16_hnd_is_the_reference_batch2_replicated():
     _record_full('batch 16 = full_hnd_faster_b2 x 8', worst_g, worst_p)
 
 
+def _hip_relu_decisions(student):
+    """[value > 0] of EVERY ReLU of the student's forward pass as the HIP engines hold them right after the forward: stem,
+    the head's ReLUs after train-mode BatchNorm, a1 / a2 / output of all Bottlenecks of layers 2-4 (CPU bool, NCHW)."""
+    body = student.backbone.body
+    head = body.layer1.head_engine()
+
+    def dec(buf, c=None):
+        return (buf[..., :c] > 0).permute(0, 3, 1, 2).cpu()
+
+    got = {'stem': dec(body.stem().a0)}
+    for k, li_ in enumerate([k for k, hc in enumerate(head.layers) if hc.relu]):
+        got['head.relu%d' % k] = dec(head.y[li_] * head.scale[li_] + head.shift[li_])
+    for li in (2, 3, 4):
+        eng = body.layer_engine('layer%d' % li)
+        for i in range(len(body['layer%d' % li])):
+            x_in, a1, a2, out_ = (eng._b(t) for t in eng.acts[i])
+            got['layer%d.%d.a1' % (li, i)], got['layer%d.%d.a2' % (li, i)] = dec(a1), dec(a2)
+            got['layer%d.%d.out' % (li, i)] = dec(out_)
+    return got
+
+
+def _oracle_relu_values(orc32, student, inter, s_hooked, x_batch):
+    """the same ReLU maps as the fp32 CPU oracle computes them (values, NCHW), keyed like _hip_relu_decisions"""
+    import torch.nn.functional as F
+    sd, body = orc32.s, student.backbone.body
+    conv1 = F.conv2d(x_batch, sd[O.B + 'conv1.weight'], None, stride=2, padding=3)
+    ref = OrderedDict(stem=F.relu(O.frozen_bn(conv1, sd, O.B + 'bn1.')))
+    relu_names = ['%s%d' % (pfx, op[1]) for pfx, spec in ((O.B + 'layer1.encoder.encoder.', O.ENCODER_SPEC),
+                                                         (O.B + 'layer1.decoder.', O.DECODER_SPEC))
+                  for op in spec if op[0] == 'relu']
+    for k, n in enumerate(relu_names):
+        ref['head.relu%d' % k] = inter[n]
+    for li in (2, 3, 4):
+        for i in range(len(body['layer%d' % li])):
+            pfx = '%slayer%d.%d.' % (O.B, li, i)
+            xin = s_hooked['layer%d' % (li - 1)] if i == 0 else s_hooked['layer%d.%d' % (li, i - 1)]
+            a1 = F.relu(O.frozen_bn(F.conv2d(xin, sd[pfx + 'conv1.weight']), sd, pfx + 'bn1.'))
+            a2 = F.relu(O.frozen_bn(F.conv2d(a1, sd[pfx + 'conv2.weight'], None, stride=2 if (i == 0) else 1,
+                                             padding=1), sd, pfx + 'bn2.'))
+            ref['layer%d.%d.a1' % (li, i)], ref['layer%d.%d.a2' % (li, i)] = a1, a2
+            ref['layer%d.%d.out' % (li, i)] = s_hooked['layer%d.%d' % (li, i)]
+    return ref
+
+
+def _count_relu_flips(got, ref, top=None):
+    """(flips, total, largest differing value relative to its map's max, {map: flips}) between HIP decisions and oracle
+    values; `top`: only maps at or below that layer carry gradient (HND: the head and the stem)."""
+    flips = total = 0
+    worst_rel, where = 0.0, {}
+    for key, r in ref.items():
+        if top is not None and key.startswith('layer') and int(key[5]) > top:
+            continue
+        g_ = got[key][:, :r.shape[1]]
+        assert tuple(g_.shape) == tuple(r.shape), (key, g_.shape, r.shape)
+        d = g_ != (r > 0)
+        total += d.numel()
+        if bool(d.any()):
+            flips += int(d.sum())
+            where[key] = int(d.sum())
+            worst_rel = max(worst_rel, float(r[d].abs().max() / r.abs().max()))
+    return flips, total, worst_rel, where
+
+
 DENSE_MAXABS_RMS = 1e-3      # worst |d| of any element, in units of its map's rms (achieved ~9e-5: a tail-tile bug is O(1))
 DENSE = {   # name -> (fixture whose seeded inputs / weights are reused, number of images taken from it)
     'ghnd_faster_b2': ('full_ghnd_faster_b4', 2),
@@ -635,12 +698,24 @@ def test_full_size_dense_parity_every_element(case):
         random.seed(100)                   # the box draws the same sizes again (tool.py:45-48)
     ims, tgs = _to_dev(images, targets)
     loss = box(ims, tgs)
+    decisions = _hip_relu_decisions(student)          # before the backward pass touches any buffer
     opt.zero_grad()
     loss.backward()
     torch.set_num_threads(min(32, os.cpu_count() or 1))
     ms = meta['min_size'] if isinstance(meta['min_size'], list) else [meta['min_size']]
     orc32 = O.DistillOracle(t_sd, s_sd, terms=terms, min_size=tuple(ms), max_size=meta['max_size'])
-    o_loss, o_terms, t_hooked, s_hooked, _, _, x = orc32.forward(images, fixed)
+    inter = {}
+    o_loss, o_terms, t_hooked, s_hooked, _, _, x = orc32.forward(images, fixed, intermediates=inter)
+    # ReLU decisions of the student's forward pass that differ from the fp32 oracle's: each one
+    # switches a gradient path on in one implementation and off in the other -- the gradient figure below is made of them
+    with torch.no_grad():
+        top_term = max(int(k[5]) for k in terms if k.startswith('layer') and k[5:6].isdigit())
+        flips, total, flip_rel, where = _count_relu_flips(
+            decisions, _oracle_relu_values(orc32, student, {k: v.detach() for k, v in inter.items()},
+                                           {k: v.detach() for k, v in s_hooked.items()}, x.detach()),
+            top=top_term)
+    del decisions, inter
+    assert flip_rel < 1e-5, (flips, total, flip_rel, where)      # only values that are rounding noise may decide differently
     o_loss.backward()
     g32 = OrderedDict((k, orc32.s[k].grad.detach().clone()) for k in orc32.keys)
     report = []
@@ -675,14 +750,17 @@ def test_full_size_dense_parity_every_element(case):
     for n, p in student.named_parameters():
         if p.requires_grad and not n.endswith(G.ZERO_GRAD_SUFFIXES):
             worst_g = max(worst_g, _grad_check(n, p.grad, g32[n], orc64.s[n].grad))
-    print('\n[dense %s, batched %s] %s\n  loss rel %.1e; worst gradient rel-L2 vs fp64 %.2e'
-          % (case, tuple(x.shape), '\n  '.join(report), abs(loss.item() - float(l64)) / abs(float(l64)), worst_g))
+    flip_txt = '%d of %d ReLU decisions upstream of a loss term differ from the fp32 oracle (largest such value %.1e of its ' \
+               'map\'s max%s)' % (flips, total, flip_rel, '' if not where else '; ' + ', '.join(
+                   '%s: %d' % kv for kv in sorted(where.items(), key=lambda kv: -kv[1])[:5]))
+    print('\n[dense %s, batched %s] %s\n  loss rel %.1e; worst gradient rel-L2 vs fp64 %.2e; %s'
+          % (case, tuple(x.shape), '\n  '.join(report), abs(loss.item() - float(l64)) / abs(float(l64)), worst_g, flip_txt))
     from tests.conftest import record_achieved
     worst_map = max(float(r.split('rel ')[1].split(' ')[0]) for r in report)
     record_achieved('[dense %s] every element of %d maps: worst rel-L2 %.1e (tol %.0e), worst max|d| / rms %.1e (tol %.0e); '
-                    'loss rel %.1e; worst gradient rel-L2 vs fp64 %.2e'
+                    'loss rel %.1e; worst gradient rel-L2 vs fp64 %.2e; %s'
                     % (case, len(report), worst_map, FEAT_TOL, worst_abs_rms, DENSE_MAXABS_RMS,
-                       abs(loss.item() - float(l64)) / abs(float(l64)), worst_g))
+                       abs(loss.item() - float(l64)) / abs(float(l64)), worst_g, flip_txt))
     for r in report:
         record_achieved('    ' + r)
 
@@ -827,8 +905,10 @@ def test_shared_trunk_halves_equal_the_separate_passes_bit_for_bit(case, first, 
 def test_mask_nibbles_change_no_bit_of_the_step(case, monkeypatch):
     """engine.MASK_BITS: the conv1 data gradients of the frozen Bottlenecks read [x > 0] as nibbles written by the forward
     epilogue instead of the fp32 activation -- the same decisions, so loss, terms and EVERY gradient are bit-identical to
-    the fp32-mask step."""
-    from hnd_ghnd_object_detectors_amd import engine as E
+    the fp32-mask step.  Held inside the NATIVE family (HND_BF16X3=0's build): the emulation kernel reads masks as nibbles
+    only, so a launch with an fp32 mask and one with nibbles would sit in two different rounding families."""
+    from hnd_ghnd_object_detectors_amd import engine as E, ops as OPS
+    monkeypatch.setattr(OPS, 'BX3_MODE', ['off'])
     z, meta = G.load(case)
     if case.startswith('full'):
         meta = dict(meta, sizes=meta['sizes'][:2])

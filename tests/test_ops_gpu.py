@@ -23,6 +23,16 @@ def ops():
     return o
 
 
+@pytest.fixture(autouse=True)
+def native_family(ops):
+    """Every test of this file holds the NATIVE fp32-MFMA kernels (tiled, B-resident, B-streamed, ring, vector-ALU) to torch
+    and to one another bit for bit: launches are built with the bf16x3 emulation off.  The emulated family has the same
+    kind of tests -- fp64 beside the native kernel, identical bits across batch / team / tail inside the family, the policy
+    that picks it -- in tests/test_bx3_gpu.py."""
+    with ops.emulation('off'):
+        yield
+
+
 def nhwc(t_nchw, cpad=None):
     """NCHW cpu tensor -> NHWC device tensor (channels zero-padded to cpad)."""
     t = t_nchw.permute(0, 2, 3, 1).contiguous()

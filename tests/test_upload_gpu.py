@@ -150,6 +150,19 @@ def test_upload_inside_the_step_costs_under_one_percent_and_the_runner_keeps_ben
     assert out['upload']['batches'] >= 13 and out['upload']['mbytes_per_step'] > 200
     assert out['value'] >= 0.99 * out['value_resident'], (out['value'], out['value_resident'])
     assert abs(out['runner']['ms_per_it'] - out['ms_per_step']) <= 0.02 * out['ms_per_step'], (out['runner'], out['ms_per_step'])
+    # the default line carries the native-fp32 build of the same steps beside it (a fresh child
+    # process with HND_BF16X3=0), the storage dtype, what is emulated, and a roofline priced on the pipe the dominant family
+    # runs on
+    nat, emu, roof = out['native_fp32'], out['emulation'], out['roofline']
+    assert out['dtype'] == 'f32' and emu['planes'] == 3 and emu['products'] == 6 and emu['launches'] > 100 and emu['ms'] > 10
+    assert isinstance(out['value_native_fp32'], float) and out['value_native_fp32'] == nat['value'], nat
+    assert 0.75 * out['value'] < out['value_native_fp32'] < out['value'], (out['value_native_fp32'], out['value'])
+    assert nat['worst_first_step_rel_err'] < 1e-3 and out['loss_check']['worst_rel_err'] < 1e-3
+    assert set(roof['families']) == {'emulated_bf16x3', 'native_fp32'}
+    assert roof['families']['emulated_bf16x3']['peak'] == 2500.0 and roof['families']['native_fp32']['peak'] == 157.3
+    assert roof['kernel'] in (roof['families']['emulated_bf16x3']['kernel'], roof['families']['native_fp32']['kernel'])
+    assert 0.2 < roof['frac'] < 1.0 and abs(roof['frac'] - roof['achieved'] / roof['peak']) < 1e-3
+    assert out['upload']['data_wait_ms_per_step'] < 1.0 and out['upload']['pool_batches'] == 0
     # (b) the CLI
     from hnd_ghnd_object_detectors_amd import mimic_runner
     cfg_path = os.path.join(ROOT, 'config', 'ghnd', 'faster_rcnn-backbone_resnet50-b3ch.yaml')
@@ -170,6 +183,8 @@ def test_upload_inside_the_step_costs_under_one_percent_and_the_runner_keeps_ben
     assert abs(runner_ms - out['ms_per_step']) <= 0.02 * out['ms_per_step'], (runner_ms, out['ms_per_step'])
     from tests.conftest import record_achieved
     record_achieved('upload in the step: value %.2f img/s vs resident %.2f (%.2f %%); bench runner loop %.2f ms/it, '
-                    'mimic_runner CLI %.2f ms/it, bench step %.2f ms'
+                    'mimic_runner CLI %.2f ms/it, bench step %.2f ms; value_native_fp32 %.2f img/s (HND_BF16X3=0, fresh child '
+                    'process); data wait %.3f ms/step'
                     % (out['value'], out['value_resident'], 100 * (out['value'] / out['value_resident'] - 1),
-                       out['runner']['ms_per_it'], runner_ms, out['ms_per_step']))
+                       out['runner']['ms_per_it'], runner_ms, out['ms_per_step'], out['value_native_fp32'],
+                       out['upload']['data_wait_ms_per_step']))
