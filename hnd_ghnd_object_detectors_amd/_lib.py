@@ -74,6 +74,7 @@ _SIGNATURES = {
     'hnd_bf16x3_recommended': (C.c_int, [C.c_int64, C.c_int, C.c_int]),
     'hnd_pack_bf16x3_elems': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     'hnd_pack_bf16x3': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int64, vp]),
+    'hnd_bf16x3s_recommended': (C.c_int, [C.c_int64, C.c_int, C.c_int, C.c_int]),
     'hnd_pack_bf16x3s_elems': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     'hnd_pack_bf16x3s': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int64, vp]),
     'hnd_scale_packed_k': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]),

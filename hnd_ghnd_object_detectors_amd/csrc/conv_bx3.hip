@@ -207,6 +207,13 @@ __global__ void __launch_bounds__(256, 1) bx3_kernel(const hnd_conv_desc d, cons
           split_pair(x0, x1, pl[0][0][mi][j], pl[0][1][mi][j], pl[0][2][mi][j]);
         }
       f32x4 acc[MI][NI];
+      // the B fragments of the NEXT k step's first column tile are read during the current step's last one (round 6): at
+      // the top of a step the matrix pipe no longer waits for an LDS round trip
+      bf8 bfirst[3];
+      {
+        const uint16_t* br = Bs + l16 * K + ((g4 ^ l16) * 8);
+        bfirst[0] = *(const bf8*)(br); bfirst[1] = *(const bf8*)(br + PLANE); bfirst[2] = *(const bf8*)(br + 2 * PLANE);
+      }
       f32x4 resv[MI][4];                        // RES: the tile's residual rows (row 4 g4 + r of row group mi)
       uint32_t resm[MI][4];                     // MK: ... and their mask bytes
       for (; cc < seg_hi; cc += 4) {
@@ -272,15 +279,15 @@ __global__ void __launch_bounds__(256, 1) bx3_kernel(const hnd_conv_desc d, cons
           }
           const int pos = ((ks * 4 + g4) ^ l16) * 8;
           bf8 bcur[3], bnxt[3];
-          {
-            const uint16_t* br = Bs + l16 * K + pos;
-            bcur[0] = *(const bf8*)(br); bcur[1] = *(const bf8*)(br + PLANE); bcur[2] = *(const bf8*)(br + 2 * PLANE);
-          }
+          bcur[0] = bfirst[0]; bcur[1] = bfirst[1]; bcur[2] = bfirst[2];
           xfor<NI>([&](auto NIc) __attribute__((always_inline)) {
             constexpr int ni = decltype(NIc)::value;
             if constexpr (ni + 1 < NI) {
               const uint16_t* br = Bs + ((ni + 1) * 16 + l16) * K + pos;
               bnxt[0] = *(const bf8*)(br); bnxt[1] = *(const bf8*)(br + PLANE); bnxt[2] = *(const bf8*)(br + 2 * PLANE);
+            } else {                            // (the next step, or step 0 of the next tile: the same resident slice)
+              const uint16_t* br = Bs + l16 * K + ((((ks + 1) % KS) * 4 + g4) ^ l16) * 8;
+              bfirst[0] = *(const bf8*)(br); bfirst[1] = *(const bf8*)(br + PLANE); bfirst[2] = *(const bf8*)(br + 2 * PLANE);
             }
             xfor<MI>([&](auto MIc) __attribute__((always_inline)) {
               constexpr int mi = decltype(MIc)::value;

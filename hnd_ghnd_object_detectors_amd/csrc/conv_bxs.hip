@@ -12,6 +12,8 @@
 //     global_load_dwordx4 into the accumulator half of the register file), ring of 4 k steps = one 128-k iteration ahead;
 //     out-of-range taps read a page of zeros; the BatchNorm(+ReLU) prologue is applied during the split (padding stays 0);
 //   * the split of k step s + 1 into bf16 planes rides between the MFMAs of k step s (conv_bx3.hip);
+//     (measured and not kept, round 6: the stage's DMA pieces issued one per MFMA tile instead of at the top of the step --
+//     4 % slower; the next step's first B fragments read a step early -- nothing)
 //   * tiles 128 x 128 (two wave columns) or 256 x 64, every wave 64 x 64; the stream-K relay of conv_bstream.hip (a
 //     workgroup whose share ends inside a tile parks the accumulators, its neighbour continues the same k chain) keeps
 //     every CU busy whatever the tile count; epilogue = conv_epilogue.h (any operand set, statistics, backward sums).
@@ -399,8 +401,9 @@ __global__ void __launch_bounds__(256, 1) bxs_kernel(const hnd_conv_desc d, cons
         await8<(u & 1) ? W_ODD : W_EVEN>(ring[u1][0][0], ring[u1][0][1], ring[u1][1][0], ring[u1][1][1], ring[u1][2][0],
                                          ring[u1][2][1], ring[u1][3][0], ring[u1][3][1]);
         // the step being split (u + 1 of this iteration, or step 0 of the next): its prologue constants and tap validity
-        const unsigned oks = u == 3 ? okn[0] : okc[(u + 1) >> 1];
-        pro_fetch((u == 3 ? chn[0] : chc[(u + 1) >> 1]) + ((u + 1) & 1) * 32);
+        constexpr int hs = ((u + 1) >> 1) & 1;            // half of the iteration the split step lies in
+        const unsigned oks = u == 3 ? okn[0] : okc[hs];
+        pro_fetch((u == 3 ? chn[0] : chc[hs]) + ((u + 1) & 1) * 32);
         const uint16_t* stage = Bs + rbuf * STG + frow;
         const int pos = ((par * 4 + g4) ^ swz) * 8;
         bf8 bcur[3], bnxt[3];
@@ -657,6 +660,17 @@ int launch_bxs(const hnd_conv_desc& d, hipStream_t stream) {
 }
 
 }  // namespace hnd
+
+// By LAYER, never by batch (like hnd_bf16x3_recommended): rows one image contributes priced at 16 images per GPU.  Settled
+// by per-launch HIP events of the step (profiles/r06_bxs_shapes.txt, r06_per_launch_events.txt): the kernel wins 1.2-1.5x
+// from K = 256 on; at K = 128 (the masked conv1 data gradients of layer2, one-tap parity launches) the launch is HBM-bound
+// either way and the tiled kernel keeps it.
+extern "C" int hnd_bf16x3s_recommended(int64_t rows_per_image, int kdim, int cout, int taps) {
+  (void)taps;
+  if (rows_per_image <= 0 || cout <= 0 || cout % 64 != 0 || kdim % 128 != 0) return 0;
+  if (const char* e = getenv("HND_BXS")) if (e[0] == '0') return 0;       // A/B: the native B-streamed / tiled kernels
+  return (rows_per_image * 16 >= 16384 && kdim >= 256) ? 1 : 0;
+}
 
 extern "C" size_t hnd_pack_bf16x3s_elems(int rows_pad, int kdim, int groups) {
   if (rows_pad <= 0 || rows_pad % 64 != 0 || kdim <= 0 || kdim % 128 != 0 || groups < 1) return 0;

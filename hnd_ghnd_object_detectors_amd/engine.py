@@ -243,7 +243,8 @@ WINOGRAD6 = os.environ.get('HND_WINOGRAD6', '1') != '0'       # F(6x6,3x3) on ma
 # Which of the STUDENT's forward launches the bf16x3 emulation may take (the teacher, the backward pass and the loss-dead
 # pyramid always may): the student's forward pass makes the ReLU / BatchNorm decisions every gradient hangs on
 BX3_STUDENT_FWD = os.environ.get('HND_BX3_STUDENT_FWD', '1') != '0'
-BX3_HEAD_FWD = os.environ.get('HND_BX3_HEAD_FWD', '1') != '0' 
+_hf = os.environ.get('HND_BX3_HEAD_FWD', '1')        # '0' none, '1' all, or the head conv indices, e.g. '0,1,5'
+BX3_HEAD_FWD = set(range(8)) if _hf == '1' else (set() if _hf == '0' else set(int(v) for v in _hf.split(',')))
 
 
 def use_winograd(cin, cout, stride):
@@ -728,8 +729,7 @@ class HeadEngine(object):
         self._out_buf = self.out_provider(self.out_shape(x)) if self.out_provider is not None else None
         key = (x.data_ptr(), tuple(x.shape), training, ptrs, None if self._out_buf is None else self._out_buf.data_ptr())
         if key != self.plan_key:
-            with ops.emulation_unless(BX3_HEAD_FWD):
-                self._build_forward(x, training)
+            self._build_forward(x, training)
             self.plan_key = key
             self.bwd_key = None
         b = self.bufs
@@ -785,14 +785,16 @@ class HeadEngine(object):
                 if training:        # the transformed input is kept: the weight gradient reuses it
                     v = b.get('wino_keep_v%d' % i,
                               (ops.Wino2Conv.scratch_elems(n, oh, ow, hc.cs_in, hc.cs_out, t2)[0],))
-                wl = ops.Wino2Conv(cur, hc.wino.get(False, t2), y, v, mm, hc.pad, pro_scale=cur_scale,
-                                   pro_shift=cur_shift, pro_relu=cur_relu, stats=st)
+                with ops.emulation_unless(i in BX3_HEAD_FWD):
+                    wl = ops.Wino2Conv(cur, hc.wino.get(False, t2), y, v, mm, hc.pad, pro_scale=cur_scale,
+                                       pro_shift=cur_shift, pro_relu=cur_relu, stats=st)
                 self.wino_fwd[i] = wl
                 self.convs.append(wl.launches('layer1.conv%d' % i))
             else:
-                self.convs.append([(ops.conv_forward(cur, hc.wc.get(False, hc.cs_in), y, 2, 1, hc.pad,
-                                                     pro_scale=cur_scale, pro_shift=cur_shift, pro_relu=cur_relu,
-                                                     stats=st), 'layer1.conv%d' % i)])
+                with ops.emulation_unless(i in BX3_HEAD_FWD):
+                    self.convs.append([(ops.conv_forward(cur, hc.wc.get(False, hc.cs_in), y, 2, 1, hc.pad,
+                                                         pro_scale=cur_scale, pro_shift=cur_shift, pro_relu=cur_relu,
+                                                         stats=st), 'layer1.conv%d' % i)])
             self.ntiles.append(nt)
             flops += 2 * m * hc.cout * 4 * hc.cin
             self.y.append(y)
@@ -1036,13 +1038,14 @@ class HeadEngine(object):
                 ls, _ = _dgrad_with_pack(gbuf[i], hc, tgt, pk)
                 prev = self.layers[i - 1] if i > 0 else None
                 if (FOLD_BNBWD_REDUCE and prev is not None and prev.cs_out == prev.cout and tgt.shape[3] == prev.cs_out
-                        and ls[0].variant in ('igemm_128x128', 'igemm_128x64')):
-                    # a tiled launch: the BatchNorm-backward sums of layer i-1 come out of its epilogue (per 128 pixels)
+                        and ls[0].variant in _STATS_KERNELS):
+                    # a tiled (or B-streamed emulated) launch: the BatchNorm-backward sums of layer i-1 come out of its
+                    # epilogue (per 128 pixels)
                     nblk = ops.stats_tiles(tgt.shape[0] * tgt.shape[1] * tgt.shape[2])
                     part = b.get('bpart_folded%d' % (i - 1), (nblk, 2, prev.cs_out))
                     ls, _ = _dgrad_with_pack(gbuf[i], hc, tgt, pk, stats=part, bwd_stats=(
                         self.y[i - 1], self.scale[i - 1], self.shift[i - 1], self.mean[i - 1], self.rstd[i - 1], prev.relu))
-                    assert ls[0].variant in ('igemm_128x128', 'igemm_128x64'), ls[0].variant
+                    assert ls[0].variant in _STATS_KERNELS, ls[0].variant
                     self.bsteps[i - 1]['folded'] = (part, nblk)
                 st['dgrad'] = [(l, 'layer1.conv%d.dgrad' % i) for l in ls]
                 flops += 2 * npix * hc.cout * 4 * hc.cin
@@ -1054,6 +1057,10 @@ class HeadEngine(object):
                 st['wgrad'], st['dgrad'] = st['wgrad'][1:], st['dgrad'][1:]       # (their own transforms are dropped)
             self.bsteps[i] = st
         self.flops_bwd = flops
+
+
+# kernels whose epilogue can make BatchNorm statistics / backward sums per 128-pixel tile (hnd_conv_desc.stats, .bwd_x)
+_STATS_KERNELS = ('igemm_128x128', 'igemm_128x64', 'bxs_128', 'bxs_64')
 
 
 def _dgrad_with_pack(dy, hc, dx, pk, **kw):

@@ -82,6 +82,11 @@ def emulation_unless(allowed):
     return contextlib.nullcontext() if allowed else emulation('off')
 
 
+def bxs_recommended(rows_per_image, kdim, cout, taps):
+    """the B-streamed emulation kernel, by LAYER (never by batch): hnd_bf16x3s_recommended"""
+    return bool(_L.hnd_bf16x3s_recommended(int(rows_per_image), int(kdim), int(cout), int(taps)))
+
+
 def bx3_recommended(rows_per_image, kdim, cout):
     return bool(_L.hnd_bf16x3_recommended(int(rows_per_image), int(kdim), int(cout)))
 
@@ -99,9 +104,22 @@ def bx3_image(buf, rows_pad, kdim, groups=1, group_stride=0, out=None, force=Fal
     return out
 
 
+def bxs_image(buf, rows_pad, kdim, groups=1, group_stride=0, out=None, force=False):
+    """(re)build the STREAM image (hnd_pack_bf16x3s: the B-streamed emulation kernel, csrc/conv_bxs.hip) of a packed fp32
+    operand; None when the emulation is off (unless `force`) or the kernel cannot use this operand"""
+    if not (bx3_on() or force) or kdim % 128 != 0 or rows_pad % 64 != 0:
+        return None
+    n = int(_L.hnd_pack_bf16x3s_elems(rows_pad, kdim, groups))
+    if out is None or out.numel() != n:
+        out = torch.empty(n, dtype=torch.int16, device=buf.device)
+    check(_L.hnd_pack_bf16x3s(buf.data_ptr(), out.data_ptr(), rows_pad, kdim, groups, int(group_stride), stream_ptr()),
+          'hnd_pack_bf16x3s')
+    return out
+
+
 class PackedWeight(object):
     """K-contiguous GEMM operand made by hnd_pack_weights."""
-    __slots__ = ('buf', 'rows', 'kdim', 'ni', 'nj', 'chan_pad', 'chan_real', 'src', 'args', 'kscale', 'bx3')
+    __slots__ = ('buf', 'rows', 'kdim', 'ni', 'nj', 'chan_pad', 'chan_real', 'src', 'args', 'kscale', 'bx3', 'bxs')
 
     def repack(self):
         if PACK_BATCH['open'] and getattr(self, 'kscale', None) is None:
@@ -119,6 +137,10 @@ class PackedWeight(object):
         if self.ni * self.nj == 1 and self.kdim == self.chan_pad:          # tap-free operands only
             if bx3_on() or getattr(self, 'bx3', None) is not None:          # (an image made once is kept in step with the weights)
                 self.bx3 = bx3_image(self.buf, round_up(self.rows, 64), self.kdim, out=getattr(self, 'bx3', None), force=True)
+        taps = self.ni * self.nj
+        if self.kdim % 128 == 0 and self.chan_pad % 64 == 0 and self.kdim == taps * self.chan_pad:
+            if bx3_on() or getattr(self, 'bxs', None) is not None:
+                self.bxs = bxs_image(self.buf, round_up(self.rows, 64), self.kdim, out=getattr(self, 'bxs', None), force=True)
 
 
 # A caller that refreshes many small operands in a row (the trainable head after every optimizer step) brackets the loop
@@ -205,7 +227,8 @@ class ConvLaunch(object):
         tile = _L.hnd_conv2d_igemm_tile(self.ref)
         self.variant = ('stem7_lds' if tile == 9 else 'igemm_c4_128x64') if self.desc.cin == 4 else \
             ('igemm_128x128', 'igemm_128x64', 'igemm_64x128', 'igemm_64x64', 'thin_n4', 'bres_128',
-             'bres_64', 'bres2_128', 'bres2_64', 'stem7_lds', 'unused', 'bstream_128', 'bstream_64', 'bx3_64')[tile]
+             'bres_64', 'bres2_128', 'bres2_64', 'stem7_lds', 'unused', 'bstream_128', 'bstream_64', 'bx3_64',
+             'bxs_128', 'bxs_64')[tile]
 
     def run(self, stream=None):
         rc = _L.hnd_conv2d_igemm(self.ref, stream if stream is not None else stream_ptr())
@@ -262,6 +285,12 @@ def conv_desc(x, pw, y, *, kh, kw, oh, ow, sh, dh, bh, sw, dw, bw, cout, y_sh=1,
             oh * ow if rows_per_image is None else rows_per_image, pw.kdim, cout))):
         img = None
     d.w_bf16x3 = ptr(img)
+    # ... and its B-streamed build for what the B-resident kernel does not take (taps, long K, strided outputs, statistics)
+    imgs = getattr(pw, 'bxs', None)
+    if imgs is not None and not (BX3_MODE[0] == 'force' or (BX3_MODE[0] == 'policy' and bxs_recommended(
+            oh * ow if rows_per_image is None else rows_per_image, pw.kdim, cout, kh * kw))):
+        imgs = None
+    d.w_bf16x3s = ptr(imgs)
     if stats is not None:
         assert stats.numel() >= stats_tiles(n * oh * ow) * 2 * cout
     if bwd_stats is not None:
@@ -272,7 +301,7 @@ def conv_desc(x, pw, y, *, kh, kw, oh, ow, sh, dh, bh, sw, dw, bw, cout, y_sh=1,
         d.bwd_x, d.bwd_scale, d.bwd_shift, d.bwd_mean, d.bwd_rstd = ptr(bx), ptr(bsc), ptr(bsh), ptr(bmu), ptr(brs)
         d.bwd_relu = int(brelu)
     keep = (x, pw, y, pro_scale, pro_shift, epi_scale, epi_shift, res1, res2, mask, stats, mask_bits, mask_out,
-            bwd_stats, img)
+            bwd_stats, img, imgs)
     return ConvLaunch(d, keep, flops=2 * n * oh * ow * min(cout, pw.rows) * kh * kw * min(cin, pw.chan_real))
 
 

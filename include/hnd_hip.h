@@ -181,6 +181,7 @@ int hnd_pack_bf16x3(const float* w_packed, uint16_t* img, int rows_pad, int kdim
 
 /* The STREAM image for hnd_conv_desc.w_bf16x3s (ABI 12): per (group, 64-row slice, 64-k stage) three planes [64 rows][64 k]
  * of bf16, 16-byte chunk c of row r at position c ^ ((r >> 1) & 7); any packed operand with kdim % 128 == 0 (taps included). */
+int hnd_bf16x3s_recommended(int64_t rows_per_image, int kdim, int cout, int taps);     /* by layer, like hnd_bf16x3_recommended */
 size_t hnd_pack_bf16x3s_elems(int rows_pad, int kdim, int groups);
 int hnd_pack_bf16x3s(const float* w_packed, uint16_t* img, int rows_pad, int kdim, int groups, int64_t group_stride,
                      void* stream);

@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Audit of the inline-asm register rings of bres2_kernel (csrc/conv_bres.hip), bstream_kernel
-(csrc/conv_bstream.hip), wgrad_ring_kernel (csrc/conv_wgrad_ring.hip) and bx3_kernel (csrc/conv_bx3.hip, the opt-in
-bf16x3 emulation) in hipcc's assembly output.
+(csrc/conv_bstream.hip), wgrad_ring_kernel (csrc/conv_wgrad_ring.hip), bx3_kernel (csrc/conv_bx3.hip, the bf16x3
+emulation) and bxs_kernel (csrc/conv_bxs.hip, its B-streamed build: the LDS-DMA pieces of the weight stages sit in the same
+in-order queue) in hipcc's assembly output.
 
 hipcc does not know that a `global_load_dwordx4` inside an asm statement writes its destination LATER: between that
 statement and the `s_waitcnt vmcnt(N)` statement that names the same registers it is free to copy / spill / reuse them.
@@ -38,7 +39,7 @@ def regs_of(text):
 def audit(path):
     kernels, cur, name = {}, None, None
     for line in open(path):
-        m = re.match(r'^(_ZN\S*(?:bres2|bstream|wgrad_ring|(?<!pack_)bx3)_kernel\S*):', line)
+        m = re.match(r'^(_ZN\S*(?:bres2|bstream|wgrad_ring|(?<!pack_)bx3|(?<!pack_)bxs)_kernel\S*):', line)
         if m:
             name, cur = m.group(1), []
             kernels[name] = cur
@@ -89,6 +90,10 @@ def audit(path):
                         for r in dst:
                             pending[r] = no
                         order.append((no, frozenset(dst)))
+                    elif in_asm and text.startswith('global_load_lds_'):
+                        # LDS-DMA (bxs_kernel's weight stages): no register, but a place in the in-order queue that the
+                        # kernel's counts name
+                        order.append((no, frozenset()))
                     elif in_asm and text.startswith('global_load_dwordx4'):
                         dst = regs_of(text.split(',')[0])
                         clash = dst & set(pending)
@@ -148,7 +153,7 @@ def main():
     paths = sys.argv[1:]
     if not paths:
         tmp = tempfile.mkdtemp()
-        for stem in ('conv_bres', 'conv_bstream', 'conv_wgrad_ring', 'conv_bx3'):
+        for stem in ('conv_bres', 'conv_bstream', 'conv_wgrad_ring', 'conv_bx3', 'conv_bxs'):
             path = os.path.join(tmp, stem + '.s')
             src = os.path.join(ROOT, 'hnd_ghnd_object_detectors_amd', 'csrc', stem + '.hip')
             subprocess.check_call(['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950',

@@ -18,7 +18,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
 def family(name):
-    for key, lab in (('bx3_kernel', 'bx3_64 (bf16x3 emulation)'), ('bres2_kernel', 'bres2'), ('bres_kernel', 'bres'),
+    for key, lab in (('bx3_kernel', 'bx3_64 (bf16x3 emulation, B resident)'), ('bxs_kernel', 'bxs (bf16x3 emulation, B streamed)'), ('bres2_kernel', 'bres2'), ('bres_kernel', 'bres'),
                      ('bstream_kernel', 'bstream'), ('wgrad_ring_kernel', 'wgrad_ring'), ('igemm_kernel', 'igemm (tiled)'),
                      ('wgrad_kernel', 'wgrad (LDS-staged)'), ('stem7_wgrad', 'stem7_wgrad'), ('stem7_kernel', 'stem7_lds'),
                      ('wino6_input', 'wino6_input'), ('wino6_output', 'wino6_output'), ('wino26_', 'wino26_*'),

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Per-shape A/B of the opt-in bf16x3 emulation kernel (csrc/conv_bx3.hip) against the native fp32 picker's choice on the 1x1
+"""Per-shape A/B of the B-resident bf16x3 emulation kernel (csrc/conv_bx3.hip) against the native fp32 picker's choice on the 1x1
 shapes of the step it does not take yet or has just started to take: ms per launch (HIP events over 20 launches after 5
 warm-ups, operands re-used, so L2 / MALL-warm like inside the step) and TF-equivalent.
 
@@ -25,6 +25,8 @@ SHAPES = [  # name, cin, cout, n, h, w, stride, residual
     ('fpn.inner3 2048->256', 2048, 256, 16, 25, 42, 1, False),
     ('fpn.inner2 1024->256', 1024, 256, 16, 50, 84, 1, False),
     ('layer2.x.conv1 512->128', 512, 128, 16, 100, 168, 1, False),
+    ('fpn.inner0 256->256 @200x336', 256, 256, 16, 200, 336, 1, False),
+    ('layer2.x.conv3 128->512 +res @100x168', 128, 512, 16, 100, 168, 1, True),
     ('layer3.0.conv1 512->256', 512, 256, 16, 100, 168, 1, False),
 ]
 
@@ -53,10 +55,13 @@ def main():
         pk = ops.pack_weights(wt)
         y = torch.empty(n, oh, ow, cout, device=DEV)
         kw = dict(epi_scale=es, epi_shift=eb, relu=True, res1=r)
-        l0 = ops.conv_forward(x, pk, y, 1, stride, 0, **kw)
+        with ops.emulation('off'):
+            l0 = ops.conv_forward(x, pk, y, 1, stride, 0, **kw)
         t0 = timed(l0)
         pk.bx3 = ops.bx3_image(pk.buf, ops.round_up(cout, 64), cin, force=True)
-        l1 = ops.conv_forward(x, pk, y, 1, stride, 0, **kw)
+        pk.bxs = None                               # (the B-streamed build has its own bench: tools/bench_bxs.py)
+        with ops.emulation('force'):
+            l1 = ops.conv_forward(x, pk, y, 1, stride, 0, **kw)
         gf = 2.0 * n * oh * ow * cin * cout / 1e9
         if l1.variant != 'bx3_64':
             print('%-38s %10.3f %8.1f %10s  (%s: not eligible)' % (name, t0, gf / t0, '-', l0.variant))

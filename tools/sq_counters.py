@@ -19,7 +19,7 @@ from collections import defaultdict
 
 
 def waves_per_simd(name):
-    if 'bres2_kernel' in name or 'bstream_kernel' in name or 'wgrad_ring' in name:
+    if 'bres2_kernel' in name or 'bstream_kernel' in name or 'wgrad_ring' in name or 'bx3_kernel' in name or 'bxs_kernel' in name:
         return 1
     if 'bres_kernel' in name:
         return 2

@@ -28,6 +28,15 @@ def short(name):
     if m:           # B-streamed persistent GEMM (conv_bstream.hip)
         return 'bstream_%d' % (64 * int(m.group(1))) + (('[prologue]' if m.group(2) == 'true' else '') +
                                                       ('[taps]' if m.group(3) == 'true' else '') if FULLNAMES else '')
+    m = re.search(r'bx3_kernel<(\d+), (true|false), (true|false)(?:, (true|false))?>', name)
+    if m:           # fp32 emulated on the bf16 pipe, B resident (conv_bx3.hip): k steps of 32, residual, mask out, mask in
+        return 'bx3_64' + ('[K%d%s%s%s]' % (32 * int(m.group(1)), ', res' if m.group(2) == 'true' else '',
+                                            ', bits out' if m.group(3) == 'true' else '', ', bits in' if m.group(4) == 'true' else '')
+                           if FULLNAMES else '')
+    m = re.search(r'bxs_kernel<(\d+), (true|false), (true|false)>', name)
+    if m:           # ... B streamed (conv_bxs.hip)
+        return 'bxs_%d' % (64 * int(m.group(1))) + (('[prologue]' if m.group(2) == 'true' else '') +
+                                                  ('[taps]' if m.group(3) == 'true' else '') if FULLNAMES else '')
     m = re.search(r'wgrad_ring_kernel<(\d+), (\d+), (true|false), (\d+)>', name)
     if m:           # ring weight gradient (conv_wgrad_ring.hip): wave tile 64 AH x 64 BH, taps, waves per SIMD
         return 'wgrad_ring' + ('[%dx%d%s]' % (64 * int(m.group(1)), 64 * int(m.group(2)), ', taps' if m.group(3) == 'true' else '')
