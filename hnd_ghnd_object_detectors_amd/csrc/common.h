@@ -60,7 +60,7 @@ inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }
 //   igemm_tile=0..3   block tile of the tiled kernel (128x128, 128x64, 64x128, 64x64)
 //   wgrad_ring_taps   the ring weight-gradient kernel also for tap (direct 2x2) problems
 //   bstream_k1024 / bstream_parity   the B-streamed kernel also for K = 1024 -> 256 launches / for stride-2 parity launches
-//   bx3_short_passes                 (opt-in bf16x3 kernel) K > 512 launches of fewer than 16 chunks per team too
+//   bxs_wn1                          (B-streamed emulation kernel) the 256 x 64 tile also where the output has 128-column blocks
 // Returns -1 when `key` is absent, its value (1 without "=value") otherwise.  Read per call: in-process A/B.
 inline int debug_picker(const char* key) {
   const char* e = getenv("HND_DEBUG_PICKER");

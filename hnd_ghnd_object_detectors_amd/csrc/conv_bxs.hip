@@ -89,12 +89,20 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
 // PRO: BatchNorm(+ReLU) of the input on load (pro_scale / pro_shift per input channel); TAPS: kh * kw > 1 or padding.
 template <int WN, bool PRO, bool TAPS>
 __global__ void __launch_bounds__(256, 1) bxs_kernel(const hnd_conv_desc d, const BxsArgs a) {
-  constexpr int WM = 4 / WN, BM = 64 * WM, BN = 64 * WN, MI = 4, NI = 4, NST = 3;
+  // BIG (the 256 x 64 tile: one 64-column slice per workgroup): an LDS stage holds a whole 128-k iteration of the slice and
+  // two stages alternate -- ONE workgroup barrier per 128 k instead of two (round 6: SQ counters showed the 128 x 128 build's
+  // waves parked at waits / barriers 23-30 % of their life against 8-19 % for the barrier-free B-resident kernel)
+  constexpr bool BIG = WN == 1;
+  constexpr int WM = 4 / WN, BM = 64 * WM, BN = 64 * WN, MI = 4, NI = 4, NST = BIG ? 2 : 3;
   constexpr int PLANE = 64 * 64;            // bf16 elements of one plane of a slice stage
   constexpr int SLICE = 3 * PLANE;          // one 64-column slice, one 64-k stage: 24 KB
-  constexpr int STG = WN * SLICE;           // bf16 elements of an LDS stage
-  constexpr int NBL = 6 * WN;               // LDS-DMA pieces per lane and stage
-  constexpr int W_ODD = 24 + NBL, W_EVEN = 24 + 2 * NBL, W_STAGE = 32 + NBL;
+  constexpr int STG = 2 * SLICE;            // bf16 elements of an LDS stage: two slices x 64 k, or one slice x 128 k (48 KB)
+  constexpr int NBL = 12;                   // LDS-DMA pieces per lane and stage
+  // waits (see the counter note): 128 x 128 build as described there; BIG: the pieces of iteration i + 1 are issued at the
+  // top of iteration i (after its barrier), so the stage wait has the 4 x 8 ring loads of one iteration behind it, a slot
+  // wait at steps 0 .. 2 three steps' ring loads + the pieces, at step 3 (slot 0 of the next iteration) three steps' loads
+  constexpr int W_ODD = 24 + NBL, W_EVEN = 24 + 2 * NBL, W_STAGE = BIG ? 32 : 32 + NBL;
+  constexpr int W_BIG_012 = 24 + NBL, W_BIG_3 = 24;
   static_assert(W_EVEN <= 63 && W_STAGE <= 63, "vmcnt holds 6 bits");
   extern __shared__ __attribute__((aligned(16))) uint16_t Bs[];     // [NST][WN][3 planes][64 rows][64 k]
   float* pro = (float*)(Bs + NST * STG);                            // [2][cin] prologue scale, shift
@@ -218,11 +226,12 @@ __global__ void __launch_bounds__(256, 1) bxs_kernel(const hnd_conv_desc d, cons
     return d.w_bf16x3s + ((grp * (size_t)nsl + (size_t)(nt * WN)) * (size_t)(2 * nit)) * (size_t)SLICE + (size_t)tid * 8;
   };
   const size_t slice_stride = (size_t)(2 * nit) * (size_t)SLICE;     // elements between two slices of one group
+  // stage_in_tile counts 64-k stages; BIG: the two consecutive stages of an iteration are 48 contiguous KB of the image
   auto b_issue = [&](const uint16_t* bt, int stage_in_tile, int lds_stage) {
     const unsigned dst0 = lds0 + (unsigned)lds_stage * (unsigned)(STG * 2) + wave_u * 1024u;
 #pragma unroll
-    for (int w = 0; w < WN; ++w) {
-      const uint16_t* src = bt + (size_t)w * slice_stride + (size_t)stage_in_tile * (size_t)SLICE;
+    for (int w = 0; w < 2; ++w) {
+      const uint16_t* src = bt + (BIG ? (size_t)0 : (size_t)w * slice_stride) + (size_t)(stage_in_tile + (BIG ? w : 0)) * (size_t)SLICE;
 #pragma unroll
       for (int j = 0; j < 6; ++j)
         glds16(src + j * 2048, (unsigned)__builtin_amdgcn_readfirstlane((int)(dst0 + (unsigned)(w * SLICE * 2 + j * 4096))));
@@ -262,11 +271,11 @@ __global__ void __launch_bounds__(256, 1) bxs_kernel(const hnd_conv_desc d, cons
   a_addr(rn, pn.it * 128 + 64, lpn[1], okn[1], chn[1]);
 
   f32x4 ring[4][MI][2];
-  // ---- fill, in the steady state's issue order: B(0) A(0) A(1) B(1) A(2) A(3)
+  // ---- fill, in the steady state's issue order: B(0) A(0) A(1) B(1) A(2) A(3); BIG: B(0, 1) A(0) A(1) A(2) A(3)
   b_issue(bt, 2 * pn.it, 0);
   zfor<4>([&](auto U) __attribute__((always_inline)) {
     constexpr int u = decltype(U)::value, hf = u >> 1, o = (u & 1) * 128;
-    if constexpr (u == 2) b_issue(bt, 2 * pn.it + 1, 1);
+    if constexpr (u == 2 && !BIG) b_issue(bt, 2 * pn.it + 1, 1);
     zfor<MI>([&](auto I) __attribute__((always_inline)) {
       constexpr int mi = decltype(I)::value;
       aload<o>(ring[u][mi][0], lpn[hf][mi]);
@@ -310,8 +319,8 @@ __global__ void __launch_bounds__(256, 1) bxs_kernel(const hnd_conv_desc d, cons
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // the prologue table is complete
   }
   // step 0 of the first iteration: split before the loop (a wait in the place of step "-1")
-  await8<W_ODD>(ring[0][0][0], ring[0][0][1], ring[0][1][0], ring[0][1][1], ring[0][2][0], ring[0][2][1], ring[0][3][0],
-                ring[0][3][1]);
+  await8<BIG ? W_BIG_3 : W_ODD>(ring[0][0][0], ring[0][0][1], ring[0][1][0], ring[0][1][1], ring[0][2][0], ring[0][2][1],
+                                ring[0][3][0], ring[0][3][1]);
   pro_fetch(chc[0]);
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
@@ -331,7 +340,7 @@ __global__ void __launch_bounds__(256, 1) bxs_kernel(const hnd_conv_desc d, cons
 
   int rbuf = 0;                                         // LDS stage the MFMAs read; stage rbuf + 2 is being filled
   const int swz = l16 >> 1;                             // chunk c of row r sits at position c ^ ((r >> 1) & 7)
-  const int frow = wn * SLICE + l16 * 64;               // the lane's fragment row (ni = 0) inside a stage
+  const int frow = (BIG ? 0 : wn * SLICE) + l16 * 64;   // the lane's fragment row (ni = 0) inside a stage (BIG: of its first half)
 
   for (int sg = 0; sg < nseg; ++sg) {
     int tile, it0, it1, kind;
@@ -385,12 +394,12 @@ __global__ void __launch_bounds__(256, 1) bxs_kernel(const hnd_conv_desc d, cons
     for (int it = it0; it < it1; ++it) {
       zfor<4>([&](auto U) __attribute__((always_inline)) {
         constexpr int u = decltype(U)::value, hf = u >> 1, par = u & 1, u1 = (u + 1) & 3;
-        if constexpr ((u & 1) == 0) {
-          // this lane's pieces of stage `rbuf` have landed (issued two stages ago); then everybody's
+        if constexpr (BIG ? (u == 0) : ((u & 1) == 0)) {
+          // this lane's pieces of stage `rbuf` have landed (issued two stages / one iteration ago); then everybody's
           asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(W_STAGE) : "memory");
-          int wst = rbuf + 2;
+          int wst = rbuf + (BIG ? 1 : 2);
           wst = wst >= NST ? wst - NST : wst;
-          b_issue(bt, 2 * pn.it + hf, wst);             // the same half of the NEXT iteration
+          b_issue(bt, 2 * pn.it + (BIG ? 0 : hf), wst);         // the same half (BIG: the whole) of the NEXT iteration
         }
         // slot u was split during the previous step: refill it with step u of the next iteration
         zfor<MI>([&](auto I) __attribute__((always_inline)) {
@@ -398,13 +407,13 @@ __global__ void __launch_bounds__(256, 1) bxs_kernel(const hnd_conv_desc d, cons
           aload<par * 128>(ring[u][mi][0], lpn[hf][mi]);
           aload<par * 128 + 16>(ring[u][mi][1], lpn[hf][mi]);
         });
-        await8<(u & 1) ? W_ODD : W_EVEN>(ring[u1][0][0], ring[u1][0][1], ring[u1][1][0], ring[u1][1][1], ring[u1][2][0],
+        await8<BIG ? (u == 3 ? W_BIG_3 : W_BIG_012) : ((u & 1) ? W_ODD : W_EVEN)>(ring[u1][0][0], ring[u1][0][1], ring[u1][1][0], ring[u1][1][1], ring[u1][2][0],
                                          ring[u1][2][1], ring[u1][3][0], ring[u1][3][1]);
         // the step being split (u + 1 of this iteration, or step 0 of the next): its prologue constants and tap validity
         constexpr int hs = ((u + 1) >> 1) & 1;            // half of the iteration the split step lies in
         const unsigned oks = u == 3 ? okn[0] : okc[hs];
         pro_fetch((u == 3 ? chn[0] : chc[hs]) + ((u + 1) & 1) * 32);
-        const uint16_t* stage = Bs + rbuf * STG + frow;
+        const uint16_t* stage = Bs + rbuf * STG + frow + (BIG ? hf * SLICE : 0);
         const int pos = ((par * 4 + g4) ^ swz) * 8;
         bf8 bcur[3], bnxt[3];
         bcur[0] = *(const bf8*)(stage + pos);
@@ -453,7 +462,7 @@ __global__ void __launch_bounds__(256, 1) bxs_kernel(const hnd_conv_desc d, cons
           });
           if constexpr (ni + 1 < NI) { bcur[0] = bnxt[0]; bcur[1] = bnxt[1]; bcur[2] = bnxt[2]; }
         });
-        if constexpr ((u & 1) == 1) rbuf = rbuf + 1 >= NST ? 0 : rbuf + 1;
+        if constexpr (BIG ? (u == 3) : ((u & 1) == 1)) rbuf = rbuf + 1 >= NST ? 0 : rbuf + 1;
       });
       // the loaded iteration becomes the computed one; the stream moves on
 #pragma unroll
@@ -586,7 +595,7 @@ int launch_w(const hnd_conv_desc& d, const BxsArgs& a, size_t lds, int grid, hip
 }
 
 size_t bxs_lds_bytes(const hnd_conv_desc& d, int wn) {
-  return (size_t)3 * wn * 3 * 4096 * sizeof(uint16_t) + (d.pro_scale ? 2 * (size_t)d.cin : 0) * sizeof(float) +
+  return (size_t)(wn == 1 ? 2 : 3) * 2 * 3 * 4096 * sizeof(uint16_t) + (d.pro_scale ? 2 * (size_t)d.cin : 0) * sizeof(float) +
          4 * 128 * sizeof(int) + (size_t)(4 / wn) * 2 * 64 * wn * sizeof(float);
 }
 
@@ -612,11 +621,12 @@ int bxs_variant(const hnd_conv_desc& d) {
   if (!taps && ((long long)(d.oh - 1) * d.sh >= d.h || (long long)(d.ow - 1) * d.sw >= d.w_)) return 0;
   if (d.cout % 64 != 0 || d.cout > 4096 || d.cin > 4096) return 0;
   if ((long long)d.n * d.h * d.w_ * d.cin >= (1ll << 32)) return 0;      // 32-bit pixel arithmetic on the tap path
-  const int wn = d.cout % 128 == 0 ? 2 : 1;
+  // 128 x 128 tiles where the output has whole 128-column blocks, else 256 x 64 (HND_DEBUG_PICKER=bxs_wn1: always the
+  // latter -- A/B of the one-barrier-per-128-k build)
+  const int wn = (d.cout % 128 == 0 && hnd::debug_picker("bxs_wn1") <= 0) ? 2 : 1;
   const int bm = 64 * (4 / wn);
   if (d.w_group_rows % bm != 0) return 0;
   if (d.stats && d.cout != d.ldc && d.bwd_x) return 0;
-  if (d.mask_out && wn != 2) return 0;                                   // (a lane owns whole nibbles in both builds; kept like the tiled kernel)
   if (bxs_lds_bytes(d, wn) > 160 * 1024) return 0;
   return wn;
 }

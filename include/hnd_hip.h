@@ -141,7 +141,9 @@ typedef struct hnd_conv_desc {
    *     a finite value; native fp32 gives +-Inf where no Inf - Inf / 0 * Inf occurs.  (Inf splits into Inf + NaN + NaN.)
    *   denormal / tiny: the bf16 pipe flushes denormal plane values.  An operand element |x| < 2^-126 counts as 0; for
    *     2^-126 <= |x| < 2^-110 its mid / lo planes (|.| < 2^-8 |x|, 2^-16 |x|) may flush, i.e. x is used with relative error
-   *     <= 2^-8: absolute error per product <= 2^-118 |b|.  Elements >= 2^-110 (7.7e-34) are exact. */
+   *     <= 2^-8: absolute error per product <= 2^-118 |b|.  Elements >= 2^-110 (7.7e-34) are exact.  (Upper bounds; measured
+   *     on gfx950, worst |y - exact| / sum |a||b|: 9e-6 in the middle range, 3.4e-2 for denormal inputs, 3e-7 above 2^-110;
+   *     native fp32 MFMA 4e-7 ... 5e-6.) */
   const uint16_t* w_bf16x3;
   /* ABI 12: the STREAM image of the same three planes (hnd_pack_bf16x3s), or NULL.  Attached, it asks for the B-streamed
    * emulation kernel (csrc/conv_bxs.hip) on launches the B-resident one above does not take: convolutions over taps (cin %

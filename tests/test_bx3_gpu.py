@@ -402,8 +402,9 @@ def test_bx3_non_finite_inputs_are_loud_and_denormals_behave_as_documented(ops):
     """VERDICT r5 item 1(b), through hnd_conv2d_igemm (include/hnd_hip.h, hnd_conv_desc.w_bf16x3 'DEVIATIONS'):
     (i) an Inf / -Inf / NaN anywhere in an A row makes EVERY output of that row non-finite -- never a finite value -- and
     leaves every other row's bits alone; a non-finite weight does the same to its output channel;
-    (ii) tiny operands: |x| < 2^-126 count as zero, 2^-126 <= |x| < 2^-110 are used with relative error <= 2^-8, anything
-    larger is exact -- so the result stays within 2^-8 sum |a||b| of the exact one (native fp32: 1e-6 of it)."""
+    (ii) tiny operands (the header's bounds: |x| < 2^-126 may count as zero, 2^-126 <= |x| < 2^-110 may lose their mid / lo
+    planes, anything larger is exact): asserted at ~10x the ACHIEVED figures -- 9e-6 of sum |a||b| in the middle range, 3.4e-2
+    for denormal inputs (the pipe keeps their hi plane), 3e-7 above 2^-110; native fp32 MFMA: 4e-7 ... 5e-6."""
     g = torch.Generator().manual_seed(1234)
     n, h, w, cin, cout = 2, 64, 96, 256, 256
     x = torch.randn(n, h, w, cin, generator=g)
@@ -448,8 +449,8 @@ def test_bx3_non_finite_inputs_are_loud_and_denormals_behave_as_documented(ops):
     assert torch.equal(yw[:, kc], clean[:, kc])
     # (ii) tiny operands
     from tests.conftest import record_achieved
-    for name, scale, frac in (('2^-126 <= |x| < 2^-110', 2.0 ** -118, 2.0 ** -8), ('denormal |x| < 2^-126', 2.0 ** -130, 1.0),
-                              ('|x| >= 2^-110 (exact planes; partial products near 2^-126)', 2.0 ** -100, 2.0 ** -12)):
+    for name, scale, frac in (('2^-126 <= |x| < 2^-110', 2.0 ** -118, 1e-4), ('denormal |x| < 2^-126', 2.0 ** -130, 0.35),
+                              ('|x| >= 2^-110 (exact planes; partial products near 2^-126)', 2.0 ** -100, 3e-6)):
         xt = (x.sign() * (x.abs().clamp(2.0 ** -6, 8.0)) * scale)
         if name.startswith('denormal'):
             assert float(xt.abs().max()) < 2.0 ** -126
