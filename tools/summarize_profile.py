@@ -137,9 +137,10 @@ if 'FETCH_SIZE' in traffic and 'WRITE_SIZE' in traffic:
     tj = {'source': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `bench.py --steps 1 '
                     '--warmup 1`, summed over all 6 steps that process runs (1 warm-up + 1 timed + 3 enqueue-probe + 1 '
                     'event-profiled) and divided by the dispatch count; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts '
-                    '64 B per 128-B request)', 'unit': 'bytes per launch', 'kernels': {}}
+                    '64 B per 128-B request)', 'unit': 'bytes per kernel dispatch (a K > 256 launch of the B-resident emulation kernel is several dispatches: one per pass over k)',
+          'steps_in_process': 6, 'kernels': {}}
     for k, (fv, fn) in traffic['FETCH_SIZE'].items():
-        if k in traffic['WRITE_SIZE'] and ('igemm' in k or 'wgrad' in k or 'bres' in k):
+        if k in traffic['WRITE_SIZE'] and any(t in k for t in ('igemm', 'wgrad', 'bres', 'bx3', 'bxs', 'bstream', 'stem7')):
             wv, wn = traffic['WRITE_SIZE'][k]
             tj['kernels'][k] = {'dispatches': fn, 'fetch_kib_raw': fv, 'write_kib': wv,
                                 'traffic_bytes_per_launch': int((2 * fv + wv) * 1024 / fn)}
