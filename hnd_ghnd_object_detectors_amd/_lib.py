@@ -116,6 +116,8 @@ _SIGNATURES = {
     'hnd_adam_step_flat': (C.c_int, [vp, vp, vp, vp, C.c_int64] + [C.c_float] * 4 + [C.c_int64, C.c_float, vp]),
     'hnd_subsample2': (C.c_int, [vp, vp] + [C.c_int] * 6 + [vp]),
     'hnd_fill': (C.c_int, [vp, C.c_int64, C.c_float, vp]),
+    'hnd_upsample_nearest_bwd': (C.c_int, [vp, vp] + [C.c_int] * 7 + [vp]),
+    'hnd_add_inplace': (C.c_int, [vp, vp, C.c_int64, vp]),
     'hnd_minmax_scratch_elems': (C.c_size_t, []),
     'hnd_quantize_u8': (C.c_int, [vp, C.c_int64, C.c_int, C.c_int, vp, vp, vp, vp]),
     'hnd_dequantize_u8': (C.c_int, [vp, vp, vp, C.c_int64, C.c_int, C.c_int, vp]),

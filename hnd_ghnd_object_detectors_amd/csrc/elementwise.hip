@@ -701,6 +701,39 @@ __global__ void subsample2_kernel(const float* __restrict__ x, float* __restrict
   }
 }
 
+// backward of F.interpolate(coarse, size=(H, W), mode='nearest') (the FPN's top-down path, torchvision 0.4.2
+// ops/feature_pyramid_network.py): fine pixel (Y, X) reads coarse pixel (floor(Y h / H), floor(X w / W)), so coarse pixel
+// (y, x) receives the sum over its preimage rows [ceil(y H / h), ceil((y + 1) H / h)) x columns likewise -- a fixed order
+// (row-major), no atomics.  accumulate: added to what g_coarse holds.
+__global__ void upsample_nearest_bwd_kernel(const float* __restrict__ g_fine, float* __restrict__ g_coarse, int n, int H,
+                                            int W, int h, int w, int c, int accumulate) {
+  const int c4n = c >> 2;
+  const long long total = (long long)n * h * w * c4n;
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(e % c4n);
+    long long p = e / c4n;
+    const int x = (int)(p % w);
+    p /= w;
+    const int y = (int)(p % h), b = (int)(p / h);
+    const int y0 = (int)(((long long)y * H + h - 1) / h), y1 = (int)(((long long)(y + 1) * H + h - 1) / h);
+    const int x0 = (int)(((long long)x * W + w - 1) / w), x1 = (int)(((long long)(x + 1) * W + w - 1) / w);
+    f32x4 acc = accumulate ? *(const f32x4*)(g_coarse + e * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int yy = y0; yy < y1 && yy < H; ++yy)
+      for (int xx = x0; xx < x1 && xx < W; ++xx)
+        acc += *(const f32x4*)(g_fine + (((size_t)b * H + yy) * W + xx) * c + c4 * 4);
+    *(f32x4*)(g_coarse + e * 4) = acc;
+  }
+}
+
+__global__ void add_inplace_kernel(float* __restrict__ x, const float* __restrict__ y, long long n4) {
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < n4; e += (long long)gridDim.x * blockDim.x) {
+    f32x4 v = *(const f32x4*)(x + e * 4);
+    v += *(const f32x4*)(y + e * 4);
+    *(f32x4*)(x + e * 4) = v;
+  }
+}
+
 __global__ void fill_kernel(float* x, long long n, float v) {
   for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x)
     x[e] = v;
@@ -1109,6 +1142,22 @@ int hnd_subsample2(const float* x, float* y, int n, int h, int w, int c, int oh,
   hipLaunchKernelGGL(subsample2_kernel, dim3(grid_for((long long)n * oh * ow * (c / 4))), dim3(256), 0,
                      hnd::as_stream(stream), x, y, n, h, w, c, oh, ow);
   return hnd::check_launch("hnd_subsample2");
+}
+
+int hnd_upsample_nearest_bwd(const float* g_fine, float* g_coarse, int n, int H, int W, int h, int w, int c, int accumulate,
+                             void* stream) {
+  HND_REQUIRE(g_fine && g_coarse && n > 0 && H >= h && W >= w && h > 0 && w > 0 && c > 0 && c % 4 == 0,
+              "hnd_upsample_nearest_bwd: bad arguments (the fine map must not be smaller than the coarse one; c %% 4 == 0)");
+  hipLaunchKernelGGL(upsample_nearest_bwd_kernel, dim3(grid_for((long long)n * h * w * (c / 4))), dim3(256), 0,
+                     hnd::as_stream(stream), g_fine, g_coarse, n, H, W, h, w, c, accumulate);
+  return hnd::check_launch("hnd_upsample_nearest_bwd");
+}
+
+int hnd_add_inplace(float* x, const float* y, int64_t numel, void* stream) {
+  HND_REQUIRE(x && y && numel > 0 && numel % 4 == 0, "hnd_add_inplace: bad arguments (numel %% 4 == 0)");
+  hipLaunchKernelGGL(add_inplace_kernel, dim3(grid_for(numel / 4)), dim3(256), 0, hnd::as_stream(stream), x, y,
+                     (long long)(numel / 4));
+  return hnd::check_launch("hnd_add_inplace");
 }
 
 size_t hnd_minmax_scratch_elems(void) { return 2 * kMinMaxBlocks; }

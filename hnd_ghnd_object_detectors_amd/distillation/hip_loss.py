@@ -75,7 +75,7 @@ class _DistillLossFn(torch.autograd.Function):
         go = grad_output.detach().reshape(()).float().contiguous()
         for buf in st['grad_bufs']:
             ops.scale_by_device_scalar(buf, go)
-        body.hnd_backward(st['top'], st['loss_grads'], grad_dst, st['top_block'], st['block_grads'])
+        body.hnd_backward(st['top'], st['loss_grads'], grad_dst, st['top_block'], st['block_grads'], fpn=st.get('fpn'))
         del views
         hook = getattr(body, '_post_backward', None)
         if hook is not None:        # parallel.DistributedStudent: the stem's wgrad (last kernel) is enqueued -> exchange
@@ -121,7 +121,8 @@ def _early_host_copy(loss_value):
 
 _ORDER = ('layer1', 'layer2', 'layer3', 'layer4')
 _SUPPORTED = ('backbone.body.layerN; backbone.body.layerN.K (a Bottleneck of layer2-4); backbone.body.layer1.decoder '
-              '(= the layer1 output)')
+              '(= the layer1 output); backbone.body.layer1.encoder (the bottleneck tensor); backbone.fpn.layer_blocks.K '
+              '(a pyramid map)')
 
 
 def _student_position(src, body):
@@ -133,8 +134,7 @@ def _student_position(src, body):
     if sub is None or sub == 'decoder':
         return lname, None
     if sub == 'encoder':
-        raise NotImplementedError('a loss term on backbone.body.layer1.encoder (the bottleneck tensor itself) has no '
-                                  'backward plan on the HIP path; supported student-side paths: %s' % _SUPPORTED)
+        return lname, 'encoder'             # below the layer1 output: the gradient enters in the middle of the head
     nblocks = len(body[lname])
     if not (isinstance(sub, int) and 0 <= sub < nblocks):
         raise NotImplementedError('unexpected source %r of a student tensor' % (src[1:],))
@@ -146,26 +146,62 @@ def distill_loss(terms):
     Teacher tensors may be ANY tensor produced by the HIP path; student tensors are located in the backward plan by
     their ``_hnd_src`` tag (see _student_position)."""
     srcs = [getattr(s, '_hnd_src', None) for _, _, s, _ in terms]
-    body = srcs[0][0] if srcs[0] is not None else None
-    if isinstance(body, str):           # ('fpn', ...): a pyramid map on the student side
-        raise NotImplementedError('a loss term on the student\'s feature pyramid would need the backward of the (frozen) '
-                                  'FPN, which is not built; supported student-side paths: %s' % _SUPPORTED)
+    # a pyramid map on the student side is tagged ('fpn', 'layer_blocks', level, FeaturePyramidNetwork module, engine)
+    is_fpn = [src is not None and isinstance(src[0], str) and src[0] == 'fpn' for src in srcs]
+    body = None
+    for src, f in zip(srcs, is_fpn):
+        if src is not None:
+            body = src[3].__dict__.get('_body') if f else src[0]
+            break
+    for src, f in zip(srcs, is_fpn):
+        if f and (src[1] != 'layer_blocks' or src[3].__dict__.get('_body') is not body):
+            raise NotImplementedError('student-side pyramid terms must sit on backbone.fpn.layer_blocks.K of the student; '
+                                      'supported student-side paths: %s' % _SUPPORTED)
     trainable = body is not None and getattr(body, '_last_keep', False)
-    pos = [_student_position(src, body) for src in srcs]
+    pos = [('fpn', src[2]) if f else _student_position(src, body) for src, f in zip(srcs, is_fpn)]
     dev = terms[0][2].device
+    fpn_levels = [p[1] for p in pos if p[0] == 'fpn']
+    if fpn_levels and any(src[3].__dict__.get('_engine') is not src[4] for src, f in zip(srcs, is_fpn) if f):
+        raise NotImplementedError('a loss term on a pyramid map with the shared trunk on (HND_MERGE_TRUNK=1) is not built')
 
     def rank(p):
+        if p[0] == 'fpn':
+            return (-2, 0)                  # never the entry point itself: its gradient reaches layer4 through the pyramid
+        if p[1] == 'encoder':
+            return (0, -1)                  # below the layer1 output
         nb = len(body[p[0]]) if p[0] != 'layer1' else 1
         return (_ORDER.index(p[0]), nb - 1 if p[1] is None else p[1])
     top = max(pos, key=rank)
+    if fpn_levels:
+        # a pyramid map depends on every coarser layer output down the top-down path: the backward starts at layer4
+        if top[0] != 'fpn' and rank(top) > rank(('layer4', None)):
+            raise NotImplementedError('unexpected position %r above layer4' % (top,))
+        if any(p[0] == 'layer4' and p[1] is not None for p in pos):
+            raise NotImplementedError('a pyramid term together with a term on an inner Bottleneck of layer4 is not built')
+        top = ('layer4', None)
     pairs, loss_grads, block_grads, grad_bufs = [], {}, {}, []
+    fpn_grads, fpn_state, enc_seen = {}, [None], [False]
     for (tname, t_out, s_out, factor), p in zip(terms, pos):
         t_buf, s_buf = to_nhwc(t_out), to_nhwc(s_out)
         if tuple(t_buf.shape) != tuple(s_buf.shape):
             raise ValueError('teacher/student shapes differ for term %s: %s vs %s'
                              % (tname, tuple(t_buf.shape), tuple(s_buf.shape)))
         grad = None
-        if trainable:
+        if trainable and p[0] == 'fpn':
+            fpn_eng = srcs[pos.index(p)][4]
+            if p[1] in fpn_grads:
+                raise NotImplementedError('two loss terms on pyramid map %d' % p[1])
+            grad = fpn_grads[p[1]] = fpn_eng.term_grad_buffer(p[1])
+            fpn_state[0] = fpn_eng
+            grad_bufs.append(grad)
+        elif trainable and p[1] == 'encoder':
+            head = body.layer_engine('layer1')
+            if enc_seen[0]:
+                raise NotImplementedError('two loss terms on the bottleneck tensor')
+            enc_seen[0] = True
+            grad = head.enc_grad_buffer(top=(p == top))
+            grad_bufs.append(grad)
+        elif trainable:
             lname, blk = p
             eng = body.layer_engine(lname)          # its own engine, or the SharedTrunk's (engine.SharedTrunk)
             if p == top:
@@ -182,7 +218,9 @@ def distill_loss(terms):
                     raise NotImplementedError('two loss terms on the output of %s.%d' % (lname, blk))
                 block_grads[lname][blk] = grad
             grad_bufs.append(grad)
-        pairs.append((t_buf, s_buf, grad, float(factor), p == top))
+        # (masked by the producing ReLU only where the tensor IS a ReLU output that starts the backward: layer outputs /
+        # Bottleneck outputs -- not the bottleneck tensor, a raw conv output, nor a pyramid map)
+        pairs.append((t_buf, s_buf, grad, float(factor), p == top and p[0] != 'fpn' and p[1] != 'encoder'))
     if len([p for p in pos if p == top]) > 1:
         raise NotImplementedError('two loss terms on the same (top) student tensor')
     key = tuple((p[0].data_ptr(), p[1].data_ptr(), None if p[2] is None else p[2].data_ptr(), p[3], p[4])
@@ -202,8 +240,9 @@ def distill_loss(terms):
     if arena is None or [id(p) for p in arena.params] != [id(p) for p in params]:
         arena = GradArena(params)
         body._grad_arena = arena
-    state = {'body': body, 'arena': arena, 'top': top[0], 'top_block': top[1], 'loss_grads': loss_grads,
-             'block_grads': block_grads, 'grad_bufs': grad_bufs}
+    state = {'body': body, 'arena': arena, 'top': top[0], 'top_block': None if top[1] == 'encoder' else top[1],
+             'loss_grads': loss_grads, 'block_grads': block_grads, 'grad_bufs': grad_bufs,
+             'fpn': (fpn_state[0], fpn_grads, any(p == ('layer4', None) for p in pos)) if fpn_grads else None}
     loss = _DistillLossFn.apply(loss_value, state, *params)
     if EARLY_LOSS_COPY and loss.is_cuda:
         host = _early_host_copy(loss)

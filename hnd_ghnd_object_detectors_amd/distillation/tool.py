@@ -72,7 +72,9 @@ class DistillationBox(nn.Module):
         self.overlap_teacher = os.environ.get('HND_TEACHER_STREAM', '1') != '0'
         self._side_stream = None
         # the criterion ignores the models' own outputs (org_loss_factor 0): their FPNs may trail into the backward
-        self.defer_fpn = _defer_fpn_default() and getattr(self.criterion, 'org_loss_factor', 1) == 0
+        # ... unless a term sits on a pyramid map (hooks on backbone.fpn.*): then the pyramids are part of the loss
+        fpn_terms = any('.fpn.' in p or p.startswith('fpn.') for pair in self.target_module_pairs for p in pair)
+        self.defer_fpn = _defer_fpn_default() and getattr(self.criterion, 'org_loss_factor', 1) == 0 and not fpn_terms
         self._fpn_stream = None
         self._trunk = None          # engine.SharedTrunk, built lazily when both backbones qualify
 

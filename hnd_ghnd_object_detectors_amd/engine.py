@@ -898,10 +898,27 @@ class HeadEngine(object):
         self.g_out = self.bufs.get('g_out', self.out.shape)
         return self.g_out
 
+    def enc_grad_buffer(self, top):
+        """where the loss gradient of a term on the BOTTLENECK TENSOR (a hook on ``layer1.encoder``: the raw output of the
+        encoder's last conv) is written.  top: no term sits above it -- the backward then STARTS there (the decoder carries
+        no gradient) and the buffer is that conv's dy itself; else it is added to the dy arriving from the decoder."""
+        zi = self.encoder_len - 1
+        self._enc = (self.bufs.get('g%d' % zi if top else 'enc_loss_grad', self.y[zi].shape), bool(top))
+        if top:
+            self.g_out = None
+        return self._enc[0]
+
     def backward(self, grad_dst, need_input_grad):
         """self.g_out = grad w.r.t. the layer output. grad_dst: dict param -> destination tensor (or missing).
         Returns the buffer holding the gradient w.r.t. the layer input (stem output) if need_input_grad."""
-        key = (self.g_out.data_ptr(), need_input_grad, tuple(sorted((id(p), t.data_ptr()) for p, t in grad_dst.items())))
+        enc = getattr(self, '_enc', None)
+        self._enc = None                    # (set again by the next forward's loss, if it still has such a term)
+        enc_top = enc is not None and enc[1]
+        zi = self.encoder_len - 1
+        if enc_top and self.g_out is None:
+            self.g_out = self.bufs.get('g_out', self.out.shape)       # (never read: the plan below skips the decoder)
+        key = (self.g_out.data_ptr(), need_input_grad, tuple(sorted((id(p), t.data_ptr()) for p, t in grad_dst.items())),
+               None if enc is None else (enc[0].data_ptr(), enc_top))
         if key != self.bwd_key:
             self._build_backward(grad_dst, need_input_grad)
             self.bwd_key = key
@@ -914,6 +931,19 @@ class HeadEngine(object):
         for i in range(len(self.layers) - 1, -1, -1):
             hc, st = self.layers[i], self.bsteps[i]
             g = st['g']
+            if enc_top and i >= zi:
+                # the gradient enters at the bottleneck tensor: the decoder (and the BatchNorm behind the bottleneck, which
+                # is decoder.0) has none -- its parameters get exact zeros, as autograd leaves them untouched
+                for t in ([st['dgamma'], st['dbeta']] + ([grad_dst[hc.conv.weight]] if (i > zi and hc.conv.weight in grad_dst) else [])):
+                    ops.fill(t, 0.0)
+                if i > zi:
+                    continue
+                # i == zi: g (= enc[0]) already holds dy of the encoder's last conv
+                for l, tag in st['wgrad']:
+                    _run(l, tag)
+                for l, tag in st['dgrad']:
+                    _run(l, tag)
+                continue
             if st['folded'] is None:
                 ops.bn_bwd_reduce(g, self.y[i], self.scale[i], self.shift[i], self.mean[i], self.rstd[i], hc.relu,
                                   st['part'])
@@ -926,6 +956,8 @@ class HeadEngine(object):
                 _run(st['fused'], 'layer1.conv%d.bnbwd_transforms' % i)
             else:
                 ops.bn_bwd_apply(g, self.y[i], self.scale[i], self.shift[i], st['k123'], hc.relu, g)   # in place -> dy
+                if enc is not None and i == zi:          # + the gradient of the term on the bottleneck tensor
+                    ops.add_inplace(g, enc[0])
             if side is not None and st['wgrad']:
                 # dy (or Z) of this layer is complete on the main stream here; the weight gradient reads it, the kept
                 # forward V and buffers of its own, and writes only dW: it runs beside the data-gradient chain
@@ -1131,6 +1163,53 @@ class FpnEngine(object):
             self.flops_fwd = flops
             self.plan_key = key
         return self.results + [self.pool]
+
+    def term_grad_buffer(self, level):
+        """where the loss gradient of a term on pyramid map `level` (a hook on ``backbone.fpn.layer_blocks.level``) is written"""
+        return self.bufs.get('g_p%d' % level, self.results[level].shape)
+
+    def backward(self, term_grads, sinks):
+        """Gradient of loss terms on pyramid maps down to the layer outputs (the pyramid's own weights are frozen in every
+        config: no weight gradients).  torchvision 0.4.2 FeaturePyramidNetwork.forward, backwards:
+            P_i = conv3x3_i(inner_i),   inner_i = lateral_i(C_i) + nearest_up(inner_{i+1})
+        term_grads: {level: dL/dP_level};  sinks: {level: (dst, mask, accumulate)} -- dL/dC_level is written (accumulate:
+        added) to dst, masked by [mask > 0] when a mask tensor is given (the top layer's gradient buffer holds MASKED
+        gradients).  Levels below the finest term level receive nothing."""
+        assert term_grads and all(0 <= k < len(self.results) for k in term_grads)
+        key = (tuple(sorted((k, t.data_ptr()) for k, t in term_grads.items())),
+               tuple(sorted((k, v[0].data_ptr(), None if v[1] is None else v[1].data_ptr(), bool(v[2]))
+                            for k, v in sinks.items())), self.plan_key)
+        if key != getattr(self, 'bwd_key', None):
+            self.bwd, kmin, nlev = [], min(term_grads), len(self.results)
+            prev = None
+            for i in range(kmin, nlev):
+                n, h, w, c = self.results[i].shape
+                g_inner = self.bufs.get('g_inner%d' % i, (n, h, w, c))
+                have = False
+                if i in term_grads:
+                    ml, wl = self.layer[i]
+                    if self.wino[i] is not None:
+                        tile = wino_tile_for(self.wino[i].tile, n, h, w)
+                        nv, nm = ops.WinoConv.scratch_elems(n, h, w, c, c, tile)
+                        v, mm = self.bufs.get('wino_v_bwd', (nv,)), self.bufs.get('wino_m_bwd', (nm,))
+                        self.bwd += ops.WinoConv(term_grads[i], self.wino[i].get(True, tile), g_inner, v,
+                                                 mm).launches('fpn.layer%d.dgrad' % i)
+                    else:
+                        ls, _ = ops.conv_dgrad(term_grads[i], wl, g_inner, 3, 1, 1)
+                        self.bwd += [(l, 'fpn.layer%d.dgrad' % i) for l in ls]
+                    have = True
+                if prev is not None:
+                    self.bwd.append((ops._Step(lambda s, a=prev, b_=g_inner, acc=have: ops.upsample_nearest_bwd(a, b_, acc),
+                                               'upsample_nearest_bwd', 4 * (prev.numel() + g_inner.numel())),
+                                     'fpn.inner%d.topdown.bwd' % (i - 1)))
+                dst, mask, accumulate = sinks[i]
+                kw = {'mask': mask} if mask is not None else {}
+                ls, _ = ops.conv_dgrad(g_inner, self.inner[i][1], dst, 1, 1, 0, accumulate=bool(accumulate), **kw)
+                self.bwd += [(l, 'fpn.inner%d.dgrad' % i) for l in ls]
+                prev = g_inner
+            self.bwd_key = key
+        for l, tag in self.bwd:
+            _run(l, tag)
 
     def forward(self, feats):
         """feats: list of NHWC layer outputs (fine -> coarse).  Returns list of NHWC pyramid maps + 'pool'."""

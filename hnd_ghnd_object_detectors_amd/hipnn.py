@@ -264,8 +264,11 @@ class IntermediateLayerGetter(nn.ModuleDict):
         """(parameters that receive gradients, in state-dict order)."""
         return [p for _, p in self.named_parameters() if p.requires_grad]
 
-    def hnd_backward(self, top, loss_grads, grad_dst, top_block=None, block_grads=None):
+    def hnd_backward(self, top, loss_grads, grad_dst, top_block=None, block_grads=None, fpn=None):
         """Run the hand-written backward.
+        fpn: (FpnEngine, {level: loss gradient w.r.t. pyramid map `level`}) for terms on ``backbone.fpn.layer_blocks.K``
+        of the STUDENT: the pyramid's backward runs first and delivers into the layer outputs' gradient buffers (the top
+        layer's masked g_out, the lower layers' unmasked loss-gradient buffers).
         top: name of the highest layer that carries a loss term (its engine's g_out already holds the masked
         loss gradient); top_block: the block of that layer the gradient enters at (None = the layer output).
         loss_grads: {layer name: unmasked loss-gradient buffer} for lower layers with a term on their output.
@@ -274,6 +277,23 @@ class IntermediateLayerGetter(nn.ModuleDict):
         order = ['layer4', 'layer3', 'layer2', 'layer1']
         start = order.index(top)
         block_grads = block_grads or {}
+        if fpn is not None:
+            fpn_eng, term_grads, top_has_term = fpn
+            assert top == 'layer4' and top_block is None
+            sinks = {}
+            for level in range(min(term_grads), 4):
+                name = 'layer%d' % (level + 1)
+                eng = self.layer_engine(name)
+                if name == top:
+                    # g_out of the top layer holds MASKED gradients; a body term on layer4 has already written its own
+                    sinks[level] = (eng.grad_out_buffer(), eng.bwd_out(), bool(top_has_term))
+                else:
+                    have = name in loss_grads
+                    if not have:
+                        loss_grads = dict(loss_grads)
+                        loss_grads[name] = eng.bufs.get('loss_grad', tuple(eng.bwd_out().shape))
+                    sinks[level] = (loss_grads[name], None, have)
+            fpn_eng.backward(term_grads, sinks)
         for name in order[start:-1]:
             prev_name = order[order.index(name) + 1]
             prev_eng = self.layer_engine(prev_name)
@@ -330,7 +350,7 @@ class FeaturePyramidNetwork(nn.Module):
             eng = self._engine
         for i, m in enumerate(self.layer_blocks):           # hooks on backbone.fpn.layer_blocks.K: the pyramid maps
             if m._forward_hooks:
-                fire_forward_hooks(m, None, attach(E.logical(outs[i]), outs[i], ('fpn', 'layer_blocks', i)))
+                fire_forward_hooks(m, None, attach(E.logical(outs[i]), outs[i], ('fpn', 'layer_blocks', i, self, eng)))
         for i, m in enumerate(self.inner_blocks):
             if m._forward_hooks:
                 if i != len(self.inner_blocks) - 1:
@@ -338,7 +358,7 @@ class FeaturePyramidNetwork(nn.Module):
                                               'bare lateral output does not exist on the HIP path (the top level, '
                                               'inner_blocks.%d, does)' % (i, len(self.inner_blocks) - 1))
                 t = half(eng.bufs.t['inner%d' % i])
-                fire_forward_hooks(m, None, attach(E.logical(t), t, ('fpn', 'inner_blocks', i)))
+                fire_forward_hooks(m, None, attach(E.logical(t), t, ('fpn', 'inner_blocks', i, self, eng)))
         if self.extra_blocks is None:
             outs = outs[:-1]
         else:
@@ -356,6 +376,7 @@ class BackboneWithFPN(nn.Sequential):
 
     def forward(self, x):
         feats = self.body(x)
+        self.fpn.__dict__['_body'] = self.body       # (a loss term on a pyramid map finds the backward plan through it)
         if not self.run_fpn:
             return feats
         side = E.DEFER_FPN['stream']

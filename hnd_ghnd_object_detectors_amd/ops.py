@@ -621,6 +621,21 @@ def subsample2(x, y):
     check(_L.hnd_subsample2(ptr(x), ptr(y), n, h, w, c, y.shape[1], y.shape[2], stream_ptr()), 'hnd_subsample2')
 
 
+def upsample_nearest_bwd(g_fine, g_coarse, accumulate):
+    """backward of F.interpolate(coarse, size=fine.shape, mode='nearest'): g_coarse (+)= the sums of g_fine over the fine
+    pixels that read each coarse one (NHWC, same channels)"""
+    n, H, W, c = g_fine.shape
+    nc, h, w, cc = g_coarse.shape
+    assert (n, c) == (nc, cc) and g_fine.is_contiguous() and g_coarse.is_contiguous()
+    check(_L.hnd_upsample_nearest_bwd(ptr(g_fine), ptr(g_coarse), n, H, W, h, w, c, int(bool(accumulate)), stream_ptr()),
+          'hnd_upsample_nearest_bwd')
+
+
+def add_inplace(x, y):
+    assert x.numel() == y.numel() and x.is_contiguous() and y.is_contiguous()
+    check(_L.hnd_add_inplace(ptr(x), ptr(y), x.numel(), stream_ptr()), 'hnd_add_inplace')
+
+
 def fill(x, value):
     check(_L.hnd_fill(ptr(x), x.numel(), float(value), stream_ptr()), 'hnd_fill')
 

@@ -426,6 +426,14 @@ int hnd_adam_step_flat(float* param, const float* grad, float* exp_avg, float* e
 /* LastLevelMaxPool: F.max_pool2d(x, 1, 2, 0) == x[:, ::2, ::2] (torchvision FPN). */
 int hnd_subsample2(const float* x, float* y, int n, int h, int w, int c, int oh, int ow, void* stream);
 int hnd_fill(float* x, int64_t numel, float value, void* stream);
+/* ABI 12, student-side loss terms below the layer outputs (src/distillation/tool.py:25-35 hooks ANY module):
+ * hnd_upsample_nearest_bwd: autograd backward of F.interpolate(coarse, size=(H, W), mode='nearest') in the FPN's top-down path
+ * (torchvision 0.4.2 ops/feature_pyramid_network.py): g_coarse[n][h][w][c] (+)= the sum of g_fine over every fine pixel
+ * that read it (fixed order, no atomics); hnd_add_inplace: x += y (the gradient of a term on the bottleneck tensor joins the
+ * gradient arriving from the decoder). */
+int hnd_upsample_nearest_bwd(const float* g_fine, float* g_coarse, int n, int H, int W, int h, int w, int c, int accumulate,
+                             void* stream);
+int hnd_add_inplace(float* x, const float* y, int64_t numel, void* stream);
 
 /* Eval-time bottleneck codec: Quantizer / Dequantizer of src/structure/transformer.py:131-153
  * over myutils tensor_util.quantize_tensor / dequantize_tensor (un-vendored; semantics as used at :139,:152):

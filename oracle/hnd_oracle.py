@@ -309,10 +309,13 @@ def quantize_dequantize(z, num_bits=8):
     return dequantize_tensor(quantize_tensor(z, num_bits=num_bits))
 
 
-def student_layer1(x, sd, training=True, update_buffers=True, intermediates=None, codec_bits=None):
+def student_layer1(x, sd, training=True, update_buffers=True, intermediates=None, codec_bits=None, hooked=None):
     """Bottleneck4LargeResNet.forward == decoder(encoder(x)) (base.py:50-58 with
-    use_bottleneck_transformer False, as mimic_runner.py:90 forces during distillation)."""
+    use_bottleneck_transformer False, as mimic_runner.py:90 forces during distillation).
+    hooked: receives the bottleneck tensor as 'layer1.encoder' (a forward hook on backbone.body.layer1.encoder)."""
     for prefix, spec in ((B + 'layer1.encoder.encoder.', ENCODER_SPEC), (B + 'layer1.decoder.', DECODER_SPEC)):
+        if spec is DECODER_SPEC and hooked is not None:
+            hooked['layer1.encoder'] = x
         if spec is DECODER_SPEC and codec_bits is not None and not training:
             x = quantize_dequantize(x, codec_bits)        # base.py:54-57: eval only, between encoder and decoder
         for op in spec:
@@ -349,7 +352,7 @@ def backbone_forward(x, sd, student, training=True, update_buffers=True, with_fp
     if intermediates is not None:
         intermediates['stem'] = x
     if student:
-        x = student_layer1(x, sd, training, update_buffers, intermediates, codec_bits)
+        x = student_layer1(x, sd, training, update_buffers, intermediates, codec_bits, hooked)
         hooked['layer1.decoder'] = x            # the decoder's output IS the layer's (base.py:50-58)
     else:
         x = resnet_layer(x, sd, 1, hooked)
@@ -358,7 +361,20 @@ def backbone_forward(x, sd, student, training=True, update_buffers=True, with_fp
         x = resnet_layer(x, sd, li, hooked)
         hooked['layer%d' % li] = x
     feats = fpn([hooked['layer%d' % i] for i in (1, 2, 3, 4)], sd) if with_fpn else None
+    if feats is not None:                       # forward hooks on backbone.fpn.layer_blocks.K (keys relative to `backbone.`)
+        for i in range(4):
+            hooked['fpn.layer_blocks.%d' % i] = feats[i]
     return hooked, feats
+
+
+def rel_key(path):
+    """dotted module path of a forward hook -> the key its tensor is hooked under here: relative to ``backbone.body.`` for
+    the body's modules ('layer2', 'layer2.1', 'layer1.decoder', 'layer1.encoder'), to ``backbone.`` for the pyramid's
+    ('fpn.layer_blocks.1')"""
+    for pre in ('backbone.body.', 'backbone.'):
+        if path.startswith(pre):
+            return path[len(pre):]
+    return path
 
 
 def mimic_loss(t_hooked, s_hooked, terms):
@@ -386,8 +402,15 @@ class DistillOracle(object):
     """Mirrors mimic_runner.distill_model (:38-59) for a fixed teacher/student pair on CPU."""
 
     def __init__(self, teacher_sd, student_sd, terms=GHND_TERMS, lr=1e-3, min_size=(800,), max_size=1333,
-                 warmup_iters=0, warmup_factor=1e-3, with_fpn=True, dtype=torch.float32):
+                 warmup_iters=0, warmup_factor=1e-3, with_fpn=True, dtype=torch.float32, teacher_is_student_arch=False):
+        """teacher_is_student_arch: the teacher is itself a bottleneck-injected model (config teacher_model = a custom
+        backbone): run eval-mode through the student's layer1 -- needed for a term on backbone.body.layer1.encoder, which
+        only such a teacher can pair a tensor with."""
         self.dtype = dtype
+        self.teacher_is_student_arch = teacher_is_student_arch
+        if any(isinstance(v, (tuple, list)) and (str(v[0]).startswith('fpn.') or str(v[1]).startswith('fpn.'))
+               for v in terms.values()):
+            with_fpn = True                     # a term on a pyramid map needs the pyramids
         self.t = cast_state(teacher_sd, dtype)
         self.s = cast_state(student_sd, dtype)
         self.terms, self.min_size, self.max_size, self.with_fpn = terms, min_size, max_size, with_fpn
@@ -409,7 +432,11 @@ class DistillOracle(object):
         images = [im.to(self.dtype) for im in images]
         x, _ = transform_images(images, self.min_size, self.max_size, training=False, fixed_sizes=fixed_sizes)
         with torch.no_grad():
-            t_hooked, t_feats = backbone_forward(x, self.t, student=False, with_fpn=self.with_fpn)
+            if self.teacher_is_student_arch:
+                t_hooked, t_feats = backbone_forward(x, self.t, student=True, training=False, update_buffers=False,
+                                                     with_fpn=self.with_fpn)
+            else:
+                t_hooked, t_feats = backbone_forward(x, self.t, student=False, with_fpn=self.with_fpn)
         # student transform in train mode draws random.choice(min_size) (rcnn.py:36-37): identical to
         # eval for single-size configs; Keypoint passes fixed_sizes (tool.py:45-48)
         s_hooked, s_feats = backbone_forward(x, self.s, student=True, training=True,
@@ -422,7 +449,9 @@ class DistillOracle(object):
         loss, per_term, *_ = self.forward(images, fixed_sizes)
         self.opt.zero_grad()
         loss.backward()
-        grads = OrderedDict((k, self.s[k].grad.detach().clone()) for k in self.keys)
+        # (a parameter no term reaches -- the decoder under a lone term on the bottleneck tensor -- has no gradient: zeros)
+        grads = OrderedDict((k, torch.zeros_like(self.s[k]) if self.s[k].grad is None else self.s[k].grad.detach().clone())
+                            for k in self.keys)
         self.opt.step()
         lr = self.opt.param_groups[0]['lr']
         if self.sched is not None:
@@ -574,7 +603,9 @@ class FilterOracle(object):
         loss = F.cross_entropy(logits, labels)
         self.opt.zero_grad()
         loss.backward()
-        grads = OrderedDict((k, self.s[k].grad.detach().clone()) for k in self.keys)
+        # (a parameter no term reaches -- the decoder under a lone term on the bottleneck tensor -- has no gradient: zeros)
+        grads = OrderedDict((k, torch.zeros_like(self.s[k]) if self.s[k].grad is None else self.s[k].grad.detach().clone())
+                            for k in self.keys)
         self.opt.step()
         lr = self.opt.param_groups[0]['lr']
         if self.sched is not None:

@@ -63,6 +63,21 @@ CASES = OrderedDict((
                                            ['l2b1', 'backbone.body.layer2.1', 'backbone.body.layer2.1', 0.5],
                                            ['layer3', 'backbone.body.layer3', 'backbone.body.layer3', 1.0],
                                            ['l4b0', 'backbone.body.layer4.0', 'backbone.body.layer4.0', 2.0]])),
+    # round 6: student-side terms BELOW / BESIDE the layer outputs.  (a) a pyramid map (backbone.fpn.layer_blocks.1, the
+    # stride-8 map) beside layer1 and layer3: its gradient reaches layer2, layer3 AND layer4 through the top-down path, so
+    # the backward starts at layer4 although no term sits there; (b) the bottleneck tensor itself
+    # (backbone.body.layer1.encoder) -- only a teacher that is itself bottleneck-injected has a tensor to pair with it, so
+    # the teacher is built from the yaml's student_model section (another seed), eval mode
+    ('tiny_ghnd_fpn_term', dict(yaml='ghnd/faster_rcnn-backbone_resnet50-b3ch.yaml', model='faster_rcnn',
+                                sizes=[(60, 90), (56, 100)], min_size=64, max_size=128, steps=2, seed=41,
+                                terms=[['layer1', 'backbone.body.layer1', 'backbone.body.layer1', 1.0],
+                                       ['p3', 'backbone.fpn.layer_blocks.1', 'backbone.fpn.layer_blocks.1', 0.5],
+                                       ['layer3', 'backbone.body.layer3', 'backbone.body.layer3', 1.0]])),
+    ('tiny_enc_term', dict(yaml='ghnd/faster_rcnn-backbone_resnet50-b3ch.yaml', model='faster_rcnn',
+                           sizes=[(60, 90), (56, 100)], min_size=64, max_size=128, steps=2, seed=42,
+                           teacher='student_arch',
+                           terms=[['enc', 'backbone.body.layer1.encoder', 'backbone.body.layer1.encoder', 2.0],
+                                  ['layer2', 'backbone.body.layer2', 'backbone.body.layer2', 1.0]])),
     ('full_ghnd_faster', dict(yaml='ghnd/faster_rcnn-backbone_resnet50-b3ch.yaml', model='faster_rcnn',
                               sizes=[(800, 1333)], min_size=800, max_size=1333, steps=1, seed=16, full=True)),
     # full-size pins of every BASELINE.json config (round 2).  b4 is the reference's own train batch_size
@@ -94,6 +109,9 @@ def build_reference_models(case):
                                   'params': {'pretrained': False, 'min_size': case['min_size'],
                                              'max_size': case['max_size']}}}
     main_util.overwrite_config(config, json.dumps(override))       # same path as the CLI's --json
+    if case.get('teacher') == 'student_arch':                      # a bottleneck-injected teacher: the yaml's student section
+        import copy
+        config['teacher_model'] = copy.deepcopy(config['student_model'])
     device = torch.device('cpu')
     teacher = get_model(config['teacher_model'], device)
     module_util.freeze_module_params(teacher)                      # mimic_runner.py:132
@@ -144,6 +162,9 @@ def run_case(name, case):
     bch = case.get('bch', 3)
     t_sd = O.init_teacher_state(case['seed'], case['model'], num_classes=case.get('num_classes', 91))
     s_sd = O.init_student_state(t_sd, case['seed'] + 1000, bch=bch)
+    student_arch_teacher = case.get('teacher') == 'student_arch'
+    if student_arch_teacher:
+        t_sd = O.init_student_state(t_sd, case['seed'] + 500, bch=bch)
     config, teacher, student = build_reference_models(case)
     teacher.load_state_dict(t_sd, strict=True)      # also proves the oracle's key layout == reference's
     student.load_state_dict(s_sd, strict=True)
@@ -155,8 +176,7 @@ def run_case(name, case):
         proto = next(iter(crit['terms'].values()))['criterion']
         crit['terms'] = OrderedDict((name, {'ts_modules': [tp, sp], 'criterion': proto, 'factor': f})
                                     for name, tp, sp, f in case['terms'])
-        strip = len('backbone.body.')
-        terms = OrderedDict((name, (tp[strip:], sp[strip:], f)) for name, tp, sp, f in case['terms'])
+        terms = OrderedDict((name, (O.rel_key(tp), O.rel_key(sp), f)) for name, tp, sp, f in case['terms'])
     else:
         terms = OrderedDict((k, v['factor']) for k, v in crit['terms'].items())
     box = DistillationBox(teacher, student, crit)
@@ -171,7 +191,8 @@ def run_case(name, case):
 
     min_size = case['min_size'] if isinstance(case['min_size'], list) else [case['min_size']]
     oracle = O.DistillOracle(t_sd, s_sd, terms=terms, lr=opt_cfg['params']['lr'], min_size=tuple(min_size),
-                             max_size=case['max_size'], warmup_iters=4, warmup_factor=1e-3)
+                             max_size=case['max_size'], warmup_iters=4, warmup_factor=1e-3,
+                             teacher_is_student_arch=student_arch_teacher)
     images, targets = make_inputs(case)
     out = OrderedDict()
     out['meta'] = np.array(json.dumps({k: v for k, v in case.items()}))

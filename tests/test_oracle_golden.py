@@ -8,19 +8,21 @@ from oracle import hnd_oracle as O
 from tests import golden_util as G
 
 TINY = ['tiny_ghnd_faster', 'tiny_hnd_faster', 'tiny_ghnd_mask', 'tiny_ghnd_keypoint', 'tiny_ghnd_faster_b6',
-        'tiny_ghnd_custom_hooks']
+        'tiny_ghnd_custom_hooks', 'tiny_ghnd_fpn_term', 'tiny_enc_term']
 
 
 def _oracle_for(meta, z):
     t_sd = O.init_teacher_state(meta['seed'], meta['model'], num_classes=meta.get('num_classes', 91))
     s_sd = O.init_student_state(t_sd, meta['seed'] + 1000, bch=meta.get('bch', 3))
     terms = O.HND_TERMS if meta['yaml'].startswith('hnd/') else O.GHND_TERMS
-    if 'terms' in meta:             # non-standard hook paths: (teacher key, student key, factor) relative to backbone.body
-        strip = len('backbone.body.')
-        terms = OrderedDict((name, (tp[strip:], sp[strip:], f)) for name, tp, sp, f in meta['terms'])
+    if 'terms' in meta:             # non-standard hook paths: (teacher key, student key, factor), O.rel_key of the paths
+        terms = OrderedDict((name, (O.rel_key(tp), O.rel_key(sp), f)) for name, tp, sp, f in meta['terms'])
+    student_arch = meta.get('teacher') == 'student_arch'      # a bottleneck-injected teacher (tiny_enc_term)
+    if student_arch:
+        t_sd = O.init_student_state(t_sd, meta['seed'] + 500, bch=meta.get('bch', 3))
     ms = meta['min_size'] if isinstance(meta['min_size'], list) else [meta['min_size']]
     return O.DistillOracle(t_sd, s_sd, terms=terms, min_size=tuple(ms), max_size=meta['max_size'],
-                           warmup_iters=4, warmup_factor=1e-3), terms
+                           warmup_iters=4, warmup_factor=1e-3, teacher_is_student_arch=student_arch), terms
 
 
 @pytest.mark.parametrize('name', TINY)
