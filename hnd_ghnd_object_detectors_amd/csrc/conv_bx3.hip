@@ -434,6 +434,8 @@ namespace hnd {
 static bool bx3_recommended(long long rows_per_image, int kdim, int cout) {
   if (rows_per_image <= 0 || cout <= 0 || cout % 64 != 0) return false;
   if (kdim != 128 && (kdim % 256 != 0 || kdim > 2048)) return false;
+  // (round 6 A/B, same box, img/s at batch 16 / batch 4: K >= 1024 launches on the B-streamed build instead 214.2 / 170.7,
+  // K >= 512 210.5 / 161.2, as shipped 216.2 / 176.6 -- the passes over k stay)
   const int per_xcd = cu_count_bx3() / 8, nsl = cout / 64;
   if (per_xcd < 1 || nsl > per_xcd || per_xcd % nsl != 0) return false;
   const long long nteams = 8ll * (per_xcd / nsl);
