@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Randomised bit-identity stress of the hnd_conv2d_igemm kernel variants: for random geometries / epilogues the tiled
+"""Randomised bit-identity stress of the hnd_conv2d_igemm kernel variants (--family native | emulated, round 6): for random geometries / epilogues the tiled
 kernel (HND_BRES=0 HND_BSTREAM=0), the default dispatch and the B-streamed kernel forced on (HND_DEBUG_PICKER=bstream_all, with and
 without its work-balancing relay) must produce IDENTICAL bits, and launching twice on one workspace must too.
 usage: python tools/stress_gemm_variants.py [--cases 200] [--seed 0]"""
@@ -19,7 +19,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--cases', type=int, default=200)
     ap.add_argument('--seed', type=int, default=0)
+    ap.add_argument('--family', default='native', choices=['native', 'emulated'],
+                    help="native: launches built with the bf16x3 emulation off (tiled == B-resident == B-streamed bits); "
+                         "emulated: built with it forced on (the B-streamed emulation kernel with and without its relay, "
+                         "launched twice: the same bits)")
     args = ap.parse_args()
+    ops.BX3_MODE[0] = 'off' if args.family == 'native' else 'force'
     rnd = random.Random(args.seed)
     dev = 'cuda:0'
     counts, bad = {}, 0
