@@ -1,16 +1,17 @@
-// OPT-IN (never the default): B-resident persistent GEMM with fp32 EMULATED on the bf16 matrix pipe of gfx950 -- the
-// design the round-5 probe (tools/probes/bf16x3_gemm_probe.hip, profiles/r05_bf16x3_probe.txt) measured, carried into the
-// library so that the whole step can be run on it side by side with the native fp32-MFMA build.  Taken only for launches
-// whose descriptor carries a pre-split weight image (hnd_conv_desc.w_bf16x3, made by hnd_pack_bf16x3; the Python host
-// attaches one only under HND_BF16X3=1).
+// B-resident persistent GEMM with fp32 EMULATED on the bf16 matrix pipe of gfx950 -- the design the round-5 probe
+// (tools/probes/bf16x3_gemm_probe.hip, profiles/r05_bf16x3_probe.txt) measured; opt-in in round 5, the DEFAULT for the
+// launches it covers since round 6.  Taken for launches whose descriptor carries a pre-split weight
+// image (hnd_conv_desc.w_bf16x3, made by hnd_pack_bf16x3); the host attaches one by LAYER (hnd_bf16x3_recommended below:
+// rows one image contributes, depth, output channels -- never the launch's batch), HND_BF16X3=0 attaches none.
 //
 // Arithmetic.  Every fp32 operand is the exact sum of three bf16 planes obtained by truncation (hi = top 16 bits, mid = top
 // 16 bits of x - hi, lo = x - hi - mid: 8 + 8 + 8 significant bits).  A product a b is taken as the six plane products with
 // i + j <= 2 (hi.hi, hi.mid, mid.hi, hi.lo, lo.hi, mid.mid) on v_mfma_f32_16x16x32_bf16 with fp32 accumulation, smallest
 // terms first inside every 32-deep k step; the three dropped products are <= 2^-24 of a b each.  Measured against fp64 on
 // N(0,1) and wide-dynamic-range data: rel-L2 2.4e-7 / 2.1e-7, native fp32 MFMA 2.9e-7 / 2.7e-7.  NOT bit-identical to the
-// fp32 kernels (a different summation), which is why it is opt-in; denormal inputs are flushed by the bf16 pipe and an
-// infinite input gives NaN (Inf - Inf in the split) -- neither occurs in a healthy training step.
+// fp32 kernels (a different summation): a second rounding family, bit-identical inside (conv_bxs.hip is its other member).
+// Stated deviations (include/hnd_hip.h at w_bf16x3, tests/test_bx3_gpu.py): an Inf / NaN input makes every dependent output
+// NaN (Inf - Inf in the split) and moves no other bit; plane values below 2^-126 are flushed by the bf16 pipe.
 //
 // Structure = bres2 (conv_bres.hip): one wave per SIMD, the weight slice resident in LDS (three pre-split planes of
 // [64 columns][K], 96 KB at K = 256, XOR-swizzled 16-byte chunks), A fragments straight from global memory through a

@@ -108,6 +108,27 @@ def test_synthetic_loader_and_meters():
     assert m.loss.median == 2.0 and abs(m.loss.global_avg - 2.0) < 1e-12
 
 
+@pytest.mark.parametrize('workers', [0, 2])
+def test_synthetic_loader_pool_hands_out_the_same_first_batches_and_then_rotates(workers):
+    """on a host whose CPU share per rank cannot generate a batch per step the loader keeps a rotating pool
+    of P pre-generated batches -- batches 0 .. P-1 hold the values the unpooled loader makes (so the pinned first-step losses
+    still gate the run), batch k >= P is batch k % P again (the SAME tensors: nothing is generated), and the generation cost
+    the step would have paid is accounted for separately"""
+    from hnd_ghnd_object_detectors_amd.utils import data_util
+    plain = list(data_util.SyntheticDetectionLoader(5, 2, 16, 24, 'faster_rcnn', seed=9, rank=3, workers=workers))
+    pooled_ld = data_util.SyntheticDetectionLoader(5, 2, 16, 24, 'faster_rcnn', seed=9, rank=3, workers=workers, pool_batches=2)
+    pooled = list(pooled_ld)
+    assert len(pooled) == 5
+    for k in range(5):
+        for a, b in zip(pooled[k][0], plain[k % 2][0]):
+            assert torch.equal(a, b), k
+        assert all(torch.equal(pooled[k][1][i]['boxes'], plain[k][1][i]['boxes']) for i in range(2))
+    assert all(pooled[2][0][i] is pooled[0][0][i] for i in range(2))          # the pool's own tensors, not copies
+    plain_ld = data_util.SyntheticDetectionLoader(3, 2, 16, 24, 'faster_rcnn', seed=9, workers=workers)
+    list(plain_ld)
+    assert plain_ld.gen_batches == 3 and plain_ld.gen_cpu_s > 0 and pooled_ld.gen_batches == 0
+
+
 def test_load_ckpt_tuple_arity_and_roundtrip(tmp_path):
     from hnd_ghnd_object_detectors_amd.models import load_ckpt, save_ckpt
     assert load_ckpt(str(tmp_path / 'missing.pt')) == (None, None)      # reference quirk: 2-tuple when missing
