@@ -89,7 +89,7 @@ _SIGNATURES = {
     'hnd_wino_tiles_pad': (C.c_int64, [C.c_int] * 4),
     'hnd_wino_weights': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     'hnd_wino_input': (C.c_int, [vp, vp] + [C.c_int] * 4 + [vp, vp, C.c_int, C.c_int, vp]),
-    'hnd_wino_output': (C.c_int, [vp, vp] + [C.c_int] * 5 + [vp, vp, vp, vp, C.c_int, C.c_int, vp]),
+    'hnd_wino_output': (C.c_int, [vp, vp] + [C.c_int] * 5 + [vp, vp, vp, vp, C.c_int, C.c_int, vp, vp]),
     'hnd_wino2_tiles_pad': (C.c_int64, [C.c_int] * 4),
     'hnd_wino2_stats_blocks': (C.c_int, [C.c_int] * 5),
     'hnd_wino2_weights': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),

@@ -147,7 +147,17 @@ struct WinoEpilogue {
   const float* res1;
   const float* mask;
   int relu;
+  uint8_t* mask_out;      // F(4x4) / F(6x6): [stored value > 0] as nibbles, one byte per pixel and four channels (hnd_conv_desc.mask_out)
 };
+
+// a thread of the F(4x4) / F(6x6) output transforms owns TWO channels of a pixel: half a nibble.  The even thread of a
+// pair (adjacent lanes: same tile, channels c2 * 2 and c2 * 2 + 2) fetches its neighbour's two bits and writes the byte.
+// Both lanes of a pair take every branch around this call together (same tile, same pixel).
+__device__ __forceinline__ void wino_store_nibble(uint8_t* mask_out, size_t off, int c2, f32x2 v) {
+  const unsigned bits = (v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u);
+  const unsigned other = (unsigned)__shfl_xor((int)bits, 1);
+  if (!(c2 & 1)) mask_out[off >> 2] = (uint8_t)(bits | (other << 2));
+}
 
 // y[2ty+a][2tx+b][c] = epilogue( (A^T m A)[a][b] ), m = the 16 GEMM results of tile t; same epilogue order as the
 // implicit-GEMM kernel: scale/shift, + res1, mask (ReLU backward), ReLU.
@@ -395,6 +405,7 @@ __global__ void wino4_output_kernel(const float* __restrict__ m, float* __restri
           if (MASK) { v.x = kc[bb].x > 0.f ? v.x : 0.f; v.y = kc[bb].y > 0.f ? v.y : 0.f; }
           if (ep.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); }
           *(f32x2*)(y + off) = v;
+          if (ep.mask_out) wino_store_nibble(ep.mask_out, off, c2, v);
         }
       }
     };
@@ -605,6 +616,7 @@ __global__ void __launch_bounds__(256) wino6_output_kernel(const float* __restri
           if (MASK) { v.x = kc[bb].x > 0.f ? v.x : 0.f; v.y = kc[bb].y > 0.f ? v.y : 0.f; }
           if (ep.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); }
           *(f32x2*)(y + off) = v;
+          if (ep.mask_out) wino_store_nibble(ep.mask_out, off, c2, v);
         }
       }
     };
@@ -1366,11 +1378,13 @@ int hnd_wino_input(const float* x, float* v, int n, int h, int w, int c, const f
 }
 
 int hnd_wino_output(const float* m, float* y, int n, int h, int w, int cout, int ldc, const float* epi_scale,
-                    const float* epi_shift, const float* res1, const float* mask, int relu, int tile, void* stream) {
+                    const float* epi_shift, const float* res1, const float* mask, int relu, int tile, uint8_t* mask_out,
+                    void* stream) {
   HND_REQUIRE(m && y && n > 0 && h > 0 && w > 0 && cout > 0 && cout % 4 == 0 && ldc >= cout && ldc % 4 == 0 &&
                   (tile == 2 || tile == 4 || tile == 6), "hnd_wino_output: bad arguments");
+  HND_REQUIRE(!mask_out || (tile != 2 && cout == ldc), "hnd_wino_output: mask_out needs tile 4 / 6 and cout == ldc");
   WinoGeom g{n, h, w, ldc, (h + tile - 1) / tile, (w + tile - 1) / tile, (int)hnd_wino_tiles_pad(n, h, w, tile)};
-  WinoEpilogue ep{epi_scale, epi_shift, res1, mask, relu};
+  WinoEpilogue ep{epi_scale, epi_shift, res1, mask, relu, mask_out};
   const long long tiles = (long long)n * g.th * g.tw;
   if (tile == 2)
     hipLaunchKernelGGL(wino_output_kernel, dim3(grid_for(tiles * (cout / 4))), dim3(256), 0, hnd::as_stream(stream), m,

@@ -519,20 +519,26 @@ class FrozenLayerEngine(object):
                 out = self._out_buf
             self.fwd.append((ops.conv_forward(cur, b.w1.get(), a1, 1, 1, 0, epi_scale=a1f[0], epi_shift=a1f[1],
                                               relu=True), tagp + '.conv1'))
-            if b.wino is not None:      # stride-1 3x3, >= 256 channels: Winograd F(2x2,3x3)
-                tile = wino_tile_for(b.wino.tile, n, h, w)
-                v, m = self._wino_scratch(n, h, w, b.planes, b.planes, tile)
-                self.fwd += ops.WinoConv(a1, b.wino.get(False, tile), a2, v, m, epi_scale=a2f[0], epi_shift=a2f[1],
-                                         relu=True).launches(tagp + '.conv2')
-            else:
-                self.fwd.append((ops.conv_forward(a1, b.w2.get(), a2, 3, b.stride, 1, epi_scale=a2f[0],
-                                                  epi_shift=a2f[1], relu=True), tagp + '.conv2'))
-            # with the bf16x3 emulation (the default): [a2 > 0] as nibbles for conv3's data gradient -- the emulation kernel's masked build
-            # reads mask BYTES (a second fp32 row set does not fit its registers); made here, where a2 is cache-hot
+            # with the bf16x3 emulation (the default): [a2 > 0] as nibbles for conv3's data gradient -- the emulation kernel's
+            # masked build reads mask BYTES (a second fp32 row set does not fit its registers).  Since round 6 they come out of
+            # the launch that stores a2 (the Winograd output transform / the conv epilogue), not a pass of their own
             a2b = None
             if (keep and getattr(self, 'for_backward', True) and ops.bx3_on() and MASK_BITS
                     and b.planes % 128 == 0):
                 a2b = self.bufs.get('a2bits_' + sfx, tuple(a2.shape[:3]) + (a2.shape[3] // 4,), torch.uint8)
+            bits_step = a2b is not None
+            if b.wino is not None:      # stride-1 3x3, >= 256 channels: Winograd F(2x2,3x3)
+                tile = wino_tile_for(b.wino.tile, n, h, w)
+                v, m = self._wino_scratch(n, h, w, b.planes, b.planes, tile)
+                in_transform = a2b is not None and tile in (4, 6)
+                self.fwd += ops.WinoConv(a1, b.wino.get(False, tile), a2, v, m, epi_scale=a2f[0], epi_shift=a2f[1],
+                                         relu=True, mask_out=a2b if in_transform else None).launches(tagp + '.conv2')
+                bits_step = bits_step and not in_transform
+            else:
+                self.fwd.append((ops.conv_forward(a1, b.w2.get(), a2, 3, b.stride, 1, epi_scale=a2f[0],
+                                                  epi_shift=a2f[1], relu=True, mask_out=a2b), tagp + '.conv2'))
+                bits_step = False
+            if bits_step:               # (F(2x2,3x3): its output transform owns whole pixels per thread, not channel pairs)
                 self.fwd.append((ops._Step(lambda s, a2=a2, a2b=a2b: ops.relu_mask_nibbles(a2, a2b, s), 'relu_mask_nibbles',
                                            a2.numel() * 4 + a2b.numel()), tagp + '.conv2.bits'))
             self.a2_bits.append(a2b)

@@ -692,7 +692,8 @@ class WinoConv(object):
     launch -> output transform.  x [N,H,W,C] -> y [N,H,W,ldc]; v / m are caller-provided scratch (see scratch_elems)."""
 
     def __init__(self, x, ww, y, v, m, pro_scale=None, pro_shift=None, pro_relu=False, epi_scale=None, epi_shift=None,
-                 res1=None, mask=None, relu=False):
+                 res1=None, mask=None, relu=False, mask_out=None):
+        """mask_out: uint8 nibbles of the STORED output (mask_nibbles_like(y)), written by the output transform (tile 4 / 6)"""
         n, h, w, c = _nhwc(x)
         assert tuple(y.shape[:3]) == (n, h, w) and c == ww.depth
         self.x, self.y, self.ww = x, y, ww
@@ -708,6 +709,9 @@ class WinoConv(object):
             pro_shift = _zeros(c, x.device)
         self.pro = (pro_scale, pro_shift, int(pro_relu))
         self.epi = (epi_scale, epi_shift, res1, mask, int(relu))
+        self.mask_out = mask_out
+        assert mask_out is None or (tile in (4, 6) and self.cout == y.shape[3] and mask_out.dtype == torch.uint8
+                                    and tuple(mask_out.shape) == tuple(y.shape[:3]) + (y.shape[3] // 4,))
         for t in (res1, mask):
             assert t is None or tuple(t.shape) == tuple(y.shape)
         self.v = v[:need_v].view(1, 1, nc * self.tiles_pad, c)
@@ -741,8 +745,8 @@ class WinoConv(object):
         n, h, w, c = self.geom
         es, eb, r1, mk, relu = self.epi
         check(_L.hnd_wino_output(ptr(self.m), ptr(self.y), n, h, w, self.cout, self.y.shape[3], ptr(es), ptr(eb),
-                                 ptr(r1), ptr(mk), relu, self.tile, stream if stream is not None else stream_ptr()),
-              'hnd_wino_output')
+                                 ptr(r1), ptr(mk), relu, self.tile, ptr(self.mask_out),
+                                 stream if stream is not None else stream_ptr()), 'hnd_wino_output')
 
     def launches(self, tag):
         """[(launch, tag)] for an engine plan: the two transforms carry no flops (not event-timed by bench.py), the
@@ -752,6 +756,8 @@ class WinoConv(object):
         extra = sum(1 for t in (self.epi[2], self.epi[3]) if t is not None)
         b_in = 4 * (n * h * w * c + nc * tiles * c)                                 # read x once, write V
         b_out = 4 * (nc * tiles * self.cout + (1 + extra) * n * h * w * self.cout)  # read M (+ res / mask), write y
+        if self.mask_out is not None:
+            b_out += n * h * w * self.cout // 4
         return [(_Step(self._run_input, 'wino_input', b_in), tag + '.wino_in'), (self.gemm, tag),
                 (_Step(self._run_output, 'wino_output', b_out), tag + '.wino_out')]
 

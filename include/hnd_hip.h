@@ -304,13 +304,16 @@ int hnd_scale_boxes(const hnd_boxes_desc* items, int count, void* stream);
  * hnd_wino_input:     x [n][h][w][c] (+ optional per-channel prologue scale/shift/relu on in-bounds elements)
  *                     -> v [ncomp][tiles_pad][c].
  * hnd_wino_output:    m [ncomp][tiles_pad][cout] -> y [n][h][w][ldc], epilogue order as hnd_conv2d_igemm:
- *                     scale/shift, + res1, mask (ReLU backward), ReLU. */
+ *                     scale/shift, + res1, mask (ReLU backward), ReLU.  mask_out (ABI 12; NULL = off; tile 4 / 6, cout ==
+ *                     ldc): [stored value > 0] as nibbles beside y, like hnd_conv_desc.mask_out -- the ReLU mask conv3's
+ *                     data gradient applies comes out of the transform that writes a2, not a pass of its own. */
 int64_t hnd_wino_tiles_pad(int n, int h, int w, int tile);
 int hnd_wino_weights(const float* weight, float* u, int cout, int cin, int dgrad, int tile, void* stream);
 int hnd_wino_input(const float* x, float* v, int n, int h, int w, int c, const float* pro_scale,
                    const float* pro_shift, int pro_relu, int tile, void* stream);
 int hnd_wino_output(const float* m, float* y, int n, int h, int w, int cout, int ldc, const float* epi_scale,
-                    const float* epi_shift, const float* res1, const float* mask, int relu, int tile, void* stream);
+                    const float* epi_shift, const float* res1, const float* mask, int relu, int tile, uint8_t* mask_out,
+                    void* stream);
 
 /* ---- Winograd F(tile x tile, 2x2), tile = 4 or 6, for the student head's 2x2 convolutions
  * (src/models/mimic/resnet_layer.py:43-62), forward (padding 1 in the encoder, 0 in the decoder) and data gradient (the

@@ -1654,3 +1654,31 @@ def test_batched_transform_equals_the_per_image_launches_bitwise(ops):
             ops.transform_image(src, b, i, oh, ow, rh, rw, mean, std)
     ops.sync_check()
     assert not bool(torch.isnan(a).any()) and torch.equal(a, b)
+
+
+@pytest.mark.parametrize('c,n,h,w,tile', [(128, 2, 38, 50, 6), (256, 3, 24, 31, 4), (128, 2, 100, 168, 6)])
+def test_winograd_output_transform_writes_the_relu_mask_nibbles_of_the_values_it_stores(ops, c, n, h, w, tile):
+    """hnd_wino_output(mask_out) (ABI 12): the F(4x4) / F(6x6) output transforms own two channels of a pixel per thread; the
+    even thread of a pair writes the byte [stored value > 0] of four channels -- byte-exact against the stored tensor,
+    edge tiles included, and y itself unchanged by the option (round 6: conv3's data gradient reads these nibbles)"""
+    g = torch.Generator().manual_seed(3 + c + h)
+    x = torch.randn(n, c, h, w, generator=g)
+    wt = torch.randn(c, c, 3, 3, generator=g) / (9 * c) ** 0.5
+    es, eb = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.3
+    xd, wd = nhwc(x), wt.to(DEV).contiguous()
+    ww = ops.WinoWeights(wd, False, tile)
+    nv, nm = ops.WinoConv.scratch_elems(n, h, w, c, c, tile)
+    v, m = torch.empty(nv, device=DEV), torch.empty(nm, device=DEV)
+    y0 = torch.full((n, h, w, c), float('nan'), device=DEV)
+    y1 = torch.full((n, h, w, c), float('nan'), device=DEV)
+    bits = torch.full((n, h, w, c // 4), 255, dtype=torch.uint8, device=DEV)
+    kw = dict(epi_scale=es.to(DEV), epi_shift=eb.to(DEV), relu=True)
+    ops.WinoConv(xd, ww, y0, v, m, **kw).run()
+    ops.WinoConv(xd, ww, y1, v, m, mask_out=bits, **kw).run()
+    ops.sync_check()
+    assert torch.equal(y0, y1) and not bool(torch.isnan(y1).any())
+    yv = y1.view(n, h, w, c // 4, 4) > 0
+    want = (yv[..., 0].to(torch.uint8) | (yv[..., 1].to(torch.uint8) << 1) | (yv[..., 2].to(torch.uint8) << 2)
+            | (yv[..., 3].to(torch.uint8) << 3))
+    assert torch.equal(bits, want)
+    assert 0.2 < float((y1 > 0).float().mean()) < 0.8
