@@ -901,6 +901,58 @@ def test_student_side_terms_on_a_pyramid_map_and_on_the_bottleneck_tensor_match_
                                          worst['grad'], worst['param']))
 
 
+def test_full_size_pyramid_and_bottleneck_terms_against_the_oracle():
+    """the two new kinds of student-side terms at 3x800x1333, batch 2 (no reference-made fixture at this size: the oracle,
+    pinned to the reference by the tiny fixtures of the same paths, runs on the host): a term on the stride-8 pyramid map
+    beside layer1 and layer3 -- F(6x6,3x3) data gradient of the pyramid's 3x3 conv, lateral data gradients into 100x168 /
+    50x84 / 25x42 maps, the nearest-upsample backward -- and, with a bottleneck-injected teacher, a term on the bottleneck
+    tensor beside layer2.  Loss and terms against the fp32 oracle, every gradient against fp64 (_grad_check)."""
+    import copy
+    from hnd_ghnd_object_detectors_amd.distillation.tool import DistillationBox
+    from hnd_ghnd_object_detectors_amd.myutils.pytorch import func_util
+    from tests.conftest import record_achieved
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    for fixture in ('tiny_ghnd_fpn_term', 'tiny_enc_term'):
+        z, meta = G.load(fixture)
+        meta = dict(meta, sizes=[(800, 1333), (800, 1333)], min_size=800, max_size=1333)
+        cfg = MU.config_for(meta)
+        crit = cfg['train']['criterion']
+        proto = next(iter(crit['terms'].values()))['criterion']
+        crit['terms'] = OrderedDict((tn, {'ts_modules': [tp, sp], 'criterion': proto, 'factor': f})
+                                    for tn, tp, sp, f in meta['terms'])
+        terms = OrderedDict((tn, (O.rel_key(tp), O.rel_key(sp), f)) for tn, tp, sp, f in meta['terms'])
+        t_sd, s_sd = MU.oracle_states(meta['seed'], meta['model'])
+        student_arch = meta.get('teacher') == 'student_arch'
+        if student_arch:
+            t_sd = O.init_student_state(t_sd, meta['seed'] + 500)
+            cfg['teacher_model'] = copy.deepcopy(cfg['student_model'])
+        teacher, student = MU.build_pair(cfg, t_sd, s_sd, DEV)
+        box = DistillationBox(teacher, student, crit)
+        opt = func_util.get_optimizer(student, 'Adam', {'lr': 1e-3})
+        images, targets = G.case_inputs(meta)
+        ims, tgs = _to_dev(images, targets)
+        loss = box(ims, tgs)
+        opt.zero_grad()
+        loss.backward()
+        kw = dict(terms=terms, min_size=(800,), max_size=1333, teacher_is_student_arch=student_arch)
+        orc32 = O.DistillOracle(t_sd, s_sd, **kw)
+        l32, t32, g32, _ = orc32.step(images)
+        worst_t = abs(loss.item() - l32) / abs(l32)
+        for i, tn in enumerate(terms):
+            worst_t = max(worst_t, abs(float(loss.per_term[i]) - t32[tn]) / abs(t32[tn]))
+        assert worst_t < LOSS_TOL, worst_t
+        del orc32
+        orc64 = O.DistillOracle(t_sd, s_sd, dtype=torch.float64, **kw)
+        _, _, g64, _ = orc64.step(images)
+        worst_g = 0.0
+        for n, p in student.named_parameters():
+            if p.requires_grad and not n.endswith(G.ZERO_GRAD_SUFFIXES):
+                worst_g = max(worst_g, _grad_check(n, p.grad, g32[n], g64[n]))
+        record_achieved('[student-side terms at 3x800x1333 b2, %s] loss / terms vs the fp32 oracle %.1e, worst gradient rel-L2 vs '
+                        'fp64 %.2e' % (', '.join(sp for _, _, sp, _ in meta['terms']), worst_t, worst_g))
+        del teacher, student, box, orc64
+
+
 def test_a_lone_term_on_the_bottleneck_tensor_starts_the_backward_in_the_middle_of_the_head():
     """the bottleneck tensor as the ONLY (hence top) student-side term: the decoder and decoder.0's BatchNorm carry no
     gradient (exact zeros, as autograd leaves them), the backward starts at the encoder's last conv.  Against the fp64
