@@ -119,7 +119,8 @@ def bxs_image(buf, rows_pad, kdim, groups=1, group_stride=0, out=None, force=Fal
 
 class PackedWeight(object):
     """K-contiguous GEMM operand made by hnd_pack_weights."""
-    __slots__ = ('buf', 'rows', 'kdim', 'ni', 'nj', 'chan_pad', 'chan_real', 'src', 'args', 'kscale', 'bx3', 'bxs')
+    __slots__ = ('buf', 'rows', 'kdim', 'ni', 'nj', 'chan_pad', 'chan_real', 'src', 'args', 'kscale', 'bx3', 'bxs',
+                 'used3', 'useds')
 
     def repack(self):
         if PACK_BATCH['open'] and getattr(self, 'kscale', None) is None:
@@ -134,13 +135,27 @@ class PackedWeight(object):
         self.refresh_bx3()
 
     def refresh_bx3(self):
+        """the pre-split images of this operand: made with the first pack, and from then on re-made only while a launch
+        descriptor points at them (conv_desc sets used3 / useds and brings a stale image up to date when it attaches one) --
+        a trainable head re-packs ~28 operands per step and its launches read about a third of their images"""
         if self.ni * self.nj == 1 and self.kdim == self.chan_pad:          # tap-free operands only
-            if bx3_on() or getattr(self, 'bx3', None) is not None:          # (an image made once is kept in step with the weights)
+            have = getattr(self, 'bx3', None) is not None
+            if (bx3_on() and not have) or (have and getattr(self, 'used3', None) is not False):
                 self.bx3 = bx3_image(self.buf, round_up(self.rows, 64), self.kdim, out=getattr(self, 'bx3', None), force=True)
         taps = self.ni * self.nj
         if self.kdim % 128 == 0 and self.chan_pad % 64 == 0 and self.kdim == taps * self.chan_pad:
-            if bx3_on() or getattr(self, 'bxs', None) is not None:
+            have = getattr(self, 'bxs', None) is not None
+            if (bx3_on() and not have) or (have and getattr(self, 'useds', None) is not False):
                 self.bxs = bxs_image(self.buf, round_up(self.rows, 64), self.kdim, out=getattr(self, 'bxs', None), force=True)
+
+    def attach_image(self, which):
+        """a launch descriptor is about to point at the image: from now on every re-pack re-makes it"""
+        if which == 3 and getattr(self, 'used3', None) is False:
+            self.used3 = True
+            bx3_image(self.buf, round_up(self.rows, 64), self.kdim, out=self.bx3, force=True)
+        elif which == 's' and getattr(self, 'useds', None) is False:
+            self.useds = True
+            bxs_image(self.buf, round_up(self.rows, 64), self.kdim, out=self.bxs, force=True)
 
 
 # A caller that refreshes many small operands in a row (the trainable head after every optimizer step) brackets the loop
@@ -184,6 +199,7 @@ def pack_weights(w, transposed=False, chan_pad=None, taps=None, kscale=None):
     pw.buf = torch.empty(round_up(rows, 64) * pw.kdim, dtype=torch.float32, device=w.device)
     pw.args = (cout, cin, kh, kw, int(transposed), chan_pad, i0, istep, ni, j0, jstep, nj)
     pw.kscale = kscale
+    pw.used3 = pw.useds = False
     pw.repack()
     return pw
 
@@ -284,12 +300,16 @@ def conv_desc(x, pw, y, *, kh, kw, oh, ow, sh, dh, bh, sw, dw, bw, cout, y_sh=1,
     if img is not None and not (BX3_MODE[0] == 'force' or (BX3_MODE[0] == 'policy' and bx3_recommended(
             oh * ow if rows_per_image is None else rows_per_image, pw.kdim, cout))):
         img = None
+    if img is not None and getattr(pw, 'used3', None) is False:
+        pw.attach_image(3)
     d.w_bf16x3 = ptr(img)
     # ... and its B-streamed build for what the B-resident kernel does not take (taps, long K, strided outputs, statistics)
     imgs = getattr(pw, 'bxs', None)
     if imgs is not None and not (BX3_MODE[0] == 'force' or (BX3_MODE[0] == 'policy' and bxs_recommended(
             oh * ow if rows_per_image is None else rows_per_image, pw.kdim, cout, kh * kw))):
         imgs = None
+    if imgs is not None and getattr(pw, 'useds', None) is False:
+        pw.attach_image('s')
     d.w_bf16x3s = ptr(imgs)
     if stats is not None:
         assert stats.numel() >= stats_tiles(n * oh * ow) * 2 * cout

@@ -398,6 +398,47 @@ def _rowsum_abs(x, wt):
     return x.abs().double().flatten(0, 2) @ wt.abs().double().flatten(1).t()
 
 
+def test_weight_images_follow_the_weights_once_a_launch_points_at_them(ops):
+    """A re-packed operand re-makes its pre-split images only while a launch descriptor reads them (a training step
+    re-packs ~28 head operands and its launches read about a third of their images): an image nobody reads may go stale,
+    attaching it brings it up to date, and from then on every re-pack refreshes it -- the launch always computes with the
+    CURRENT weights, bit for bit what a freshly packed operand gives."""
+    g = torch.Generator().manual_seed(5)
+    for k, cin, cout, h, w, pad in ((1, 256, 128, 40, 64, 0), (2, 64, 128, 41, 65, 1)):
+        x = torch.randn(2, h, w, cin, generator=g).to(DEV)
+        wt = (torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5).to(DEV)
+        oh, ow = ops.conv_out_size(h, k, 1, pad), ops.conv_out_size(w, k, 1, pad)
+        y, y_ref = torch.empty(2, oh, ow, cout, device=DEV), torch.empty(2, oh, ow, cout, device=DEV)
+
+        def fresh():
+            with ops.emulation('force'):
+                launch = ops.conv_forward(x, ops.pack_weights(wt), y_ref, k, 1, pad)
+            launch.run()
+            ops.sync_check()
+            return launch.variant, y_ref.clone()
+
+        pk = ops.pack_weights(wt)
+        img = pk.bx3 if k == 1 else pk.bxs
+        assert img is not None and pk.used3 is False and pk.useds is False
+        before = img.clone()
+        wt.mul_(1.5).add_(0.01)                                 # an optimizer step
+        pk.repack()
+        assert torch.equal(img, before)                         # nobody reads it: not re-made
+        with ops.emulation('force'):
+            launch = ops.conv_forward(x, pk, y, k, 1, pad)      # attaching brings it up to date
+        assert (pk.used3 if k == 1 else pk.useds) is True and not torch.equal(img, before)
+        launch.run()
+        ops.sync_check()
+        variant, want = fresh()
+        assert launch.variant == variant and variant.startswith('bx3' if k == 1 else 'bxs'), (launch.variant, variant)
+        assert torch.equal(y, want)
+        wt.mul_(0.5).sub_(0.02)                                 # the next step: the re-pack refreshes the image itself
+        pk.repack()
+        launch.run()
+        ops.sync_check()
+        assert torch.equal(y, fresh()[1])
+
+
 def test_bx3_non_finite_inputs_are_loud_and_denormals_behave_as_documented(ops):
     """VERDICT r5 item 1(b), through hnd_conv2d_igemm (include/hnd_hip.h, hnd_conv_desc.w_bf16x3 'DEVIATIONS'):
     (i) an Inf / -Inf / NaN anywhere in an A row makes EVERY output of that row non-finite -- never a finite value -- and

@@ -153,13 +153,17 @@ def main():
     paths = sys.argv[1:]
     if not paths:
         tmp = tempfile.mkdtemp()
-        for stem in ('conv_bres', 'conv_bstream', 'conv_wgrad_ring', 'conv_bx3', 'conv_bxs'):
+        procs = []
+        for stem in ('conv_bres', 'conv_bstream', 'conv_wgrad_ring', 'conv_bx3', 'conv_bxs'):      # (the five compile side by side)
             path = os.path.join(tmp, stem + '.s')
             src = os.path.join(ROOT, 'hnd_ghnd_object_detectors_amd', 'csrc', stem + '.hip')
-            subprocess.check_call(['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950',
-                                   '-I' + os.path.join(ROOT, 'include'), '-ffp-contract=fast', '-S',
-                                   '--cuda-device-only', src, '-o', path], stderr=subprocess.DEVNULL)
+            procs.append(subprocess.Popen(['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950',
+                                           '-I' + os.path.join(ROOT, 'include'), '-ffp-contract=fast', '-S',
+                                           '--cuda-device-only', src, '-o', path], stderr=subprocess.DEVNULL))
             paths.append(path)
+        for pr in procs:
+            if pr.wait() != 0:
+                raise subprocess.CalledProcessError(pr.returncode, pr.args)
     rc = 0
     for path in paths:
         kernels, problems, stats = audit(path)
