@@ -134,28 +134,35 @@ class PackedWeight(object):
                                         stream_ptr()), 'hnd_scale_packed_k')
         self.refresh_bx3()
 
+    def can_bx3(self):
+        return self.ni * self.nj == 1 and self.kdim == self.chan_pad          # tap-free operands only
+
+    def can_bxs(self):
+        return self.kdim % 128 == 0 and self.chan_pad % 64 == 0 and self.kdim == self.ni * self.nj * self.chan_pad
+
     def refresh_bx3(self):
-        """the pre-split images of this operand: made with the first pack, and from then on re-made only while a launch
-        descriptor points at them (conv_desc sets used3 / useds and brings a stale image up to date when it attaches one) --
-        a trainable head re-packs ~28 operands per step and its launches read about a third of their images"""
-        if self.ni * self.nj == 1 and self.kdim == self.chan_pad:          # tap-free operands only
+        """the pre-split images of this operand: made with the first pack while the emulation is on (or by the first launch
+        that asks for one: attach_image), and from then on re-made only while a launch descriptor points at them (conv_desc
+        sets used3 / useds and brings a stale image up to date when it attaches one) -- a trainable head re-packs ~28
+        operands per step and its launches read about a third of their images"""
+        if self.can_bx3():
             have = getattr(self, 'bx3', None) is not None
             if (bx3_on() and not have) or (have and getattr(self, 'used3', None) is not False):
                 self.bx3 = bx3_image(self.buf, round_up(self.rows, 64), self.kdim, out=getattr(self, 'bx3', None), force=True)
-        taps = self.ni * self.nj
-        if self.kdim % 128 == 0 and self.chan_pad % 64 == 0 and self.kdim == taps * self.chan_pad:
+        if self.can_bxs():
             have = getattr(self, 'bxs', None) is not None
             if (bx3_on() and not have) or (have and getattr(self, 'useds', None) is not False):
                 self.bxs = bxs_image(self.buf, round_up(self.rows, 64), self.kdim, out=getattr(self, 'bxs', None), force=True)
 
     def attach_image(self, which):
-        """a launch descriptor is about to point at the image: from now on every re-pack re-makes it"""
-        if which == 3 and getattr(self, 'used3', None) is False:
+        """a launch descriptor is about to point at the image: make it if there is none yet (`with ops.emulation('force')`
+        under HND_BF16X3=0), bring a stale one up to date, and from now on every re-pack re-makes it"""
+        if which == 3 and getattr(self, 'used3', None) is False and self.can_bx3():
             self.used3 = True
-            bx3_image(self.buf, round_up(self.rows, 64), self.kdim, out=self.bx3, force=True)
-        elif which == 's' and getattr(self, 'useds', None) is False:
+            self.bx3 = bx3_image(self.buf, round_up(self.rows, 64), self.kdim, out=getattr(self, 'bx3', None), force=True)
+        elif which == 's' and getattr(self, 'useds', None) is False and self.can_bxs():
             self.useds = True
-            bxs_image(self.buf, round_up(self.rows, 64), self.kdim, out=self.bxs, force=True)
+            self.bxs = bxs_image(self.buf, round_up(self.rows, 64), self.kdim, out=getattr(self, 'bxs', None), force=True)
 
 
 # A caller that refreshes many small operands in a row (the trainable head after every optimizer step) brackets the loop
@@ -296,21 +303,17 @@ def conv_desc(x, pw, y, *, kh, kw, oh, ow, sh, dh, bh, sw, dw, bw, cout, y_sh=1,
                              and tuple(t.shape) == (ny, yh, yw, ldc // 4)), (None if t is None else t.shape, y.shape)
     assert mask is None or mask_bits is None
     d.mask_bits, d.mask_out = ptr(mask_bits), ptr(mask_out)
-    img = getattr(pw, 'bx3', None)          # fp32 emulated on the bf16 matrix pipe: by layer, never by batch
-    if img is not None and not (BX3_MODE[0] == 'force' or (BX3_MODE[0] == 'policy' and bx3_recommended(
-            oh * ow if rows_per_image is None else rows_per_image, pw.kdim, cout))):
-        img = None
-    if img is not None and getattr(pw, 'used3', None) is False:
+    # fp32 emulated on the bf16 matrix pipe: by layer, never by batch
+    rpi = oh * ow if rows_per_image is None else rows_per_image
+    want = BX3_MODE[0] == 'force' or (BX3_MODE[0] == 'policy' and bx3_recommended(rpi, pw.kdim, cout))
+    if want and getattr(pw, 'used3', None) is False:
         pw.attach_image(3)
-    d.w_bf16x3 = ptr(img)
+    d.w_bf16x3 = ptr(getattr(pw, 'bx3', None) if want else None)
     # ... and its B-streamed build for what the B-resident kernel does not take (taps, long K, strided outputs, statistics)
-    imgs = getattr(pw, 'bxs', None)
-    if imgs is not None and not (BX3_MODE[0] == 'force' or (BX3_MODE[0] == 'policy' and bxs_recommended(
-            oh * ow if rows_per_image is None else rows_per_image, pw.kdim, cout, kh * kw))):
-        imgs = None
-    if imgs is not None and getattr(pw, 'useds', None) is False:
+    want = BX3_MODE[0] == 'force' or (BX3_MODE[0] == 'policy' and bxs_recommended(rpi, pw.kdim, cout, kh * kw))
+    if want and getattr(pw, 'useds', None) is False:
         pw.attach_image('s')
-    d.w_bf16x3s = ptr(imgs)
+    d.w_bf16x3s = ptr(getattr(pw, 'bxs', None) if want else None)
     if stats is not None:
         assert stats.numel() >= stats_tiles(n * oh * ow) * 2 * cout
     if bwd_stats is not None:
@@ -321,7 +324,7 @@ def conv_desc(x, pw, y, *, kh, kw, oh, ow, sh, dh, bh, sw, dw, bw, cout, y_sh=1,
         d.bwd_x, d.bwd_scale, d.bwd_shift, d.bwd_mean, d.bwd_rstd = ptr(bx), ptr(bsc), ptr(bsh), ptr(bmu), ptr(brs)
         d.bwd_relu = int(brelu)
     keep = (x, pw, y, pro_scale, pro_shift, epi_scale, epi_shift, res1, res2, mask, stats, mask_bits, mask_out,
-            bwd_stats, img, imgs)
+            bwd_stats, getattr(pw, 'bx3', None), getattr(pw, 'bxs', None))
     return ConvLaunch(d, keep, flops=2 * n * oh * ow * min(cout, pw.rows) * kh * kw * min(cin, pw.chan_real))
 
 

@@ -24,6 +24,14 @@ def ops():
     return O
 
 
+@pytest.fixture(autouse=True)
+def emulated_family(ops):
+    """this file holds the EMULATED rounding family: the round-6 default (choice by layer), also when the suite runs under
+    HND_BF16X3=0 (tests/test_ops_gpu.py is the native family's file the other way round)"""
+    with ops.emulation('policy'):
+        yield
+
+
 def _nhwc(t):
     return t.permute(0, 2, 3, 1).contiguous().to(DEV)
 

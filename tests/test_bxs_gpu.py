@@ -17,6 +17,14 @@ def ops():
     return O
 
 
+@pytest.fixture(autouse=True)
+def emulated_family(ops):
+    """this file holds the EMULATED rounding family: the round-6 default (choice by layer), also when the suite runs under
+    HND_BF16X3=0 (tests/test_ops_gpu.py is the native family's file the other way round)"""
+    with ops.emulation('policy'):
+        yield
+
+
 def _nhwc(t):
     return t.permute(0, 2, 3, 1).contiguous().to(DEV)
 
@@ -53,8 +61,7 @@ def test_bxs_conv_against_fp64_beside_the_native_kernel(ops, cin, cout, n, h, w,
     ref = F.relu(F.conv2d(x.double(), wt.double(), None, stride, pad) * es.double()[None, :, None, None]
                  + eb.double()[None, :, None, None]).permute(0, 2, 3, 1)
     xd, pk = _nhwc(x), ops.pack_weights(wt.to(DEV).contiguous())
-    assert pk.bxs is not None
-    pk.bx3 = None                                 # (tap-free shapes the B-resident kernel would take first)
+    pk.bx3 = pk.used3 = None                      # (tap-free shapes the B-resident kernel would take first: no image, none made)
     oh, ow = ref.shape[1], ref.shape[2]
     ys = [torch.full((n, oh, ow, cout), float('nan'), device=DEV) for _ in range(4)]
     kw = dict(epi_scale=es.to(DEV), epi_shift=eb.to(DEV), relu=True)
@@ -204,7 +211,7 @@ def test_bxs_randomised_shapes_against_the_native_kernel(ops):
         if mask_bits:
             kw['mask_bits'] = torch.randint(0, 16, (n, oh, ow, cout // 4), generator=g, dtype=torch.uint8).to(DEV)
         pk = ops.pack_weights(wt)
-        pk.bx3 = None
+        pk.bx3 = pk.used3 = None
         outs = []
         for emu in (False, True, True):
             y = torch.full((n, oh, ow, cout), float('nan'), device=DEV)

@@ -153,15 +153,16 @@ def test_upload_inside_the_step_costs_under_one_percent_and_the_runner_keeps_ben
     # the default line carries the native-fp32 build of the same steps beside it (a fresh child
     # process with HND_BF16X3=0), the storage dtype, what is emulated, and a roofline priced on the pipe the dominant family
     # runs on
-    nat, emu, roof = out['native_fp32'], out['emulation'], out['roofline']
-    assert out['dtype'] == 'f32' and emu['planes'] == 3 and emu['products'] == 6 and emu['launches'] > 100 and emu['ms'] > 10
-    assert isinstance(out['value_native_fp32'], float) and out['value_native_fp32'] == nat['value'], nat
-    assert 0.75 * out['value'] < out['value_native_fp32'] < out['value'], (out['value_native_fp32'], out['value'])
-    assert nat['worst_first_step_rel_err'] < 1e-3 and out['loss_check']['worst_rel_err'] < 1e-3
-    assert set(roof['families']) == {'emulated_bf16x3', 'native_fp32'}
-    assert roof['families']['emulated_bf16x3']['peak'] == 2500.0 and roof['families']['native_fp32']['peak'] == 157.3
-    assert roof['kernel'] in (roof['families']['emulated_bf16x3']['kernel'], roof['families']['native_fp32']['kernel'])
-    assert 0.2 < roof['frac'] < 1.0 and abs(roof['frac'] - roof['achieved'] / roof['peak']) < 1e-3
+    if os.environ.get('HND_BF16X3', '1') != '0':        # (a suite run under the native switch has no second leg to show)
+        nat, emu, roof = out['native_fp32'], out['emulation'], out['roofline']
+        assert out['dtype'] == 'f32' and emu['planes'] == 3 and emu['products'] == 6 and emu['launches'] > 100 and emu['ms'] > 10
+        assert isinstance(out['value_native_fp32'], float) and out['value_native_fp32'] == nat['value'], nat
+        assert 0.75 * out['value'] < out['value_native_fp32'] < out['value'], (out['value_native_fp32'], out['value'])
+        assert nat['worst_first_step_rel_err'] < 1e-3 and out['loss_check']['worst_rel_err'] < 1e-3
+        assert set(roof['families']) == {'emulated_bf16x3', 'native_fp32'}
+        assert roof['families']['emulated_bf16x3']['peak'] == 2500.0 and roof['families']['native_fp32']['peak'] == 157.3
+        assert roof['kernel'] in (roof['families']['emulated_bf16x3']['kernel'], roof['families']['native_fp32']['kernel'])
+        assert 0.2 < roof['frac'] < 1.0 and abs(roof['frac'] - roof['achieved'] / roof['peak']) < 1e-3
     assert out['upload']['data_wait_ms_per_step'] < 1.0 and out['upload']['pool_batches'] == 0
     # (b) the CLI
     from hnd_ghnd_object_detectors_amd import mimic_runner

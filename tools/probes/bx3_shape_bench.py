@@ -59,7 +59,7 @@ def main():
             l0 = ops.conv_forward(x, pk, y, 1, stride, 0, **kw)
         t0 = timed(l0)
         pk.bx3 = ops.bx3_image(pk.buf, ops.round_up(cout, 64), cin, force=True)
-        pk.bxs = None                               # (the B-streamed build has its own bench: tools/bench_bxs.py)
+        pk.bxs = pk.useds = None                    # (the B-streamed build has its own bench: tools/bench_bxs.py)
         with ops.emulation('force'):
             l1 = ops.conv_forward(x, pk, y, 1, stride, 0, **kw)
         gf = 2.0 * n * oh * ow * cin * cout / 1e9
