@@ -143,8 +143,7 @@ class PackedWeight(object):
     def refresh_bx3(self):
         """the pre-split images of this operand: made with the first pack while the emulation is on (or by the first launch
         that asks for one: attach_image), and from then on re-made only while a launch descriptor points at them (conv_desc
-        sets used3 / useds and brings a stale image up to date when it attaches one) -- a trainable head re-packs ~28
-        operands per step and its launches read about a third of their images"""
+        sets used3 / useds and brings a stale image up to date when it attaches one)"""
         if self.can_bx3():
             have = getattr(self, 'bx3', None) is not None
             if (bx3_on() and not have) or (have and getattr(self, 'used3', None) is not False):

@@ -407,8 +407,7 @@ def _rowsum_abs(x, wt):
 
 
 def test_weight_images_follow_the_weights_once_a_launch_points_at_them(ops):
-    """A re-packed operand re-makes its pre-split images only while a launch descriptor reads them (a training step
-    re-packs ~28 head operands and its launches read about a third of their images): an image nobody reads may go stale,
+    """A re-packed operand re-makes its pre-split images only while a launch descriptor reads them: an image nobody reads may go stale,
     attaching it brings it up to date, and from then on every re-pack refreshes it -- the launch always computes with the
     CURRENT weights, bit for bit what a freshly packed operand gives."""
     g = torch.Generator().manual_seed(5)
