@@ -81,6 +81,7 @@ def init_distributed_mode(world_size=1, dist_url='env://', backend=None):
     backend = backend or os.environ.get('HND_DIST_BACKEND')
     if os.environ.get('HND_SHARE_DEVICE', '0') != '0':
         device_id = 0
+        os.environ.setdefault('HND_SHARED_DEVICE', '1')      # ... and the engines treat the card as shared (engine.process_owns_device)
     if has_gpu:
         torch.cuda.set_device(device_id)
     print('| distributed init (rank {}): {}'.format(rank, dist_url), flush=True)
