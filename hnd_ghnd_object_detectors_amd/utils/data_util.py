@@ -13,6 +13,7 @@ and the flip run inside the device transform kernel.
 """
 import os
 import random
+import threading
 
 import torch
 
@@ -55,7 +56,7 @@ class SyntheticDetectionLoader(object):
         # of the batch (src/mimic_runner.py:49-50), which still happens every step; random-number generation is its
         # DataLoader workers' cost, not the step's.
         self.pool_batches = int(pool_batches)
-        self._pool, self._pool_seed = None, None
+        self._pool, self._pool_seed, self._slot_locks, self._pool_lock = None, None, {}, threading.Lock()
         # host cost of making batches: thread CPU seconds spent in raw_images / batches made (bench.py reports it)
         self.gen_cpu_s, self.gen_batches = 0.0, 0
 
@@ -89,12 +90,15 @@ class SyntheticDetectionLoader(object):
         import time
         es = self._epoch_seed() if epoch_seed is None else epoch_seed
         if self.pool_batches > 0:
-            if self._pool_seed != es:
-                self._pool, self._pool_seed = {}, es
             j = k % self.pool_batches
-            if j not in self._pool:             # (workers may race for a slot: both make the same values, one wins)
-                self._pool[j] = self._generate(j, es)
-            return self._pool[j]
+            with self._pool_lock:               # (feeder threads: ONE of them makes a slot, the others wait for it)
+                if self._pool_seed != es:
+                    self._pool, self._pool_seed, self._slot_locks = {}, es, {}
+                slot_lock = self._slot_locks.setdefault(j, threading.Lock())
+            with slot_lock:
+                if j not in self._pool:
+                    self._pool[j] = self._generate(j, es)
+                return self._pool[j]
         t0 = time.thread_time()
         out = self._generate(k, es)
         self.gen_cpu_s += time.thread_time() - t0

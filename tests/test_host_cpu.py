@@ -129,6 +129,24 @@ def test_synthetic_loader_pool_hands_out_the_same_first_batches_and_then_rotates
     assert plain_ld.gen_batches == 3 and plain_ld.gen_cpu_s > 0 and pooled_ld.gen_batches == 0
 
 
+def test_synthetic_loader_pool_slot_is_made_once_when_feeder_threads_race_for_it(monkeypatch):
+    """with 2 feeder threads and a pool of 2, batch 2 asks for slot 0 while batch 0 may still be generating it: one thread
+    makes the slot, the other waits (seen once under load: two copies of slot 0, the second replacing the first)"""
+    import time
+    from hnd_ghnd_object_detectors_amd.utils import data_util
+    ld = data_util.SyntheticDetectionLoader(6, 2, 16, 24, 'faster_rcnn', seed=9, workers=3, pool_batches=2)
+    made, real = [], ld._generate
+
+    def slow(k, es):
+        made.append(k)
+        time.sleep(0.05)
+        return real(k, es)
+    monkeypatch.setattr(ld, '_generate', slow)
+    got = list(ld)
+    assert sorted(made) == [0, 1], made
+    assert all(got[k][0][i] is got[k % 2][0][i] for k in range(6) for i in range(2))
+
+
 def test_load_ckpt_tuple_arity_and_roundtrip(tmp_path):
     from hnd_ghnd_object_detectors_amd.models import load_ckpt, save_ckpt
     assert load_ckpt(str(tmp_path / 'missing.pt')) == (None, None)      # reference quirk: 2-tuple when missing
